@@ -1,0 +1,306 @@
+"""ctypes binding of the C-ABI library ``libclo_hip.so`` (see ``include/curvlinops_amd.h``).
+
+PyTorch only provides device memory and the HIP stream; every function here hands raw
+device pointers to the hand-written gfx950 kernels.  There is deliberately NO fallback: if
+the shared object is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
+from pathlib import Path
+
+import torch
+from torch import Tensor
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libclo_hip.so"
+_lib = None
+
+ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+LOSS_MSE, LOSS_CE, LOSS_BCE, LOSS_RANK1 = 0, 1, 2, 3
+
+# name -> (restype, argtypes); mirrors include/curvlinops_amd.h one to one
+_PF = c_void_p  # float* passed as integer address
+_SIGNATURES = {
+    "clo_version": (c_int, []),
+    "clo_last_error": (c_char_p, []),
+    "clo_gemm_f32": (
+        c_int,
+        [c_int, c_int, c_int, c_float, _PF, c_long, c_long, c_long, _PF, c_long, c_long, c_long,
+         c_float, _PF, c_long, c_long, c_int, c_int, _PF, c_void_p],
+    ),
+    "clo_gemm_suggest_splitk": (c_int, [c_int, c_int, c_int, c_int]),
+    "clo_syrk_accum_f32": (
+        c_int,
+        [_PF, c_long, _PF, c_long, c_int, c_long, c_int, c_float, c_float, c_int, _PF, c_void_p],
+    ),
+    "clo_mlp_fwd_jvp_layer": (
+        c_int,
+        [_PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, c_int, c_int, c_void_p],
+    ),
+    "clo_loss_hessian_apply": (
+        c_int,
+        [c_int, _PF, _PF, c_int, _PF, _PF, _PF, c_int, c_int, c_float, c_void_p],
+    ),
+    "clo_mlp_bwd_layer": (
+        c_int,
+        [_PF, _PF, _PF, _PF, _PF, _PF, _PF, c_float, c_float, c_int, c_int, c_int, _PF, c_void_p],
+    ),
+    "clo_mlp_bwd_ws_floats": (c_long, [c_int, c_int, c_int]),
+    "clo_mlp_ggn_matvec": (
+        c_int,
+        [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
+         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _PF, c_int,
+         c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
+    ),
+    "clo_mlp_ggn_ws_floats": (c_long, [c_int, POINTER(c_int), c_int]),
+    "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
+    "clo_transpose_f32": (c_int, [_PF, _PF, c_long, c_long, c_void_p]),
+    "clo_rowscale_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_int, c_float, c_void_p]),
+    "clo_pack_probes_f32": (c_int, [_PF, c_long, c_long, c_uint64, c_int, c_void_p]),
+}
+
+
+def exported_symbols() -> list[str]:
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return list(_SIGNATURES)
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared object once; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: run `python -m curvlinops_amd.csrc.build` "
+                "(hipcc, gfx950). curvlinops_amd has no fallback path."
+            )
+        lib = ctypes.CDLL(str(_LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().clo_last_error().decode(errors="replace")
+        kind = {-1: ValueError, -3: RuntimeError}.get(rc, RuntimeError)
+        raise kind(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Tensor | None) -> int | None:
+    """Device address of a float32 CUDA(HIP) tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise ValueError(f"expected a float32 GPU tensor, got {t.dtype} on {t.device}")
+    return t.data_ptr()
+
+
+def _pc(t: Tensor | None) -> int | None:
+    if t is not None and not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return _p(t)
+
+
+# --------------------------------------------------------------------------------------
+# GEMM family
+# --------------------------------------------------------------------------------------
+def gemm(A: Tensor, B: Tensor, out: Tensor | None = None, alpha: float = 1.0, beta: float = 0.0,
+         splitk: int | None = None) -> Tensor:
+    """``out = alpha * A @ B + beta * out`` for 2-D or batched 3-D fp32 GPU tensors.
+
+    ``A``/``B`` may be arbitrary strided views (e.g. ``.T`` / ``.mT``); ``out`` must be
+    row-major (last stride 1).
+    """
+    lib = load()
+    batched = A.dim() == 3 or B.dim() == 3
+    A3 = A if A.dim() == 3 else A.unsqueeze(0)
+    B3 = B if B.dim() == 3 else B.unsqueeze(0)
+    nb = max(A3.shape[0], B3.shape[0])
+    M, K = A3.shape[1], A3.shape[2]
+    K2, N = B3.shape[1], B3.shape[2]
+    if K != K2 or A3.shape[0] not in (1, nb) or B3.shape[0] not in (1, nb):
+        raise ValueError(f"gemm shape mismatch: {tuple(A.shape)} @ {tuple(B.shape)}")
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an `out` tensor")
+        out = torch.empty((nb, M, N) if batched else (M, N), device=A.device, dtype=torch.float32)
+    O3 = out if out.dim() == 3 else out.unsqueeze(0)
+    if O3.shape != (nb, M, N) or (N > 1 and O3.stride(2) != 1) or O3.stride(1) < N:
+        if not (N == 1 and O3.shape == (nb, M, N)):
+            raise ValueError(f"bad out tensor {tuple(out.shape)} / strides {out.stride()}")
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        if beta == 0.0:
+            out.zero_()
+        else:
+            out.mul_(beta)
+        return out
+    sa_b = A3.stride(0) if A3.shape[0] == nb and nb > 1 else 0
+    sb_b = B3.stride(0) if B3.shape[0] == nb and nb > 1 else 0
+    if splitk is None:
+        splitk = lib.clo_gemm_suggest_splitk(M, N, K, nb)
+    ws = None
+    if splitk > 1:
+        ws = torch.empty(nb * splitk * M * N, device=A.device, dtype=torch.float32)
+    ldc = O3.stride(1) if M > 1 else max(N, O3.stride(1))
+    rc = lib.clo_gemm_f32(
+        M, N, K, alpha, _p(A3), A3.stride(1), A3.stride(2), sa_b, _p(B3), B3.stride(1),
+        B3.stride(2), sb_b, beta, _p(O3), ldc, O3.stride(0) if nb > 1 else 0, nb, splitk, _p(ws),
+        _stream(),
+    )
+    _check(rc, "clo_gemm_f32")
+    return out
+
+
+def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones_col: bool = False,
+               splitk: int | None = None) -> Tensor:
+    """``C = beta*C + alpha * [X|1]^T [X|1]`` for row-major ``X[rows, d]`` (view with stride ok)."""
+    lib = load()
+    if X.dim() != 2 or (X.shape[1] > 1 and X.stride(1) != 1):
+        raise ValueError("X must be 2-D with unit column stride")
+    rows, d = X.shape
+    dd = d + (1 if ones_col else 0)
+    if C.shape != (dd, dd) or C.stride(1) != 1:
+        raise ValueError(f"C must be [{dd},{dd}] row-major, got {tuple(C.shape)}")
+    if splitk is None:
+        splitk = lib.clo_gemm_suggest_splitk(d, d, rows, 1)
+    ws = torch.empty(splitk * d * d, device=X.device, dtype=torch.float32) if splitk > 1 else None
+    ldx = X.stride(0) if rows > 1 else max(d, 1)
+    rc = lib.clo_syrk_accum_f32(_p(C), C.stride(0), _p(X), rows, d, ldx, int(ones_col), alpha, beta,
+                                splitk, _p(ws), _stream())
+    _check(rc, "clo_syrk_accum_f32")
+    return C
+
+
+# --------------------------------------------------------------------------------------
+# MLP fast path
+# --------------------------------------------------------------------------------------
+def mlp_fwd_jvp_layer(W, b, VW, Vb, a_in, da_in, act: int):
+    lib = load()
+    N, d_in = a_in.shape
+    d_out = W.shape[0]
+    a_out = torch.empty(N, d_out, device=W.device, dtype=torch.float32)
+    dphi = torch.empty_like(a_out)
+    da_out = torch.empty_like(a_out) if (VW is not None or da_in is not None) else None
+    rc = lib.clo_mlp_fwd_jvp_layer(_pc(W), _pc(b), _pc(VW), _pc(Vb), _pc(a_in), _pc(da_in),
+                                   _pc(a_out), _pc(da_out), _pc(dphi), N, d_in, d_out, act,
+                                   _stream())
+    _check(rc, "clo_mlp_fwd_jvp_layer")
+    return a_out, da_out, dphi
+
+
+def loss_hessian_apply(kind: int, f, u, scale: float, aux=None, dphi_last=None):
+    lib = load()
+    N, C = f.shape
+    w = torch.empty_like(f)
+    rank = 1 if aux is None else (aux.shape[1] if aux.dim() == 3 else 1)
+    rc = lib.clo_loss_hessian_apply(kind, _pc(f), _pc(aux), rank, _pc(u), _pc(dphi_last), _pc(w),
+                                    N, C, scale, _stream())
+    _check(rc, "clo_loss_hessian_apply")
+    return w
+
+
+def mlp_bwd_layer(W, delta, a_prev, dphi_prev, out_W, out_b, alpha: float, beta: float,
+                  want_delta_prev: bool):
+    lib = load()
+    N, d_out = delta.shape
+    d_in = W.shape[1]
+    dprev = ws = None
+    if want_delta_prev:
+        dprev = torch.empty(N, d_in, device=W.device, dtype=torch.float32)
+        ws = torch.empty(lib.clo_mlp_bwd_ws_floats(N, d_in, d_out), device=W.device,
+                         dtype=torch.float32)
+    rc = lib.clo_mlp_bwd_layer(_pc(W), _pc(delta), _pc(a_prev), _pc(dphi_prev), _pc(out_W),
+                               _pc(out_b), _pc(dprev), alpha, beta, N, d_in, d_out, _pc(ws),
+                               _stream())
+    _check(rc, "clo_mlp_bwd_layer")
+    return dprev
+
+
+class MLPPlan:
+    """Pre-marshalled argument tables for ``clo_mlp_ggn_matvec`` (one per operator)."""
+
+    def __init__(self, dims: list[int], acts: list[int]):
+        self.L = len(acts)
+        self.dims = (c_int * (self.L + 1))(*dims)
+        self.acts = (c_int * self.L)(*acts)
+        self._dims_list = list(dims)
+        self._ws: dict[tuple[int, str], Tensor] = {}
+
+    def _ptr_array(self, tensors):
+        arr = (c_void_p * self.L)()
+        for i, t in enumerate(tensors):
+            arr[i] = None if t is None else _pc(t)
+        return arr
+
+    def workspace(self, N: int, device) -> Tensor:
+        key = (N, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            n = load().clo_mlp_ggn_ws_floats(self.L, self.dims, N)
+            ws = torch.empty(n, device=device, dtype=torch.float32)
+            self._ws = {key: ws}  # keep only the latest batch size
+        return ws
+
+    def ggn_matvec(self, W, b, VW, Vb, OW, Ob, X, loss_kind: int, loss_scale: float, alpha: float,
+                   beta: float, aux=None) -> None:
+        lib = load()
+        N = X.shape[0]
+        rank = 1 if aux is None else (aux.shape[1] if aux.dim() == 3 else 1)
+        rc = lib.clo_mlp_ggn_matvec(
+            self.L, self.dims, self.acts, self._ptr_array(W), self._ptr_array(b),
+            self._ptr_array(VW), self._ptr_array(Vb), self._ptr_array(OW), self._ptr_array(Ob),
+            _pc(X), N, loss_kind, _pc(aux), rank, loss_scale, alpha, beta,
+            _pc(self.workspace(N, X.device)), _stream(),
+        )
+        _check(rc, "clo_mlp_ggn_matvec")
+
+
+# --------------------------------------------------------------------------------------
+# streaming helpers
+# --------------------------------------------------------------------------------------
+def axpby(y: Tensor, x: Tensor, alpha: float, beta: float) -> Tensor:
+    if y.shape != x.shape:
+        raise ValueError("axpby shape mismatch")
+    _check(load().clo_axpby_f32(_pc(y), _pc(x), y.numel(), alpha, beta, _stream()), "clo_axpby_f32")
+    return y
+
+
+def transpose(x: Tensor) -> Tensor:
+    rows, cols = x.shape
+    out = torch.empty(cols, rows, device=x.device, dtype=torch.float32)
+    _check(load().clo_transpose_f32(_pc(out), _pc(x), rows, cols, _stream()), "clo_transpose_f32")
+    return out
+
+
+def rowscale(x: Tensor, s: Tensor, reciprocal: bool = False, shift: float = 0.0) -> Tensor:
+    rows, K = x.shape
+    y = torch.empty_like(x)
+    _check(load().clo_rowscale_f32(_pc(y), _pc(x), _pc(s), rows, K, int(reciprocal), shift,
+                                   _stream()), "clo_rowscale_f32")
+    return y
+
+
+def pack_probes(D: int, K: int, seed: int, distribution: str, device) -> Tensor:
+    dist = {"rademacher": 0, "normal": 1}.get(distribution)
+    if dist is None:
+        raise ValueError(f"Unknown distribution {distribution!r}.")
+    out = torch.empty(D, K, device=device, dtype=torch.float32)
+    _check(load().clo_pack_probes_f32(_pc(out), D, K, seed & (2**64 - 1), dist, _stream()),
+           "clo_pack_probes_f32")
+    return out

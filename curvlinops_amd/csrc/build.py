@@ -1,0 +1,62 @@
+"""Build libclo_hip.so (gfx950) in-tree with hipcc.
+
+``python -m curvlinops_amd.csrc.build`` or ``build()``; hipcc cross-compiles without a GPU.
+The shared object lands in ``curvlinops_amd/lib/`` so it travels with the source tree.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+LIB_DIR = CSRC.parent / "lib"
+LIB_PATH = LIB_DIR / "libclo_hip.so"
+SOURCES = ["gemm.hip", "mlp.hip", "stream_ops.hip", "linalg.hip", "kfac.hip"]
+HEADERS = ["clo_common.h", "../../include/curvlinops_amd.h"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found; cannot build libclo_hip.so")
+
+
+def _stale() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES if (CSRC / s).exists()] + [CSRC / h for h in HEADERS]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source into one shared object for gfx950."""
+    if not force and not _stale():
+        return LIB_PATH
+    LIB_DIR.mkdir(exist_ok=True)
+    srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
+    cmd = [
+        _hipcc(),
+        "--offload-arch=gfx950",
+        "-O3",
+        "-std=c++17",
+        "-fPIC",
+        "-shared",
+        "-o",
+        str(LIB_PATH),
+        *srcs,
+    ]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

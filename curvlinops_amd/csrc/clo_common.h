@@ -1,0 +1,71 @@
+// Shared helpers for libclo_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/curvlinops_amd.h"
+
+namespace clo {
+
+void set_error(const char *fmt, ...);
+
+inline int check_hip(hipError_t e, const char *what) {
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return CLO_EHIP;
+  }
+  return CLO_OK;
+}
+
+#define CLO_CHECK_LAUNCH(what)                                   \
+  do {                                                           \
+    int _rc = ::clo::check_hip(hipGetLastError(), what);         \
+    if (_rc != CLO_OK) return _rc;                               \
+  } while (0)
+
+#define CLO_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::clo::set_error(__VA_ARGS__);      \
+      return CLO_EINVAL;                  \
+    }                                     \
+  } while (0)
+
+__host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;   // MI355X
+constexpr int kNumXCD = 8;
+
+// Sum over the 64 lanes of a wave; every lane gets the result.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(int act, float z, float &dphi) {
+  switch (act) {
+    case CLO_ACT_RELU:
+      dphi = z > 0.f ? 1.f : 0.f;
+      return z > 0.f ? z : 0.f;
+    case CLO_ACT_TANH: {
+      float t = tanhf(z);
+      dphi = 1.f - t * t;
+      return t;
+    }
+    case CLO_ACT_SIGMOID: {
+      float s = 1.f / (1.f + __expf(-z));
+      dphi = s * (1.f - s);
+      return s;
+    }
+    default:
+      dphi = 1.f;
+      return z;
+  }
+}
+
+}  // namespace clo

@@ -1,0 +1,195 @@
+// Error state, version, and the HBM-bound streaming helpers of libclo_hip:
+// axpby (batch accumulate), transpose ([D,K] <-> [K,D]), row scaling (eigenvalue
+// scaling of EighDecomposed operators) and counter-based probe packing.
+#include "clo_common.h"
+
+namespace clo {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// Grid for a streaming kernel over n work items of `per_thread` elements: cap at ~8 blocks
+// per CU and grid-stride the rest.
+static inline unsigned stream_grid(long n_items, int block) {
+  long g = cdiv(n_items, block);
+  const long cap = (long)kNumCU * 8;
+  return (unsigned)std::max<long>(1, std::min<long>(g, cap));
+}
+
+// y = beta*y + alpha*x, 16 B per lane when aligned.
+__global__ void axpby_vec_kernel(float4 *__restrict__ y, const float4 *__restrict__ x, long n4,
+                                 float alpha, float beta) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x) {
+    const float4 xv = x[i];
+    float4 yv;
+    if (beta != 0.f) {
+      yv = y[i];
+      yv.x = beta * yv.x + alpha * xv.x; yv.y = beta * yv.y + alpha * xv.y;
+      yv.z = beta * yv.z + alpha * xv.z; yv.w = beta * yv.w + alpha * xv.w;
+    } else {
+      yv = make_float4(alpha * xv.x, alpha * xv.y, alpha * xv.z, alpha * xv.w);
+    }
+    y[i] = yv;
+  }
+}
+__global__ void axpby_scalar_kernel(float *__restrict__ y, const float *__restrict__ x, long n,
+                                    float alpha, float beta) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    y[i] = (beta != 0.f ? beta * y[i] : 0.f) + alpha * x[i];
+}
+
+// 64x64 tile transpose through LDS (padded), coalesced on both sides.
+__global__ void transpose_kernel(float *__restrict__ out, const float *__restrict__ in, long rows,
+                                 long cols) {
+  __shared__ float tile[64][65];
+  const long tiles_c = cdiv(cols, 64);
+  const long ntiles = cdiv(rows, 64) * tiles_c;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long r = r0 + ty + 4 * i, c = c0 + tx;
+      tile[ty + 4 * i][tx] = (r < rows && c < cols) ? in[r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long c = c0 + ty + 4 * i, r = r0 + tx;
+      if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + 4 * i];
+    }
+    __syncthreads();
+  }
+}
+
+// y[i][k] = f(s[i]) * x[i][k]; f(s) = s, or 1/(s+shift) when reciprocal.
+__global__ void rowscale_kernel(float *__restrict__ y, const float *__restrict__ x,
+                                const float *__restrict__ s, long rows, long K, int reciprocal,
+                                float shift) {
+  const long total = rows * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const long i = e / K;
+    float sv = s[i];
+    if (reciprocal) sv = 1.f / (sv + shift);
+    y[e] = sv * x[e];
+  }
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter = element-group index, key = seed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float u01(uint32_t x) {  // (0, 1]
+  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+// Each thread produces 4 consecutive outputs from one Philox block.
+__global__ void pack_probes_kernel(float *__restrict__ out, long n, uint64_t seed, int dist) {
+  const long ngroups = cdiv(n, 4);
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+       g += (long)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32), 0u, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float v[4];
+    if (dist == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (c[e] & 1u) ? 1.f : -1.f;
+    } else {  // Box-Muller, two pairs
+      const float r0 = sqrtf(-2.f * __logf(u01(c[0]))), t0 = 6.28318530718f * u01(c[1]);
+      const float r1 = sqrtf(-2.f * __logf(u01(c[2]))), t1 = 6.28318530718f * u01(c[3]);
+      v[0] = r0 * __cosf(t0); v[1] = r0 * __sinf(t0);
+      v[2] = r1 * __cosf(t1); v[3] = r1 * __sinf(t1);
+    }
+    const long base = g * 4;
+    if (base + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
+      *reinterpret_cast<float4 *>(out + base) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (base + e < n) out[base + e] = v[e];
+    }
+  }
+}
+
+}  // namespace clo
+
+using namespace clo;
+
+extern "C" int clo_version(void) { return 100; }
+extern "C" const char *clo_last_error(void) { return g_err; }
+
+extern "C" int clo_axpby_f32(float *y, const float *x, long n, float alpha, float beta,
+                             void *stream) {
+  CLO_REQUIRE(n >= 0, "clo_axpby_f32: negative n");
+  if (n == 0) return CLO_OK;
+  CLO_REQUIRE(y && x, "clo_axpby_f32: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (n % 4 == 0 && aligned16(y) && aligned16(x)) {
+    hipLaunchKernelGGL(axpby_vec_kernel, dim3(stream_grid(n / 4, 256)), dim3(256), 0, st,
+                       reinterpret_cast<float4 *>(y), reinterpret_cast<const float4 *>(x), n / 4,
+                       alpha, beta);
+  } else {
+    hipLaunchKernelGGL(axpby_scalar_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, y, x, n,
+                       alpha, beta);
+  }
+  CLO_CHECK_LAUNCH("axpby");
+  return CLO_OK;
+}
+
+extern "C" int clo_transpose_f32(float *out, const float *in, long rows, long cols, void *stream) {
+  CLO_REQUIRE(rows >= 0 && cols >= 0, "clo_transpose_f32: negative size");
+  if (rows == 0 || cols == 0) return CLO_OK;
+  CLO_REQUIRE(out && in && out != in, "clo_transpose_f32: null or aliased pointers");
+  const long ntiles = cdiv(rows, 64) * cdiv(cols, 64);
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)std::min<long>(ntiles, kNumCU * 16L)),
+                     dim3(256), 0, (hipStream_t)stream, out, in, rows, cols);
+  CLO_CHECK_LAUNCH("transpose_kernel");
+  return CLO_OK;
+}
+
+extern "C" int clo_rowscale_f32(float *y, const float *x, const float *s, long rows, long K,
+                                int reciprocal, float shift, void *stream) {
+  CLO_REQUIRE(rows >= 0 && K >= 0, "clo_rowscale_f32: negative size");
+  if (rows == 0 || K == 0) return CLO_OK;
+  CLO_REQUIRE(y && x && s, "clo_rowscale_f32: null pointer");
+  hipLaunchKernelGGL(rowscale_kernel, dim3(stream_grid(rows * K, 256)), dim3(256), 0,
+                     (hipStream_t)stream, y, x, s, rows, K, reciprocal, shift);
+  CLO_CHECK_LAUNCH("rowscale_kernel");
+  return CLO_OK;
+}
+
+extern "C" int clo_pack_probes_f32(float *out, long D, long K, uint64_t seed, int dist,
+                                   void *stream) {
+  CLO_REQUIRE(D >= 0 && K >= 0, "clo_pack_probes_f32: negative size");
+  CLO_REQUIRE(dist == 0 || dist == 1, "clo_pack_probes_f32: dist must be 0 or 1");
+  if (D == 0 || K == 0) return CLO_OK;
+  CLO_REQUIRE(out, "clo_pack_probes_f32: null pointer");
+  const long n = D * K;
+  hipLaunchKernelGGL(pack_probes_kernel, dim3(stream_grid(cdiv(n, 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, out, n, seed, dist);
+  CLO_CHECK_LAUNCH("pack_probes_kernel");
+  return CLO_OK;
+}

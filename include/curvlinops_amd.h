@@ -1,0 +1,150 @@
+/*
+ * curvlinops_amd.h -- C ABI of libclo_hip.so, the MI355X (gfx950) backend for the
+ * curvature-matvec hot path of f-dangel/curvlinops.
+ *
+ * Every entry point takes raw DEVICE pointers (fp32 unless stated), explicit
+ * sizes/strides in ELEMENTS, and a hipStream_t passed as void*.  The caller
+ * (PyTorch, or any other host) owns all memory.  Return value: 0 on success,
+ * a negative CLO_E* code otherwise; clo_last_error() gives the message for the
+ * calling thread.  No global state besides that per-thread message.
+ *
+ * Each function names the reference (f-dangel/curvlinops) call site it replaces;
+ * paths are relative to the reference repository root.
+ */
+#ifndef CURVLINOPS_AMD_H
+#define CURVLINOPS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLO_OK 0
+#define CLO_EINVAL -1   /* bad argument (shape / stride / enum)            */
+#define CLO_EHIP -2     /* a HIP runtime call or kernel launch failed       */
+#define CLO_ENOTPD -3   /* Cholesky: matrix not positive definite           */
+#define CLO_EUNSUP -4   /* valid request this build does not implement      */
+
+/* Activation codes (elementwise nonlinearity after a Linear layer). */
+#define CLO_ACT_IDENTITY 0
+#define CLO_ACT_RELU 1
+#define CLO_ACT_TANH 2
+#define CLO_ACT_SIGMOID 3
+
+/* Output-space curvature ("loss Hessian") kinds applied between J v and J^T. */
+#define CLO_LOSS_MSE 0       /* w = s * u                         (ggn_utils.py:52-55) */
+#define CLO_LOSS_CE 1        /* w = s * (p*u - p*(p.u))           (ggn_utils.py:56-75) */
+#define CLO_LOSS_BCE 2       /* w = s * sig*(1-sig)*u             (ggn_utils.py:76-79) */
+#define CLO_LOSS_RANK1 3     /* w = s * sum_m g_m*(g_m.u), g given per row (gradient_moments.py:48-87,
+                                ggn.py:140-166: EF / MC pseudo-losses)                 */
+
+int clo_version(void);
+const char *clo_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Dense fp32 GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+ *   C[b][m][n] = alpha * sum_k A_b(m,k) * B_b(k,n) + beta * C[b][m][n]
+ * A_b(m,k) = A[b*sa_b + m*sa_m + k*sa_k], B_b(k,n) = B[b*sb_b + k*sb_k + n*sb_n],
+ * C row-major with leading dimension ldc and batch stride sc_b.  Either stride of
+ * an operand may be 1 (both layouts are loaded coalesced); arbitrary strides work
+ * (slow path).  splitk > 1 splits K over grid.z: `ws` must then hold
+ * batch*splitk*M*N floats and is reduced deterministically by a second kernel.
+ * Replaces torch.einsum / @ in kronecker.py:141-171, eigh.py:84-105 and the
+ * Linear-layer GEMMs that torch.func.jvp/vjp issue for ggn.py:61-71.
+ * ------------------------------------------------------------------------- */
+int clo_gemm_f32(int M, int N, int K, float alpha,
+                 const float *A, long sa_m, long sa_k, long sa_b,
+                 const float *B, long sb_k, long sb_n, long sb_b,
+                 float beta, float *C, long ldc, long sc_b,
+                 int batch, int splitk, float *ws, void *stream);
+
+/* Suggested split-K factor for a (M,N,K,batch) problem (1 = none). */
+int clo_gemm_suggest_splitk(int M, int N, int K, int batch);
+
+/* ------------------------------------------------------------------------- *
+ * KFAC factor accumulation: C[d][d] = beta*C + alpha * X^T X for row-major
+ * X[rows][ldx] (first d columns used).  If ones_col != 0 the matrix is treated
+ * as [X | 1] (joint weight+bias, kfac_math.py:115-116) and C is (d+1)x(d+1).
+ * Only the upper block-triangle is computed on the MFMA pipe and mirrored.
+ * `ws`: split-K workspace as for clo_gemm_f32 (may be NULL when splitk == 1).
+ * Replaces einsum("b s i, b s j -> i j") in computers/kfac_hooks.py:350,390.
+ * ------------------------------------------------------------------------- */
+int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, long ldx,
+                       int ones_col, float alpha, float beta,
+                       int splitk, float *ws, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * MLP fast path (Sequential of Linear + elementwise activation), one mini-batch,
+ * K = 1 column.  All activations are row-major [N][d].
+ *
+ * clo_mlp_fwd_jvp_layer: fused forward + forward-mode (JVP) pass through one
+ * Linear layer, reading W and VW exactly once:
+ *   z  = a_in W^T + b ;  dz = da_in W^T + a_in VW^T + Vb
+ *   a_out = act(z) ; da_out = act'(z) * dz ; dphi_out = act'(z)
+ * da_in may be NULL (first layer: tangent of the input is 0); b/Vb may be NULL.
+ * VW/Vb/da_in/da_out may all be NULL for a pure forward pass.
+ * Replaces jvp(f) in ggn.py:61 for Linear layers.
+ * ------------------------------------------------------------------------- */
+int clo_mlp_fwd_jvp_layer(const float *W, const float *b, const float *VW, const float *Vb,
+                          const float *a_in, const float *da_in,
+                          float *a_out, float *da_out, float *dphi_out,
+                          int N, int d_in, int d_out, int act, void *stream);
+
+/* Output-space curvature product for one mini-batch (jvp(jacrev(c)) in
+ * ggn.py:64-65):  w[n][:] = scale * H(f[n], .) u[n][:], then multiplied
+ * elementwise by dphi_last (if not NULL).  `aux`: for CLO_LOSS_RANK1 the per-row
+ * vectors g[n][m][C], m < aux_rank (H_n = sum_m g_nm g_nm^T); ignored otherwise. */
+int clo_loss_hessian_apply(int kind, const float *f, const float *aux, int aux_rank,
+                           const float *u, const float *dphi_last, float *w, int N, int C,
+                           float scale, void *stream);
+
+/* Backward (VJP) through one Linear layer (vjp(f) in ggn.py:68-71):
+ *   out_W[j][i] = beta*out_W[j][i] + alpha * sum_n delta[n][j] * a_prev[n][i]
+ *   out_b[j]    = beta*out_b[j]    + alpha * sum_n delta[n][j]          (if out_b)
+ *   delta_prev[n][i] = dphi_prev[n][i] * sum_j W[j][i] * delta[n][j]    (if delta_prev)
+ * `ws` must hold clo_mlp_bwd_ws_floats(N, d_in, d_out) floats when delta_prev != NULL. */
+int clo_mlp_bwd_layer(const float *W, const float *delta, const float *a_prev,
+                      const float *dphi_prev, float *out_W, float *out_b, float *delta_prev,
+                      float alpha, float beta, int N, int d_in, int d_out,
+                      float *ws, void *stream);
+long clo_mlp_bwd_ws_floats(int N, int d_in, int d_out);
+
+/* Whole-network GGN-type matvec for one mini-batch, K = 1 (ggn.py:41-72 with
+ * _torch_base.py:937-942 accumulation):  out += / = alpha * J^T H J v.
+ *   L            number of Linear layers
+ *   dims[L+1]    d_0 .. d_L
+ *   acts[L]      activation after each layer (CLO_ACT_*)
+ *   W,b,VW,Vb,OW,Ob  host arrays of L device pointers (b/Vb/Ob entries may be NULL)
+ *   X [N][d_0]   input batch;  loss_kind/aux/loss_scale as clo_loss_hessian_apply
+ *   ws           workspace of clo_mlp_ggn_ws_floats(L, dims, N) floats
+ * Works for any N (N > 16 runs the MFMA GEMM path). */
+int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
+                       const float *const *W, const float *const *b,
+                       const float *const *VW, const float *const *Vb,
+                       float *const *OW, float *const *Ob,
+                       const float *X, int N, int loss_kind, const float *aux, int aux_rank,
+                       float loss_scale, float alpha, float beta,
+                       float *ws, void *stream);
+long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
+
+/* ------------------------------------------------------------------------- *
+ * Streaming helpers (HBM-bound).
+ * ------------------------------------------------------------------------- */
+/* y = beta*y + alpha*x  (batch accumulate, _torch_base.py:942) */
+int clo_axpby_f32(float *y, const float *x, long n, float alpha, float beta, void *stream);
+/* out[r][c] = in[c][r]  ([D,K] <-> [K,D] probe-layout conversion) */
+int clo_transpose_f32(float *out, const float *in, long rows, long cols, void *stream);
+/* y[i] = s[i] * x[i*K + k] for all k (EighDecomposed scaling, eigh.py:103-105) */
+int clo_rowscale_f32(float *y, const float *x, const float *s, long rows, long K, int reciprocal,
+                     float shift, void *stream);
+/* Probe packing (sampling.py:6-56, trace/hutchinson.py:71-75): fill out[D][K]
+ * (K trailing) with Rademacher (+-1, dist=0) or standard normal (dist=1) draws
+ * from a counter-based Philox4x32-10 stream keyed by (seed, element index). */
+int clo_pack_probes_f32(float *out, long D, long K, uint64_t seed, int dist, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURVLINOPS_AMD_H */

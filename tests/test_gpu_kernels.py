@@ -1,0 +1,262 @@
+"""GPU parity tests of the raw C-ABI kernels (through the ctypes binding) against float64 CPU
+references.  Tolerance: max|y - y_ref| / max|y_ref| <= 1e-4 for fp32 device
+results; the kernels here are expected to do ~10x better, which the asserts enforce."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, mlp_case_tensors
+from oracle import mlp_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from curvlinops_amd import _hip
+
+    _hip.load()
+    return _hip
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+
+
+# ------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [
+    (128, 128, 64), (256, 384, 128), (1, 1, 1), (7, 5, 3), (130, 257, 33), (64, 2689, 2688),
+    (2688, 10, 512), (10, 300, 17), (513, 129, 1000),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts(hip, M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.rand((K, M) if ta else (M, K), generator=g, dtype=torch.float64) - 0.5
+    B = torch.rand((N, K) if tb else (K, N), generator=g, dtype=torch.float64) - 0.5
+    Ad, Bd = A.float().cuda(), B.float().cuda()
+    Av = Ad.T if ta else Ad
+    Bv = Bd.T if tb else Bd
+    out = hip.gemm(Av, Bv)
+    ref = (A.T if ta else A) @ (B.T if tb else B)
+    assert rel_err(out.cpu(), ref) < TOL
+
+
+def test_gemm_alpha_beta_and_splitk(hip):
+    g = torch.Generator().manual_seed(0)
+    A = torch.rand(100, 3000, generator=g, dtype=torch.float64) - 0.5
+    B = torch.rand(3000, 70, generator=g, dtype=torch.float64) - 0.5
+    C = torch.rand(100, 70, generator=g, dtype=torch.float64)
+    for splitk in (1, 4, 13):
+        out = C.float().cuda()
+        hip.gemm(A.float().cuda(), B.float().cuda(), out=out, alpha=0.5, beta=-2.0, splitk=splitk)
+        assert rel_err(out.cpu(), 0.5 * A @ B - 2.0 * C) < TOL
+
+
+def test_gemm_batched_and_broadcast(hip):
+    g = torch.Generator().manual_seed(1)
+    A = torch.rand(5, 33, 47, generator=g, dtype=torch.float64) - 0.5
+    B = torch.rand(47, 29, generator=g, dtype=torch.float64) - 0.5
+    out = hip.gemm(A.float().cuda(), B.float().cuda())
+    assert rel_err(out.cpu(), A @ B) < TOL
+    B3 = torch.rand(5, 47, 29, generator=g, dtype=torch.float64) - 0.5
+    out = hip.gemm(A.float().cuda(), B3.float().cuda())
+    assert rel_err(out.cpu(), A @ B3) < TOL
+
+
+def test_gemm_unaligned_views(hip):
+    g = torch.Generator().manual_seed(2)
+    big = torch.rand(301, 203, generator=g, dtype=torch.float64) - 0.5
+    bigd = big.float().cuda()
+    A, Ad = big[1:200, 3:150], bigd[1:200, 3:150]       # odd offsets -> scalar load path
+    B, Bd = big[5:152, 7:90], bigd[5:152, 7:90]
+    out = hip.gemm(Ad, Bd)
+    assert rel_err(out.cpu(), A @ B) < TOL
+
+
+@pytest.mark.parametrize("rows,d", [(1, 1), (37, 5), (1000, 26), (4096, 151), (300, 401), (64, 2689), (50000, 27)])
+@pytest.mark.parametrize("ones", [False, True])
+def test_syrk_accum(hip, rows, d, ones):
+    g = torch.Generator().manual_seed(rows + d)
+    X = torch.rand(rows, d, generator=g, dtype=torch.float64) - 0.3
+    Xa = torch.cat([X, torch.ones(rows, 1, dtype=torch.float64)], 1) if ones else X
+    dd = Xa.shape[1]
+    C0 = torch.rand(dd, dd, generator=g, dtype=torch.float64)
+    C0 = C0 + C0.T
+    for beta in (0.0, 1.0):
+        C = C0.float().cuda()
+        hip.syrk_accum(C, X.float().cuda(), alpha=0.25, beta=beta, ones_col=ones)
+        ref = 0.25 * Xa.T @ Xa + beta * C0
+        assert rel_err(C.cpu(), ref) < TOL
+        assert torch.equal(C, C.T)
+
+
+def test_syrk_splitk_and_strided_rows(hip):
+    g = torch.Generator().manual_seed(5)
+    big = torch.rand(9000, 40, generator=g, dtype=torch.float64)
+    X = big[:, :36]
+    C = torch.zeros(36, 36).cuda()
+    hip.syrk_accum(C, big.float().cuda()[:, :36], alpha=1.0, beta=0.0, splitk=7)
+    assert rel_err(C.cpu(), X.T @ X) < TOL
+
+
+# ------------------------------------------------------------------------ streaming helpers
+def test_axpby_transpose_rowscale(hip):
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 5, 1024, 100003):
+        x, y = torch.rand(n, generator=g), torch.rand(n, generator=g)
+        out = hip.axpby(y.cuda().clone(), x.cuda(), 0.3, -1.5)
+        assert torch.allclose(out.cpu(), 0.3 * x - 1.5 * y, atol=1e-6)
+        out = hip.axpby(torch.full((n,), float("nan")).cuda(), x.cuda(), 2.0, 0.0)
+        assert torch.allclose(out.cpu(), 2.0 * x, atol=1e-6)
+    for r, c in ((1, 1), (3, 700), (257, 65), (1000, 32)):
+        x = torch.rand(r, c, generator=g)
+        assert torch.equal(hip.transpose(x.cuda()).cpu(), x.T.contiguous())
+    x, s = torch.rand(77, 5, generator=g), torch.rand(77, generator=g) + 0.1
+    assert torch.allclose(hip.rowscale(x.cuda(), s.cuda()).cpu(), s[:, None] * x, atol=1e-6)
+    assert torch.allclose(hip.rowscale(x.cuda(), s.cuda(), True, 0.5).cpu(), x / (s[:, None] + 0.5), atol=1e-6)
+
+
+def test_pack_probes(hip):
+    P = hip.pack_probes(100001, 3, 1234, "rademacher", "cuda")
+    assert P.shape == (100001, 3)
+    assert torch.all(P.abs() == 1.0)
+    assert abs(P.mean().item()) < 0.01
+    assert torch.equal(P, hip.pack_probes(100001, 3, 1234, "rademacher", "cuda"))
+    assert not torch.equal(P, hip.pack_probes(100001, 3, 1235, "rademacher", "cuda"))
+    G = hip.pack_probes(200000, 2, 7, "normal", "cuda")
+    assert abs(G.mean().item()) < 0.01 and abs(G.std().item() - 1.0) < 0.01
+    # columns must be (nearly) uncorrelated
+    assert abs((G[:, 0] * G[:, 1]).mean().item()) < 0.01
+    with pytest.raises(ValueError):
+        hip.pack_probes(10, 1, 0, "cauchy", "cuda")
+
+
+# --------------------------------------------------------------------- MLP layer kernels
+ACT_CODE = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+
+
+@pytest.mark.parametrize("N", [1, 3, 8, 13, 16])
+@pytest.mark.parametrize("d_in,d_out", [(16, 8), (1024, 2688), (37, 10), (2688, 10), (260, 9)])
+@pytest.mark.parametrize("act", ["relu", "tanh", "identity", "sigmoid"])
+def test_fwd_jvp_layer(hip, N, d_in, d_out, act):
+    g = np.random.default_rng(N * 100 + d_in + d_out)
+    W = (g.random((d_out, d_in)) - 0.5) / np.sqrt(d_in)
+    VW = g.random((d_out, d_in)) - 0.5
+    b, Vb = g.random(d_out) - 0.5, g.random(d_out) - 0.5
+    a, da = g.random((N, d_in)), g.random((N, d_in)) - 0.5
+    z = a @ W.T + b
+    dz = da @ W.T + a @ VW.T + Vb
+    out, p1, _ = O._act(act, z)
+    a_o, da_o, dphi = hip.mlp_fwd_jvp_layer(dev(W), dev(b), dev(VW), dev(Vb), dev(a), dev(da), ACT_CODE[act])
+    assert rel_err(a_o.cpu(), out) < TOL
+    assert rel_err(da_o.cpu(), p1 * dz) < TOL
+    # first-layer form (no incoming tangent, no bias) and pure forward
+    a_o, da_o, _ = hip.mlp_fwd_jvp_layer(dev(W), None, dev(VW), None, dev(a), None, ACT_CODE[act])
+    z0 = a @ W.T
+    out0, p10, _ = O._act(act, z0)
+    assert rel_err(a_o.cpu(), out0) < TOL
+    assert rel_err(da_o.cpu(), p10 * (a @ VW.T)) < TOL
+    a_o, da_o, _ = hip.mlp_fwd_jvp_layer(dev(W), dev(b), None, None, dev(a), None, ACT_CODE[act])
+    assert da_o is None and rel_err(a_o.cpu(), out) < TOL
+
+
+@pytest.mark.parametrize("kind,loss", [(0, "mse"), (1, "ce"), (2, "bce")])
+@pytest.mark.parametrize("N,C", [(1, 1), (8, 10), (5, 1000), (3, 7)])
+def test_loss_hessian(hip, kind, loss, N, C):
+    g = np.random.default_rng(N + C)
+    f, u = 3 * (g.random((N, C)) - 0.5), g.random((N, C)) - 0.5
+    y = g.integers(0, C, N) if loss == "ce" else g.random((N, C))
+    ref = O.loss_hessian_apply(loss, "sum", f, y, u)
+    scale = 2.0 if loss == "mse" else 1.0
+    w = hip.loss_hessian_apply(kind, dev(f), dev(u), 0.7 * scale)
+    assert rel_err(w.cpu(), 0.7 * ref) < TOL
+
+
+def test_loss_hessian_rank(hip):
+    g = np.random.default_rng(0)
+    N, M, C = 6, 3, 11
+    f, u, aux = g.random((N, C)), g.random((N, C)) - 0.5, g.random((N, M, C)) - 0.5
+    ref = 0.3 * np.einsum("nmc,nm->nc", aux, np.einsum("nmc,nc->nm", aux, u))
+    w = hip.loss_hessian_apply(3, dev(f), dev(u), 0.3, aux=dev(aux))
+    assert rel_err(w.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("N", [1, 8, 11, 16])
+@pytest.mark.parametrize("d_in,d_out", [(16, 8), (2688, 2688), (1024, 2688), (2688, 10), (37, 10), (261, 70)])
+def test_bwd_layer(hip, N, d_in, d_out):
+    g = np.random.default_rng(N + d_in * 3 + d_out)
+    W = (g.random((d_out, d_in)) - 0.5) / np.sqrt(d_out)
+    delta, a_prev = g.random((N, d_out)) - 0.5, g.random((N, d_in))
+    dphi_prev = g.random((N, d_in))
+    oW0, ob0 = g.random((d_out, d_in)), g.random(d_out)
+    for beta in (0.0, 1.0):
+        oW, ob = dev(oW0), dev(ob0)
+        dprev = hip.mlp_bwd_layer(dev(W), dev(delta), dev(a_prev), dev(dphi_prev), oW, ob, 0.5, beta, True)
+        assert rel_err(oW.cpu(), 0.5 * delta.T @ a_prev + beta * oW0) < TOL
+        assert rel_err(ob.cpu(), 0.5 * delta.sum(0) + beta * ob0) < TOL
+        assert rel_err(dprev.cpu(), (delta @ W) * dphi_prev) < TOL
+
+
+# ------------------------------------------------------------- whole-network GGN matvec
+def _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, loss_kind, scale, alpha, beta, out0=None, aux=None):
+    plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    dW, db = [dev(W) for W in Ws], [None if b is None else dev(b) for b in bs]
+    dVW, dVb = [dev(v) for v in vWs], [None if v is None else dev(v) for v in vbs]
+    if out0 is None:
+        oW = [torch.full_like(w, float("nan")) for w in dW]
+        ob = [None if b is None else torch.full_like(b, float("nan")) for b in db]
+    else:
+        oW = [dev(w) for w in out0[0]]
+        ob = [None if b is None else dev(b) for b in out0[1]]
+    plan.ggn_matvec(dW, db, dVW, dVb, oW, ob, dev(X), loss_kind, scale, alpha, beta, aux=aux)
+    torch.cuda.synchronize()
+    return [w.cpu().numpy() for w in oW], [None if b is None else b.cpu().numpy() for b in ob]
+
+
+LOSS_KIND = {"mse": 0, "ce": 1, "bce": 2}
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("mlp_curvature")))
+def test_ggn_matvec_vs_oracle_per_batch(hip, golden_mlp, case):
+    rec = golden_mlp[case]
+    dims, acts, bias, loss, red, Ws, bs, data = mlp_case_tensors(rec)
+    vWs, vbs = O.unflatten_params(rec["v"], [W.shape for W in Ws], bias)
+    for X, y in data:
+        N, C = X.shape[0], dims[-1]
+        rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, red, vWs, vbs)
+        c = O.reduction_factor(loss, red, N, C)
+        scale = (2.0 if loss == "mse" else 1.0) * c
+        gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 1.0, 0.0)
+        ref = O.flatten_params(rW, rb)
+        got = O.flatten_params(gW, gb)
+        assert rel_err(got, ref) < 1e-4, case
+
+
+@pytest.mark.parametrize("N", [8, 16, 24, 200])
+def test_ggn_matvec_large_layers(hip, N):
+    """C2-like shapes (scaled down in width so the float64 oracle stays fast)."""
+    g = np.random.default_rng(N)
+    dims, acts = [256, 672, 672, 10], ["relu", "relu", "identity"]
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [g.random(dims[i + 1]) - 0.5 for i in range(3)]
+    vWs = [g.random(W.shape) - 0.5 for W in Ws]
+    vbs = [g.random(b.shape) - 0.5 for b in bs]
+    X, y = g.random((N, dims[0])), g.random((N, dims[-1]))
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, "mse", "mean", vWs, vbs)
+    scale = 2.0 / (N * dims[-1])
+    out0 = ([g.random(W.shape) for W in Ws], [g.random(b.shape) for b in bs])
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 0, scale, 0.5, 1.0, out0=out0)
+    ref = O.flatten_params([0.5 * r + o for r, o in zip(rW, out0[0])], [0.5 * r + o for r, o in zip(rb, out0[1])])
+    assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
