@@ -31,14 +31,21 @@ _SIGNATURES = {
          c_float, _PF, c_long, c_long, c_int, c_int, _PF, c_void_p],
     ),
     "clo_gemm_suggest_splitk": (c_int, [c_int, c_int, c_int, c_int]),
+    "clo_gemm_sqsum_f32": (
+        c_int,
+        [c_int, c_int, c_int, c_float, _PF, c_long, c_long, c_long, _PF, c_long, c_long, c_long,
+         c_float, _PF, c_long, c_int, c_int, _PF, c_void_p],
+    ),
+    "clo_gemm_sqsum_suggest_splits": (c_int, [c_int, c_int, c_int]),
     "clo_syrk_accum_f32": (
         c_int,
         [_PF, c_long, _PF, c_long, c_int, c_long, c_int, c_float, c_float, c_int, _PF, c_void_p],
     ),
     "clo_mlp_fwd_jvp_layer": (
         c_int,
-        [_PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, c_int, c_int, c_void_p],
+        [_PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, c_int, c_int, _PF, c_void_p],
     ),
+    "clo_mlp_fwd_ws_floats": (c_long, [c_int, c_int, c_int]),
     "clo_loss_hessian_apply": (
         c_int,
         [c_int, _PF, _PF, c_int, _PF, _PF, _PF, c_int, c_int, c_float, c_void_p],
@@ -87,6 +94,11 @@ def load() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def has(symbol: str) -> bool:
+    """Whether this build of the library exports ``symbol``."""
+    return symbol in _SIGNATURES and hasattr(load(), symbol)
 
 
 def _check(rc: int, what: str) -> None:
@@ -167,6 +179,24 @@ def gemm(A: Tensor, B: Tensor, out: Tensor | None = None, alpha: float = 1.0, be
     return out
 
 
+def gemm_sqsum(A: Tensor, B: Tensor, out: Tensor, alpha: float = 1.0, beta: float = 0.0) -> Tensor:
+    """``out = beta*out + alpha * sum_b (A[b] @ B[b])**2`` for batched ``A [nb,M,K]``, ``B [nb,K,N]``
+    (strided views allowed), ``out [M,N]`` row-major."""
+    lib = load()
+    nb, M, K = A.shape
+    nb2, K2, N = B.shape
+    if nb != nb2 or K != K2 or out.shape != (M, N) or (N > 1 and out.stride(1) != 1):
+        raise ValueError(f"gemm_sqsum shape mismatch: {tuple(A.shape)} {tuple(B.shape)} -> {tuple(out.shape)}")
+    splits = lib.clo_gemm_sqsum_suggest_splits(M, N, nb)
+    ws = torch.empty(splits * M * N, device=A.device, dtype=torch.float32) if splits > 1 else None
+    rc = lib.clo_gemm_sqsum_f32(M, N, K, alpha, _p(A), A.stride(1), A.stride(2), A.stride(0), _p(B),
+                                B.stride(1), B.stride(2), B.stride(0), beta, _p(out),
+                                out.stride(0) if M > 1 else max(N, out.stride(0)), nb, splits, _p(ws),
+                                _stream())
+    _check(rc, "clo_gemm_sqsum_f32")
+    return out
+
+
 def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones_col: bool = False,
                splitk: int | None = None) -> Tensor:
     """``C = beta*C + alpha * [X|1]^T [X|1]`` for row-major ``X[rows, d]`` (view with stride ok)."""
@@ -197,9 +227,10 @@ def mlp_fwd_jvp_layer(W, b, VW, Vb, a_in, da_in, act: int):
     a_out = torch.empty(N, d_out, device=W.device, dtype=torch.float32)
     dphi = torch.empty_like(a_out)
     da_out = torch.empty_like(a_out) if (VW is not None or da_in is not None) else None
+    ws = torch.empty(lib.clo_mlp_fwd_ws_floats(N, d_in, d_out), device=W.device, dtype=torch.float32)
     rc = lib.clo_mlp_fwd_jvp_layer(_pc(W), _pc(b), _pc(VW), _pc(Vb), _pc(a_in), _pc(da_in),
                                    _pc(a_out), _pc(da_out), _pc(dphi), N, d_in, d_out, act,
-                                   _stream())
+                                   _pc(ws), _stream())
     _check(rc, "clo_mlp_fwd_jvp_layer")
     return a_out, da_out, dphi
 

@@ -1,0 +1,420 @@
+"""Kronecker-factor computers: the ``backend`` plug-in point of ``KFACLinearOperator`` /
+``EKFACLinearOperator`` (reference ``curvlinops/kfac.py:89-92``, ``computers/_base.py``).
+
+``HipKFACComputer.compute()`` returns ``(input_covariances, gradient_covariances, mapping)`` and
+``HipEKFACComputer.compute()`` the 4-tuple ``(Q_a, Q_g, corrected_eigenvalues, mapping)``, exactly
+the contract of ``computers/_base.py:181-197, 305-327``.  Layer inputs and output-gradients are
+harvested with module hooks during ordinary PyTorch forward/backward passes (host framework);
+every contraction on them -- ``A += x^T x / (N S)``, ``G += corr * g^T g``
+(``computers/kfac_hooks.py:350,390``), the eigenvalue correction
+(``computers/ekfac_hooks.py:25-238``), the eigendecompositions -- runs on the HIP library when the
+tensors are fp32 on the GPU.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Callable, Iterable, MutableMapping
+from contextlib import contextmanager
+from functools import partial
+from typing import Any
+
+import torch
+from torch import Tensor
+from torch.func import vmap
+from torch.nn import BCEWithLogitsLoss, Conv2d, CrossEntropyLoss, Linear, Module, MSELoss
+from torch.nn.functional import unfold
+from torch.nn.modules.utils import _pair
+
+from curvlinops_amd import _hip, linalg_native
+from curvlinops_amd.canonical import ParamGroup
+from curvlinops_amd.enums import FisherType, KFACType
+from curvlinops_amd.loss_sampling import make_grad_output_fn
+from curvlinops_amd.risk import EmpiricalRiskMixin
+from curvlinops_amd.utils import flatten_output_and_labels, is_native_tensor, seed_generator
+
+ParamGroupKey = tuple[str, ...]
+
+
+# ------------------------------------------------------------------------------------------
+# weight-sharing formats (reference computers/kfac_math.py, kfac_utils.py:78-180)
+# ------------------------------------------------------------------------------------------
+def _conv_hyperparams(mod: Module) -> dict[str, Any]:
+    if isinstance(mod, Conv2d):
+        return dict(kernel_size=mod.kernel_size, stride=mod.stride, padding=mod.padding,
+                    dilation=mod.dilation, groups=mod.groups)
+    return {}
+
+
+def _string_padding(kernel_size: int, padding: str, dilation: int) -> tuple[int, int]:
+    """(left, right) zero padding of ``padding='valid'|'same'`` (einconv.utils.get_conv_paddings)."""
+    if padding == "valid":
+        return 0, 0
+    if padding == "same":
+        total = dilation * (kernel_size - 1)
+        return total // 2, total - total // 2
+    raise ValueError(f"Unknown string padding {padding!r}.")
+
+
+def _index_pattern(input_size: int, kernel_size: int, stride: int, padding, dilation: int,
+                   device, dtype) -> Tensor:
+    """``pattern[k, o, i] = (i == o*stride + k*dilation - pad_left)`` -- the connectivity of a
+    1-d convolution (einconv ``index_pattern``; pinned by the reference's KFAC-reduce tests)."""
+    left, right = _string_padding(kernel_size, padding, dilation) if isinstance(padding, str) else (padding, padding)
+    out = (input_size + left + right - dilation * (kernel_size - 1) - 1) // stride + 1
+    k = torch.arange(kernel_size, device=device).view(-1, 1, 1)
+    o = torch.arange(out, device=device).view(1, -1, 1)
+    i = torch.arange(input_size, device=device).view(1, 1, -1)
+    return (i == o * stride + k * dilation - left).to(dtype)
+
+
+def _group_mean(x: Tensor, groups: int) -> Tensor:
+    if groups == 1:
+        return x
+    b, c, h, w = x.shape
+    return x.reshape(b, groups, c // groups, h, w).mean(dim=1)
+
+
+def extract_patches(x: Tensor, kernel_size, stride, padding, dilation, groups: int) -> Tensor:
+    """im2col: ``[B, C, I1, I2] -> [B, O1*O2, C/groups * K1*K2]`` (groups averaged)."""
+    if isinstance(padding, str):
+        pads = []
+        for k, d in zip(_pair(kernel_size), _pair(dilation)):
+            left, right = _string_padding(k, padding, d)
+            if left != right:
+                raise NotImplementedError("Unequal padding not supported in unfold.")
+            pads.append(left)
+        padding = tuple(pads)
+    cols = unfold(_group_mean(x, groups), kernel_size, dilation=dilation, padding=padding, stride=stride)
+    return cols.transpose(1, 2)
+
+
+def extract_averaged_patches(x: Tensor, kernel_size, stride, padding, dilation, groups: int) -> Tensor:
+    """KFAC-reduce for convolutions: patches averaged over output positions,
+    ``[B, C, I1, I2] -> [B, C/groups * K1*K2]``."""
+    x = _group_mean(x, groups)
+    pats = []
+    pad_pair = (padding, padding) if isinstance(padding, str) else _pair(padding)
+    for size, k, s, p, d in zip(x.shape[-2:], _pair(kernel_size), _pair(stride), pad_pair, _pair(dilation)):
+        pats.append(_index_pattern(size, k, s, p, d, x.device, x.dtype).mean(dim=1))  # [k, i]
+    out = torch.einsum("bcij,ki,lj->bckl", x, pats[0], pats[1])
+    return out.flatten(1)
+
+
+def input_to_weight_sharing_format(x: Tensor, kfac_approx: str, hyper: dict | None = None) -> Tensor:
+    """Layer input -> ``[batch, shared, d_in]`` (``shared = 1`` for KFAC-reduce / plain Linear)."""
+    if hyper:
+        fn = extract_patches if kfac_approx == KFACType.EXPAND else extract_averaged_patches
+        x = fn(x, hyper["kernel_size"], hyper["stride"], hyper["padding"], hyper["dilation"], hyper["groups"])
+    if x.ndim == 2:
+        return x.unsqueeze(1)
+    if kfac_approx == KFACType.REDUCE:
+        return x.flatten(1, -2).mean(dim=1, keepdim=True)
+    return x.flatten(1, -2)
+
+
+def grad_to_weight_sharing_format(g: Tensor, kfac_approx: str, hyper: dict | None = None) -> Tensor:
+    """Output gradient -> ``[batch, shared, d_out]`` (KFAC-reduce SUMS over shared positions)."""
+    if hyper:
+        g = g.movedim(1, -1)
+    if g.ndim == 2:
+        return g.unsqueeze(1)
+    if kfac_approx == KFACType.REDUCE:
+        return g.flatten(1, -2).sum(dim=1, keepdim=True)
+    return g.flatten(1, -2)
+
+
+def compute_loss_correction(batch_size: int, terms_per_datum: int, reduction: str, n_data: int | None) -> float:
+    """Undo the mean-reduction scaling that was baked into the backpropagated vectors:
+    ``(B T)^2 / (T N_data)`` for 'mean', 1 for 'sum' (``computers/kfac_math.py:172-203``)."""
+    if reduction == "sum":
+        return 1.0
+    denom = terms_per_datum * (n_data if n_data is not None else 1)
+    return (batch_size * terms_per_datum) ** 2 / denom
+
+
+@contextmanager
+def _use_params(module: Module, params: dict[str, Tensor]):
+    """Temporarily point the module's Parameters at the tensors in ``params``."""
+    saved = {}
+    for name, p in module.named_parameters():
+        if name in params:
+            saved[name] = p.data
+            p.data = params[name]
+    try:
+        yield
+    finally:
+        for name, p in module.named_parameters():
+            if name in saved:
+                p.data = saved[name]
+
+
+def _gram_accumulate(store: dict, key, X2d: Tensor, alpha: float, ones_col: bool) -> None:
+    """``store[key] += alpha * [X|1]^T [X|1]`` -- HIP SYRK for fp32 GPU tensors."""
+    d = X2d.shape[1] + (1 if ones_col else 0)
+    if is_native_tensor(X2d):
+        X2d = X2d if X2d.stride(-1) == 1 else X2d.contiguous()
+        C = store.get(key)
+        first = C is None
+        if first:
+            C = torch.empty(d, d, device=X2d.device, dtype=torch.float32)
+            store[key] = C
+        _hip.syrk_accum(C, X2d, alpha=alpha, beta=0.0 if first else 1.0, ones_col=ones_col)
+        return
+    if ones_col:
+        X2d = torch.cat([X2d, X2d.new_ones(X2d.shape[0], 1)], dim=1)
+    upd = (X2d.T @ X2d).mul_(alpha)
+    if key in store:
+        store[key].add_(upd)
+    else:
+        store[key] = upd
+
+
+class HipKFACComputer(EmpiricalRiskMixin):
+    """Computes KFAC's Kronecker factors ``A_l`` (input covariance) and ``G_l`` (output-gradient
+    covariance) for every Linear / Conv2d parameter group."""
+
+    _SUPPORTED_LOSSES = (MSELoss, CrossEntropyLoss, BCEWithLogitsLoss)
+    _SUPPORTED_MODULES = (Linear, Conv2d)
+    _SUPPORTED_FISHER_TYPE = FisherType
+    _SUPPORTED_KFAC_APPROX = KFACType
+    NEEDS_NUM_PER_EXAMPLE_LOSS_TERMS: bool = True
+
+    def __init__(
+        self,
+        model_func: Module,
+        loss_func: MSELoss | CrossEntropyLoss | BCEWithLogitsLoss,
+        params: dict[str, Tensor],
+        data: Iterable[tuple[Tensor | MutableMapping, Tensor]],
+        progressbar: bool = False,
+        check_deterministic: bool = True,
+        seed: int = 2_147_483_647,
+        fisher_type: str = FisherType.MC,
+        mc_samples: int = 1,
+        kfac_approx: str = KFACType.EXPAND,
+        num_per_example_loss_terms: int | None = None,
+        separate_weight_and_bias: bool = True,
+        num_data: int | None = None,
+        batch_size_fn: Callable[[MutableMapping | Tensor], int] | None = None,
+    ):
+        if not isinstance(model_func, Module):
+            raise ValueError(
+                "The hooks-based backends require model_func to be an nn.Module."
+            )
+        if not isinstance(loss_func, self._SUPPORTED_LOSSES):
+            raise ValueError(f"Invalid loss: {loss_func}. Supported: {self._SUPPORTED_LOSSES}.")
+        if fisher_type not in self._SUPPORTED_FISHER_TYPE:
+            raise ValueError(f"Invalid fisher_type: {fisher_type}. Supported: {self._SUPPORTED_FISHER_TYPE}.")
+        if fisher_type != FisherType.MC and mc_samples != 1:
+            raise ValueError(
+                f"Invalid mc_samples: {mc_samples}. Only mc_samples=1 is supported for "
+                "`fisher_type != FisherType.MC`."
+            )
+        if kfac_approx not in self._SUPPORTED_KFAC_APPROX:
+            raise ValueError(f"Invalid kfac_approx: {kfac_approx}. Supported: {self._SUPPORTED_KFAC_APPROX}.")
+        self._seed = seed
+        self._generator: torch.Generator | None = None
+        self._separate_weight_and_bias = separate_weight_and_bias
+        self._fisher_type = fisher_type
+        self._mc_samples = mc_samples
+        self._kfac_approx = kfac_approx
+        randomness = "different" if fisher_type == FisherType.MC else "same"
+        self._grad_outputs_computer = vmap(
+            make_grad_output_fn(loss_func, fisher_type, mc_samples), in_dims=(0, 0, None), out_dims=1,
+            randomness=randomness,
+        )
+        super().__init__(
+            model_func, loss_func, params, data, progressbar=progressbar,
+            check_deterministic=check_deterministic, num_data=num_data,
+            num_per_example_loss_terms=num_per_example_loss_terms, batch_size_fn=batch_size_fn,
+        )
+
+    # ------------------------------------------------------------------ public
+    def compute(self):
+        with _use_params(self._model_module, self._params):
+            return self._compute_kronecker_factors()
+
+    @classmethod
+    def compute_parameter_groups(cls, params: dict[str, Tensor], model: Module,
+                                 separate_weight_and_bias: bool = True) -> list[ParamGroup]:
+        """One group per supported layer (joint W+b) or per parameter (separate)."""
+        role = {"weight": "W", "bias": "b"}
+        wanted = set(params.keys())
+        groups: list[ParamGroup] = []
+        seen: set[str] = set()
+        for mod_name, mod in model.named_modules():
+            if not isinstance(mod, cls._SUPPORTED_MODULES):
+                continue
+            roles: ParamGroup = {}
+            for p_name, _ in mod.named_parameters(recurse=False):
+                full = f"{mod_name}.{p_name}" if mod_name else p_name
+                if full in wanted:
+                    roles[role[p_name]] = full
+                    seen.add(full)
+            if roles:
+                groups.extend([{r: n} for r, n in roles.items()] if separate_weight_and_bias else [roles])
+        if wanted - seen:
+            raise NotImplementedError(
+                f"Parameters {wanted - seen} are not in supported layers ({cls._SUPPORTED_MODULES})."
+            )
+        return groups
+
+    # ------------------------------------------------------------------ internals
+    def _module_of(self, group: ParamGroup) -> Module:
+        name = next(iter(group.values()))
+        return self._model_module.get_submodule(name.rsplit(".", 1)[0] if "." in name else "")
+
+    def _rearrange_output(self, output: Tensor, y: Tensor) -> tuple[Tensor, Tensor]:
+        return flatten_output_and_labels(output, y, self._loss_func)
+
+    def _compute_kronecker_factors(self):
+        mapping = self.compute_parameter_groups(self._params, self._model_module, self._separate_weight_and_bias)
+        A: dict[ParamGroupKey, Tensor] = {}
+        G: dict[ParamGroupKey, Tensor] = {}
+        handles = []
+        for group in mapping:
+            mod = self._module_of(group)
+            hyper = _conv_hyperparams(mod)
+            if "W" in group:
+                handles.append(mod.register_forward_pre_hook(partial(self._input_hook, group=group, hyper=hyper, store=A)))
+            handles.append(mod.register_forward_hook(partial(self._output_hook, group=group, hyper=hyper, store=G)))
+        self._generator = seed_generator(self._generator, self.device, self._seed)
+        try:
+            for X, y in self._loop_over_data(desc="KFAC matrices"):
+                output = self._model_module(X)
+                output, y = self._rearrange_output(output, y)
+                self._backpropagate(output, y)
+        finally:
+            for h in handles:
+                h.remove()
+        if self._fisher_type == FisherType.FORWARD_ONLY:
+            for group in mapping:
+                p = self._params[next(iter(group.values()))]
+                G[tuple(group.values())] = torch.eye(p.shape[0], dtype=p.dtype, device=self.device)
+        return A, G, mapping
+
+    def _backpropagate(self, output: Tensor, y: Tensor) -> None:
+        """Backpropagate V vectors per datum (0 forward-only, 1 empirical, M for MC, C for
+        type-2); the tensor hooks registered on the layer outputs see each of them."""
+        if output.ndim != 2 or y.ndim not in {1, 2}:
+            raise ValueError(f"Only 2d output and 1d/2d target are supported. Got {output.ndim=} and {y.ndim=}.")
+        grad_outputs = self._grad_outputs_computer(output.detach(), y, self._generator)
+        if self._loss_func.reduction == "mean":
+            grad_outputs.mul_(1.0 / output.shape[0])
+        module_params = dict(self._model_module.named_parameters())
+        wrt = [module_params[n] for n in self._params]
+        V = grad_outputs.shape[0]
+        for v in range(V):
+            torch.autograd.grad(output, wrt, grad_outputs=grad_outputs[v], retain_graph=v < V - 1)
+
+    def _input_hook(self, module, inputs, group, hyper, store) -> None:
+        if len(inputs) != 1:
+            raise ValueError("Modules with multiple inputs are not supported.")
+        x = input_to_weight_sharing_format(inputs[0].data.detach(), self._kfac_approx, hyper)
+        shared = x.shape[1]
+        joint = "W" in group and "b" in group
+        _gram_accumulate(store, tuple(group.values()), x.reshape(-1, x.shape[-1]),
+                         1.0 / (self._N_data * shared), ones_col=joint)
+
+    def _output_hook(self, module, inputs, output, group, hyper, store) -> None:
+        output.register_hook(partial(self._grad_hook, group=group, hyper=hyper, store=store))
+
+    def _grad_hook(self, grad_output: Tensor, group, hyper, store) -> None:
+        g = grad_output.data.detach()
+        corr = compute_loss_correction(g.shape[0], self._num_per_example_loss_terms,
+                                       self._loss_func.reduction, self._N_data)
+        g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
+        _gram_accumulate(store, tuple(group.values()), g.reshape(-1, g.shape[-1]), corr, ones_col=False)
+
+
+# ------------------------------------------------------------------------------------------
+# EKFAC
+# ------------------------------------------------------------------------------------------
+def compute_eigenvalue_correction(g: Tensor, Qg: Tensor, a: Tensor | None, Qa: Tensor | None) -> Tensor:
+    """``sum_{v,n} (Q_g^T (sum_s g_vns a_ns^T) Q_a)^2`` (``[d_out, d_in]``), or for a bias-only
+    group ``sum_{v,n} (Q_g^T sum_s g_vns)^2`` (``[d_out]``).
+
+    ``g``: ``[V, B, S, d_out]``; ``a``: ``[B, S, d_in]`` (reference
+    ``computers/ekfac_hooks.py:25-238`` -- both of its strategies compute this quantity)."""
+    if (a is None) != (Qa is None):
+        raise ValueError(f"Both (a, aaT_eigvecs) must be None or Tensor. Got {(type(a), type(Qa))}.")
+    V, B, S, d1 = g.shape
+    native = is_native_tensor(g) and is_native_tensor(Qg)
+    if a is None:
+        gs = g.sum(dim=2).reshape(V * B, d1)
+        rot = _hip.gemm(gs.contiguous(), Qg) if native else gs @ Qg
+        return rot.square_().sum(dim=0)
+    d2 = a.shape[-1]
+    if native:
+        g_rot = _hip.gemm(g.reshape(V * B * S, d1).contiguous(), Qg).view(V, B, S, d1)
+        a_rot = _hip.gemm(a.reshape(B * S, d2).contiguous(), Qa).view(B, S, d2)
+        out = torch.zeros(d1, d2, device=g.device, dtype=torch.float32)
+        for v in range(V):
+            # per-example products P_n = g_rot_n^T a_rot_n, squared and summed over n, fused
+            _hip.gemm_sqsum(g_rot[v].transpose(1, 2), a_rot, out, beta=1.0)
+        return out
+    g_rot = g @ Qg
+    a_rot = a @ Qa
+    per_example = torch.einsum("vnsi,nsj->vnij", g_rot, a_rot)
+    return per_example.square_().sum(dim=(0, 1))
+
+
+class HipEKFACComputer(HipKFACComputer):
+    """KFAC factors -> their eigenbases -> eigenvalues re-fitted in that basis (second sweep)."""
+
+    _SUPPORTED_FISHER_TYPE = (FisherType.TYPE2, FisherType.MC, FisherType.EMPIRICAL)
+
+    def _rearrange_output(self, output: Tensor, y: Tensor) -> tuple[Tensor, Tensor]:
+        if output.ndim != 2 or y.ndim not in {1, 2}:
+            raise ValueError(
+                f"Only 2d output and 1d/2d target are supported for EKFAC. Got {output.ndim=} and {y.ndim=}."
+            )
+        return output, y
+
+    def compute(self):
+        with _use_params(self._model_module, self._params):
+            A, G, mapping = self._compute_kronecker_factors()
+            Qa = {k: linalg_native.eigh(v)[1] for k, v in A.items()}
+            Qg = {k: linalg_native.eigh(v)[1] for k, v in G.items()}
+            lam = self._eigenvalue_correction(Qa, Qg, mapping)
+        return Qa, Qg, lam, mapping
+
+    def _eigenvalue_correction(self, Qa, Qg, mapping):
+        lam: dict[ParamGroupKey, Tensor] = {}
+        handles = []
+        for group in mapping:
+            mod = self._module_of(group)
+            handles.append(mod.register_forward_hook(partial(self._corr_output_hook, group=group, Qa=Qa, Qg=Qg, lam=lam)))
+        self._generator = seed_generator(self._generator, self.device, self._seed)
+        try:
+            for X, y in self._loop_over_data(desc="Eigenvalue correction"):
+                output = self._model_module(X)
+                output, y = self._rearrange_output(output, y)
+                self._backpropagate(output, y)
+        finally:
+            for h in handles:
+                h.remove()
+        return lam
+
+    def _corr_output_hook(self, module, inputs, output, group, Qa, Qg, lam) -> None:
+        output.register_hook(partial(self._corr_grad_hook, module=module, inputs=inputs, group=group, Qa=Qa, Qg=Qg, lam=lam))
+
+    def _corr_grad_hook(self, grad_output: Tensor, module, inputs, group, Qa, Qg, lam) -> None:
+        if len(inputs) != 1:
+            raise ValueError("Modules with multiple inputs are not supported.")
+        g = grad_output.data.detach()
+        batch_size = g.shape[0]
+        hyper = _conv_hyperparams(module)
+        g = grad_to_weight_sharing_format(g, KFACType.EXPAND, hyper).unsqueeze(0)
+        a = None
+        if "W" in group:
+            a = input_to_weight_sharing_format(inputs[0].data.detach(), KFACType.EXPAND, hyper)
+            if "b" in group:
+                a = torch.cat([a, a.new_ones(*a.shape[:-1], 1)], dim=-1)
+        corr = compute_loss_correction(batch_size, self._num_per_example_loss_terms,
+                                       self._loss_func.reduction, self._N_data)
+        key = tuple(group.values())
+        upd = compute_eigenvalue_correction(g, Qg[key], a, Qa.get(key)).mul_(corr)
+        if key in lam:
+            lam[key].add_(upd)
+        else:
+            lam[key] = upd

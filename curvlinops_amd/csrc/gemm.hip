@@ -38,6 +38,7 @@ struct GemmArgs {
   int sym;  // 1: compute only block-upper triangle, mirror on write (SYRK)
   int mode_a, mode_b;
   int tiles_m, tiles_n;
+  int nbatch, batch_per_split;  // SQSUM mode only
 };
 
 // Load one [BK x 128] operand tile into 8 registers per thread.
@@ -124,6 +125,7 @@ __device__ __forceinline__ void tile_store(const float (&r)[8], int mode, float 
   }
 }
 
+template <bool SQSUM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * LDS_STRIDE];
   float *As = lds;                        // [2][BK][LDS_STRIDE]
@@ -153,12 +155,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   }
   if (p.sym && bn < bm) return;
 
+  // plain GEMM: grid.y = batch * splitk, each block one (batch, k-range).
+  // SQSUM:     grid.y = splitk, each block sums (A_b B_b)^2 over its range of batches.
   const int z = blockIdx.y;
-  const int batch = z / p.splitk, split = z % p.splitk;
-  const int kb = split * p.k_per_split;
-  const int ke = min(p.K, kb + p.k_per_split);
-  const float *A = p.A + (long)batch * p.sa_b;
-  const float *B = p.B + (long)batch * p.sb_b;
+  const int batch = SQSUM ? 0 : z / p.splitk, split = SQSUM ? z : z % p.splitk;
+  const int kb = SQSUM ? 0 : split * p.k_per_split;
+  const int ke = SQSUM ? p.K : min(p.K, kb + p.k_per_split);
+  const int b_begin = SQSUM ? split * p.batch_per_split : batch;
+  const int b_end = SQSUM ? min(p.nbatch, b_begin + p.batch_per_split) : batch + 1;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -166,16 +170,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = bm * BM, n0 = bn * BN;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], sq[SQSUM ? 2 : 1][SQSUM ? 2 : 1];
+  if (SQSUM) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sq[SQSUM ? i : 0][SQSUM ? j : 0][r] = 0.f;
+  }
+  const int nk = (ke - kb + BK - 1) / BK;
+  float ra[8], rb[8];
+
+  for (int bcur = b_begin; bcur < b_end; ++bcur) {
+  const float *A = p.A + (long)bcur * p.sa_b;
+  const float *B = p.B + (long)bcur * p.sb_b;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = (ke - kb + BK - 1) / BK;
-  float ra[8], rb[8];
   if (nk > 0) {
     tile_load(ra, p.mode_a, A, p.sa_m, p.sa_k, m0, kb, p.M, ke, tid);
     tile_load(rb, p.mode_b, B, p.sb_n, p.sb_k, n0, kb, p.N, ke, tid);
@@ -211,10 +226,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     }
     __syncthreads();
   }
+  if (SQSUM) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sq[SQSUM ? i : 0][SQSUM ? j : 0][r] += acc[i][j][r] * acc[i][j][r];
+  }
+  }  // batch loop
+  if (SQSUM) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = sq[SQSUM ? i : 0][SQSUM ? j : 0];
+  }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool to_ws = p.splitk > 1;
-  float *C = to_ws ? p.ws + (long)z * p.M * p.N : p.C + (long)batch * p.sc_b;
+  float *C = to_ws ? p.ws + (long)z * p.M * p.N : p.C + (long)batch * p.sc_b;  // SQSUM: batch == 0
   const long ldc = to_ws ? p.N : p.ldc;
   const float alpha = to_ws ? 1.f : p.alpha;
   const float beta = to_ws ? 0.f : p.beta;
@@ -312,7 +343,7 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   a.mode_a = pick_mode(a.A, a.sa_m, a.sa_k, a.sa_b, batch);
   a.mode_b = pick_mode(a.B, a.sb_n, a.sb_k, a.sb_b, batch);
   dim3 grid(a.tiles_m * a.tiles_n, batch * a.splitk);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, a);
   CLO_CHECK_LAUNCH("gemm_f32_kernel");
   if (a.splitk > 1) {
     const long total = (long)a.M * a.N;
@@ -324,9 +355,67 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   return CLO_OK;
 }
 
+// C = beta*C + alpha * sum_b (A_b B_b)^2 (elementwise square); the batch range is split over
+// grid.y into `splits` partial slabs (ws) that the reduce kernel sums.
+int launch_gemm_sqsum(GemmArgs a, int batch, int splits, hipStream_t stream) {
+  a.tiles_m = (int)cdiv(a.M, BM);
+  a.tiles_n = (int)cdiv(a.N, BN);
+  a.nbatch = batch;
+  splits = std::max(1, std::min(splits, batch));
+  a.batch_per_split = (int)cdiv(batch, splits);
+  splits = (int)cdiv(batch, a.batch_per_split);
+  a.splitk = splits;
+  a.k_per_split = 0;
+  if (splits > 1 && a.ws == nullptr) {
+    set_error("clo_gemm_sqsum: %d batch splits need a workspace", splits);
+    return CLO_EINVAL;
+  }
+  a.mode_a = pick_mode(a.A, a.sa_m, a.sa_k, a.sa_b, batch);
+  a.mode_b = pick_mode(a.B, a.sb_n, a.sb_k, a.sb_b, batch);
+  a.sym = 0;
+  dim3 grid(a.tiles_m * a.tiles_n, splits);
+  hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, a);
+  CLO_CHECK_LAUNCH("gemm_f32_kernel<sqsum>");
+  if (splits > 1) {
+    const long total = (long)a.M * a.N;
+    dim3 rgrid((unsigned)std::min<long>(cdiv(total, 256), 4096), 1);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a.C, a.ldc, 0L, a.ws, a.M,
+                       a.N, splits, a.alpha, a.beta, 0);
+    CLO_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return CLO_OK;
+}
+
 }  // namespace clo
 
 using namespace clo;
+
+extern "C" int clo_gemm_sqsum_suggest_splits(int M, int N, int batch) {
+  const long tiles = cdiv(M, BM) * cdiv(N, BN);
+  if (tiles >= kNumCU || batch <= 1) return 1;
+  return (int)std::max<long>(1, std::min<long>({(long)batch, (2L * kNumCU) / tiles, 64L}));
+}
+
+extern "C" int clo_gemm_sqsum_f32(int M, int N, int K, float alpha, const float *A, long sa_m,
+                                  long sa_k, long sa_b, const float *B, long sb_k, long sb_n,
+                                  long sb_b, float beta, float *C, long ldc, int batch, int splits,
+                                  float *ws, void *stream) {
+  CLO_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "clo_gemm_sqsum_f32: negative size");
+  CLO_REQUIRE(ldc >= N, "clo_gemm_sqsum_f32: ldc (%ld) < N (%d)", ldc, N);
+  if (M == 0 || N == 0) return CLO_OK;
+  CLO_REQUIRE(C && (batch == 0 || (A && B)), "clo_gemm_sqsum_f32: null operand");
+  GemmArgs a{};
+  a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.beta = beta;
+  a.A = A; a.sa_m = sa_m; a.sa_k = sa_k; a.sa_b = sa_b;
+  a.B = B; a.sb_k = sb_k; a.sb_n = sb_n; a.sb_b = sb_b;
+  a.C = C; a.ldc = ldc; a.sc_b = 0; a.ws = ws;
+  if (batch == 0) {  // nothing to add: C = beta * C
+    a.K = 0;
+    a.splitk = 1;
+    return launch_gemm(a, 1, (hipStream_t)stream);
+  }
+  return launch_gemm_sqsum(a, batch, splits, (hipStream_t)stream);
+}
 
 extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
   const long tiles = cdiv(M, BM) * cdiv(N, BN) * (long)(batch > 0 ? batch : 1);

@@ -1,14 +1,17 @@
 // MLP fast path for GGN-type curvature-vector products (ggn.py:41-72 of the reference).
 //
 // For mini-batches of up to 8 rows per pass the per-layer products are GEMV-shaped and
-// HBM-bound: the kernels below stream each weight matrix exactly once per pass with
-// 16-byte-per-lane coalesced loads, keep the (tiny) activations in LDS / registers and
-// reduce with wavefront shuffles.  Larger batches go through the MFMA GEMM (gemm.hip).
+// HBM-bound.  The kernels stream every weight matrix exactly once per pass with 16-byte
+// per-lane coalesced loads issued a whole k-chunk ahead of use (8 KiB in flight per
+// wave), keep the tiny activations in LDS / registers, and reduce with wavefront shuffles.
+// Larger batches go through the MFMA GEMM (gemm.hip).
 //
-//   fwd_jvp_skinny : z = a W^T + b, dz = da W^T + a VW^T + Vb, activation + its derivative
-//   loss_hessian   : w = s * H(f) u                    (per sample, tiny)
-//   bwd_outer      : out_W = beta out_W + alpha delta^T a_prev   (pure write stream)
-//   bwd_dprev      : delta_prev = dphi_prev * (delta W)           (reads W once)
+//   fwd_jvp_kernel   z = a W^T + b, dz = da W^T + a VW^T + Vb, activation + derivative;
+//                    lanes split k, a wave owns 2 output features, 8 waves per block,
+//                    optional split-K over blocks for narrow layers
+//   loss_hessian     w = s * H(f) u per sample (also merges split-K slabs of the last layer)
+//   bwd_fused_kernel out_W = beta out_W + alpha delta^T a_prev  (write stream)  and
+//                    delta_prev = dphi_prev * (delta W)         (reads W once), same sweep
 #include "clo_common.h"
 
 namespace clo {
@@ -17,171 +20,284 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
                        const float *B, long sb_k, long sb_n, float beta, float *C, long ldc,
                        float *ws, long ws_floats, hipStream_t st);
 
-constexpr int KS = 256;  // k-slice per wave step: 64 lanes x 4 floats
-constexpr int NB = 8;    // batch rows per skinny pass
+constexpr int NB = 8;        // batch rows per skinny pass
+constexpr int QN = 1;        // 256-float sub-slices per k-chunk
+constexpr int KC = 256 * QN; // k-chunk of the forward kernel: 64 lanes x QN x float4
+constexpr int FWD_WAVES = 8;
+constexpr int FWD_R = 2;     // output features per wave
+constexpr int FWD_ROWS = FWD_WAVES * FWD_R;
+constexpr int CW = 256;      // column chunk of the backward kernel: 64 lanes x float4
+constexpr int BWD_WAVES = 8;
 
-__device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
-  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+// acc + a.b as a chain of 4 FMAs (no separate multiply / add)
+__device__ __forceinline__ float fma4(const float4 &a, const float4 &b, float acc) {
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc))));
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Load the lane's 4 floats of 256-wide sub-slice q of a row (k offset k0).
+// VEC: lane owns 4 consecutive floats (one 16-byte load); scalar: 4 loads strided by 64.
+// All loads are UNCONDITIONAL (out-of-range lanes read a clamped, valid address and the
+// value is zeroed by a select): a predicated load makes hipcc branch around it and drain
+// vmcnt per element, which serialises the whole prefetch.
+template <bool VEC>
+__device__ __forceinline__ float4 load_row4(const float *__restrict__ row, int k0, int lane, int q,
+                                            int d_in) {
+  float4 v;
+  if (VEC) {
+    const int k = k0 + q * 256 + lane * 4;
+    const bool ok = k < d_in;
+    v = ld4(row + (ok ? k : 0));
+    if (!ok) v = zero4();
+  } else {
+    float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + q * 256 + e * 64 + lane;
+      const bool ok = k < d_in;
+      const float x = row[ok ? k : 0];
+      pv[e] = ok ? x : 0.f;
+    }
+  }
+  return v;
+}
+
+// Same addressing, but out-of-range lanes keep whatever the clamped address holds (the
+// consumer multiplies it by a zeroed operand).  No select -> no wait right behind the load.
+template <bool VEC>
+__device__ __forceinline__ float4 load_row4_raw(const float *__restrict__ row, int k0, int lane,
+                                                int q, int d_in) {
+  float4 v;
+  if (VEC) {
+    const int k = k0 + q * 256 + lane * 4;
+    v = ld4(row + (k < d_in ? k : 0));
+  } else {
+    float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + q * 256 + e * 64 + lane;
+      pv[e] = row[k < d_in ? k : 0];
+    }
+  }
+  return v;
+}
+// Zero the lanes of a staged 4-vector that lie beyond d_in (or the whole vector if !row_ok).
+// Bitwise AND with an all-ones / all-zeros mask: branch-free on purpose (a uniform `if` here
+// splits the k-loop body into several basic blocks and the scheduler then drains the
+// prefetch before the FMAs).
+__device__ __forceinline__ float and_mask(float x, unsigned m) {
+  return __uint_as_float(__float_as_uint(x) & m);
+}
+template <bool VEC>
+__device__ __forceinline__ float4 mask_row4(float4 v, int k0, int lane, int q, int d_in, bool row_ok) {
+  if (VEC) {
+    const unsigned m = (row_ok && k0 + q * 256 + lane * 4 < d_in) ? 0xFFFFFFFFu : 0u;
+    v.x = and_mask(v.x, m); v.y = and_mask(v.y, m); v.z = and_mask(v.z, m); v.w = and_mask(v.w, m);
+  } else {
+    float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned m = (row_ok && k0 + q * 256 + e * 64 + lane < d_in) ? 0xFFFFFFFFu : 0u;
+      pv[e] = and_mask(pv[e], m);
+    }
+  }
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------
 // Fused forward + JVP through one Linear layer, N <= 8 batch rows.
-// Block = 4 waves, each wave owns R output features (rows of W); lanes split k.
+// grid = (ceil(d_out / 16), ksplit); block = 8 waves.
 // ------------------------------------------------------------------------------------------
-template <int R, bool VEC, bool HAS_V, bool HAS_DA>
-__global__ __launch_bounds__(256) void fwd_jvp_skinny_kernel(
+template <bool VEC, bool HAS_V, bool HAS_DA>
+__global__ __launch_bounds__(512, QN == 1 ? 4 : 2) void fwd_jvp_kernel(
     const float *__restrict__ W, const float *__restrict__ b, const float *__restrict__ VW,
     const float *__restrict__ Vb, const float *__restrict__ a_in,
     const float *__restrict__ da_in, float *__restrict__ a_out, float *__restrict__ da_out,
-    float *__restrict__ dphi_out, int N, int d_in, int d_out, int act) {
-  __shared__ __attribute__((aligned(16))) float s_a[NB * KS];
-  __shared__ __attribute__((aligned(16))) float s_da[HAS_DA ? NB * KS : 4];
+    float *__restrict__ dphi_out, float *__restrict__ part, int N, int d_in, int d_out, int act,
+    int chunks_per_split) {
+  constexpr bool TANGENT = HAS_V || HAS_DA;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // [2 buffers][NB][KC] for a, then the same for da
+  float *s_a = smem;
+  float *s_da = smem + 2 * NB * KC;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = (blockIdx.x * 4 + wave) * R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR addressing
+  const int j0 = blockIdx.x * FWD_ROWS + wave * FWD_R;
+  const int nchunks_total = (d_in + KC - 1) / KC;
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_end = min(nchunks_total, c_begin + chunks_per_split);
 
-  float z[R][NB], dz[R][NB];
+  const float *wrow[FWD_R], *vrow[FWD_R];
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int r = 0; r < FWD_R; ++r) {
+    const bool rok = j0 + r < d_out;
+    wrow[r] = W + (long)(rok ? j0 + r : 0) * d_in;
+    vrow[r] = HAS_V ? VW + (long)(rok ? j0 + r : 0) * d_in : nullptr;
+  }
+
+  float z[FWD_R][NB], dz[FWD_R][NB];
+#pragma unroll
+  for (int r = 0; r < FWD_R; ++r)
 #pragma unroll
     for (int n = 0; n < NB; ++n) { z[r][n] = 0.f; dz[r][n] = 0.f; }
 
-  // staging registers: 2 x 4 floats per thread per activation array (8 rows x 256 floats)
-  float4 st_a[2], st_da[2];
-  float4 wn[R], vn[R];
+  // activation staging: wave w loads batch row n = w (8 waves <-> 8 rows), both sub-slices
+  float4 st_a[QN], st_da[QN];
+  float4 wn[FWD_R][QN], vn[FWD_R][QN];
 
-  auto load_slice = [&](int ks) {
-    // activations: thread t covers rows n = (t>>6) + 4q, elements (t&63)*4.. (VEC) or lane+64e
+  auto issue_loads = [&](int c) {
+    const int k0 = c * KC;
+    const long noff = (long)(wave < N ? wave : 0) * d_in;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int n = (tid >> 6) + 4 * q;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vd = va;
-      if (n < N) {
-        if (VEC) {
-          const int k = ks + lane * 4;
-          if (k < d_in) {
-            va = *reinterpret_cast<const float4 *>(a_in + (long)n * d_in + k);
-            if (HAS_DA) vd = *reinterpret_cast<const float4 *>(da_in + (long)n * d_in + k);
-          }
-        } else {
-          float *pa = reinterpret_cast<float *>(&va), *pd = reinterpret_cast<float *>(&vd);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k = ks + lane + 64 * e;
-            if (k < d_in) {
-              pa[e] = a_in[(long)n * d_in + k];
-              if (HAS_DA) pd[e] = da_in[(long)n * d_in + k];
-            }
-          }
-        }
-      }
-      st_a[q] = va;
-      st_da[q] = vd;
+    for (int q = 0; q < QN; ++q) {
+      st_a[q] = load_row4_raw<VEC>(a_in + noff, k0, lane, q, d_in);
+      if (HAS_DA) st_da[q] = load_row4_raw<VEC>(da_in + noff, k0, lane, q, d_in);
     }
-    // weights
+    // weights: out-of-range k lanes / rows >= d_out read valid dummy data; the matching
+    // activations are zeroed in stage_store (k) or the result is never written (rows)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = w4;
-      const int j = j0 + r;
-      if (j < d_out) {
-        if (VEC) {
-          const int k = ks + lane * 4;
-          if (k < d_in) {
-            w4 = *reinterpret_cast<const float4 *>(W + (long)j * d_in + k);
-            if (HAS_V) v4 = *reinterpret_cast<const float4 *>(VW + (long)j * d_in + k);
-          }
-        } else {
-          float *pw = reinterpret_cast<float *>(&w4), *pv = reinterpret_cast<float *>(&v4);
+    for (int r = 0; r < FWD_R; ++r)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k = ks + lane + 64 * e;
-            if (k < d_in) {
-              pw[e] = W[(long)j * d_in + k];
-              if (HAS_V) pv[e] = VW[(long)j * d_in + k];
-            }
-          }
+      for (int q = 0; q < QN; ++q) {
+        wn[r][q] = load_row4_raw<VEC>(wrow[r], k0, lane, q, d_in);
+        if (HAS_V) vn[r][q] = load_row4_raw<VEC>(vrow[r], k0, lane, q, d_in);
+      }
+  };
+  auto stage_store = [&](int buf, int c) {
+    float *pa = s_a + (buf * NB + wave) * KC;
+    float *pd = s_da + (buf * NB + wave) * KC;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      st_a[q] = mask_row4<VEC>(st_a[q], c * KC, lane, q, d_in, wave < N);
+      if (HAS_DA) st_da[q] = mask_row4<VEC>(st_da[q], c * KC, lane, q, d_in, wave < N);
+      if (VEC) {
+        *reinterpret_cast<float4 *>(pa + q * 256 + lane * 4) = st_a[q];
+        if (HAS_DA) *reinterpret_cast<float4 *>(pd + q * 256 + lane * 4) = st_da[q];
+      } else {
+        const float *xa = reinterpret_cast<const float *>(&st_a[q]);
+        const float *xd = reinterpret_cast<const float *>(&st_da[q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pa[q * 256 + e * 64 + lane] = xa[e];
+          if (HAS_DA) pd[q * 256 + e * 64 + lane] = xd[e];
         }
       }
-      wn[r] = w4;
-      vn[r] = v4;
     }
   };
 
-  load_slice(0);
-  for (int ks = 0; ks < d_in; ks += KS) {
-    __syncthreads();  // everyone finished reading the previous slice from LDS
-    // stage -> LDS.  VEC layout: [n][4*lane .. 4*lane+3]; scalar layout: [n][lane + 64e]
+  if (c_begin < c_end) {
+    issue_loads(c_begin);
+    stage_store(0, c_begin);
+  }
+  __syncthreads();
+
+  // Branch-free loop body (one basic block, so the sched_barriers below hold): the last
+  // iteration harmlessly re-loads its own chunk instead of testing for "more".
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    float4 wc[FWD_R][QN], vc[FWD_R][QN];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int n = (tid >> 6) + 4 * q;
-      if (VEC) {
-        *reinterpret_cast<float4 *>(&s_a[n * KS + lane * 4]) = st_a[q];
-        if (HAS_DA) *reinterpret_cast<float4 *>(&s_da[n * KS + lane * 4]) = st_da[q];
-      } else {
-        const float *pa = reinterpret_cast<const float *>(&st_a[q]);
-        const float *pd = reinterpret_cast<const float *>(&st_da[q]);
+    for (int r = 0; r < FWD_R; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s_a[n * KS + lane + 64 * e] = pa[e];
-          if (HAS_DA) s_da[n * KS + lane + 64 * e] = pd[e];
-        }
-      }
-    }
-    float4 wc[R], vc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { wc[r] = wn[r]; vc[r] = vn[r]; }
-    __syncthreads();
-    if (ks + KS < d_in) load_slice(ks + KS);  // in flight while we compute
+      for (int q = 0; q < QN; ++q) { wc[r][q] = wn[r][q]; vc[r][q] = vn[r][q]; }
+    const int cn = min(c + 1, c_end - 1);
+    issue_loads(cn);  // 8 KiB of weights per wave in flight during the FMAs
+    __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      float4 a4, d4;
-      if (VEC) {
-        a4 = *reinterpret_cast<const float4 *>(&s_a[n * KS + lane * 4]);
-        if (HAS_DA) d4 = *reinterpret_cast<const float4 *>(&s_da[n * KS + lane * 4]);
-      } else {
-        a4 = make_float4(s_a[n * KS + lane], s_a[n * KS + lane + 64], s_a[n * KS + lane + 128],
-                         s_a[n * KS + lane + 192]);
-        if (HAS_DA)
-          d4 = make_float4(s_da[n * KS + lane], s_da[n * KS + lane + 64],
-                           s_da[n * KS + lane + 128], s_da[n * KS + lane + 192]);
-      }
+    for (int q = 0; q < QN; ++q)
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        z[r][n] += dot4(wc[r], a4);
-        if (HAS_V) dz[r][n] += dot4(vc[r], a4);
-        if (HAS_DA) dz[r][n] += dot4(wc[r], d4);
+      for (int n = 0; n < NB; ++n) {
+        float4 a4, d4;
+        const float *pa = s_a + (buf * NB + n) * KC;
+        const float *pd = s_da + (buf * NB + n) * KC;
+        if (VEC) {
+          a4 = ld4(pa + q * 256 + lane * 4);
+          if (HAS_DA) d4 = ld4(pd + q * 256 + lane * 4);
+        } else {
+          a4 = make_float4(pa[q * 256 + lane], pa[q * 256 + 64 + lane], pa[q * 256 + 128 + lane],
+                           pa[q * 256 + 192 + lane]);
+          if (HAS_DA)
+            d4 = make_float4(pd[q * 256 + lane], pd[q * 256 + 64 + lane],
+                             pd[q * 256 + 128 + lane], pd[q * 256 + 192 + lane]);
+        }
+#pragma unroll
+        for (int r = 0; r < FWD_R; ++r) {
+          z[r][n] = fma4(wc[r][q], a4, z[r][n]);
+          if (HAS_V) dz[r][n] = fma4(vc[r][q], a4, dz[r][n]);
+          if (HAS_DA) dz[r][n] = fma4(wc[r][q], d4, dz[r][n]);
+        }
+        // keep at most two batch rows of LDS operands live (register budget)
+        if (n & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    __builtin_amdgcn_sched_barrier(0);  // the wait for chunk c+1 must stay behind the FMAs
+    stage_store(buf ^ 1, cn);
+    __syncthreads();
+  }
+
+  // Transposing butterfly reduction: 32 partial sums (16 z + 16 dz) x 64 lanes -> lane l
+  // ends up with the full sum of value (l >> 1): lanes 0..31 hold z, lanes 32..63 hold dz.
+  float v[2 * FWD_R * NB];
+#pragma unroll
+  for (int r = 0; r < FWD_R; ++r)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      v[r * NB + n] = z[r][n];
+      v[FWD_R * NB + r * NB + n] = dz[r][n];
+    }
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int half = 16 >> s, off = 32 >> s;
+    const bool upper = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float send = upper ? v[i] : v[i + half];
+      const float keep = upper ? v[i + half] : v[i];
+      v[i] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  const float mine = v[0] + __shfl_xor(v[0], 1, 64);
+  const float other = __shfl(mine, (lane + 32) & 63, 64);  // lane < 32: the matching dz
+  if (lane < 32 && !(lane & 1)) {
+    const int idx = lane >> 1, r = idx / NB, n = idx % NB;
+    const int j = j0 + r;
+    if (j < d_out && n < N) {
+      if (gridDim.y > 1) {  // raw partial sums: part[split][2][NB][d_out]
+        float *pz = part + ((long)blockIdx.y * 2 * NB + n) * d_out + j;
+        pz[0] = mine;
+        if (TANGENT) pz[(long)NB * d_out] = other;
+      } else {
+        float dphi;
+        const float av = act_apply(act, mine + (b ? b[j] : 0.f), dphi);
+        a_out[(long)n * d_out + j] = av;
+        if (dphi_out) dphi_out[(long)n * d_out + j] = dphi;
+        if (TANGENT) da_out[(long)n * d_out + j] = dphi * (other + ((HAS_V && Vb) ? Vb[j] : 0.f));
       }
     }
   }
+}
 
-  // wavefront reduction; afterwards every lane holds every sum
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      z[r][n] = wave_sum(z[r][n]);
-      if (HAS_V || HAS_DA) dz[r][n] = wave_sum(dz[r][n]);
+// Sum the split-K slabs of fwd_jvp_kernel and apply bias + activation.
+__global__ void fwd_finish_kernel(const float *__restrict__ part, int ksplit,
+                                  const float *__restrict__ b, const float *__restrict__ Vb,
+                                  float *__restrict__ a_out, float *__restrict__ da_out,
+                                  float *__restrict__ dphi_out, int N, int d_out, int act) {
+  const int total = N * d_out;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int n = e / d_out, j = e % d_out;
+    float zz = b ? b[j] : 0.f, dzz = Vb ? Vb[j] : 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+      const float *p = part + ((long)s * 2 * NB + n) * d_out + j;
+      zz += p[0];
+      if (da_out) dzz += p[(long)NB * d_out];
     }
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      if (lane == r * NB + n) {
-        const int j = j0 + r;
-        if (j < d_out && n < N) {
-          float zz = z[r][n] + (b ? b[j] : 0.f);
-          float dphi;
-          const float av = act_apply(act, zz, dphi);
-          a_out[(long)n * d_out + j] = av;
-          if (dphi_out) dphi_out[(long)n * d_out + j] = dphi;
-          if (HAS_V || HAS_DA) {
-            float dzz = dz[r][n] + ((HAS_V && Vb) ? Vb[j] : 0.f);
-            da_out[(long)n * d_out + j] = dphi * dzz;
-          }
-        }
-      }
-    }
+    float dphi;
+    a_out[e] = act_apply(act, zz, dphi);
+    if (dphi_out) dphi_out[e] = dphi;
+    if (da_out) da_out[e] = dphi * dzz;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -209,23 +325,54 @@ __device__ __forceinline__ float block_max(float v, float *s_red) {
   return t;
 }
 
-__global__ __launch_bounds__(256) void loss_hessian_kernel(
-    int kind, const float *__restrict__ f, const float *__restrict__ aux, int aux_rank,
-    const float *__restrict__ u, const float *__restrict__ dphi_last, float *__restrict__ w, int C,
-    float scale) {
+struct LossArgs {
+  int kind;
+  const float *f;       // [N][C] prediction
+  const float *aux;     // RANK1: [N][rank][C]
+  int aux_rank;
+  const float *u;       // [N][C] J v
+  const float *dphi_last;
+  float *w;             // [N][C] result
+  int C;
+  float scale;
+  // optional split-K slabs of the last (identity-activation) layer: part[s][2][NB][C]
+  const float *part;
+  int ksplit;
+  const float *b, *Vb;
+  float *f_out, *u_out;
+};
+
+__global__ __launch_bounds__(256) void loss_hessian_kernel(const LossArgs p) {
   __shared__ float s_red[8];
-  const int n = blockIdx.x;
-  const float *fn = f + (long)n * C, *un = u + (long)n * C;
-  float *wn = w + (long)n * C;
-  const float *dp = dphi_last ? dphi_last + (long)n * C : nullptr;
-  if (kind == CLO_LOSS_MSE) {
+  const int n = blockIdx.x, C = p.C;
+  const float *fn = p.f + (long)n * C, *un = p.u + (long)n * C;
+  if (p.part) {  // finish the last Linear layer first (identity activation)
+    float *fo = p.f_out + (long)n * C, *uo = p.u_out + (long)n * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float zz = p.b ? p.b[c] : 0.f, dzz = p.Vb ? p.Vb[c] : 0.f;
+      for (int s = 0; s < p.ksplit; ++s) {
+        const float *q = p.part + ((long)s * 2 * NB + n) * C + c;
+        zz += q[0];
+        dzz += q[(long)NB * C];
+      }
+      fo[c] = zz;
+      uo[c] = dzz;
+    }
+    __syncthreads();
+    fn = fo;
+    un = uo;
+  }
+  float *wn = p.w + (long)n * C;
+  const float *dp = p.dphi_last ? p.dphi_last + (long)n * C : nullptr;
+  const float scale = p.scale;
+  if (p.kind == CLO_LOSS_MSE) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) wn[c] = scale * un[c] * (dp ? dp[c] : 1.f);
-  } else if (kind == CLO_LOSS_BCE) {
+  } else if (p.kind == CLO_LOSS_BCE) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       const float s = 1.f / (1.f + __expf(-fn[c]));
       wn[c] = scale * s * (1.f - s) * un[c] * (dp ? dp[c] : 1.f);
     }
-  } else if (kind == CLO_LOSS_CE) {
+  } else if (p.kind == CLO_LOSS_CE) {
     float mx = -INFINITY;
     for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmaxf(mx, fn[c]);
     mx = block_max(mx, s_red);
@@ -240,13 +387,13 @@ __global__ __launch_bounds__(256) void loss_hessian_kernel(
     const float inv = 1.f / se;
     const float pu = spu * inv;  // p . u
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      const float p = __expf(fn[c] - mx) * inv;
-      wn[c] = scale * p * (un[c] - pu) * (dp ? dp[c] : 1.f);
+      const float pc = __expf(fn[c] - mx) * inv;
+      wn[c] = scale * pc * (un[c] - pu) * (dp ? dp[c] : 1.f);
     }
-  } else {  // CLO_LOSS_RANK1 (rank-`aux_rank` sum of outer products g g^T)
+  } else {  // CLO_LOSS_RANK1: H_n = sum_m g_nm g_nm^T
     for (int c = threadIdx.x; c < C; c += blockDim.x) wn[c] = 0.f;
-    for (int m = 0; m < aux_rank; ++m) {
-      const float *g = aux + ((long)n * aux_rank + m) * C;
+    for (int m = 0; m < p.aux_rank; ++m) {
+      const float *g = p.aux + ((long)n * p.aux_rank + m) * C;
       float s = 0.f;
       for (int c = threadIdx.x; c < C; c += blockDim.x) s += g[c] * un[c];
       s = block_sum(s, s_red);
@@ -260,203 +407,155 @@ __global__ __launch_bounds__(256) void loss_hessian_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward, parameter part: out_W[j][i] = beta out_W[j][i] + alpha sum_n delta[n][j] a_prev[n][i]
-// grid = (i-chunks of 256 columns, row tiles of JT rows); pure write stream.
+// Fused backward through one Linear layer, N <= 8.
+//   out_W[j][i] = beta out_W[j][i] + alpha sum_n delta[n][j] a_prev[n][i]       (if OUTER)
+//   out_b[j]    = beta out_b[j]    + alpha sum_n delta[n][j]                    (if out_b)
+//   P[jb][n][i] = sum_{j in rows(jb)} W[j][i] delta[n][j]                       (if DPREV)
+// grid = (column chunks of 256, JB row ranges); block = 8 waves; a wave walks rows
+// jbase + wave, +8, ... with the W loads of 4 rows in flight.  If JB == 1 the kernel
+// applies dphi_prev and writes delta_prev directly, else bwd_finish_kernel sums the slabs.
 // ------------------------------------------------------------------------------------------
-constexpr int JT = 32;
-
-template <bool VEC>
-__global__ __launch_bounds__(256) void bwd_outer_kernel(
-    const float *__restrict__ delta, const float *__restrict__ a_prev, float *__restrict__ out_W,
-    float *__restrict__ out_b, float alpha, float beta, int N, int d_in, int d_out) {
-  __shared__ __attribute__((aligned(16))) float s_d[JT * NB];  // [row][n]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i0 = blockIdx.x * KS;
-  const int jbase = blockIdx.y * JT;
-
-  {  // delta tile -> LDS, transposed to [j][n]
-    const int jj = tid >> 3, n = tid & 7;  // 32 rows x 8
-    const int j = jbase + jj;
-    s_d[jj * NB + n] = (j < d_out && n < N) ? delta[(long)n * d_out + j] : 0.f;
-  }
-  float4 a[NB];
-#pragma unroll
-  for (int n = 0; n < NB; ++n) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) {
-      if (VEC) {
-        const int i = i0 + lane * 4;
-        if (i < d_in) v = *reinterpret_cast<const float4 *>(a_prev + (long)n * d_in + i);
-      } else {
-        float *pv = reinterpret_cast<float *>(&v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = i0 + lane + 64 * e;
-          if (i < d_in) pv[e] = a_prev[(long)n * d_in + i];
-        }
-      }
-    }
-    a[n] = v;
-  }
-  __syncthreads();
-
-  if (out_b && blockIdx.x == 0 && tid < JT) {
-    const int j = jbase + tid;
-    if (j < d_out) {
-      float s = 0.f;
-#pragma unroll
-      for (int n = 0; n < NB; ++n) s += s_d[tid * NB + n];
-      out_b[j] = (beta != 0.f ? beta * out_b[j] : 0.f) + alpha * s;
-    }
-  }
-
-  for (int jj = wave; jj < JT; jj += 4) {
-    const int j = jbase + jj;
-    if (j >= d_out) break;
-    const float4 d0 = *reinterpret_cast<const float4 *>(&s_d[jj * NB]);
-    const float4 d1 = *reinterpret_cast<const float4 *>(&s_d[jj * NB + 4]);
-    const float dn[NB] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      o.x += dn[n] * a[n].x; o.y += dn[n] * a[n].y; o.z += dn[n] * a[n].z; o.w += dn[n] * a[n].w;
-    }
-    if (VEC) {
-      const int i = i0 + lane * 4;
-      if (i < d_in) {
-        float4 *po = reinterpret_cast<float4 *>(out_W + (long)j * d_in + i);
-        float4 r = make_float4(alpha * o.x, alpha * o.y, alpha * o.z, alpha * o.w);
-        if (beta != 0.f) {
-          const float4 old = *po;
-          r.x += beta * old.x; r.y += beta * old.y; r.z += beta * old.z; r.w += beta * old.w;
-        }
-        *po = r;
-      }
-    } else {
-      const float *po4 = reinterpret_cast<const float *>(&o);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = i0 + lane + 64 * e;
-        if (i < d_in) {
-          float *po = out_W + (long)j * d_in + i;
-          *po = (beta != 0.f ? beta * *po : 0.f) + alpha * po4[e];
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Backward, data part: P[jb][n][i] = sum_{j in range(jb)} W[j][i] delta[n][j]
-// grid = (i-chunks of 256 columns, JB row ranges); if JB == 1 the kernel applies dphi_prev and
-// writes delta_prev directly, otherwise bwd_dprev_finish sums the JB partial slabs.
-// ------------------------------------------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(256) void bwd_dprev_kernel(
+template <bool VEC, bool OUTER, bool DPREV>
+__global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
     const float *__restrict__ W, const float *__restrict__ delta,
-    const float *__restrict__ dphi_prev, float *__restrict__ dst, int N, int d_in, int d_out,
-    int rows_per_block, int final_write) {
+    const float *__restrict__ a_prev, const float *__restrict__ dphi_prev,
+    float *__restrict__ out_W, float *__restrict__ out_b, float *__restrict__ dst, float alpha,
+    float beta, int N, int d_in, int d_out, int rows_per_block, int final_write) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *s_d = smem;                           // [rows_per_block][NB]
-  float *s_red = smem + rows_per_block * NB;   // [4][NB][KS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i0 = blockIdx.x * KS;
+  float *s_d = smem;                          // [rows_per_block][NB]
+  float *s_red = smem + rows_per_block * NB;  // [BWD_WAVES][NB][CW]   (DPREV only)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = blockIdx.x * CW;
   const int jbase = blockIdx.y * rows_per_block;
   const int jend = min(d_out, jbase + rows_per_block);
 
-  for (int e = tid; e < rows_per_block * NB; e += 256) {
+  for (int e = tid; e < rows_per_block * NB; e += 512) {
     const int jj = e >> 3, n = e & 7;
     const int j = jbase + jj;
     s_d[e] = (j < d_out && n < N) ? delta[(long)n * d_out + j] : 0.f;
   }
+  float4 a[NB];
+  if (OUTER) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+    {
+      a[n] = load_row4<VEC>(a_prev + (long)(n < N ? n : 0) * d_in, i0, lane, 0, d_in);
+      if (n >= N) a[n] = zero4();
+    }
+  }
   __syncthreads();
+
+  if (OUTER && out_b && blockIdx.x == 0) {
+    for (int jj = tid; jj < jend - jbase; jj += 512) {
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < NB; ++n) s += s_d[jj * NB + n];
+      const int j = jbase + jj;
+      out_b[j] = (beta != 0.f ? beta * out_b[j] : 0.f) + alpha * s;
+    }
+  }
 
   float4 acc[NB];
 #pragma unroll
-  for (int n = 0; n < NB; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < NB; ++n) acc[n] = zero4();
 
-  // two rows in flight per wave iteration
-  for (int j = jbase + wave; j < jend; j += 8) {
-    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-    const int j1 = j + 4;
-    if (VEC) {
-      const int i = i0 + lane * 4;
-      if (i < d_in) {
-        w0 = *reinterpret_cast<const float4 *>(W + (long)j * d_in + i);
-        if (j1 < jend) w1 = *reinterpret_cast<const float4 *>(W + (long)j1 * d_in + i);
-      }
-    } else {
-      float *p0 = reinterpret_cast<float *>(&w0), *p1 = reinterpret_cast<float *>(&w1);
+  constexpr int P = 4;  // rows in flight per wave
+  const bool col_ok = VEC ? (i0 + lane * 4 < d_in) : true;
+  for (int j = jbase + wave; j < jend; j += BWD_WAVES * P) {
+    float4 w4[P], old4[P];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = i0 + lane + 64 * e;
-        if (i < d_in) {
-          p0[e] = W[(long)j * d_in + i];
-          if (j1 < jend) p1[e] = W[(long)j1 * d_in + i];
+    for (int t = 0; t < P; ++t) {
+      const int jt = min(j + t * BWD_WAVES, jend - 1);  // clamped: loads stay unconditional
+      w4[t] = zero4();
+      old4[t] = zero4();
+      if (DPREV) w4[t] = load_row4_raw<VEC>(W + (long)jt * d_in, i0, lane, 0, d_in);
+      if (OUTER && beta != 0.f)
+        old4[t] = load_row4_raw<VEC>(out_W + (long)jt * d_in, i0, lane, 0, d_in);
+    }
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int jt = j + t * BWD_WAVES;
+      if (jt < jend) {
+        const float *dj = &s_d[(jt - jbase) * NB];
+        const float4 d0 = ld4(dj), d1 = ld4(dj + 4);
+        const float dn[NB] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        if (OUTER) {
+          float4 o = zero4();
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            o.x += dn[n] * a[n].x; o.y += dn[n] * a[n].y;
+            o.z += dn[n] * a[n].z; o.w += dn[n] * a[n].w;
+          }
+          float4 r = make_float4(alpha * o.x + beta * old4[t].x, alpha * o.y + beta * old4[t].y,
+                                 alpha * o.z + beta * old4[t].z, alpha * o.w + beta * old4[t].w);
+          float *po = out_W + (long)jt * d_in;
+          if (VEC) {
+            if (col_ok) *reinterpret_cast<float4 *>(po + i0 + lane * 4) = r;
+          } else {
+            const float *pr = reinterpret_cast<const float *>(&r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int i = i0 + e * 64 + lane;
+              if (i < d_in) po[i] = pr[e];
+            }
+          }
+        }
+        if (DPREV) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            acc[n].x += dn[n] * w4[t].x; acc[n].y += dn[n] * w4[t].y;
+            acc[n].z += dn[n] * w4[t].z; acc[n].w += dn[n] * w4[t].w;
+          }
         }
       }
     }
-    {
-      const float *dj = &s_d[(j - jbase) * NB];
-      const float4 d0 = *reinterpret_cast<const float4 *>(dj);
-      const float4 d1 = *reinterpret_cast<const float4 *>(dj + 4);
-      const float dn[NB] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        acc[n].x += dn[n] * w0.x; acc[n].y += dn[n] * w0.y;
-        acc[n].z += dn[n] * w0.z; acc[n].w += dn[n] * w0.w;
-      }
-    }
-    if (j1 < jend) {
-      const float *dj = &s_d[(j1 - jbase) * NB];
-      const float4 d0 = *reinterpret_cast<const float4 *>(dj);
-      const float4 d1 = *reinterpret_cast<const float4 *>(dj + 4);
-      const float dn[NB] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        acc[n].x += dn[n] * w1.x; acc[n].y += dn[n] * w1.y;
-        acc[n].z += dn[n] * w1.z; acc[n].w += dn[n] * w1.w;
-      }
-    }
   }
 
-  // cross-wave reduction through LDS; column c of the chunk is lane*4+e (VEC) or lane+64e.
+  if (DPREV) {
+    // cross-wave reduction through LDS; local column c = lane*4+e (VEC) or e*64+lane
 #pragma unroll
-  for (int n = 0; n < NB; ++n) {
-    float *dstp = &s_red[(wave * NB + n) * KS];
-    if (VEC) {
-      *reinterpret_cast<float4 *>(dstp + lane * 4) = acc[n];
-    } else {
-      dstp[lane] = acc[n].x; dstp[lane + 64] = acc[n].y;
-      dstp[lane + 128] = acc[n].z; dstp[lane + 192] = acc[n].w;
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < NB * KS; e += 256) {
-    const int n = e >> 8, c = e & 255;
-    const int i = i0 + c;
-    if (n < N && i < d_in) {
-      float s = s_red[(0 * NB + n) * KS + c] + s_red[(1 * NB + n) * KS + c] +
-                s_red[(2 * NB + n) * KS + c] + s_red[(3 * NB + n) * KS + c];
-      if (final_write) {
-        dst[(long)n * d_in + i] = s * dphi_prev[(long)n * d_in + i];
+    for (int n = 0; n < NB; ++n) {
+      float *q = &s_red[(wave * NB + n) * CW];
+      if (VEC) {
+        *reinterpret_cast<float4 *>(q + lane * 4) = acc[n];
       } else {
-        dst[((long)blockIdx.y * NB + n) * d_in + i] = s;
+        q[lane] = acc[n].x; q[64 + lane] = acc[n].y; q[128 + lane] = acc[n].z;
+        q[192 + lane] = acc[n].w;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * CW; e += 512) {
+      const int n = e >> 8, c = e & 255;
+      const int i = i0 + c;
+      if (n < N && i < d_in) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < BWD_WAVES; ++w) s += s_red[(w * NB + n) * CW + c];
+        if (final_write)
+          dst[(long)n * d_in + i] = s * dphi_prev[(long)n * d_in + i];
+        else
+          dst[((long)blockIdx.y * NB + n) * d_in + i] = s;
       }
     }
   }
 }
 
-__global__ void bwd_dprev_finish_kernel(const float *__restrict__ P,
-                                        const float *__restrict__ dphi_prev,
-                                        float *__restrict__ delta_prev, int N, int d_in, int JB) {
-  const long total = (long)N * d_in;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long)gridDim.x * blockDim.x) {
+__global__ void bwd_finish_kernel(const float *__restrict__ P, const float *__restrict__ dphi_prev,
+                                  float *__restrict__ delta_prev, int N, int d_in, int JB) {
+  const int total = N * d_in;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int n = e / d_in, i = e % d_in;
-    float s = 0.f;
-    for (int jb = 0; jb < JB; ++jb) s += P[((long)jb * NB + n) * d_in + i];
-    delta_prev[e] = s * dphi_prev[e];
+    const float *p = P + (long)n * d_in + i;
+    const long stride = (long)NB * d_in;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int jb = 0;
+    for (; jb + 3 < JB; jb += 4) {
+      s0 += p[(jb + 0) * stride]; s1 += p[(jb + 1) * stride];
+      s2 += p[(jb + 2) * stride]; s3 += p[(jb + 3) * stride];
+    }
+    for (; jb < JB; ++jb) s0 += p[jb * stride];
+    delta_prev[e] = ((s0 + s1) + (s2 + s3)) * dphi_prev[e];
   }
 }
 
@@ -499,41 +598,20 @@ static inline unsigned ew_grid(long n) {
   return (unsigned)std::max<long>(1, std::min<long>(cdiv(n, 256), kNumCU * 8L));
 }
 
-// number of row ranges for bwd_dprev: aim at ~2 blocks per CU, >= 32 rows per block
-static int pick_jb(int d_in, int d_out) {
-  const long ichunks = cdiv(d_in, KS);
-  long jb = (2L * kNumCU) / ichunks;
-  jb = std::min<long>(jb, cdiv(d_out, 32));
-  jb = std::max<long>(jb, cdiv(d_out, 512));  // <= 512 rows of delta per block in LDS
-  return (int)std::max<long>(1, jb);
+// ---- launch geometry ----------------------------------------------------------------------
+static int fwd_ksplit(int d_in, int d_out) {
+  const long row_blocks = cdiv(d_out, FWD_ROWS);
+  const long nchunks = cdiv(d_in, KC);
+  if (row_blocks >= 96 || nchunks <= 1) return 1;
+  return (int)std::min<long>(nchunks, cdiv(kNumCU, row_blocks));
 }
-
-template <bool VEC>
-static int launch_fwd(const float *W, const float *b, const float *VW, const float *Vb,
-                      const float *a_in, const float *da_in, float *a_out, float *da_out,
-                      float *dphi_out, int N, int d_in, int d_out, int act, hipStream_t st) {
-  // R = 2 rows per wave -> 8 rows per block; R = 1 for small layers (more blocks in flight)
-  const bool has_v = VW != nullptr, has_da = da_in != nullptr;
-  const bool small = d_out < 8 * 2 * kNumCU / 4;  // fewer than ~128 blocks at R=2
-  const int R = small ? 1 : 2;
-  dim3 grid((unsigned)cdiv(d_out, 4 * R)), block(256);
-#define CLO_FWD(RR, HV, HD)                                                                    \
-  hipLaunchKernelGGL((fwd_jvp_skinny_kernel<RR, VEC, HV, HD>), grid, block, 0, st, W, b, VW, Vb, \
-                     a_in, da_in, a_out, da_out, dphi_out, N, d_in, d_out, act)
-  if (R == 1) {
-    if (has_v && has_da) CLO_FWD(1, true, true);
-    else if (has_v) CLO_FWD(1, true, false);
-    else if (has_da) CLO_FWD(1, false, true);
-    else CLO_FWD(1, false, false);
-  } else {
-    if (has_v && has_da) CLO_FWD(2, true, true);
-    else if (has_v) CLO_FWD(2, true, false);
-    else if (has_da) CLO_FWD(2, false, true);
-    else CLO_FWD(2, false, false);
-  }
-#undef CLO_FWD
-  CLO_CHECK_LAUNCH("fwd_jvp_skinny_kernel");
-  return CLO_OK;
+static int bwd_jb(int d_in, int d_out, bool dprev) {
+  const long cchunks = cdiv(d_in, CW);
+  long jb = cdiv(kNumCU, cchunks);                    // ~1 block per CU
+  jb = std::min<long>(jb, cdiv(d_out, 64));           // >= 64 rows (8 per wave) per block
+  if (dprev) jb = std::min<long>(jb, 32);             // bound the slab traffic
+  jb = std::max<long>(jb, cdiv(d_out, 1024));         // <= 1024 rows of delta in LDS
+  return (int)std::max<long>(1, jb);
 }
 
 static bool vec_ok(int d, std::initializer_list<const void *> ptrs) {
@@ -543,50 +621,92 @@ static bool vec_ok(int d, std::initializer_list<const void *> ptrs) {
   return true;
 }
 
-// One skinny pass (N <= 8).
+template <typename K>
+static int set_smem(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    return check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                     "hipFuncSetAttribute(smem)");
+  }
+  return CLO_OK;
+}
+
+// One forward pass over <= 8 batch rows.
 static int fwd_pass(const float *W, const float *b, const float *VW, const float *Vb,
                     const float *a_in, const float *da_in, float *a_out, float *da_out,
-                    float *dphi_out, int N, int d_in, int d_out, int act, hipStream_t st) {
-  if (vec_ok(d_in, {W, VW, a_in, da_in}))
-    return launch_fwd<true>(W, b, VW, Vb, a_in, da_in, a_out, da_out, dphi_out, N, d_in, d_out, act,
-                            st);
-  return launch_fwd<false>(W, b, VW, Vb, a_in, da_in, a_out, da_out, dphi_out, N, d_in, d_out, act,
-                           st);
+                    float *dphi_out, int N, int d_in, int d_out, int act, float *part,
+                    bool leave_partials, int *ksplit_out, hipStream_t st) {
+  const bool has_v = VW != nullptr, has_da = da_in != nullptr;
+  const bool vec = vec_ok(d_in, {W, VW, a_in, da_in});
+  int ksplit = part ? fwd_ksplit(d_in, d_out) : 1;
+  const int nchunks = (int)cdiv(d_in, KC);
+  const int cps = (int)cdiv(nchunks, ksplit);
+  ksplit = (int)cdiv(nchunks, cps);
+  if (ksplit_out) *ksplit_out = ksplit;
+  dim3 grid((unsigned)cdiv(d_out, FWD_ROWS), (unsigned)ksplit), block(512);
+  const size_t smem = (size_t)(has_da ? 4 : 2) * NB * KC * sizeof(float);
+#define CLO_FWD(V, HV, HD)                                                                    \
+  hipLaunchKernelGGL((fwd_jvp_kernel<V, HV, HD>), grid, block, smem, st, W, b, VW, Vb, a_in,  \
+                     da_in, a_out, da_out, dphi_out, part, N, d_in, d_out, act, cps)
+  if (vec) {
+    if (has_v && has_da) CLO_FWD(true, true, true);
+    else if (has_v) CLO_FWD(true, true, false);
+    else if (has_da) CLO_FWD(true, false, true);
+    else CLO_FWD(true, false, false);
+  } else {
+    if (has_v && has_da) CLO_FWD(false, true, true);
+    else if (has_v) CLO_FWD(false, true, false);
+    else if (has_da) CLO_FWD(false, false, true);
+    else CLO_FWD(false, false, false);
+  }
+#undef CLO_FWD
+  CLO_CHECK_LAUNCH("fwd_jvp_kernel");
+  if (ksplit > 1 && !leave_partials) {
+    hipLaunchKernelGGL(fwd_finish_kernel, dim3(ew_grid((long)N * d_out)), dim3(256), 0, st, part,
+                       ksplit, b, Vb, a_out, (has_v || has_da) ? da_out : nullptr, dphi_out, N,
+                       d_out, act);
+    CLO_CHECK_LAUNCH("fwd_finish_kernel");
+  }
+  return CLO_OK;
 }
 
 static int bwd_pass(const float *W, const float *delta, const float *a_prev,
                     const float *dphi_prev, float *out_W, float *out_b, float *delta_prev,
                     float alpha, float beta, int N, int d_in, int d_out, float *ws,
                     hipStream_t st) {
-  if (out_W) {
-    dim3 grid((unsigned)cdiv(d_in, KS), (unsigned)cdiv(d_out, JT));
-    if (vec_ok(d_in, {a_prev, out_W}))
-      hipLaunchKernelGGL((bwd_outer_kernel<true>), grid, dim3(256), 0, st, delta, a_prev, out_W,
-                         out_b, alpha, beta, N, d_in, d_out);
-    else
-      hipLaunchKernelGGL((bwd_outer_kernel<false>), grid, dim3(256), 0, st, delta, a_prev, out_W,
-                         out_b, alpha, beta, N, d_in, d_out);
-    CLO_CHECK_LAUNCH("bwd_outer_kernel");
+  const bool outer = out_W != nullptr, dprev = delta_prev != nullptr;
+  if (!outer && !dprev) return CLO_OK;
+  const int JB = bwd_jb(d_in, d_out, dprev);
+  const int rpb = (int)cdiv(d_out, JB);
+  const int JBe = (int)cdiv(d_out, rpb);
+  const size_t smem = ((size_t)rpb * NB + (dprev ? BWD_WAVES * NB * CW : 0)) * sizeof(float);
+  dim3 grid((unsigned)cdiv(d_in, CW), (unsigned)JBe), block(512);
+  float *dst = dprev ? (JBe == 1 ? delta_prev : ws) : nullptr;
+  const int fin = JBe == 1 ? 1 : 0;
+  const bool vec = vec_ok(d_in, {W, a_prev, out_W});
+  int rc = CLO_OK;
+#define CLO_BWD(V, O, D)                                                                        \
+  do {                                                                                          \
+    rc = set_smem(bwd_fused_kernel<V, O, D>, smem);                                             \
+    if (rc != CLO_OK) return rc;                                                                \
+    hipLaunchKernelGGL((bwd_fused_kernel<V, O, D>), grid, block, smem, st, W, delta, a_prev,    \
+                       dphi_prev, out_W, out_b, dst, alpha, beta, N, d_in, d_out, rpb, fin);    \
+  } while (0)
+  if (vec) {
+    if (outer && dprev) CLO_BWD(true, true, true);
+    else if (outer) CLO_BWD(true, true, false);
+    else CLO_BWD(true, false, true);
+  } else {
+    if (outer && dprev) CLO_BWD(false, true, true);
+    else if (outer) CLO_BWD(false, true, false);
+    else CLO_BWD(false, false, true);
   }
-  if (delta_prev) {
-    const int JB = pick_jb(d_in, d_out);
-    const int rpb = (int)cdiv(d_out, JB);
-    const int JBe = (int)cdiv(d_out, rpb);
-    const size_t smem = ((size_t)rpb * NB + 4 * NB * KS) * sizeof(float);
-    dim3 grid((unsigned)cdiv(d_in, KS), (unsigned)JBe);
-    float *dst = JBe == 1 ? delta_prev : ws;
-    if (vec_ok(d_in, {W}))
-      hipLaunchKernelGGL((bwd_dprev_kernel<true>), grid, dim3(256), smem, st, W, delta, dphi_prev,
-                         dst, N, d_in, d_out, rpb, JBe == 1 ? 1 : 0);
-    else
-      hipLaunchKernelGGL((bwd_dprev_kernel<false>), grid, dim3(256), smem, st, W, delta, dphi_prev,
-                         dst, N, d_in, d_out, rpb, JBe == 1 ? 1 : 0);
-    CLO_CHECK_LAUNCH("bwd_dprev_kernel");
-    if (JBe > 1) {
-      hipLaunchKernelGGL(bwd_dprev_finish_kernel, dim3(ew_grid((long)N * d_in)), dim3(256), 0, st,
-                         ws, dphi_prev, delta_prev, N, d_in, JBe);
-      CLO_CHECK_LAUNCH("bwd_dprev_finish_kernel");
-    }
+#undef CLO_BWD
+  CLO_CHECK_LAUNCH("bwd_fused_kernel");
+  if (dprev && JBe > 1) {
+    hipLaunchKernelGGL(bwd_finish_kernel, dim3(ew_grid((long)N * d_in)), dim3(256), 0, st, ws,
+                       dphi_prev, delta_prev, N, d_in, JBe);
+    CLO_CHECK_LAUNCH("bwd_finish_kernel");
   }
   return CLO_OK;
 }
@@ -598,19 +718,36 @@ static long gemm_ws_floats(int N, int dmax) {
   return 16L * (long)std::max(N, 128) * dmax;
 }
 
+static int launch_loss(int kind, const float *f, const float *aux, int aux_rank, const float *u,
+                       const float *dphi_last, float *w, int N, int C, float scale,
+                       const float *part, int ksplit, const float *b, const float *Vb, float *f_out,
+                       float *u_out, hipStream_t st) {
+  LossArgs a{};
+  a.kind = kind; a.f = f; a.aux = aux; a.aux_rank = aux_rank; a.u = u; a.dphi_last = dphi_last;
+  a.w = w; a.C = C; a.scale = scale; a.part = part; a.ksplit = ksplit; a.b = b; a.Vb = Vb;
+  a.f_out = f_out; a.u_out = u_out;
+  hipLaunchKernelGGL(loss_hessian_kernel, dim3(N), dim3(C <= 64 ? 64 : 256), 0, st, a);
+  CLO_CHECK_LAUNCH("loss_hessian_kernel");
+  return CLO_OK;
+}
+
 }  // namespace clo
 
 using namespace clo;
 
+extern "C" long clo_mlp_fwd_ws_floats(int N, int d_in, int d_out) {
+  (void)N;
+  return (long)fwd_ksplit(d_in, d_out) * 2 * NB * d_out + 64;
+}
 extern "C" long clo_mlp_bwd_ws_floats(int N, int d_in, int d_out) {
   (void)N;
-  return (long)pick_jb(d_in, d_out) * NB * d_in + 64;
+  return (long)bwd_jb(d_in, d_out, true) * NB * d_in + 64;
 }
 
 extern "C" int clo_mlp_fwd_jvp_layer(const float *W, const float *b, const float *VW,
                                      const float *Vb, const float *a_in, const float *da_in,
                                      float *a_out, float *da_out, float *dphi_out, int N, int d_in,
-                                     int d_out, int act, void *stream) {
+                                     int d_out, int act, float *ws, void *stream) {
   CLO_REQUIRE(N >= 0 && d_in > 0 && d_out > 0, "clo_mlp_fwd_jvp_layer: bad sizes");
   CLO_REQUIRE(act >= 0 && act <= 3, "clo_mlp_fwd_jvp_layer: unknown activation %d", act);
   CLO_REQUIRE(W && a_in && a_out, "clo_mlp_fwd_jvp_layer: null operand");
@@ -623,7 +760,8 @@ extern "C" int clo_mlp_fwd_jvp_layer(const float *W, const float *b, const float
     int rc = fwd_pass(W, b, VW, Vb, a_in + (long)n0 * d_in,
                       da_in ? da_in + (long)n0 * d_in : nullptr, a_out + (long)n0 * d_out,
                       da_out ? da_out + (long)n0 * d_out : nullptr,
-                      dphi_out ? dphi_out + (long)n0 * d_out : nullptr, nn, d_in, d_out, act, st);
+                      dphi_out ? dphi_out + (long)n0 * d_out : nullptr, nn, d_in, d_out, act, ws,
+                      false, nullptr, st);
     if (rc != CLO_OK) return rc;
   }
   return CLO_OK;
@@ -638,10 +776,8 @@ extern "C" int clo_loss_hessian_apply(int kind, const float *f, const float *aux
   CLO_REQUIRE(f && u && w, "clo_loss_hessian_apply: null operand");
   CLO_REQUIRE(kind != CLO_LOSS_RANK1 || (aux && aux_rank >= 1),
               "clo_loss_hessian_apply: RANK1 needs aux and aux_rank >= 1");
-  hipLaunchKernelGGL(loss_hessian_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, kind, f, aux,
-                     aux_rank, u, dphi_last, w, C, scale);
-  CLO_CHECK_LAUNCH("loss_hessian_kernel");
-  return CLO_OK;
+  return launch_loss(kind, f, aux, aux_rank, u, dphi_last, w, N, C, scale, nullptr, 0, nullptr,
+                     nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int clo_mlp_bwd_layer(const float *W, const float *delta, const float *a_prev,
@@ -652,24 +788,26 @@ extern "C" int clo_mlp_bwd_layer(const float *W, const float *delta, const float
   CLO_REQUIRE(N <= SKINNY_MAX_N, "clo_mlp_bwd_layer: N=%d > %d, use clo_mlp_ggn_matvec", N,
               SKINNY_MAX_N);
   CLO_REQUIRE(delta && (!out_W || a_prev), "clo_mlp_bwd_layer: null operand");
-  CLO_REQUIRE(!delta_prev || (W && dphi_prev && ws), "clo_mlp_bwd_layer: delta_prev needs W, dphi_prev, ws");
+  CLO_REQUIRE(!delta_prev || (W && dphi_prev && ws),
+              "clo_mlp_bwd_layer: delta_prev needs W, dphi_prev, ws");
   hipStream_t st = (hipStream_t)stream;
-  for (int n0 = 0; n0 < N || n0 == 0; n0 += NB) {
+  int n0 = 0;
+  do {
     const int nn = std::max(0, std::min(NB, N - n0));
     int rc = bwd_pass(W, delta + (long)n0 * d_out, a_prev ? a_prev + (long)n0 * d_in : nullptr,
                       dphi_prev ? dphi_prev + (long)n0 * d_in : nullptr, out_W, out_b,
                       delta_prev ? delta_prev + (long)n0 * d_in : nullptr, alpha,
                       n0 == 0 ? beta : 1.f, nn, d_in, d_out, ws, st);
     if (rc != CLO_OK) return rc;
-    if (N == 0) break;
-  }
+    n0 += NB;
+  } while (n0 < N);
   return CLO_OK;
 }
 
 // Workspace layout of clo_mlp_ggn_matvec (floats):
 //   per layer l = 1..L : a_l, da_l, dphi_l, each [N][d_l]
 //   delta ping/pong    : 2 x [N][dmax]
-//   bwd partial slabs  : max_l clo_mlp_bwd_ws_floats
+//   slabs              : max over layers of the fwd split-K / bwd row-range partial slabs
 //   GEMM split-K slabs : only when N > SKINNY_MAX_N
 extern "C" long clo_mlp_ggn_ws_floats(int L, const int *dims, int N) {
   if (L <= 0 || !dims || N < 0) return 0;
@@ -679,8 +817,10 @@ extern "C" long clo_mlp_ggn_ws_floats(int L, const int *dims, int N) {
   for (int l = 1; l <= L; ++l) total += 3L * N * dims[l];
   total += 2L * N * dmax;
   long part = 0;
-  for (int l = 1; l <= L; ++l)
+  for (int l = 1; l <= L; ++l) {
     part = std::max(part, clo_mlp_bwd_ws_floats(N, dims[l - 1], dims[l]));
+    part = std::max(part, clo_mlp_fwd_ws_floats(N, dims[l - 1], dims[l]));
+  }
   total += part;
   if (N > SKINNY_MAX_N) total += gemm_ws_floats(N, dmax);
   return total + 256;
@@ -692,9 +832,11 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
                                   const float *X, int N, int loss_kind, const float *aux,
                                   int aux_rank, float loss_scale, float alpha, float beta,
                                   float *ws, void *stream) {
-  CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW, "clo_mlp_ggn_matvec: bad layer table");
+  CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW,
+              "clo_mlp_ggn_matvec: bad layer table");
   CLO_REQUIRE(N >= 0 && X && ws, "clo_mlp_ggn_matvec: bad batch / workspace");
-  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_ggn_matvec: unknown loss kind %d", loss_kind);
+  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_ggn_matvec: unknown loss kind %d",
+              loss_kind);
   CLO_REQUIRE(loss_kind != CLO_LOSS_RANK1 || (aux && aux_rank >= 1),
               "clo_mlp_ggn_matvec: RANK1 needs aux and aux_rank >= 1");
   for (int l = 0; l <= L; ++l) CLO_REQUIRE(dims[l] > 0, "clo_mlp_ggn_matvec: dims[%d] <= 0", l);
@@ -730,22 +872,33 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   float *dl1 = p; p += (long)N * dmax;
   float *part = p;
   long part_sz = 0;
-  for (int l = 1; l <= L; ++l)
+  for (int l = 1; l <= L; ++l) {
     part_sz = std::max(part_sz, clo_mlp_bwd_ws_floats(N, dims[l - 1], dims[l]));
+    part_sz = std::max(part_sz, clo_mlp_fwd_ws_floats(N, dims[l - 1], dims[l]));
+  }
   p += part_sz;
   float *gws = p;
   const long gws_sz = N > SKINNY_MAX_N ? gemm_ws_floats(N, dmax) : 0;
 
   const bool skinny = N <= SKINNY_MAX_N;
+  const bool last_linear = acts[L - 1] == CLO_ACT_IDENTITY;
   int rc;
+  int last_ksplit = 1;
   // ---- forward + JVP
   for (int l = 1; l <= L; ++l) {
     const int di = dims[l - 1], dout = dims[l];
     const float *bl = b ? b[l - 1] : nullptr, *vbl = Vb ? Vb[l - 1] : nullptr;
     if (skinny) {
-      rc = clo_mlp_fwd_jvp_layer(W[l - 1], bl, VW[l - 1], vbl, a[l - 1], da[l - 1], a[l], da[l],
-                                 dphi[l], N, di, dout, acts[l - 1], stream);
-      if (rc != CLO_OK) return rc;
+      // the last layer's split-K slabs are merged by the loss kernel (single 8-row pass only)
+      const bool defer = l == L && last_linear && N <= NB;
+      for (int n0 = 0; n0 < N; n0 += NB) {
+        const int nn = std::min(NB, N - n0);
+        rc = fwd_pass(W[l - 1], bl, VW[l - 1], vbl, a[l - 1] + (long)n0 * di,
+                      da[l - 1] ? da[l - 1] + (long)n0 * di : nullptr, a[l] + (long)n0 * dout,
+                      da[l] + (long)n0 * dout, dphi[l] + (long)n0 * dout, nn, di, dout,
+                      acts[l - 1], part, defer, defer ? &last_ksplit : nullptr, st);
+        if (rc != CLO_OK) return rc;
+      }
     } else {
       // Z = A W^T ; dZ = A VW^T (+ dA W^T)
       rc = launch_gemm_simple(N, dout, di, 1.f, a[l - 1], di, 1, W[l - 1], 1, di, 0.f, a[l], dout,
@@ -767,10 +920,11 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   // ---- output-space curvature: delta_L = dphi_L * (alpha * s * H u)
   {
     const int C = dims[L];
-    const bool last_linear = acts[L - 1] == CLO_ACT_IDENTITY;
-    hipLaunchKernelGGL(loss_hessian_kernel, dim3(N), dim3(256), 0, st, loss_kind, a[L], aux,
-                       aux_rank, da[L], last_linear ? nullptr : dphi[L], dl0, C, loss_scale * alpha);
-    CLO_CHECK_LAUNCH("loss_hessian_kernel");
+    const bool merge = last_ksplit > 1;
+    rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], last_linear ? nullptr : dphi[L], dl0, N,
+                     C, loss_scale * alpha, merge ? part : nullptr, last_ksplit,
+                     b ? b[L - 1] : nullptr, Vb ? Vb[L - 1] : nullptr, a[L], da[L], st);
+    if (rc != CLO_OK) return rc;
   }
   // ---- backward
   float *dcur = dl0, *dnext = dl1;

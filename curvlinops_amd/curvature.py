@@ -1,0 +1,338 @@
+"""Curvature-matrix linear operators of an empirical risk: Hessian, GGN (exact / Monte-Carlo)
+and empirical Fisher, behind the reference's constructor and ``@`` contract.
+
+Two execution paths, chosen per operator at construction:
+
+* **native** -- fully-connected nets in fp32 on the GPU (``mlp_native.detect_mlp``): the
+  GGN / EF product of every mini-batch is one call into the HIP library
+  (``clo_mlp_ggn_matvec``); no autograd, no vmap, weights streamed once per pass.
+* **autograd** -- any other model: the per-batch product is written with ``torch.func``
+  (forward-over-reverse for the Hessian, ``jvp -> loss-Hessian -> vjp`` for GGN-type
+  matrices) and ``vmap``ped over the trailing column axis, on whatever device the parameters
+  live; this is the host-framework part the north star leaves in PyTorch.
+
+Reference: ``curvlinops/_torch_base.py:817-1007`` (base class, batch loop),
+``hessian.py:13-145``, ``ggn.py:17-366``, ``gradient_moments.py:15-151``.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Callable, Iterable, MutableMapping
+import torch
+from torch import Tensor
+from torch.func import grad, jacrev, jvp, vjp, vmap
+from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss, Module, MSELoss
+
+from curvlinops_amd import _hip
+from curvlinops_amd.enums import FisherType
+from curvlinops_amd.linop import PyTorchLinearOperator
+from curvlinops_amd.loss_sampling import make_grad_output_fn
+from curvlinops_amd.mlp_native import NativeMLP, detect_mlp, loss_kind_and_scale
+from curvlinops_amd.risk import EmpiricalRiskMixin
+from curvlinops_amd.utils import make_functional_loss
+
+
+class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
+    """Base class: ``A @ M = sum_batches norm_b * A_b @ M`` with ``norm_b = 1`` (sum) or
+    ``B_b / N_data`` (mean).  Subclasses provide ``_matvec_batch`` (autograd path) and may
+    enable the native path through ``_NATIVE_KIND``."""
+
+    FIXED_DATA_ORDER: bool = False
+    _NATIVE_KIND: str | None = None  # "ggn" | "ef" | None
+
+    def __init__(
+        self,
+        model_func: Module | Callable[[dict[str, Tensor], Tensor | MutableMapping], Tensor],
+        loss_func: Callable[[Tensor, Tensor], Tensor] | None,
+        params: dict[str, Tensor],
+        data: Iterable[tuple[Tensor | MutableMapping, Tensor]],
+        progressbar: bool = False,
+        check_deterministic: bool = True,
+        num_data: int | None = None,
+        num_per_example_loss_terms: int | None = None,
+        batch_size_fn: Callable[[MutableMapping | Tensor], int] | None = None,
+    ):
+        EmpiricalRiskMixin.__init__(
+            self, model_func, loss_func, params, data, progressbar=progressbar,
+            batch_size_fn=batch_size_fn, num_data=num_data,
+            num_per_example_loss_terms=num_per_example_loss_terms,
+            check_deterministic=check_deterministic,
+        )
+        PyTorchLinearOperator.__init__(self, self._get_in_shape(), self._get_out_shape())
+        self._native: NativeMLP | None = None
+        self._native_aux: dict[int, Tensor] = {}
+        self._init_mp()
+        self._init_native()
+        if check_deterministic:
+            self._check_deterministic_matvec()
+
+    # ------------------------------------------------------------------ shapes
+    def _get_in_shape(self) -> list[tuple[int, ...]]:
+        return [tuple(p.shape) for p in self._params.values()]
+
+    def _get_out_shape(self) -> list[tuple[int, ...]]:
+        return [tuple(p.shape) for p in self._params.values()]
+
+    # ------------------------------------------------------------------ autograd path
+    def _init_mp(self) -> None:
+        """``self._mp(X, y, M_tuple)``: ``_matvec_batch`` vmapped over the trailing axis."""
+        keys = list(self._params.keys())
+
+        def one_column(X, y, v: tuple[Tensor, ...]) -> tuple[Tensor, ...]:
+            out = self._matvec_batch(X, y, dict(zip(keys, v)))
+            return tuple(out[k] for k in keys)
+
+        self._mp = vmap(one_column, in_dims=(None, None, -1), out_dims=-1, randomness="same")
+
+    def _matmat_batch(self, X, y: Tensor, M: list[Tensor]) -> list[Tensor]:
+        return list(self._mp(X, y, tuple(M)))
+
+    def _matvec_batch(self, X, y: Tensor, v: dict[str, Tensor]) -> dict[str, Tensor]:
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ native path
+    def _init_native(self) -> None:
+        if self._NATIVE_KIND is None or self._loss_func is None:
+            return
+        structure = detect_mlp(self._model_module, self._params)
+        if structure is None or loss_kind_and_scale(self._loss_func, 1, 1) is None:
+            return
+        _hip.load()  # a GPU fp32 MLP must run natively: fail loudly if the library is absent
+        self._native = NativeMLP(structure, self._params)
+
+    @property
+    def uses_native_kernels(self) -> bool:
+        return self._native is not None
+
+    def _native_batch_args(self, idx: int, X: Tensor, y: Tensor):
+        """(loss_kind, scale, aux) of batch ``idx`` for the native kernel."""
+        N, C = X.shape[0], self._native.s.dims[-1]
+        if self._NATIVE_KIND == "ggn":
+            kind, scale = loss_kind_and_scale(self._loss_func, N, C)
+            return kind, scale, None
+        # empirical Fisher: H_n = (1/c) g_n g_n^T with g_n the UNREDUCED per-sample gradient
+        # of the loss w.r.t. the prediction (gradient_moments.py:48-87); params are fixed, so
+        # g_n is cached per batch.
+        aux = self._native_aux.get(idx)
+        if aux is None:
+            with torch.no_grad():
+                f = self._model_func(self._params, X)
+                if isinstance(self._loss_func, MSELoss):
+                    g = 2.0 * (f - y)
+                elif isinstance(self._loss_func, CrossEntropyLoss):
+                    g = f.softmax(dim=1)
+                    g[torch.arange(N, device=f.device), y] -= 1.0
+                else:
+                    g = f.sigmoid() - y
+            aux = g.contiguous().unsqueeze(1)  # [N, 1, C]
+            self._native_aux[idx] = aux
+        red = self._loss_func.reduction
+        c = 1.0 if red == "sum" else float(N if isinstance(self._loss_func, CrossEntropyLoss) else N * C)
+        return _hip.LOSS_RANK1, 1.0 / c, aux
+
+    def _matmat_native(self, M: list[Tensor]) -> list[Tensor] | None:
+        """All columns of ``M`` through the HIP kernels; None if some batch does not qualify
+        (then nothing has been written and the caller uses the autograd path)."""
+        nat = self._native
+        batches = []
+        for X, y in self._loop_over_data(desc="_matmat"):
+            Xn = nat.prepare_input(X)
+            if Xn is None or y.shape[0] != Xn.shape[0]:
+                return None
+            batches.append((Xn, y, self._get_normalization_factor(X, y)))
+        K = M[0].shape[-1]
+        # K-major contiguous copies so that every column is a parameter-shaped contiguous view
+        Vk = [m.movedim(-1, 0).contiguous().float() for m in M]
+        Ok = [torch.empty_like(v) for v in Vk]
+        if not batches:
+            for o in Ok:
+                o.zero_()
+        for k in range(K):
+            V = [v[k] for v in Vk]
+            O = [o[k] for o in Ok]
+            for bi, (Xn, y, norm) in enumerate(batches):
+                kind, scale, aux = self._native_batch_args(bi, Xn, y)
+                nat.matvec(V, O, Xn, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0, aux=aux)
+        return [o.movedim(0, -1) for o in Ok]
+
+    # ------------------------------------------------------------------ product
+    def _matmat(self, M: list[Tensor]) -> list[Tensor]:
+        if self._native is not None and all(m.is_cuda and m.dtype == torch.float32 for m in M):
+            out = self._matmat_native(M)
+            if out is not None:
+                return out
+        AM = [torch.zeros_like(m) for m in M]
+        for X, y in self._loop_over_data(desc="_matmat"):
+            norm = self._get_normalization_factor(X, y)
+            for acc, cur in zip(AM, self._matmat_batch(X, y, M)):
+                acc.add_(cur, alpha=norm)
+        return AM
+
+
+# ------------------------------------------------------------------------------------------
+# per-batch products written with torch.func
+# ------------------------------------------------------------------------------------------
+def make_ggn_vector_product(f: Callable, c: Callable) -> Callable:
+    """``(params, X, loss_args, v) -> J^T (nabla_f^2 c) J v`` for model ``f(params, X)`` and
+    criterion ``c(prediction, loss_args)`` (reference ``ggn.py:17-74``)."""
+
+    @torch.no_grad()
+    def ggn_vp(params: dict[str, Tensor], X, loss_args: tuple, v: dict[str, Tensor]) -> dict[str, Tensor]:
+        def net(p):
+            return f(p, X)
+
+        pred, Jv = jvp(net, (params,), (v,))
+        _, HJv = jvp(jacrev(lambda out: c(out, loss_args)), (pred,), (Jv,))
+        _, pull = vjp(net, params)
+        (JtHJv,) = pull(HJv)
+        return JtHJv
+
+    return ggn_vp
+
+
+def make_batch_hessian_vector_product(f: Callable, loss_func: Module) -> Callable:
+    """Forward-over-reverse Hessian-vector product ``jvp(jacrev(loss))`` (``hessian.py:66``)."""
+    c = make_functional_loss(loss_func)
+
+    @torch.no_grad()
+    def hvp(params, X, loss_args, v):
+        _, out = jvp(jacrev(lambda p: c(f(p, X), loss_args)), (params,), (v,))
+        return out
+
+    return hvp
+
+
+def make_batch_ef_vector_product(f: Callable, loss_func: Module) -> Callable:
+    """Empirical Fisher as the GGN of ``0.5/c sum_n <f_n, c g_n>^2`` on outputs flattened to
+    ``[(batch ...), C]`` (``gradient_moments.py:15-87``)."""
+    c = make_functional_loss(loss_func)
+
+    def f_flat(params, X):
+        out = f(params, X)
+        return out.movedim(1, -1).flatten(0, -2) if isinstance(loss_func, CrossEntropyLoss) else out.flatten(0, -2)
+
+    def c_flat(out_flat, loss_args):
+        (y,) = loss_args
+        y_flat = y.flatten() if isinstance(loss_func, CrossEntropyLoss) else y.flatten(0, -2)
+        return c(out_flat, (y_flat,))
+
+    c_grad = grad(c_flat, argnums=0)
+
+    def pseudo(out_flat, loss_args):
+        g = c_grad(out_flat.detach(), loss_args)
+        terms, C = out_flat.shape
+        red = {"mean": float(terms if isinstance(loss_func, CrossEntropyLoss) else terms * C), "sum": 1.0}[
+            loss_func.reduction
+        ]
+        ip = (out_flat * (g * red)).flatten(1).sum(1)
+        return 0.5 / red * (ip**2).sum()
+
+    return make_ggn_vector_product(f_flat, pseudo)
+
+
+def make_batch_ggn_mc_vector_product(f: Callable, loss_func: Module, mc_samples: int) -> Callable:
+    """MC-GGN: GGN of ``0.5/c sum_{n,k} <g'_nk, f_n>^2`` with would-be gradients ``g'`` drawn
+    from the model's likelihood by the global RNG (``ggn.py:100-168``)."""
+    sampler = vmap(make_grad_output_fn(loss_func, FisherType.MC, mc_samples), (0, 0), randomness="different")
+
+    def pseudo(pred, loss_args):
+        (y,) = loss_args
+        g = sampler(pred.detach(), y)  # [batch, mc, *out]
+        ip = (g * pred.unsqueeze(1)).flatten(2).sum(2)
+        red = {"mean": float(pred.shape[0]), "sum": 1.0}[loss_func.reduction]
+        return 0.5 / red * (ip**2).sum()
+
+    return make_ggn_vector_product(f, pseudo)
+
+
+# ------------------------------------------------------------------------------------------
+# operators
+# ------------------------------------------------------------------------------------------
+class HessianLinearOperator(CurvatureLinearOperator):
+    """Hessian of the empirical risk, ``c sum_n nabla^2_theta l(f(x_n), y_n)``."""
+
+    SELF_ADJOINT: bool = True
+
+    def _init_mp(self) -> None:
+        self._vp = make_batch_hessian_vector_product(self._model_func, self._loss_func)
+        super()._init_mp()
+
+    def _matvec_batch(self, X, y, v):
+        return self._vp(self._params, X, (y,), v)
+
+
+class GGNLinearOperator(CurvatureLinearOperator):
+    """Generalized Gauss-Newton matrix ``c sum_n J_n^T (nabla_f^2 l_n) J_n``; with
+    ``mc_samples > 0`` the loss Hessian is replaced by a Monte-Carlo estimate (seeded per
+    product, fixed data order required)."""
+
+    SELF_ADJOINT: bool = True
+    MC_SUPPORTED_LOSSES = (MSELoss, CrossEntropyLoss, BCEWithLogitsLoss)
+    _NATIVE_KIND = "ggn"
+
+    def __init__(
+        self,
+        model_func,
+        loss_func,
+        params: dict[str, Tensor],
+        data,
+        progressbar: bool = False,
+        check_deterministic: bool = True,
+        num_data: int | None = None,
+        batch_size_fn=None,
+        mc_samples: int = 0,
+        seed: int = 2147483647,
+    ):
+        self._mc_samples = mc_samples
+        if mc_samples > 0:
+            if not isinstance(loss_func, self.MC_SUPPORTED_LOSSES):
+                raise NotImplementedError(
+                    f"MC-GGN requires loss in {self.MC_SUPPORTED_LOSSES}. Got: {loss_func}."
+                )
+            self.FIXED_DATA_ORDER = True
+            self._seed = seed
+            self._NATIVE_KIND = None  # sampled curvature: autograd path (RNG parity with torch)
+        super().__init__(
+            model_func, loss_func, params, data, progressbar=progressbar,
+            check_deterministic=check_deterministic, num_data=num_data, batch_size_fn=batch_size_fn,
+        )
+
+    def _init_mp(self) -> None:
+        if self._mc_samples > 0:
+            self._vp = make_batch_ggn_mc_vector_product(self._model_func, self._loss_func, self._mc_samples)
+        else:
+            self._vp = make_ggn_vector_product(self._model_func, make_functional_loss(self._loss_func))
+        super()._init_mp()
+
+    def _matmat(self, M):
+        if self._mc_samples > 0:
+            with torch.random.fork_rng():
+                torch.manual_seed(self._seed)
+                return super()._matmat(M)
+        return super()._matmat(M)
+
+    def _matvec_batch(self, X, y, v):
+        return self._vp(self._params, X, (y,), v)
+
+
+class EFLinearOperator(CurvatureLinearOperator):
+    """Uncentered gradient covariance ('empirical Fisher'), ``c sum_n g_n g_n^T``."""
+
+    SELF_ADJOINT: bool = True
+    SUPPORTED_LOSSES = (MSELoss, CrossEntropyLoss, BCEWithLogitsLoss)
+    _NATIVE_KIND = "ef"
+
+    def _init_mp(self) -> None:
+        if not isinstance(self._loss_func, self.SUPPORTED_LOSSES):
+            raise NotImplementedError(f"Loss must be one of {self.SUPPORTED_LOSSES}. Got: {self._loss_func}.")
+        self._vp = make_batch_ef_vector_product(self._model_func, self._loss_func)
+        super()._init_mp()
+
+    def _matvec_batch(self, X, y, v):
+        return self._vp(self._params, X, (y,), v)
+
+
+__all__ = [
+    "CurvatureLinearOperator", "HessianLinearOperator", "GGNLinearOperator", "EFLinearOperator",
+    "make_ggn_vector_product",
+]

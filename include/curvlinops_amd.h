@@ -63,6 +63,18 @@ int clo_gemm_f32(int M, int N, int K, float alpha,
 /* Suggested split-K factor for a (M,N,K,batch) problem (1 = none). */
 int clo_gemm_suggest_splitk(int M, int N, int K, int batch);
 
+/* EKFAC eigenvalue correction (computers/ekfac_hooks.py:206-236, per-example-gradient
+ * strategy without materialising the [batch, d_out, d_in] tensor):
+ *   C[m][n] = beta*C[m][n] + alpha * sum_b ( sum_k A_b(m,k) B_b(k,n) )^2
+ * Operand addressing as clo_gemm_f32.  `splits` partitions the batch range over grid.y
+ * (`ws`: splits*M*N floats when splits > 1). */
+int clo_gemm_sqsum_f32(int M, int N, int K, float alpha,
+                       const float *A, long sa_m, long sa_k, long sa_b,
+                       const float *B, long sb_k, long sb_n, long sb_b,
+                       float beta, float *C, long ldc, int batch, int splits, float *ws,
+                       void *stream);
+int clo_gemm_sqsum_suggest_splits(int M, int N, int batch);
+
 /* ------------------------------------------------------------------------- *
  * KFAC factor accumulation: C[d][d] = beta*C + alpha * X^T X for row-major
  * X[rows][ldx] (first d columns used).  If ones_col != 0 the matrix is treated
@@ -90,7 +102,9 @@ int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, lon
 int clo_mlp_fwd_jvp_layer(const float *W, const float *b, const float *VW, const float *Vb,
                           const float *a_in, const float *da_in,
                           float *a_out, float *da_out, float *dphi_out,
-                          int N, int d_in, int d_out, int act, void *stream);
+                          int N, int d_in, int d_out, int act, float *ws, void *stream);
+/* `ws`: clo_mlp_fwd_ws_floats(N, d_in, d_out) floats (split-K slabs of narrow layers). */
+long clo_mlp_fwd_ws_floats(int N, int d_in, int d_out);
 
 /* Output-space curvature product for one mini-batch (jvp(jacrev(c)) in
  * ggn.py:64-65):  w[n][:] = scale * H(f[n], .) u[n][:], then multiplied

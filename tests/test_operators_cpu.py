@@ -1,0 +1,290 @@
+"""Host-side (CPU, float64) tests of the drop-in boundary against vectors produced by the
+reference: operator algebra and formats, curvature operators on the autograd path, Kronecker /
+eigendecomposed / block-diagonal operators, canonical converters, KFAC / EKFAC, trace estimators.
+Tolerance: float64 vs float64 reference, 1e-9 relative (reference tests use rtol 1e-5)."""
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import curvlinops_amd as C
+from conftest import load_golden, mlp_case_tensors
+from helpers import KFAC_MODELS, LOSS, build_mlp, golden_data, load_into, rel_err
+
+F64 = torch.float64
+CPU = torch.device("cpu")
+TOL = 1e-9
+
+
+def t64(x):
+    return torch.as_tensor(np.asarray(x), dtype=F64)
+
+
+# ----------------------------------------------------------------------------- curvature ops
+def _mlp_operator(rec, cls, **kw):
+    dims, acts, bias, loss, red, Ws, bs, _ = mlp_case_tensors(rec)
+    model = build_mlp(dims, acts, bias)
+    params = load_into(model, rec, F64, CPU)
+    data = golden_data(rec, F64, CPU, loss)
+    return cls(model, LOSS[loss](reduction=red), params, data, **kw), params
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("mlp_curvature")))
+@pytest.mark.parametrize("name,cls", [("ggn", C.GGNLinearOperator), ("hessian", C.HessianLinearOperator),
+                                      ("ef", C.EFLinearOperator)])
+def test_curvature_operators_match_reference(golden_mlp, case, name, cls):
+    rec = golden_mlp[case]
+    if case.startswith("c1") and name != "hessian":
+        pytest.skip("C1 is the Hessian plumbing case")
+    op, params = _mlp_operator(rec, cls, check_deterministic=not case.startswith("c1"))
+    assert not op.uses_native_kernels
+    v, V = t64(rec["v"]), t64(rec["V"])
+    assert rel_err(op @ v, rec[f"{name}_v"]) < TOL
+    assert rel_err(op @ V, rec[f"{name}_V"]) < TOL
+    if case.startswith("c1"):
+        return
+    # left multiplication (self-adjoint), tensor-list format, SciPy export
+    assert rel_err(v @ op, rec[f"{name}_v"]) < TOL
+    assert rel_err(V.T @ op, rec[f"{name}_V"].T) < TOL
+    vl = [p.reshape(s) for p, s in zip(v.split([p.numel() for p in params.values()]), [p.shape for p in params.values()])]
+    out = op @ vl
+    assert isinstance(out, list) and [o.shape for o in out] == [p.shape for p in params.values()]
+    assert rel_err(torch.cat([o.flatten() for o in out]), rec[f"{name}_v"]) < TOL
+    sp = op.to_scipy()
+    assert sp.shape == op.shape and sp.dtype == np.float64
+    assert rel_err(sp @ rec["v"], rec[f"{name}_v"]) < TOL
+    assert rel_err(sp.rmatvec(rec["v"]), rec[f"{name}_v"]) < TOL
+
+
+def test_operator_algebra_and_errors(golden_mlp):
+    rec = golden_mlp["relu_mse_mean"]
+    G, _ = _mlp_operator(rec, C.GGNLinearOperator, check_deterministic=False)
+    H, _ = _mlp_operator(rec, C.HessianLinearOperator, check_deterministic=False)
+    v = t64(rec["v"])
+    Gv, Hv = t64(rec["ggn_v"]), t64(rec["hessian_v"])
+    assert rel_err((G + H) @ v, Gv + Hv) < TOL
+    assert rel_err((G - H) @ v, Gv - Hv) < TOL
+    assert rel_err((2.5 * G) @ v, 2.5 * Gv) < TOL
+    assert rel_err((G / 4) @ v, Gv / 4) < TOL
+    chain = G @ H
+    assert len(chain) == 2 and rel_err(chain @ v, G @ Hv) < TOL
+    assert len(chain @ G) == 3 and len(G @ chain) == 3
+    assert rel_err(chain.adjoint() @ v, H @ Gv) < TOL
+    D = G.shape[0]
+    with pytest.raises(ValueError):
+        G @ torch.zeros(D + 1, dtype=F64)
+    with pytest.raises(ValueError):
+        G @ torch.zeros(D, 2, 2, dtype=F64)
+    with pytest.raises(ValueError):
+        G @ [torch.zeros(3, dtype=F64)]
+    with pytest.raises(ValueError):
+        G @ "nope"
+    with pytest.raises(ValueError):
+        C.PyTorchLinearOperator([], [(1,)])
+    with pytest.raises(TypeError):
+        C.GGNLinearOperator(nn.Linear(2, 2), nn.MSELoss(), list(nn.Linear(2, 2).parameters()),
+                            [(torch.zeros(1, 2), torch.zeros(1, 2))])
+
+
+def test_determinism_guard_detects_dropout():
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(5, 5), nn.Dropout(0.5), nn.Linear(5, 2)).double()
+    data = [(torch.rand(8, 5, dtype=F64), torch.rand(8, 2, dtype=F64))]
+    with pytest.raises(RuntimeError):
+        C.GGNLinearOperator(model, nn.MSELoss(), dict(model.named_parameters()), data)
+
+
+def test_mc_ggn_converges_in_expectation():
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(4, 5), nn.Tanh(), nn.Linear(5, 3)).double()
+    params = dict(model.named_parameters())
+    data = [(torch.rand(6, 4, dtype=F64), torch.randint(0, 3, (6,))), (torch.rand(3, 4, dtype=F64), torch.randint(0, 3, (3,)))]
+    exact = C.GGNLinearOperator(model, nn.CrossEntropyLoss(), params, data)
+    mc = C.GGNLinearOperator(model, nn.CrossEntropyLoss(), params, data, mc_samples=2000)
+    v = torch.rand(exact.shape[1], dtype=F64)
+    assert torch.allclose(mc @ v, mc @ v)  # seeded -> repeatable
+    assert rel_err(mc @ v, (exact @ v).numpy()) < 0.1
+
+
+# ----------------------------------------------------------------------------- structured ops
+@pytest.mark.parametrize("name", ["rect", "sq", "one", "three"])
+def test_kronecker_operator(golden_linops, name):
+    rec = golden_linops[f"kron_{name}"]
+    fs = [t64(rec[f"factor{i}"]) for i in range(sum(k.startswith("factor") for k in rec))]
+    K = C.KroneckerProductLinearOperator(*fs)
+    X, Y = t64(rec["X"]), t64(rec["Y"])
+    assert rel_err(K @ X, rec["KX"]) < TOL
+    assert rel_err(K.adjoint() @ Y, rec["KTY"]) < TOL
+    assert rel_err(Y.T @ K, rec["KTY"].T) < TOL
+    assert rel_err(K @ X[:, 0], rec["KX"][:, 0]) < TOL
+    if name in ("sq", "one"):
+        for prop in ("trace", "det", "logdet"):
+            assert rel_err(getattr(K, prop)(), rec[prop]) < TOL
+        assert rel_err(K.frobenius_norm(), rec["fro"]) < TOL
+        assert rel_err(K.inverse(damping=1e-2) @ X, rec["inv_plain_X"]) < 1e-8
+        assert rel_err(K.inverse(damping=1e-2, use_exact_damping=True) @ X, rec["inv_exact_X"]) < 1e-8
+        if "inv_heur_X" in rec:
+            got = K.inverse(damping=1e-2, use_heuristic_damping=True, min_damping=1e-3) @ X
+            assert rel_err(got, rec["inv_heur_X"]) < 1e-8
+        with pytest.raises(ValueError):
+            K.inverse(use_heuristic_damping=True, use_exact_damping=True)
+    else:
+        with pytest.raises(RuntimeError):
+            K.trace()
+    with pytest.raises(ValueError):
+        C.KroneckerProductLinearOperator()
+    with pytest.raises(ValueError):
+        C.KroneckerProductLinearOperator(torch.zeros(3))
+    with pytest.raises(ValueError):
+        K[0] = torch.zeros(1, 1, dtype=F64)
+
+
+def test_eigh_blockdiag_canonical(golden_linops):
+    rec = golden_linops["eigh"]
+    E = C.EighDecomposedLinearOperator(t64(rec["lam"]), C.KroneckerProductLinearOperator(t64(rec["Q1"]), t64(rec["Q2"])))
+    X = t64(rec["X"])
+    assert rel_err(E @ X, rec["EX"]) < TOL
+    assert rel_err(E.inverse(damping=0.05) @ X, rec["invEX"]) < TOL
+    for prop, key in (("trace", "trace"), ("logdet", "logdet"), ("frobenius_norm", "fro"), ("det", "det")):
+        assert rel_err(getattr(E, prop)(), rec[key]) < TOL
+    dense = torch.kron(t64(rec["Q1"]), t64(rec["Q2"]))
+    E2 = C.EighDecomposedLinearOperator(t64(rec["lam"]), dense)
+    assert rel_err(E2 @ X, rec["EX"]) < TOL
+    with pytest.raises(ValueError):
+        C.EighDecomposedLinearOperator(t64(rec["lam"])[:3], dense)
+
+    rec = golden_linops["bd"]
+    BD = C.BlockDiagonalLinearOperator([
+        C.KroneckerProductLinearOperator(t64(rec["A1"]), t64(rec["A2"])),
+        C.KroneckerProductLinearOperator(t64(rec["B1"])),
+    ])
+    assert rel_err(BD @ t64(rec["X"]), rec["BDX"]) < TOL
+    assert rel_err(BD.trace(), rec["trace"]) < TOL and rel_err(BD.frobenius_norm(), rec["fro"]) < TOL
+    assert len(BD) == 2 and BD[1].shape == (5, 5)
+
+    rec = golden_linops["canon"]
+    shapes = {"l2.bias": torch.Size([4]), "l1.weight": torch.Size([3, 5]), "c.weight": torch.Size([2, 3, 2, 2]),
+              "l2.weight": torch.Size([4, 3]), "c.bias": torch.Size([2]), "l1.bias": torch.Size([3])}
+    groups = [{"W": "l1.weight", "b": "l1.bias"}, {"W": "c.weight", "b": "c.bias"}, {"W": "l2.weight"}, {"b": "l2.bias"}]
+    PT = C.ToCanonicalLinearOperator(shapes, groups, CPU, F64)
+    X = t64(rec["X"])
+    assert rel_err(PT @ X, rec["PTX"]) < TOL
+    assert rel_err(PT.adjoint() @ (PT @ X), rec["PPTX"]) < TOL
+    assert rel_err(PT.adjoint() @ (PT @ X), rec["X"]) < TOL  # P P^T = I
+
+
+# ----------------------------------------------------------------------------- KFAC / EKFAC
+KFAC_CASES = sorted(load_golden("kfac"))
+
+
+def _kfac_setup(rec, case):
+    loss, red = str(rec["loss"]), str(rec["reduction"])
+    model = KFAC_MODELS[case]()
+    params = load_into(model, rec, F64, CPU)
+    data = golden_data(rec, F64, CPU, loss)
+    return model, LOSS[loss](reduction=red), params, data
+
+
+@pytest.mark.parametrize("case", KFAC_CASES)
+def test_kfac_matches_reference(case):
+    rec = load_golden("kfac")[case]
+    model, loss_func, params, data = _kfac_setup(rec, case)
+    V = t64(rec["V"])
+    tags = sorted({k.split("/")[0] for k in rec if "|" in k and not k.startswith("ekfac")})
+    assert tags
+    for tag in tags:
+        fisher, approx, sep = tag.split("|")
+        K = C.KFACLinearOperator(model, loss_func, params, data, fisher_type=fisher, kfac_approx=approx,
+                                 separate_weight_and_bias=sep == "sep", check_deterministic=False)
+        _, Kc, _ = K
+        for b, block in enumerate(Kc):
+            for f, fac in enumerate(block):
+                assert rel_err(fac, rec[f"{tag}/block{b}_factor{f}"]) < TOL, (case, tag, b, f)
+        assert rel_err(K @ V, rec[f"{tag}/KV"]) < TOL
+        assert rel_err(K.trace(), rec[f"{tag}/trace"]) < TOL
+        assert rel_err(K.frobenius_norm(), rec[f"{tag}/fro"]) < TOL
+        assert rel_err(K.inverse(damping=1e-2) @ V, rec[f"{tag}/inv_plain"]) < 1e-7
+        assert rel_err(K.inverse(damping=1e-2, use_exact_damping=True) @ V, rec[f"{tag}/inv_exact"]) < 1e-7
+        if f"{tag}/inv_heur" in rec:
+            got = K.inverse(damping=1e-2, use_heuristic_damping=True, min_damping=1e-4) @ V
+            assert rel_err(got, rec[f"{tag}/inv_heur"]) < 1e-7
+    # computing factors must leave .grad untouched and restore the module's parameters
+    assert all(p.grad is None for p in model.parameters())
+
+
+@pytest.mark.parametrize("case", [c for c in KFAC_CASES if not c.startswith("seq")])
+def test_ekfac_matches_reference(case):
+    rec = load_golden("kfac")[case]
+    model, loss_func, params, data = _kfac_setup(rec, case)
+    V = t64(rec["V"])
+    for tag in sorted({k.split("/")[0] for k in rec if k.startswith("ekfac")}):
+        _, fisher, sep = tag.split("|")
+        E = C.EKFACLinearOperator(model, loss_func, params, data, fisher_type=fisher,
+                                  separate_weight_and_bias=sep == "sep", check_deterministic=False)
+        assert rel_err(E.trace(), rec[f"{tag}/trace"]) < 1e-8
+        assert rel_err(E @ V, rec[f"{tag}/EV"]) < 1e-6, (case, tag)
+        assert rel_err(E.inverse(damping=1e-2) @ V, rec[f"{tag}/invEV"]) < 1e-6
+
+
+def test_kfac_argument_validation():
+    model = nn.Sequential(nn.Linear(3, 2)).double()
+    params = dict(model.named_parameters())
+    data = [(torch.rand(4, 3, dtype=F64), torch.rand(4, 2, dtype=F64))]
+    with pytest.raises(ValueError):
+        C.KFACLinearOperator(model, nn.MSELoss(), params, data, backend="nope")
+    with pytest.raises(ValueError):
+        C.KFACLinearOperator(model, nn.MSELoss(), params, data, fisher_type="bogus")
+    with pytest.raises(ValueError):
+        C.KFACLinearOperator(model, nn.MSELoss(), params, data, fisher_type="type-2", mc_samples=3)
+    with pytest.raises(ValueError):
+        C.KFACLinearOperator(model, nn.L1Loss(), params, data)
+    with pytest.raises(ValueError):
+        C.KFACLinearOperator(lambda p, x: x, nn.MSELoss(), params, data)
+    assert "mc" in C.FisherType and "bogus" not in C.FisherType and "reduce" in C.KFACType
+
+
+def test_kfac_mc_converges_to_type2():
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(4, 5), nn.ReLU(), nn.Linear(5, 3)).double()
+    params = dict(model.named_parameters())
+    data = [(torch.rand(10, 4, dtype=F64), torch.randint(0, 3, (10,)))]
+    exact = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, data, fisher_type="type-2")
+    mc = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, data, fisher_type="mc", mc_samples=3000)
+    v = torch.rand(exact.shape[1], dtype=F64)
+    assert rel_err(mc @ v, (exact @ v).numpy()) < 0.1
+
+
+# ----------------------------------------------------------------------------- trace estimators
+def test_trace_estimators_with_injected_probes():
+    rec = load_golden("trace")["t"]
+    A = t64(rec["A"])
+
+    class Dense(C.PyTorchLinearOperator):
+        SELF_ADJOINT = True
+
+        def __init__(self, M):
+            super().__init__([(M.shape[1],)], [(M.shape[0],)])
+            self.M = M
+
+        def _matmat(self, X):
+            return [self.M @ X[0]]
+
+        device = property(lambda self: self.M.device)
+        dtype = property(lambda self: self.M.dtype)
+
+    op = Dense(A)
+    for dist in ("rademacher", "normal"):
+        pool = t64(rec[f"{dist}/pool"])
+        assert rel_err(C.hutchinson_trace(op, 12, dist, probes=pool[:, :12]), rec[f"{dist}/hutch"]) < TOL
+        got = C.hutchpp_trace(op, 24, dist, probes=(pool[:, :8], pool[:, 8:16]))
+        assert rel_err(got, rec[f"{dist}/hutchpp"]) < TOL
+    torch.manual_seed(0)
+    est = C.hutchinson_trace(op, 29)
+    assert abs(est - A.trace()) / A.trace() < 0.5
+    with pytest.raises(ValueError):
+        C.hutchpp_trace(op, 10)
+    with pytest.raises(ValueError):
+        C.hutchinson_trace(op, 30)
+    with pytest.raises(ValueError):
+        C.hutchinson_trace(op, 5, "cauchy")
