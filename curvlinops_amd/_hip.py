@@ -25,6 +25,8 @@ _PF = c_void_p  # float* passed as integer address
 _SIGNATURES = {
     "clo_version": (c_int, []),
     "clo_last_error": (c_char_p, []),
+    "clo_prof_enable": (c_int, [c_int]),
+    "clo_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_long), POINTER(ctypes.c_double)]),
     "clo_gemm_f32": (
         c_int,
         [c_int, c_int, c_int, c_float, _PF, c_long, c_long, c_long, _PF, c_long, c_long, c_long,
@@ -99,6 +101,20 @@ def load() -> ctypes.CDLL:
 def has(symbol: str) -> bool:
     """Whether this build of the library exports ``symbol``."""
     return symbol in _SIGNATURES and hasattr(load(), symbol)
+
+
+def prof_enable(on: bool) -> None:
+    _check(load().clo_prof_enable(int(on)), "clo_prof_enable")
+
+
+def prof_collect() -> dict[str, dict[str, float]]:
+    """Per-kernel-family totals recorded since the last call: ms, launches, algorithmic bytes."""
+    ms = (ctypes.c_double * 8)()
+    cnt = (c_long * 8)()
+    by = (ctypes.c_double * 8)()
+    _check(load().clo_prof_collect(ms, cnt, by), "clo_prof_collect")
+    names = ["fwd_jvp", "loss_hessian", "bwd_fused", "finish", "gemm", "other", "t6", "t7"]
+    return {n: {"ms": ms[i], "launches": int(cnt[i]), "alg_bytes": by[i]} for i, n in enumerate(names) if cnt[i]}
 
 
 def _check(rc: int, what: str) -> None:

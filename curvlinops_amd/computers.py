@@ -195,11 +195,18 @@ class HipKFACComputer(EmpiricalRiskMixin):
         separate_weight_and_bias: bool = True,
         num_data: int | None = None,
         batch_size_fn: Callable[[MutableMapping | Tensor], int] | None = None,
+        distributed: bool = False,
     ):
+        """``distributed=True``: ``data`` is this rank's shard, ``num_data`` the GLOBAL count; the
+        factors (and EKFAC's corrected eigenvalues) are summed over ranks with one packed
+        all-reduce each (``curvlinops_amd.dist``).  All other arguments as in the reference."""
         if not isinstance(model_func, Module):
             raise ValueError(
                 "The hooks-based backends require model_func to be an nn.Module."
             )
+        if distributed and num_data is None:
+            raise ValueError("distributed=True needs the global num_data.")
+        self._distributed = distributed
         if not isinstance(loss_func, self._SUPPORTED_LOSSES):
             raise ValueError(f"Invalid loss: {loss_func}. Supported: {self._SUPPORTED_LOSSES}.")
         if fisher_type not in self._SUPPORTED_FISHER_TYPE:
@@ -286,6 +293,10 @@ class HipKFACComputer(EmpiricalRiskMixin):
         finally:
             for h in handles:
                 h.remove()
+        if self._distributed:
+            from curvlinops_amd.dist import allreduce_tensors_
+
+            allreduce_tensors_([*A.values(), *G.values()])
         if self._fisher_type == FisherType.FORWARD_ONLY:
             for group in mapping:
                 p = self._params[next(iter(group.values()))]
@@ -393,6 +404,10 @@ class HipEKFACComputer(HipKFACComputer):
         finally:
             for h in handles:
                 h.remove()
+        if self._distributed:
+            from curvlinops_amd.dist import allreduce_tensors_
+
+            allreduce_tensors_(list(lam.values()))
         return lam
 
     def _corr_output_hook(self, module, inputs, output, group, Qa, Qg, lam) -> None:

@@ -32,6 +32,23 @@ inline int check_hip(hipError_t e, const char *what) {
     }                                     \
   } while (0)
 
+__host__ __device__ // Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+// Tags: 0 fwd_jvp, 1 loss_hessian, 2 bwd_fused, 3 finish/reduce, 4 gemm, 5 other.
+constexpr int kProfTags = 8;
+bool prof_enabled();
+void prof_begin(int tag, double alg_bytes, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+  hipStream_t st;
+  bool on;
+  ProfScope(int tag, double alg_bytes, hipStream_t s) : st(s), on(prof_enabled()) {
+    if (on) prof_begin(tag, alg_bytes, st);
+  }
+  ~ProfScope() {
+    if (on) prof_end(st);
+  }
+};
+
 __host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

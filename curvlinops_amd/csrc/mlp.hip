@@ -645,6 +645,8 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
   if (ksplit_out) *ksplit_out = ksplit;
   dim3 grid((unsigned)cdiv(d_out, FWD_ROWS), (unsigned)ksplit), block(512);
   const size_t smem = (size_t)(has_da ? 4 : 2) * NB * KC * sizeof(float);
+  // algorithmic bytes of this launch: W (+ VW) read once
+  ProfScope prof(0, 4.0 * d_in * d_out * (has_v ? 2 : 1), st);
 #define CLO_FWD(V, HV, HD)                                                                    \
   hipLaunchKernelGGL((fwd_jvp_kernel<V, HV, HD>), grid, block, smem, st, W, b, VW, Vb, a_in,  \
                      da_in, a_out, da_out, dphi_out, part, N, d_in, d_out, act, cps)
@@ -661,7 +663,9 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
   }
 #undef CLO_FWD
   CLO_CHECK_LAUNCH("fwd_jvp_kernel");
+  if (prof.on) { prof_end(st); prof.on = false; }
   if (ksplit > 1 && !leave_partials) {
+    ProfScope pf(3, 0.0, st);
     hipLaunchKernelGGL(fwd_finish_kernel, dim3(ew_grid((long)N * d_out)), dim3(256), 0, st, part,
                        ksplit, b, Vb, a_out, (has_v || has_da) ? da_out : nullptr, dphi_out, N,
                        d_out, act);
@@ -685,6 +689,8 @@ static int bwd_pass(const float *W, const float *delta, const float *a_prev,
   const int fin = JBe == 1 ? 1 : 0;
   const bool vec = vec_ok(d_in, {W, a_prev, out_W});
   int rc = CLO_OK;
+  // algorithmic bytes: out_W written once (+ read when accumulating), W read once for delta_prev
+  ProfScope prof(2, 4.0 * d_in * d_out * ((outer ? (beta != 0.f ? 2 : 1) : 0) + (dprev ? 1 : 0)), st);
 #define CLO_BWD(V, O, D)                                                                        \
   do {                                                                                          \
     rc = set_smem(bwd_fused_kernel<V, O, D>, smem);                                             \
@@ -703,7 +709,9 @@ static int bwd_pass(const float *W, const float *delta, const float *a_prev,
   }
 #undef CLO_BWD
   CLO_CHECK_LAUNCH("bwd_fused_kernel");
+  if (prof.on) { prof_end(st); prof.on = false; }
   if (dprev && JBe > 1) {
+    ProfScope pf(3, 0.0, st);
     hipLaunchKernelGGL(bwd_finish_kernel, dim3(ew_grid((long)N * d_in)), dim3(256), 0, st, ws,
                        dphi_prev, delta_prev, N, d_in, JBe);
     CLO_CHECK_LAUNCH("bwd_finish_kernel");
@@ -726,6 +734,7 @@ static int launch_loss(int kind, const float *f, const float *aux, int aux_rank,
   a.kind = kind; a.f = f; a.aux = aux; a.aux_rank = aux_rank; a.u = u; a.dphi_last = dphi_last;
   a.w = w; a.C = C; a.scale = scale; a.part = part; a.ksplit = ksplit; a.b = b; a.Vb = Vb;
   a.f_out = f_out; a.u_out = u_out;
+  ProfScope prof(1, 0.0, st);
   hipLaunchKernelGGL(loss_hessian_kernel, dim3(N), dim3(C <= 64 ? 64 : 256), 0, st, a);
   CLO_CHECK_LAUNCH("loss_hessian_kernel");
   return CLO_OK;

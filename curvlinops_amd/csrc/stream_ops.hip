@@ -3,6 +3,8 @@
 // scaling of EighDecomposed operators) and counter-based probe packing.
 #include "clo_common.h"
 
+#include <vector>
+
 namespace clo {
 
 static thread_local char g_err[512] = "";
@@ -13,6 +15,22 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- event-based kernel timing -------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int tag; double bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<ProfRec> g_prof_pool;
+bool prof_enabled() { return g_prof_on; }
+void prof_begin(int tag, double alg_bytes, hipStream_t st) {
+  ProfRec r;
+  if (!g_prof_pool.empty()) { r = g_prof_pool.back(); g_prof_pool.pop_back(); }
+  else { hipEventCreate(&r.a); hipEventCreate(&r.b); }
+  r.tag = tag; r.bytes = alg_bytes;
+  hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+}
+void prof_end(hipStream_t st) { hipEventRecord(g_prof.back().b, st); }
 
 // Grid for a streaming kernel over n work items of `per_thread` elements: cap at ~8 blocks
 // per CU and grid-stride the rest.
@@ -139,6 +157,26 @@ __global__ void pack_probes_kernel(float *__restrict__ out, long n, uint64_t see
 using namespace clo;
 
 extern "C" int clo_version(void) { return 100; }
+
+extern "C" int clo_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return CLO_OK;
+}
+// Sum the recorded intervals per tag: ms[t], count[t], alg_bytes[t] (arrays of 8); clears them.
+extern "C" int clo_prof_collect(double *ms, long *count, double *alg_bytes) {
+  for (int t = 0; t < kProfTags; ++t) { ms[t] = 0; count[t] = 0; alg_bytes[t] = 0; }
+  for (auto &r : g_prof) {
+    int rc = check_hip(hipEventSynchronize(r.b), "hipEventSynchronize");
+    if (rc != CLO_OK) return rc;
+    float e = 0.f;
+    rc = check_hip(hipEventElapsedTime(&e, r.a, r.b), "hipEventElapsedTime");
+    if (rc != CLO_OK) return rc;
+    if (r.tag >= 0 && r.tag < kProfTags) { ms[r.tag] += e; count[r.tag] += 1; alg_bytes[r.tag] += r.bytes; }
+    g_prof_pool.push_back(r);
+  }
+  g_prof.clear();
+  return CLO_OK;
+}
 extern "C" const char *clo_last_error(void) { return g_err; }
 
 extern "C" int clo_axpby_f32(float *y, const float *x, long n, float alpha, float beta,

@@ -49,6 +49,7 @@ class KFACLinearOperator(_ChainPyTorchLinearOperator):
         num_data: int | None = None,
         batch_size_fn: Callable[[MutableMapping | Tensor], int] | None = None,
         backend: str = "hip",
+        distributed: bool = False,
     ):
         if backend not in self._BACKENDS:
             raise ValueError(f"Invalid backend: {backend!r}. Supported: {tuple(self._BACKENDS)}.")
@@ -58,7 +59,7 @@ class KFACLinearOperator(_ChainPyTorchLinearOperator):
             mc_samples=mc_samples, kfac_approx=kfac_approx,
             num_per_example_loss_terms=num_per_example_loss_terms,
             separate_weight_and_bias=separate_weight_and_bias, num_data=num_data,
-            batch_size_fn=batch_size_fn,
+            batch_size_fn=batch_size_fn, distributed=distributed,
         )
         K, mapping = self._compute_canonical_op(computer)
         P, PT = self._build_converters(computer, mapping)

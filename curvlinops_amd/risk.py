@@ -113,18 +113,19 @@ class EmpiricalRiskMixin:
             return num_data, num_per_example_loss_terms
         n_acc, t_acc = 0, 0
         for X, y in self._loop_over_data(desc="data_statistics"):
-            if need_n:
-                n_acc += self._batch_size_fn(X)
+            n_acc += self._batch_size_fn(X)
             if need_terms:
                 t_acc += y.numel() if isinstance(self._loss_func, CrossEntropyLoss) else y.shape[:-1].numel()
         N = n_acc if need_n else num_data
         if need_terms:
-            if t_acc % N != 0:
+            # terms per datum from the data actually seen (a rank's shard when num_data is the
+            # global count of a sharded data set)
+            if n_acc == 0 or t_acc % n_acc != 0:
                 raise ValueError(
                     "The number of loss terms must be divisible by the number of data points; "
-                    f"num_loss_terms={t_acc}, N_data={N}."
+                    f"num_loss_terms={t_acc}, N_data={n_acc}."
                 )
-            num_per_example_loss_terms = t_acc // N
+            num_per_example_loss_terms = t_acc // n_acc
         return N, num_per_example_loss_terms
 
     # ------------------------------------------------------------------ loss / gradient sweeps

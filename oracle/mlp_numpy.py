@@ -43,7 +43,7 @@ def _act(name: str, z: np.ndarray):
 
 def forward(Ws, bs, acts, X):
     """Forward pass; returns lists (a_0..a_L, phi'_1..L, phi''_1..L)."""
-    a = [np.asarray(X, dtype=np.float64)]
+    a = [np.asarray(X)]  # dtype follows the caller (float64 in tests, float32 for CPU timing)
     d1, d2 = [], []
     for W, b, act in zip(Ws, bs, acts):
         z = a[-1] @ W.T + (0 if b is None else b)
@@ -190,23 +190,23 @@ _BATCH_FNS = {
 }
 
 
-def matvec(kind, Ws, bs, acts, data, loss, reduction, vWs, vbs, num_data=None):
+def matvec(kind, Ws, bs, acts, data, loss, reduction, vWs, vbs, num_data=None, dtype=np.float64):
     """Whole-data-set product: sum over mini-batches with the reference's normalisation
     (``_torch_base.py:937-942``: factor 1 for 'sum', B_b / N_data for 'mean')."""
-    Ws = [np.asarray(W, dtype=np.float64) for W in Ws]
-    bs = [None if b is None else np.asarray(b, dtype=np.float64) for b in bs]
-    vWs = [np.asarray(v, dtype=np.float64) for v in vWs]
-    vbs = [None if v is None else np.asarray(v, dtype=np.float64) for v in vbs]
+    Ws = [np.asarray(W, dtype=dtype) for W in Ws]
+    bs = [None if b is None else np.asarray(b, dtype=dtype) for b in bs]
+    vWs = [np.asarray(v, dtype=dtype) for v in vWs]
+    vbs = [None if v is None else np.asarray(v, dtype=dtype) for v in vbs]
     if num_data is None:
         num_data = sum(X.shape[0] for X, _ in data)
     oW = [np.zeros_like(W) for W in Ws]
     ob = [None if b is None else np.zeros_like(b) for b in bs]
     fn = _BATCH_FNS[kind]
     for X, y in data:
-        X = np.asarray(X, dtype=np.float64)
+        X = np.asarray(X, dtype=dtype)
         y = np.asarray(y)
         if loss != "ce":
-            y = y.astype(np.float64)
+            y = y.astype(dtype)
         norm = 1.0 if reduction == "sum" else X.shape[0] / num_data
         gW, gb = fn(Ws, bs, acts, X, y, loss, reduction, vWs, vbs)
         for l in range(len(Ws)):

@@ -1,0 +1,70 @@
+"""world_size-2 gloo tests of the data-parallel path on CPU: R-rank results (local shard +
+packed all-reduce) must equal the single-process result on the same data."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import curvlinops_amd as C
+        from curvlinops_amd.dist import AllReducedLinearOperator, shard_batches, shard_rows
+
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(6, 7), nn.Tanh(), nn.Linear(7, 3)).double()
+        params = dict(model.named_parameters())
+        data = [(torch.rand(b, 6, dtype=torch.float64), torch.randint(0, 3, (b,))) for b in (5, 3, 8, 4)]
+        N = sum(x.shape[0] for x, _ in data)
+        loss = nn.CrossEntropyLoss()
+        v = torch.rand(sum(p.numel() for p in params.values()), 2, dtype=torch.float64)
+
+        full = C.GGNLinearOperator(model, loss, params, data)
+        mine = shard_batches(data)
+        local = C.GGNLinearOperator(model, loss, params, mine, num_data=N, check_deterministic=False)
+        ok = torch.allclose(AllReducedLinearOperator(local) @ v, full @ v, rtol=1e-10, atol=1e-12)
+
+        # one mini-batch split by rows
+        X, y = torch.cat([x for x, _ in data]), torch.cat([t for _, t in data])
+        Xr, yr = shard_rows(X, y)
+        local = C.HessianLinearOperator(model, loss, params, [(Xr, yr)], num_data=N, check_deterministic=False)
+        fullH = C.HessianLinearOperator(model, loss, params, [(X, y)])
+        ok &= torch.allclose(AllReducedLinearOperator(local) @ v, fullH @ v, rtol=1e-10, atol=1e-12)
+
+        for cls in (C.KFACLinearOperator, C.EKFACLinearOperator):
+            K1 = cls(model, loss, params, data, fisher_type="type-2", check_deterministic=False)
+            KR = cls(model, loss, params, mine, fisher_type="type-2", num_data=N, check_deterministic=False,
+                     distributed=True)
+            ok &= torch.allclose(KR @ v, K1 @ v, rtol=1e-8, atol=1e-10)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}

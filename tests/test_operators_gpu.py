@@ -1,0 +1,268 @@
+"""GPU parity tests through the public operator API (fp32 on the MI355X) against (a) golden
+vectors produced by the reference in float64 and (b) size-independent properties at the
+BASELINE.json sizes.  Tolerances: products and factors
+max|y - y_ref| / max|y_ref| <= 1e-4, damped inverses <= 1e-3."""
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import curvlinops_amd as C
+from conftest import load_golden, mlp_case_tensors
+from helpers import KFAC_MODELS, LOSS, build_mlp, golden_data, load_into, rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32 = torch.float32
+TOL, TOL_INV = 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from curvlinops_amd import _hip
+
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+def g32(x, dev):
+    return torch.as_tensor(np.asarray(x), dtype=F32).to(dev)
+
+
+# ----------------------------------------------------------------------------- curvature ops
+@pytest.mark.parametrize("case", sorted(load_golden("mlp_curvature")))
+@pytest.mark.parametrize("name,cls,native", [("ggn", C.GGNLinearOperator, True), ("ef", C.EFLinearOperator, True),
+                                             ("hessian", C.HessianLinearOperator, False)])
+def test_curvature_operators_gpu(dev, golden_mlp, case, name, cls, native):
+    rec = golden_mlp[case]
+    dims, acts, bias, loss, red, *_ = mlp_case_tensors(rec)
+    model = build_mlp(dims, acts, bias)
+    params = load_into(model, rec, F32, dev)
+    data = golden_data(rec, F32, dev, loss)
+    op = cls(model, LOSS[loss](reduction=red), params, data)
+    assert op.uses_native_kernels == native
+    v, V = g32(rec["v"], dev), g32(rec["V"], dev)
+    assert rel_err(op @ v, rec[f"{name}_v"]) < TOL
+    assert rel_err(op @ V, rec[f"{name}_V"]) < TOL
+    assert rel_err(V.T.contiguous() @ op, rec[f"{name}_V"].T) < TOL
+    shapes = [p.shape for p in params.values()]
+    vl = [c.reshape(s) for c, s in zip(v.split([s.numel() for s in shapes]), shapes)]
+    out = op @ vl
+    assert rel_err(torch.cat([o.flatten() for o in out]), rec[f"{name}_v"]) < TOL
+    assert rel_err(op.to_scipy() @ rec["v"], rec[f"{name}_v"]) < TOL
+
+
+def test_native_matches_autograd_path_on_gpu(dev):
+    """Same operator, both execution paths, same device and dtype."""
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(300, 500), nn.ReLU(), nn.Linear(500, 260), nn.Tanh(), nn.Linear(260, 12)).to(dev)
+    params = dict(model.named_parameters())
+    data = [(torch.rand(8, 300, device=dev), torch.randint(0, 12, (8,), device=dev)),
+            (torch.rand(5, 300, device=dev), torch.randint(0, 12, (5,), device=dev)),
+            (torch.rand(40, 300, device=dev), torch.randint(0, 12, (40,), device=dev))]
+    for cls in (C.GGNLinearOperator, C.EFLinearOperator):
+        nat = cls(model, nn.CrossEntropyLoss(), params, data, check_deterministic=False)
+        assert nat.uses_native_kernels
+        ref = cls(model, nn.CrossEntropyLoss(), params, data, check_deterministic=False)
+        ref._native = None
+        V = torch.rand(nat.shape[1], 3, device=dev)
+        a, b = nat @ V, ref @ V
+        assert rel_err(a, b.double().cpu().numpy()) < 2e-4
+
+
+class TestC2FullSize:
+    """BASELINE.json configs[1]: MLP 1024-2688-2688-10 (D = 10 010 122), MSE, GGN."""
+
+    @pytest.fixture(scope="class")
+    def setup(self):
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(1024, 2688), nn.ReLU(), nn.Linear(2688, 2688), nn.ReLU(), nn.Linear(2688, 10)).to(dev)
+        params = dict(model.named_parameters())
+        X, y = torch.rand(24, 1024, device=dev), torch.rand(24, 10, device=dev)
+        return dev, model, params, X, y
+
+    def test_shape_and_native(self, setup):
+        dev, model, params, X, y = setup
+        G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X[:8], y[:8])], check_deterministic=False)
+        assert G.shape == (10_010_122, 10_010_122) and G.uses_native_kernels
+
+    def test_linearity_symmetry_psd(self, setup):
+        dev, model, params, X, y = setup
+        G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X[:8], y[:8])], check_deterministic=False)
+        D = G.shape[1]
+        v, w = torch.rand(D, device=dev) - 0.5, torch.rand(D, device=dev) - 0.5
+        Gv, Gw = G @ v, G @ w
+        lin = G @ (2.0 * v - 3.0 * w)
+        assert rel_err(lin, (2.0 * Gv - 3.0 * Gw).double().cpu().numpy()) < 1e-4
+        vGw, wGv = torch.dot(v.double(), Gw.double()), torch.dot(w.double(), Gv.double())
+        assert abs(vGw - wGv) / max(abs(vGw), 1e-30) < 1e-3
+        assert torch.dot(v.double(), Gv.double()) >= 0
+
+    def test_batch_split_invariance(self, setup):
+        """sum over mini-batches with B_b / N_data weights == one big batch (mean reduction);
+        also exercises the 8-row, 16-row and MFMA (N > 16) kernel paths."""
+        dev, model, params, X, y = setup
+        one = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X, y)], check_deterministic=False)
+        split = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X[:8], y[:8]), (X[8:11], y[8:11]), (X[11:], y[11:])],
+                                    check_deterministic=False)
+        v = torch.rand(one.shape[1], device=dev)
+        assert rel_err(split @ v, (one @ v).double().cpu().numpy()) < 2e-4
+
+    def test_against_autograd_path(self, setup):
+        dev, model, params, X, y = setup
+        data = [(X[:8], y[:8])]
+        nat = C.GGNLinearOperator(model, nn.MSELoss(), params, data, check_deterministic=False)
+        ref = C.GGNLinearOperator(model, nn.MSELoss(), params, data, check_deterministic=False)
+        ref._native = None
+        v = torch.rand(nat.shape[1], device=dev)
+        assert rel_err(nat @ v, (ref @ v).double().cpu().numpy()) < 2e-4
+
+
+# ----------------------------------------------------------------------------- structured ops
+@pytest.mark.parametrize("name", ["rect", "sq", "one", "three"])
+def test_kronecker_gpu(dev, golden_linops, name):
+    rec = golden_linops[f"kron_{name}"]
+    fs = [g32(rec[f"factor{i}"], dev) for i in range(sum(k.startswith("factor") for k in rec))]
+    K = C.KroneckerProductLinearOperator(*fs)
+    X, Y = g32(rec["X"], dev), g32(rec["Y"], dev)
+    assert rel_err(K @ X, rec["KX"]) < TOL
+    assert rel_err(K @ X[:, 0].contiguous(), rec["KX"][:, 0]) < TOL
+    assert rel_err(K.adjoint() @ Y, rec["KTY"]) < TOL
+    if name in ("sq", "one"):
+        assert rel_err(K.inverse(damping=1e-2) @ X, rec["inv_plain_X"]) < TOL_INV
+        assert rel_err(K.inverse(damping=1e-2, use_exact_damping=True) @ X, rec["inv_exact_X"]) < TOL_INV
+        if "inv_heur_X" in rec:
+            got = K.inverse(damping=1e-2, use_heuristic_damping=True, min_damping=1e-3) @ X
+            assert rel_err(got, rec["inv_heur_X"]) < TOL_INV
+
+
+def test_kronecker_large_gpu(dev):
+    """C2-sized joint block: G 2688^2 (x) A 2689^2 against torch on the same device (fp64)."""
+    torch.manual_seed(1)
+    G = torch.rand(2688, 2688, device=dev) / 2688
+    A = torch.rand(2689, 2689, device=dev) / 2689
+    K = C.KroneckerProductLinearOperator(G, A)
+    for cols in (1, 3):
+        X = torch.rand(2688 * 2689, cols, device=dev)
+        ref = torch.einsum("Aa,abz,Bb->ABz", G.double(), X.double().view(2688, 2689, cols), A.double()).reshape(-1, cols)
+        assert rel_err(K @ X, ref.cpu().numpy()) < TOL
+
+
+def test_eigh_operator_gpu(dev, golden_linops):
+    rec = golden_linops["eigh"]
+    E = C.EighDecomposedLinearOperator(g32(rec["lam"], dev),
+                                       C.KroneckerProductLinearOperator(g32(rec["Q1"], dev), g32(rec["Q2"], dev)))
+    X = g32(rec["X"], dev)
+    assert rel_err(E @ X, rec["EX"]) < TOL
+    assert rel_err(E.inverse(damping=0.05) @ X, rec["invEX"]) < TOL
+    E2 = C.EighDecomposedLinearOperator(g32(rec["lam"], dev), torch.kron(g32(rec["Q1"], dev), g32(rec["Q2"], dev)))
+    assert rel_err(E2 @ X, rec["EX"]) < TOL
+
+
+def test_gemm_sqsum_kernel(dev):
+    from curvlinops_amd import _hip
+
+    g = torch.Generator().manual_seed(3)
+    for nb, M, K, N in ((1, 5, 3, 4), (7, 64, 16, 130), (33, 130, 1, 129), (200, 20, 49, 17)):
+        A = torch.rand(nb, M, K, generator=g, dtype=torch.float64) - 0.5
+        B = torch.rand(nb, K, N, generator=g, dtype=torch.float64) - 0.5
+        C0 = torch.rand(M, N, generator=g, dtype=torch.float64)
+        out = C0.float().to(dev)
+        _hip.gemm_sqsum(A.float().to(dev), B.float().to(dev), out, alpha=0.5, beta=2.0)
+        ref = 0.5 * (A @ B).square().sum(0) + 2.0 * C0
+        assert rel_err(out, ref.numpy()) < 2e-5
+        # transposed (strided) A operand as used by the EKFAC correction
+        At = A.transpose(1, 2).contiguous().float().to(dev)
+        out = torch.zeros(M, N, device=dev)
+        _hip.gemm_sqsum(At.transpose(1, 2), B.float().to(dev), out)
+        assert rel_err(out, (A @ B).square().sum(0).numpy()) < 2e-5
+
+
+# ----------------------------------------------------------------------------- KFAC / EKFAC
+@pytest.mark.parametrize("case", sorted(load_golden("kfac")))
+def test_kfac_gpu(dev, case):
+    rec = load_golden("kfac")[case]
+    loss, red = str(rec["loss"]), str(rec["reduction"])
+    model = KFAC_MODELS[case]()
+    params = load_into(model, rec, F32, dev)
+    data = golden_data(rec, F32, dev, loss)
+    V = g32(rec["V"], dev)
+    for tag in sorted({k.split("/")[0] for k in rec if "|" in k and not k.startswith("ekfac")}):
+        fisher, approx, sep = tag.split("|")
+        K = C.KFACLinearOperator(model, LOSS[loss](reduction=red), params, data, fisher_type=fisher,
+                                 kfac_approx=approx, separate_weight_and_bias=sep == "sep")
+        _, Kc, _ = K
+        for b, block in enumerate(Kc):
+            for f, fac in enumerate(block):
+                assert rel_err(fac, rec[f"{tag}/block{b}_factor{f}"]) < TOL, (case, tag, b, f)
+        assert rel_err(K @ V, rec[f"{tag}/KV"]) < TOL
+        assert rel_err(K.trace(), rec[f"{tag}/trace"]) < TOL
+        assert rel_err(K.inverse(damping=1e-2) @ V, rec[f"{tag}/inv_plain"]) < TOL_INV
+        assert rel_err(K.inverse(damping=1e-2, use_exact_damping=True) @ V, rec[f"{tag}/inv_exact"]) < TOL_INV
+        if f"{tag}/inv_heur" in rec:
+            got = K.inverse(damping=1e-2, use_heuristic_damping=True, min_damping=1e-4) @ V
+            assert rel_err(got, rec[f"{tag}/inv_heur"]) < TOL_INV
+    assert all(p.grad is None for p in model.parameters())
+
+
+@pytest.mark.parametrize("case", [c for c in sorted(load_golden("kfac")) if not c.startswith("seq")])
+def test_ekfac_gpu(dev, case):
+    rec = load_golden("kfac")[case]
+    loss, red = str(rec["loss"]), str(rec["reduction"])
+    model = KFAC_MODELS[case]()
+    params = load_into(model, rec, F32, dev)
+    data = golden_data(rec, F32, dev, loss)
+    V = g32(rec["V"], dev)
+    for tag in sorted({k.split("/")[0] for k in rec if k.startswith("ekfac")}):
+        _, fisher, sep = tag.split("|")
+        E = C.EKFACLinearOperator(model, LOSS[loss](reduction=red), params, data, fisher_type=fisher,
+                                  separate_weight_and_bias=sep == "sep")
+        assert rel_err(E.trace(), rec[f"{tag}/trace"]) < TOL_INV
+        # eigenvectors of nearly degenerate fp32 factors rotate freely; the regularised inverse
+        # is the stable quantity to compare
+        assert rel_err(E.inverse(damping=1e-2) @ V, rec[f"{tag}/invEV"]) < 5e-3, (case, tag)
+
+
+def test_kfac_factor_properties_lenet_size(dev):
+    """C3-like: LeNet-5 on 32x32 inputs, B = 256: factors symmetric PSD, equal to the float64
+    torch result on the same device for every layer (conv via unfold, joint bias column)."""
+    torch.manual_seed(0)
+    model = nn.Sequential(
+        nn.Conv2d(1, 6, 5), nn.ReLU(), nn.MaxPool2d(2), nn.Conv2d(6, 16, 5), nn.ReLU(), nn.MaxPool2d(2),
+        nn.Flatten(), nn.Linear(400, 120), nn.ReLU(), nn.Linear(120, 84), nn.ReLU(), nn.Linear(84, 10),
+    ).to(dev)
+    params = dict(model.named_parameters())
+    X, y = torch.rand(256, 1, 32, 32, device=dev), torch.randint(0, 10, (256,), device=dev)
+    K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], fisher_type="empirical",
+                             separate_weight_and_bias=False, check_deterministic=False)
+    m64 = nn.Sequential(
+        nn.Conv2d(1, 6, 5), nn.ReLU(), nn.MaxPool2d(2), nn.Conv2d(6, 16, 5), nn.ReLU(), nn.MaxPool2d(2),
+        nn.Flatten(), nn.Linear(400, 120), nn.ReLU(), nn.Linear(120, 84), nn.ReLU(), nn.Linear(84, 10),
+    ).to(dev).double()
+    m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+    K64 = C.KFACLinearOperator(m64, nn.CrossEntropyLoss(), dict(m64.named_parameters()), [(X.double(), y)],
+                               fisher_type="empirical", separate_weight_and_bias=False, check_deterministic=False)
+    for blk, blk64 in zip(K[1], K64[1]):
+        for f, f64 in zip(blk, blk64):
+            assert torch.equal(f, f.T)
+            assert rel_err(f, f64.cpu().numpy()) < TOL
+    v = torch.rand(K.shape[1], device=dev)
+    assert rel_err(K @ v, (K64 @ v.double()).cpu().numpy()) < TOL
+    assert rel_err(K.inverse(damping=1e-3) @ v, (K64.inverse(damping=1e-3) @ v.double()).cpu().numpy()) < TOL_INV
+
+
+# ----------------------------------------------------------------------------- trace
+def test_trace_estimators_gpu(dev):
+    rec = load_golden("trace")["t"]
+    A = g32(rec["A"], dev)
+    op = C.KroneckerProductLinearOperator(A)  # a dense symmetric operator
+    for dist in ("rademacher", "normal"):
+        pool = g32(rec[f"{dist}/pool"], dev)
+        assert rel_err(C.hutchinson_trace(op, 12, dist, probes=pool[:, :12].contiguous()), rec[f"{dist}/hutch"]) < TOL
+        got = C.hutchpp_trace(op, 24, dist, probes=(pool[:, :8].contiguous(), pool[:, 8:16].contiguous()))
+        assert rel_err(got, rec[f"{dist}/hutchpp"]) < 1e-3
+    torch.manual_seed(0)
+    ests = torch.stack([C.hutchinson_trace(op, 29) for _ in range(200)])
+    assert abs(ests.mean() - A.trace()) / A.trace() < 0.05
