@@ -14,7 +14,10 @@ from pathlib import Path
 import torch
 from torch import Tensor
 
-_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libclo_hip.so"
+import os
+
+# CLO_HIP_LIB lets kernel-ablation builds be A/B-tested; the default is the in-tree library.
+_LIB_PATH = Path(os.environ.get("CLO_HIP_LIB") or Path(__file__).resolve().parent / "lib" / "libclo_hip.so")
 _lib = None
 
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
@@ -303,6 +306,35 @@ class MLPPlan:
             ws = torch.empty(n, device=device, dtype=torch.float32)
             self._ws = {key: ws}  # keep only the latest batch size
         return ws
+
+    # ---- flat fast path: parameters / vectors addressed as base pointer + element offsets ----
+    def bind_params(self, W, b) -> None:
+        """Cache the (static) weight / bias pointer tables."""
+        self._W_arr, self._b_arr = self._ptr_array(W), self._ptr_array(b)
+        self._VW_arr, self._Vb_arr = (c_void_p * self.L)(), (c_void_p * self.L)()
+        self._OW_arr, self._Ob_arr = (c_void_p * self.L)(), (c_void_p * self.L)()
+        self._fn = load().clo_mlp_ggn_matvec
+
+    def ggn_matvec_flat(self, v_base: int, o_base: int, w_off, b_off, X_ptr: int, N: int, loss_kind: int,
+                        loss_scale: float, alpha: float, beta: float, aux_ptr, aux_rank: int, ws_ptr: int,
+                        stream: int) -> None:
+        """Like :meth:`ggn_matvec` for a flat vector / result: ``v_base``/``o_base`` are device
+        addresses, ``w_off``/``b_off`` BYTE offsets of every layer's weight / bias (None = no bias).
+        No tensor objects are created or inspected (host cost: a handful of integer adds)."""
+        VW, Vb, OW, Ob = self._VW_arr, self._Vb_arr, self._OW_arr, self._Ob_arr
+        for l in range(self.L):
+            VW[l] = v_base + w_off[l]
+            OW[l] = o_base + w_off[l]
+            if b_off[l] is None:
+                Vb[l] = None
+                Ob[l] = None
+            else:
+                Vb[l] = v_base + b_off[l]
+                Ob[l] = o_base + b_off[l]
+        rc = self._fn(self.L, self.dims, self.acts, self._W_arr, self._b_arr, VW, Vb, OW, Ob, X_ptr, N,
+                      loss_kind, aux_ptr, aux_rank, loss_scale, alpha, beta, ws_ptr, stream)
+        if rc != 0:
+            _check(rc, "clo_mlp_ggn_matvec")
 
     def ggn_matvec(self, W, b, VW, Vb, OW, Ob, X, loss_kind: int, loss_scale: float, alpha: float,
                    beta: float, aux=None) -> None:

@@ -32,7 +32,7 @@ inline int check_hip(hipError_t e, const char *what) {
     }                                     \
   } while (0)
 
-__host__ __device__ // Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
 // Tags: 0 fwd_jvp, 1 loss_hessian, 2 bwd_fused, 3 finish/reduce, 4 gemm, 5 other.
 constexpr int kProfTags = 8;
 bool prof_enabled();

@@ -279,6 +279,141 @@ __global__ __launch_bounds__(512, QN == 1 ? 4 : 2) void fwd_jvp_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA forward + JVP (16-byte aligned rows).  One v_mfma_f32_16x16x4_f32 tile per row group:
+//   A rows  0..7  = W[j .. j+7]        rows 8..15 = VW[j .. j+7]
+//   B cols  0..7  = a[n = 0..7]        cols 8..15 = da[n = 0..7]
+//   D[i][n] = z part, D[i][8+n] + D[8+i][n] = dz part (the fourth quadrant is unused).
+// Lane (idx = l & 15, s = l >> 4) feeds ONE float4 of row idx at k + 4s for A (global) and for
+// B (LDS); its four elements feed four MFMAs (the k-slot <-> k assignment is a free permutation
+// as long as A and B agree).  A 16-k step costs RG global loads, one ds_read_b128 and 4 RG
+// MFMAs per wave: ~30x fewer instructions than the VALU kernel above, no cross-lane reduction.
+//
+// grid = (row blocks of 4 waves x RG x 8 features, K ranges).  A block stages the activations of
+// its K range in LDS ONCE (shared by its waves, which own different rows), then every wave
+// streams its rows barrier-free.  Every byte a wave loads is weight data: measured on MI355X
+// the kernel time tracks the bytes requested from L2/HBM (~4.2 TB/s) whatever their source, so
+// operand re-reads and clamped prefetches must not exist.
+// ------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int MF_WAVES = 4;
+constexpr int MF_KB_MAX = 736;  // 16 x (736+4) floats = 46 KiB of LDS
+
+template <int RG, bool HAS_V, bool HAS_DA>
+__global__ __launch_bounds__(MF_WAVES * 64) void fwd_mfma_kernel(
+    const float *__restrict__ W, const float *__restrict__ b, const float *__restrict__ VW,
+    const float *__restrict__ Vb, const float *__restrict__ a_in,
+    const float *__restrict__ da_in, float *__restrict__ a_out, float *__restrict__ da_out,
+    float *__restrict__ dphi_out, float *__restrict__ part, int N, int d_in, int d_out, int act,
+    int k_per_block) {
+  constexpr bool TANGENT = HAS_V || HAS_DA;
+  extern __shared__ __attribute__((aligned(16))) float s_b[];  // [16][k_per_block + 4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = lane & 15, s4 = (lane >> 4) * 4;
+  const int kb0 = blockIdx.y * k_per_block;
+  const int kb1 = min(d_in, kb0 + k_per_block);
+  const int klen = kb1 - kb0;                 // multiple of 4
+  const int ldb = k_per_block + 4;
+
+  // ---- stage B = [a ; da] of this K range (zero beyond N rows / beyond klen / absent da)
+  {
+    const int q4 = (k_per_block + 3) >> 2;    // float4 per row
+    for (int e = tid; e < 16 * q4; e += MF_WAVES * 64) {
+      const int c = e / q4, kq = (e - c * q4) * 4;
+      float4 v = zero4();
+      const int n = c & 7;
+      const bool present = (c < 8 || HAS_DA) && n < N && kq < klen;
+      if (present) v = ld4(((c < 8) ? a_in : da_in) + (long)n * d_in + kb0 + kq);
+      *reinterpret_cast<float4 *>(&s_b[c * ldb + kq]) = v;
+    }
+  }
+  __syncthreads();
+
+  const int j0 = (blockIdx.x * MF_WAVES + wave) * RG * 8;
+  if (j0 >= d_out) return;  // whole wave idle (after the only barrier)
+
+  // Operand rows.  Without VW the upper half of A aliases W (its quadrants of D are unused);
+  // rows beyond d_out alias the last row: no predicated loads anywhere.
+  const float *pA[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int row = min(j0 + g * 8 + (idx & 7), d_out - 1);
+    pA[g] = ((HAS_V && idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
+  }
+  const float *pBs = s_b + idx * ldb + s4;
+
+  f32x4 acc[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int U = 2;  // steps per load group
+  const int nfull = klen >> 4;
+  int step = 0;
+  for (; step + U <= nfull; step += U) {
+    float4 av[U][RG], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) av[u][g] = ld4(pA[g] + (step + u) * 16);
+      bv[u] = ld4(pBs + (step + u) * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].x, bv[u].x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].y, bv[u].y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].z, bv[u].z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].w, bv[u].w, acc[g], 0, 0, 0);
+      }
+  }
+  // remaining full steps and the partial one: B is zero beyond klen, A only needs a valid address
+  for (; step * 16 < klen; ++step) {
+    const bool ok = step * 16 + s4 < klen;
+    const float4 bv = ld4(pBs + step * 16);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const float4 av = ld4(pA[g] + (ok ? step * 16 : 0));
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[g], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue straight from the accumulators.  D layout: row = (lane>>4)*4 + r, col = lane&15.
+  // z[n][j0+i]  = D[i][n]            -> lanes with lane>>4 in {0,1}, col n < 8
+  // dz[n][j0+i] = D[i][8+n] + D[8+i][n] -> lane (q, 8+n) adds the value of lane (q+2, n) = lane+24
+  const int q = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc[g][r];
+      const float up = __shfl(v, (lane + 24) & 63, 64);   // D[8+i][n] for lanes (q<2, col>=8)
+      const float zsrc = __shfl(v, (lane + 56) & 63, 64);  // D[i][n] for the same lanes (lane-8)
+      if (q < 2 && col >= 8) {
+        const int n = col - 8, j = j0 + g * 8 + q * 4 + r;
+        if (n < N && j < d_out) {
+          const float zsum = zsrc;
+          const float dzsum = (HAS_DA ? v : 0.f) + (HAS_V ? up : 0.f);
+          if (gridDim.y > 1) {  // raw partial sums: part[split][2][NB][d_out]
+            float *pz = part + ((long)blockIdx.y * 2 * NB + n) * d_out + j;
+            pz[0] = zsum;
+            if (TANGENT) pz[(long)NB * d_out] = dzsum;
+          } else {
+            float dphi;
+            const float aval = act_apply(act, zsum + (b ? b[j] : 0.f), dphi);
+            a_out[(long)n * d_out + j] = aval;
+            if (dphi_out) dphi_out[(long)n * d_out + j] = dphi;
+            if (TANGENT) da_out[(long)n * d_out + j] = dphi * (dzsum + ((HAS_V && Vb) ? Vb[j] : 0.f));
+          }
+        }
+      }
+    }
+}
+
 // Sum the split-K slabs of fwd_jvp_kernel and apply bias + activation.
 __global__ void fwd_finish_kernel(const float *__restrict__ part, int ksplit,
                                   const float *__restrict__ b, const float *__restrict__ Vb,
@@ -288,10 +423,23 @@ __global__ void fwd_finish_kernel(const float *__restrict__ part, int ksplit,
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int n = e / d_out, j = e % d_out;
     float zz = b ? b[j] : 0.f, dzz = Vb ? Vb[j] : 0.f;
-    for (int s = 0; s < ksplit; ++s) {
-      const float *p = part + ((long)s * 2 * NB + n) * d_out + j;
-      zz += p[0];
-      if (da_out) dzz += p[(long)NB * d_out];
+    const float *p0 = part + (long)n * d_out + j;
+    const long sstride = 2L * NB * d_out, dzoff = (long)NB * d_out;
+    int s = 0;
+    for (; s + 3 < ksplit; s += 4) {  // four independent slabs per trip
+      const float z0 = p0[(s + 0) * sstride], z1 = p0[(s + 1) * sstride];
+      const float z2 = p0[(s + 2) * sstride], z3 = p0[(s + 3) * sstride];
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+      if (da_out) {
+        d0 = p0[(s + 0) * sstride + dzoff]; d1 = p0[(s + 1) * sstride + dzoff];
+        d2 = p0[(s + 2) * sstride + dzoff]; d3 = p0[(s + 3) * sstride + dzoff];
+      }
+      zz += (z0 + z1) + (z2 + z3);
+      dzz += (d0 + d1) + (d2 + d3);
+    }
+    for (; s < ksplit; ++s) {
+      zz += p0[s * sstride];
+      if (da_out) dzz += p0[s * sstride + dzoff];
     }
     float dphi;
     a_out[e] = act_apply(act, zz, dphi);
@@ -350,10 +498,20 @@ __global__ __launch_bounds__(256) void loss_hessian_kernel(const LossArgs p) {
     float *fo = p.f_out + (long)n * C, *uo = p.u_out + (long)n * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float zz = p.b ? p.b[c] : 0.f, dzz = p.Vb ? p.Vb[c] : 0.f;
-      for (int s = 0; s < p.ksplit; ++s) {
-        const float *q = p.part + ((long)s * 2 * NB + n) * C + c;
-        zz += q[0];
-        dzz += q[(long)NB * C];
+      const float *q0 = p.part + (long)n * C + c;
+      const long sstride = 2L * NB * C, dzoff = (long)NB * C;
+      int s = 0;
+      for (; s + 3 < p.ksplit; s += 4) {
+        const float z0 = q0[(s + 0) * sstride], z1 = q0[(s + 1) * sstride];
+        const float z2 = q0[(s + 2) * sstride], z3 = q0[(s + 3) * sstride];
+        const float d0 = q0[(s + 0) * sstride + dzoff], d1 = q0[(s + 1) * sstride + dzoff];
+        const float d2 = q0[(s + 2) * sstride + dzoff], d3 = q0[(s + 3) * sstride + dzoff];
+        zz += (z0 + z1) + (z2 + z3);
+        dzz += (d0 + d1) + (d2 + d3);
+      }
+      for (; s < p.ksplit; ++s) {
+        zz += q0[s * sstride];
+        dzz += q0[s * sstride + dzoff];
       }
       fo[c] = zz;
       uo[c] = dzz;
@@ -423,7 +581,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
     float beta, int N, int d_in, int d_out, int rows_per_block, int final_write) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_d = smem;                          // [rows_per_block][NB]
-  float *s_red = smem + rows_per_block * NB;  // [BWD_WAVES][NB][CW]   (DPREV only)
+  float *s_red = smem + rows_per_block * NB;  // [BWD_WAVES][NB][CW]   (DPREV), [NB][CW] a_prev (else)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = blockIdx.x * CW;
@@ -435,16 +593,32 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
     const int j = jbase + jj;
     s_d[e] = (j < d_out && n < N) ? delta[(long)n * d_out + j] : 0.f;
   }
+  // a_prev[0..7][i0 .. i0+255]: loaded ONCE per block (wave n loads row n) and shared through
+  // LDS -- every byte requested from L2/HBM costs the same, so no per-wave re-loads
   float4 a[NB];
   if (OUTER) {
-#pragma unroll
-    for (int n = 0; n < NB; ++n)
-    {
-      a[n] = load_row4<VEC>(a_prev + (long)(n < N ? n : 0) * d_in, i0, lane, 0, d_in);
-      if (n >= N) a[n] = zero4();
+    const int n = wave;  // BWD_WAVES == NB
+    float4 v = load_row4<VEC>(a_prev + (long)(n < N ? n : 0) * d_in, i0, lane, 0, d_in);
+    if (n >= N) v = zero4();
+    if (VEC) {
+      *reinterpret_cast<float4 *>(&s_red[n * CW + lane * 4]) = v;
+    } else {
+      s_red[n * CW + lane] = v.x; s_red[n * CW + 64 + lane] = v.y;
+      s_red[n * CW + 128 + lane] = v.z; s_red[n * CW + 192 + lane] = v.w;
     }
   }
   __syncthreads();
+  if (OUTER) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      if (VEC)
+        a[n] = ld4(&s_red[n * CW + lane * 4]);
+      else
+        a[n] = make_float4(s_red[n * CW + lane], s_red[n * CW + 64 + lane],
+                           s_red[n * CW + 128 + lane], s_red[n * CW + 192 + lane]);
+    }
+    if (DPREV) __syncthreads();  // s_red is reused for the cross-wave reduction below
+  }
 
   if (OUTER && out_b && blockIdx.x == 0) {
     for (int jj = tid; jj < jend - jbase; jj += 512) {
@@ -605,6 +779,19 @@ static int fwd_ksplit(int d_in, int d_out) {
   if (row_blocks >= 96 || nchunks <= 1) return 1;
   return (int)std::min<long>(nchunks, cdiv(kNumCU, row_blocks));
 }
+// MFMA kernel: a block covers MF_WAVES * MF_RG * 8 features and one K range.  Aim at >= 2 blocks
+// per CU; K ranges are multiples of 32 and at most MF_KB_MAX (LDS).
+constexpr int MF_RG = 2;
+static int mfma_kpb(int d_in, int d_out) {
+  const long row_blocks = cdiv(d_out, MF_WAVES * MF_RG * 8);
+  long ksplit = std::max<long>(1, cdiv(2 * kNumCU, row_blocks));
+  ksplit = std::min<long>(ksplit, std::max<long>(1, d_in / 64));
+  ksplit = std::min<long>(ksplit, 16);  // slab merges stay short (narrow layers are tiny anyway)
+  long kpb = cdiv(cdiv(d_in, ksplit), 32) * 32;
+  kpb = std::min<long>(kpb, MF_KB_MAX);
+  return (int)kpb;
+}
+static int mfma_ksplit(int d_in, int d_out) { return (int)cdiv(d_in, mfma_kpb(d_in, d_out)); }
 static int bwd_jb(int d_in, int d_out, bool dprev) {
   const long cchunks = cdiv(d_in, CW);
   long jb = cdiv(kNumCU, cchunks);                    // ~1 block per CU
@@ -638,6 +825,38 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
                     bool leave_partials, int *ksplit_out, hipStream_t st) {
   const bool has_v = VW != nullptr, has_da = da_in != nullptr;
   const bool vec = vec_ok(d_in, {W, VW, a_in, da_in});
+  if (vec && N >= 1 && d_in >= 16) {
+    // ---- MFMA path
+    int kpb = mfma_kpb(d_in, d_out);
+    int ksplit = (int)cdiv(d_in, kpb);
+    if (!part && ksplit > 1) {  // caller gave no slab workspace: single K range per block
+      set_error("clo_mlp_fwd: split-K needs a workspace");
+      return CLO_EINVAL;
+    }
+    if (ksplit_out) *ksplit_out = ksplit;
+    dim3 grid((unsigned)cdiv(d_out, MF_WAVES * MF_RG * 8), (unsigned)ksplit), block(MF_WAVES * 64);
+    const size_t smem = (size_t)16 * (kpb + 4) * sizeof(float);
+    {
+      ProfScope prof(0, 4.0 * d_in * d_out * (has_v ? 2 : 1), st);
+#define CLO_MF(HV, HD)                                                                            \
+  hipLaunchKernelGGL((fwd_mfma_kernel<MF_RG, HV, HD>), grid, block, smem, st, W, b, VW, Vb, a_in, \
+                     da_in, a_out, da_out, dphi_out, part, N, d_in, d_out, act, kpb)
+      if (has_v && has_da) CLO_MF(true, true);
+      else if (has_v) CLO_MF(true, false);
+      else if (has_da) CLO_MF(false, true);
+      else CLO_MF(false, false);
+#undef CLO_MF
+      CLO_CHECK_LAUNCH("fwd_mfma_kernel");
+    }
+    if (ksplit > 1 && !leave_partials) {
+      ProfScope pf(3, 0.0, st);
+      hipLaunchKernelGGL(fwd_finish_kernel, dim3(ew_grid((long)N * d_out)), dim3(256), 0, st, part,
+                         ksplit, b, Vb, a_out, (has_v || has_da) ? da_out : nullptr, dphi_out, N,
+                         d_out, act);
+      CLO_CHECK_LAUNCH("fwd_finish_kernel");
+    }
+    return CLO_OK;
+  }
   int ksplit = part ? fwd_ksplit(d_in, d_out) : 1;
   const int nchunks = (int)cdiv(d_in, KC);
   const int cps = (int)cdiv(nchunks, ksplit);
@@ -683,7 +902,7 @@ static int bwd_pass(const float *W, const float *delta, const float *a_prev,
   const int JB = bwd_jb(d_in, d_out, dprev);
   const int rpb = (int)cdiv(d_out, JB);
   const int JBe = (int)cdiv(d_out, rpb);
-  const size_t smem = ((size_t)rpb * NB + (dprev ? BWD_WAVES * NB * CW : 0)) * sizeof(float);
+  const size_t smem = ((size_t)rpb * NB + (dprev ? BWD_WAVES * NB * CW : NB * CW)) * sizeof(float);
   dim3 grid((unsigned)cdiv(d_in, CW), (unsigned)JBe), block(512);
   float *dst = dprev ? (JBe == 1 ? delta_prev : ws) : nullptr;
   const int fin = JBe == 1 ? 1 : 0;
@@ -746,7 +965,8 @@ using namespace clo;
 
 extern "C" long clo_mlp_fwd_ws_floats(int N, int d_in, int d_out) {
   (void)N;
-  return (long)fwd_ksplit(d_in, d_out) * 2 * NB * d_out + 64;
+  const long ks = std::max(fwd_ksplit(d_in, d_out), mfma_ksplit(d_in, d_out));
+  return ks * 2 * NB * d_out + 64;
 }
 extern "C" long clo_mlp_bwd_ws_floats(int N, int d_in, int d_out) {
   (void)N;

@@ -25,12 +25,12 @@ bool prof_enabled() { return g_prof_on; }
 void prof_begin(int tag, double alg_bytes, hipStream_t st) {
   ProfRec r;
   if (!g_prof_pool.empty()) { r = g_prof_pool.back(); g_prof_pool.pop_back(); }
-  else { hipEventCreate(&r.a); hipEventCreate(&r.b); }
+  else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
   r.tag = tag; r.bytes = alg_bytes;
-  hipEventRecord(r.a, st);
+  (void)hipEventRecord(r.a, st);
   g_prof.push_back(r);
 }
-void prof_end(hipStream_t st) { hipEventRecord(g_prof.back().b, st); }
+void prof_end(hipStream_t st) { (void)hipEventRecord(g_prof.back().b, st); }
 
 // Grid for a streaming kernel over n work items of `per_thread` elements: cap at ~8 blocks
 // per CU and grid-stride the rest.

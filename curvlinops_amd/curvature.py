@@ -155,6 +155,63 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                 nat.matvec(V, O, Xn, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0, aux=aux)
         return [o.movedim(0, -1) for o in Ok]
 
+    # ------------------------------------------------------------------ flat fast path
+    def _native_flat_setup(self):
+        """Per-batch constants of the native path when ``data`` is a list of device-resident
+        fp32 batches (references only, nothing is copied); None otherwise."""
+        cached = getattr(self, "_native_flat", False)
+        if cached is not False:
+            return cached
+        self._native_flat = None
+        if self._native is None or not isinstance(self._data, (list, tuple)):
+            return None
+        batches = []
+        for bi, (X, y) in enumerate(self._data):
+            if not (isinstance(X, Tensor) and X.device == self.device and y.device == self.device):
+                return None
+            Xn = self._native.prepare_input(X)
+            if Xn is None or y.shape[0] != Xn.shape[0] or Xn.shape[0] == 0:
+                return None
+            kind, scale, aux = self._native_batch_args(bi, Xn, y)
+            batches.append((Xn, Xn.data_ptr(), Xn.shape[0], kind, scale,
+                            None if aux is None else aux.data_ptr(), 1, aux,
+                            self._get_normalization_factor(X, y)))
+        if not batches:
+            return None
+        nmax = max(b[2] for b in batches)
+        ws = self._native.plan.workspace(nmax, self.device)
+        self._native_flat = (batches, ws, ws.data_ptr())
+        return self._native_flat
+
+    def __matmul__(self, X):
+        """Fast path for a flat fp32 GPU vector on the native kernels: one output allocation and
+        one C call per mini-batch, no per-parameter tensor views.  Everything else takes the
+        generic route of :class:`PyTorchLinearOperator`."""
+        if (
+            self._native is not None
+            and isinstance(X, Tensor)
+            and X.dim() == 1
+            and X.is_cuda
+            and X.dtype == torch.float32
+            and X.shape[0] == self._native.D
+            and X.is_contiguous()
+            and getattr(self, "_mc_samples", 0) == 0
+        ):
+            setup = self._native_flat_setup()
+            if setup is not None:
+                batches, _ws, ws_ptr = setup
+                nat = self._native
+                out = torch.empty_like(X)
+                vp, op = X.data_ptr(), out.data_ptr()
+                stream = torch.cuda.current_stream().cuda_stream
+                beta = 0.0
+                for (_Xn, xptr, N, kind, scale, auxp, auxr, _aux, norm) in batches:
+                    nat.plan.ggn_matvec_flat(vp, op, nat.w_off, nat.b_off, xptr, N, kind, scale, norm, beta,
+                                             auxp, auxr, ws_ptr, stream)
+                    beta = 1.0
+                return out
+        return super().__matmul__(X)
+
     # ------------------------------------------------------------------ product
     def _matmat(self, M: list[Tensor]) -> list[Tensor]:
         if self._native is not None and all(m.is_cuda and m.dtype == torch.float32 for m in M):

@@ -109,6 +109,15 @@ class NativeMLP:
         self.b = [None if n is None else params[n] for n in structure.bias_names]
         self.w_idx = [self.index[n] for n in structure.weight_names]
         self.b_idx = [None if n is None else self.index[n] for n in structure.bias_names]
+        # byte offsets of every parameter inside a flat [D] vector (params order)
+        offs, pos = {}, 0
+        for n in self.names:
+            offs[n] = 4 * pos
+            pos += params[n].numel()
+        self.D = pos
+        self.w_off = [offs[n] for n in structure.weight_names]
+        self.b_off = [None if n is None else offs[n] for n in structure.bias_names]
+        self.plan.bind_params(self.W, self.b)
 
     def prepare_input(self, X: Tensor) -> Tensor | None:
         if not isinstance(X, Tensor) or not X.is_cuda or X.dtype != torch.float32:

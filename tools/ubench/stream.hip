@@ -29,6 +29,30 @@ __global__ __launch_bounds__(512) void read_rows(const float* __restrict__ W,con
   }
   if(s==123.456f) out[0]=s;
 }
+// pattern C: MFMA-operand layout: lane (idx=l&15, s=l>>4) reads float4 of row idx at k+4s: 16 rows x 64 B per load
+template<int RG,int U,int SEG>
+__global__ __launch_bounds__(512) void read_mfma(const float* __restrict__ W,const float* __restrict__ V,int d_in,int d_out,int kparts,float* out){
+  int lane=threadIdx.x&63, wave=__builtin_amdgcn_readfirstlane(threadIdx.x>>6);
+  // SEG = lanes per row segment (4 -> 64B, 8 -> 128B, 16 -> 256B); rows per load = 64/SEG
+  int idx=lane/SEG, s4=(lane%SEG)*4; int rows=64/SEG;
+  int j0=blockIdx.x*RG*(rows/2);  // half rows W half rows V
+  int klen=d_in/kparts; klen-=klen%(SEG*4); int kb=wave*klen, ke=(wave==kparts-1)?d_in-(d_in%(SEG*4)):kb+klen;
+  float s=0;
+  const float* p[RG];
+  for(int g=0;g<RG;g++){ int row=min(j0+g*(rows/2)+(idx%(rows/2)),d_out-1); p[g]=((idx>=rows/2)?V:W)+(long)row*d_in+s4; }
+  for(int k=kb;k<ke;k+=SEG*4*U){
+    float4 a[RG][U];
+    #pragma unroll
+    for(int u=0;u<U;u++)
+    #pragma unroll
+    for(int g=0;g<RG;g++){ int kk=min(k+u*SEG*4,ke-SEG*4); a[g][u]=*(const float4*)(p[g]+kk);}
+    #pragma unroll
+    for(int u=0;u<U;u++)
+    #pragma unroll
+    for(int g=0;g<RG;g++) s+=a[g][u].x+a[g][u].y*a[g][u].z+a[g][u].w;
+  }
+  if(s==123.456f) out[0]=s;
+}
 template<typename F> float timeit(F f,int iters){
   hipEvent_t a,b; hipEventCreate(&a); hipEventCreate(&b);
   for(int i=0;i<3;i++) f();
@@ -48,6 +72,10 @@ int main(){
     #define RUN(R,U,WAVES) { int rows_per_block=WAVES*R; dim3 g((d_out+rows_per_block-1)/rows_per_block), b(WAVES*64); \
       float us=timeit([&]{int i=(it++)%nb; hipLaunchKernelGGL((read_rows<R,U>),g,b,0,0,W[i],V[i],d_in,d_out,out);},50); \
       printf("rows R=%d U=%d waves=%d blocks=%d: %.1f us -> %.2f TB/s\n",R,U,WAVES,g.x,us,2*n*4/us/1e6);}
+    #define RUNM(RG,U,SEG) { int rows=64/SEG; int rpb=RG*(rows/2); dim3 g((d_out+rpb-1)/rpb), b(512); \
+      float us=timeit([&]{int i=(it++)%nb; hipLaunchKernelGGL((read_mfma<RG,U,SEG>),g,b,0,0,W[i],V[i],d_in,d_out,8,out);},50); \
+      printf("mfma-layout RG=%d U=%d SEG=%d(%dB/row) blocks=%d: %.1f us -> %.2f TB/s\n",RG,U,SEG,SEG*16,g.x,us,2*n*4/us/1e6);}
+    RUNM(2,4,4) RUNM(2,8,4) RUNM(1,8,4) RUNM(2,4,8) RUNM(4,4,8) RUNM(4,4,16) RUNM(8,2,16) RUNM(8,4,16)
     RUN(2,1,4) RUN(2,2,8) RUN(2,2,4) RUN(1,2,4) RUN(1,4,4) RUN(1,4,8) RUN(2,4,4) RUN(1,8,4) RUN(1,2,2) RUN(1,4,1)
   }
   return 0;
