@@ -53,6 +53,19 @@ def build_problem(device, batch: int, seed: int):
     return model, X, y
 
 
+def pmc_traffic_per_launch(kernel: str):
+    """Mean HBM bytes per launch of `kernel` from the committed PMC summary (collected by separate
+    rocprofv3 --pmc passes of this same command; see tools/pmc_summary.py); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_n8_pmc_traffic.json")
+    try:
+        rows = [k for k in json.load(open(path))["kernels"] if kernel in k["kernel"]]
+    except (OSError, ValueError, KeyError):
+        return None
+    if not rows:
+        return None
+    return sum(k["hbm_bytes"] for k in rows) / len(rows)
+
+
 def cpu_baseline(batch: int, budget_s: float = 12.0) -> dict:
     """Time the float32 NumPy oracle on the host cores for a bounded number of matvecs."""
     from oracle import mlp_numpy as O
@@ -178,6 +191,7 @@ def main() -> None:
         _hip.prof_enable(False)
         fam = max(prof, key=lambda k: prof[k]["ms"])
         r = prof[fam]
+        traffic = pmc_traffic_per_launch({"fwd_jvp": "fwd_mfma_kernel", "bwd_fused": "bwd_fused_kernel"}.get(fam, fam))
         achieved = r["alg_bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
         kernels_ms = sum(v["ms"] for v in prof.values()) / nprof
         result["roofline"] = {
@@ -187,7 +201,9 @@ def main() -> None:
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01_c2_n8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                              "separate passes, FETCH doubled per the gfx950 note)" if traffic else None,
             "launches": r["launches"],
             "avg_launch_us": 1e3 * r["ms"] / max(r["launches"], 1),
             "alg_bytes_per_launch": r["alg_bytes"] / max(r["launches"], 1),

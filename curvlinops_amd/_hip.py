@@ -42,6 +42,7 @@ _SIGNATURES = {
          c_float, _PF, c_long, c_int, c_int, _PF, c_void_p],
     ),
     "clo_gemm_sqsum_suggest_splits": (c_int, [c_int, c_int, c_int]),
+    "clo_potrf_diag_f32": (c_int, [_PF, c_long, c_int, _PF, c_long, c_void_p, c_int, c_void_p]),
     "clo_syrk_accum_f32": (
         c_int,
         [_PF, c_long, _PF, c_long, c_int, c_long, c_int, c_float, c_float, c_int, _PF, c_void_p],
@@ -234,6 +235,53 @@ def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones
                                 splitk, _p(ws), _stream())
     _check(rc, "clo_syrk_accum_f32")
     return C
+
+
+def cholesky_inverse(A: Tensor, damping: float = 0.0, block: int = 64) -> Tensor:
+    """``(A + damping I)^-1`` for a symmetric positive definite fp32 GPU matrix; never modifies
+    ``A``.  Blocked right-looking Cholesky: diagonal blocks by ``clo_potrf_diag_f32``, every
+    O(n^3) step (panel solve, trailing update, triangular inverse, ``L^-T L^-1``) on the MFMA GEMM.
+    Raises ``RuntimeError`` if the matrix is not positive definite."""
+    lib = load()
+    n = A.shape[0]
+    if A.dim() != 2 or A.shape[1] != n:
+        raise ValueError(f"expected a square matrix, got {tuple(A.shape)}")
+    L = A.detach().clone().contiguous()
+    if damping != 0.0:
+        L.diagonal().add_(damping)
+    if n == 0:
+        return L
+    status = torch.zeros(1, device=A.device, dtype=torch.int32)
+    nblk = (n + block - 1) // block
+    Linv = torch.zeros(nblk, block, block, device=A.device, dtype=torch.float32)
+    st = _stream()
+    for bi, j in enumerate(range(0, n, block)):
+        nb = min(block, n - j)
+        diag = L[j : j + nb, j : j + nb]
+        _check(lib.clo_potrf_diag_f32(_p(diag), L.stride(0), nb, _p(Linv[bi]), block, status.data_ptr(), j, st),
+               "clo_potrf_diag_f32")
+        if j + nb < n:
+            P = L[j + nb :, j : j + nb]
+            T = P.contiguous()
+            gemm(T, Linv[bi, :nb, :nb].T, out=P)                     # panel solve  P <- P L_jj^-T
+            gemm(P, P.T, out=L[j + nb :, j + nb :], alpha=-1.0, beta=1.0)  # trailing update
+    bad = int(status.item())
+    if bad:
+        raise RuntimeError(
+            f"cholesky: the input is not positive-definite (pivot {bad} of {n} is not positive)."
+        )
+    # Y = L^-1 (lower triangular), block row by block row; then A^-1 = Y^T Y
+    Y = torch.zeros(n, n, device=A.device, dtype=torch.float32)
+    for bi, i in enumerate(range(0, n, block)):
+        nb = min(block, n - i)
+        Li = Linv[bi, :nb, :nb]
+        Y[i : i + nb, i : i + nb] = Li
+        if i > 0:
+            T = gemm(L[i : i + nb, :i], Y[:i, :i])
+            gemm(Li, T, out=Y[i : i + nb, :i], alpha=-1.0)
+    out = torch.empty(n, n, device=A.device, dtype=torch.float32)
+    syrk_accum(out, Y, alpha=1.0, beta=0.0)
+    return out
 
 
 # --------------------------------------------------------------------------------------

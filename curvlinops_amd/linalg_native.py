@@ -6,9 +6,10 @@
 factorisation fails.  ``eigh`` replaces ``torch.linalg.eigh`` at ``kronecker.py:294`` and
 ``computers/_base.py:369-372``.
 
-fp32 GPU inputs run on the hand-written kernels of ``csrc/linalg.hip`` (blocked right-looking
-Cholesky with MFMA trailing updates; one-sided Jacobi eigensolver); everything else uses
-``torch.linalg`` on the tensor's device.
+fp32 GPU inputs: the Cholesky inverse runs on the hand-written kernels (``csrc/linalg.hip`` for
+the diagonal blocks, the MFMA GEMM of ``csrc/gemm.hip`` for every O(n^3) step; driver
+``_hip.cholesky_inverse``).  The symmetric eigensolver is NOT native yet: ``eigh`` calls
+``torch.linalg.eigh`` on the tensor's device (rocSOLVER on the GPU) -- see DESIGN.md, open items.
 """
 
 from __future__ import annotations
@@ -29,7 +30,7 @@ def _torch_damped_cholesky_inverse(A: Tensor, damping: float) -> Tensor:
 
 def damped_cholesky_inverse(A: Tensor, damping: float, retry_double_precision: bool = True) -> Tensor:
     """``(A + damping I)^-1`` for symmetric positive definite ``A`` (never modifies ``A``)."""
-    native = is_native_tensor(A) and _hip.has("clo_cholesky_inverse_f32")
+    native = is_native_tensor(A) and _hip.has("clo_potrf_diag_f32")
     try:
         if native:
             return _hip.cholesky_inverse(A, damping)

@@ -94,6 +94,16 @@ int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, lon
                        int splitk, float *ws, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Damped Cholesky inverse of a Kronecker factor (kronecker.py:328-373): the blocked algorithm
+ * (panel solve, trailing update, triangular inverse, L^-T L^-1) runs on clo_gemm_f32; this entry
+ * point factors ONE nb x nb (nb <= 64) diagonal block in place (lower) and writes the inverse of
+ * its triangular factor to Linv.  *status (device int, caller-zeroed) receives pivot_base + k + 1
+ * if pivot k is not positive.  Driver: curvlinops_amd/_hip.py:cholesky_inverse.
+ * ------------------------------------------------------------------------- */
+int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int *status,
+                       int pivot_base, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * MLP fast path (Sequential of Linear + elementwise activation), one mini-batch,
  * K = 1 column.  All activations are row-major [N][d].
  *

@@ -260,3 +260,29 @@ def test_ggn_matvec_large_layers(hip, N):
     gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 0, scale, 0.5, 1.0, out0=out0)
     ref = O.flatten_params([0.5 * r + o for r, o in zip(rW, out0[0])], [0.5 * r + o for r, o in zip(rb, out0[1])])
     assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
+
+
+# ------------------------------------------------------------------------ Cholesky inverse
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 401, 1000])
+def test_cholesky_inverse(hip, n):
+    g = torch.Generator().manual_seed(n)
+    B = torch.rand(n, n + 3, generator=g, dtype=torch.float64) - 0.5
+    A = B @ B.T / (n + 3) + 0.05 * torch.eye(n, dtype=torch.float64)
+    for damping in (0.0, 1e-2):
+        got = hip.cholesky_inverse(A.float().cuda(), damping)
+        ref = torch.linalg.inv(A + damping * torch.eye(n, dtype=torch.float64))
+        assert rel_err(got.cpu(), ref) < 1e-3
+        assert torch.equal(got, got.T)
+
+
+def test_cholesky_inverse_not_pd_raises(hip):
+    A = torch.eye(70)
+    A[40, 40] = -1.0
+    with pytest.raises(RuntimeError):
+        hip.cholesky_inverse(A.cuda())
+    # the retry-in-double path of the public wrapper succeeds when damping repairs the matrix
+    from curvlinops_amd import linalg_native
+
+    A[40, 40] = 1e-12
+    out = linalg_native.damped_cholesky_inverse(A.cuda(), 1e-3)
+    assert torch.isfinite(out).all()
