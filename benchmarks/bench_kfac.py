@@ -1,0 +1,64 @@
+"""Secondary benchmark: KFAC factor build / inverse / matvec times (BASELINE configs C3, C4).
+
+    python benchmarks/bench_kfac.py [lenet|resnet18] [--batch B]
+
+Protocol of the reference's harness (`benchmark_execute.py:288-301`): min over repeats after one
+warm-up, device synchronised around each phase; eval mode; Linear/Conv2d parameters only; joint
+weight+bias; one MC sample."""
+
+import argparse, json, os, sys, time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch import nn
+
+import curvlinops_amd as C
+from benchmarks.models import ResNet18, kfac_params, lenet5
+
+
+def timed(fn, repeats=5):
+    fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", nargs="?", default="resnet18")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--fisher", default="mc")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    if args.model == "lenet":
+        model, shape, B = lenet5(), (1, 32, 32), args.batch or 1024
+    else:
+        model, shape, B = ResNet18(), (3, 32, 32), args.batch or 512
+    model = model.to(dev).eval()
+    params = kfac_params(model)
+    X, y = torch.rand(B, *shape, device=dev), torch.randint(0, 10, (B,), device=dev)
+    data = [(X, y)]
+    kw = dict(fisher_type=args.fisher, separate_weight_and_bias=False, check_deterministic=False, num_data=B)
+    res = {"model": args.model, "batch": B, "D": sum(p.numel() for p in params.values())}
+    res["kfac_factors_ms"], K = timed(lambda: C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, data, **kw))
+    v = torch.rand(K.shape[1], device=dev)
+    res["kfac_matvec_ms"], _ = timed(lambda: K @ v)
+    res["cholesky_inverse_ms"], Kinv = timed(lambda: K.inverse(damping=1e-3), repeats=2)
+    res["inverse_matvec_ms"], _ = timed(lambda: Kinv @ v)
+    # forward+backward alone (host-framework time that any backend pays)
+    def fwdbwd():
+        out = model(X)
+        loss = nn.functional.cross_entropy(out, y)
+        return torch.autograd.grad(loss, list(params.values()))
+    res["gradient_and_loss_ms"], _ = timed(fwdbwd)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""Synthetic model definitions for the BASELINE.json configs (random init, no datasets).
+
+ResNet-18 follows the torchvision topology (torchvision itself is not installed here), with the
+CIFAR-style `num_classes=10` head the reference's benchmark uses
+(`docs/examples/basic_usage/benchmark_utils.py:341-452`)."""
+
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU()
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class ResNet18(nn.Module):
+    def __init__(self, num_classes: int = 10):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU()
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cfg = [(64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1),
+               (256, 512, 2), (512, 512, 1)]
+        self.layers = nn.Sequential(*[BasicBlock(a, b, s) for a, b, s in cfg])
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, num_classes)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layers(x)
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def lenet5() -> nn.Sequential:
+    return nn.Sequential(
+        nn.Conv2d(1, 6, 5), nn.ReLU(), nn.MaxPool2d(2), nn.Conv2d(6, 16, 5), nn.ReLU(), nn.MaxPool2d(2),
+        nn.Flatten(), nn.Linear(400, 120), nn.ReLU(), nn.Linear(120, 84), nn.ReLU(), nn.Linear(84, 10),
+    )
+
+
+def kfac_params(model: nn.Module) -> dict[str, torch.Tensor]:
+    """Linear / Conv2d parameters only (the reference's KFAC benchmarks exclude BatchNorm,
+    `benchmark_execute.py:172-183`)."""
+    keep = {}
+    for mod_name, mod in model.named_modules():
+        if isinstance(mod, (nn.Linear, nn.Conv2d)):
+            for p_name, p in mod.named_parameters(recurse=False):
+                keep[f"{mod_name}.{p_name}" if mod_name else p_name] = p
+    return keep

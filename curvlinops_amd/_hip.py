@@ -43,6 +43,13 @@ _SIGNATURES = {
     ),
     "clo_gemm_sqsum_suggest_splits": (c_int, [c_int, c_int, c_int]),
     "clo_potrf_diag_f32": (c_int, [_PF, c_long, c_int, _PF, c_long, c_void_p, c_int, c_void_p]),
+    "clo_cholesky_inverse_f32": (c_int, [_PF, c_long, _PF, c_long, c_int, c_float, _PF, c_void_p, c_void_p]),
+    "clo_cholesky_inverse_ws_floats": (c_long, [c_int]),
+    "clo_im2col_f32": (
+        c_int,
+        [_PF, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_int, c_void_p],
+    ),
     "clo_syrk_accum_f32": (
         c_int,
         [_PF, c_long, _PF, c_long, c_int, c_long, c_int, c_float, c_float, c_int, _PF, c_void_p],
@@ -228,8 +235,8 @@ def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones
     if C.shape != (dd, dd) or C.stride(1) != 1:
         raise ValueError(f"C must be [{dd},{dd}] row-major, got {tuple(C.shape)}")
     if splitk is None:
-        splitk = lib.clo_gemm_suggest_splitk(d, d, rows, 1)
-    ws = torch.empty(splitk * d * d, device=X.device, dtype=torch.float32) if splitk > 1 else None
+        splitk = lib.clo_gemm_suggest_splitk(dd, dd, rows, 1)
+    ws = torch.empty(splitk * dd * dd, device=X.device, dtype=torch.float32) if splitk > 1 else None
     ldx = X.stride(0) if rows > 1 else max(d, 1)
     rc = lib.clo_syrk_accum_f32(_p(C), C.stride(0), _p(X), rows, d, ldx, int(ones_col), alpha, beta,
                                 splitk, _p(ws), _stream())
@@ -237,50 +244,44 @@ def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones
     return C
 
 
-def cholesky_inverse(A: Tensor, damping: float = 0.0, block: int = 64) -> Tensor:
-    """``(A + damping I)^-1`` for a symmetric positive definite fp32 GPU matrix; never modifies
-    ``A``.  Blocked right-looking Cholesky: diagonal blocks by ``clo_potrf_diag_f32``, every
-    O(n^3) step (panel solve, trailing update, triangular inverse, ``L^-T L^-1``) on the MFMA GEMM.
-    Raises ``RuntimeError`` if the matrix is not positive definite."""
+def im2col(x: Tensor, kernel_size, stride, padding, dilation) -> Tensor:
+    """Patches of a ``[B, C, H, W]`` fp32 GPU tensor as ``[B, OH*OW, C*KH*KW]`` (the layout of
+    ``unfold(x).transpose(1, 2)``) in ONE launch for the whole mini-batch."""
+    B, C_, H, W = x.shape
+    (KH, KW), (SH, SW), (PH, PW), (DH, DW) = kernel_size, stride, padding, dilation
+    OH = (H + 2 * PH - DH * (KH - 1) - 1) // SH + 1
+    OW = (W + 2 * PW - DW * (KW - 1) - 1) // SW + 1
+    out = torch.empty(B, OH * OW, C_ * KH * KW, device=x.device, dtype=torch.float32)
+    rc = load().clo_im2col_f32(_pc(x.contiguous()), _pc(out), B, C_, H, W, KH, KW, SH, SW, PH, PW, DH, DW,
+                               OH, OW, _stream())
+    _check(rc, "clo_im2col_f32")
+    return out
+
+
+def cholesky_inverse(A: Tensor, damping: float = 0.0) -> Tensor:
+    """``(A + damping I)^-1`` for a symmetric positive definite fp32 GPU matrix (never modifies
+    ``A``): one call into ``clo_cholesky_inverse_f32`` (recursive blocked Cholesky carrying the
+    triangular inverse; leaves in LDS, every O(n^3) step on the MFMA GEMM).  Raises
+    ``RuntimeError`` if the matrix is not positive definite."""
     lib = load()
     n = A.shape[0]
     if A.dim() != 2 or A.shape[1] != n:
         raise ValueError(f"expected a square matrix, got {tuple(A.shape)}")
-    L = A.detach().clone().contiguous()
-    if damping != 0.0:
-        L.diagonal().add_(damping)
+    if A.stride(-1) != 1 and n > 1:
+        A = A.contiguous()
+    out = torch.empty(n, n, device=A.device, dtype=torch.float32)
     if n == 0:
-        return L
-    status = torch.zeros(1, device=A.device, dtype=torch.int32)
-    nblk = (n + block - 1) // block
-    Linv = torch.zeros(nblk, block, block, device=A.device, dtype=torch.float32)
-    st = _stream()
-    for bi, j in enumerate(range(0, n, block)):
-        nb = min(block, n - j)
-        diag = L[j : j + nb, j : j + nb]
-        _check(lib.clo_potrf_diag_f32(_p(diag), L.stride(0), nb, _p(Linv[bi]), block, status.data_ptr(), j, st),
-               "clo_potrf_diag_f32")
-        if j + nb < n:
-            P = L[j + nb :, j : j + nb]
-            T = P.contiguous()
-            gemm(T, Linv[bi, :nb, :nb].T, out=P)                     # panel solve  P <- P L_jj^-T
-            gemm(P, P.T, out=L[j + nb :, j + nb :], alpha=-1.0, beta=1.0)  # trailing update
+        return out
+    ws = torch.empty(lib.clo_cholesky_inverse_ws_floats(n), device=A.device, dtype=torch.float32)
+    status = torch.empty(1, device=A.device, dtype=torch.int32)
+    rc = lib.clo_cholesky_inverse_f32(_p(A), A.stride(0) if n > 1 else 1, _p(out), n, n, damping, _p(ws),
+                                      status.data_ptr(), _stream())
+    _check(rc, "clo_cholesky_inverse_f32")
     bad = int(status.item())
     if bad:
         raise RuntimeError(
             f"cholesky: the input is not positive-definite (pivot {bad} of {n} is not positive)."
         )
-    # Y = L^-1 (lower triangular), block row by block row; then A^-1 = Y^T Y
-    Y = torch.zeros(n, n, device=A.device, dtype=torch.float32)
-    for bi, i in enumerate(range(0, n, block)):
-        nb = min(block, n - i)
-        Li = Linv[bi, :nb, :nb]
-        Y[i : i + nb, i : i + nb] = Li
-        if i > 0:
-            T = gemm(L[i : i + nb, :i], Y[:i, :i])
-            gemm(Li, T, out=Y[i : i + nb, :i], alpha=-1.0)
-    out = torch.empty(n, n, device=A.device, dtype=torch.float32)
-    syrk_accum(out, Y, alpha=1.0, beta=0.0)
     return out
 
 

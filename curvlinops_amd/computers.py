@@ -84,7 +84,10 @@ def extract_patches(x: Tensor, kernel_size, stride, padding, dilation, groups: i
                 raise NotImplementedError("Unequal padding not supported in unfold.")
             pads.append(left)
         padding = tuple(pads)
-    cols = unfold(_group_mean(x, groups), kernel_size, dilation=dilation, padding=padding, stride=stride)
+    x = _group_mean(x, groups)
+    if is_native_tensor(x):  # one HIP launch for the whole batch (torch unfold: one per sample)
+        return _hip.im2col(x, _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation))
+    cols = unfold(x, kernel_size, dilation=dilation, padding=padding, stride=stride)
     return cols.transpose(1, 2)
 
 

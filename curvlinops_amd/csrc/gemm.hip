@@ -39,13 +39,16 @@ struct GemmArgs {
   int mode_a, mode_b;
   int tiles_m, tiles_n;
   int nbatch, batch_per_split;  // SQSUM mode only
+  int ones;  // 1: outer index M-1 of A / N-1 of B is an implicit column of ones ([X | 1])
 };
 
 // Load one [BK x 128] operand tile into 8 registers per thread.
 // Element (o, k) lives at P[o*so + k*sk]; o in [o0, o0+128), k in [k0, k0+16).
+// `ones` (outer-contiguous modes only): outer index O-1 is an implicit column of ones.
 __device__ __forceinline__ void tile_load(float (&r)[8], int mode, const float *__restrict__ P,
                                           long so, long sk, int o0, int k0, int O, int Kend,
-                                          int tid) {
+                                          int tid, int ones) {
+  const int Oreal = O - ones;  // entries that exist in memory
   if (mode == MODE_OC_VEC) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -53,12 +56,14 @@ __device__ __forceinline__ void tile_load(float (&r)[8], int mode, const float *
       const int k = k0 + (f >> 5);
       const int o = o0 + ((f & 31) << 2);
       const float *p = P + (long)k * sk + o;
-      if (k < Kend && o + 3 < O) {
+      if (k < Kend && o + 3 < Oreal) {
         const float4 v = *reinterpret_cast<const float4 *>(p);
         r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[4 * q + e] = (k < Kend && o + e < O) ? p[e] : 0.f;
+        for (int e = 0; e < 4; ++e)
+          r[4 * q + e] = (k < Kend && o + e < Oreal) ? p[e]
+                         : ((ones && k < Kend && o + e == Oreal) ? 1.f : 0.f);
       }
     }
   } else if (mode == MODE_KC_VEC) {
@@ -81,7 +86,8 @@ __device__ __forceinline__ void tile_load(float (&r)[8], int mode, const float *
     for (int q = 0; q < 8; ++q) {
       const int e = tid + 256 * q;
       const int o = o0 + (e & 127), k = k0 + (e >> 7);
-      r[q] = (o < O && k < Kend) ? P[(long)o * so + (long)k * sk] : 0.f;
+      r[q] = (o < Oreal && k < Kend) ? P[(long)o * so + (long)k * sk]
+             : ((ones && k < Kend && o == Oreal) ? 1.f : 0.f);
     }
   } else {
 #pragma unroll
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (nk > 0) {
-    tile_load(ra, p.mode_a, A, p.sa_m, p.sa_k, m0, kb, p.M, ke, tid);
-    tile_load(rb, p.mode_b, B, p.sb_n, p.sb_k, n0, kb, p.N, ke, tid);
+    tile_load(ra, p.mode_a, A, p.sa_m, p.sa_k, m0, kb, p.M, ke, tid, p.ones);
+    tile_load(rb, p.mode_b, B, p.sb_n, p.sb_k, n0, kb, p.N, ke, tid, p.ones);
     tile_store(ra, p.mode_a, As, tid);
     tile_store(rb, p.mode_b, Bs, tid);
   }
@@ -204,8 +210,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     const bool more = it + 1 < nk;
     if (more) {
       const int k0 = kb + (it + 1) * BK;
-      tile_load(ra, p.mode_a, A, p.sa_m, p.sa_k, m0, k0, p.M, ke, tid);
-      tile_load(rb, p.mode_b, B, p.sb_n, p.sb_k, n0, k0, p.N, ke, tid);
+      tile_load(ra, p.mode_a, A, p.sa_m, p.sa_k, m0, k0, p.M, ke, tid, p.ones);
+      tile_load(rb, p.mode_b, B, p.sb_n, p.sb_k, n0, k0, p.N, ke, tid, p.ones);
     }
     const float *as = As + cur * BK * LDS_STRIDE + wm * 64 + li;
     const float *bs = Bs + cur * BK * LDS_STRIDE + wn * 64 + li;
@@ -292,33 +298,6 @@ __global__ void splitk_reduce_kernel(float *C, long ldc, long sc_b, const float 
     if (beta != 0.f) v += beta * *c;
     *c = v;
   }
-}
-
-// out[j] (stride so) = beta*out[j] + alpha * sum_r X[r][j]; used for the [X | 1] bias column.
-__global__ void colsum_kernel(float *out, long so, float *out2, long so2, const float *X, long rows,
-                              int d, long ldx, float alpha, float beta) {
-  // one block per 64 columns; 4 waves stride over rows, LDS reduce.
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (j < d)
-    for (long r = wave; r < rows; r += 4) s += X[r * ldx + j];
-  part[wave][lane] = s;
-  __syncthreads();
-  if (wave == 0 && j < d) {
-    float t = alpha * (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
-    float v = t + (beta != 0.f ? beta * out[j * so] : 0.f);
-    out[j * so] = v;
-    if (out2) {
-      float v2 = t + (beta != 0.f ? beta * out2[j * so2] : 0.f);
-      out2[j * so2] = v2;
-    }
-  }
-}
-
-__global__ void scale_add_scalar_kernel(float *p, float alpha_val, float beta) {
-  *p = alpha_val + (beta != 0.f ? beta * *p : 0.f);
 }
 
 static int pick_mode(const float *P, long so, long sk, long sbatch, int batch) {
@@ -454,27 +433,15 @@ extern "C" int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows,
   if (dd == 0) return CLO_OK;
   CLO_REQUIRE(C && (X || rows == 0 || d == 0), "clo_syrk_accum_f32: null operand");
   hipStream_t st = (hipStream_t)stream;
-  if (d > 0) {
-    GemmArgs a{};
-    a.M = d; a.N = d; a.K = (int)rows; a.alpha = alpha; a.beta = beta;
-    a.A = X; a.sa_m = 1; a.sa_k = ldx; a.sa_b = 0;   // A = X^T : A(m,k) = X[k][m]
-    a.B = X; a.sb_k = ldx; a.sb_n = 1; a.sb_b = 0;
-    a.C = C; a.ldc = ldc; a.sc_b = 0;
-    a.splitk = splitk; a.ws = ws; a.sym = 1;
-    int rc = launch_gemm(a, 1, st);
-    if (rc != CLO_OK) return rc;
-  }
-  if (ones_col) {
-    if (d > 0) {
-      // last row and last column: column sums of X
-      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(d, 64)), dim3(256), 0, st,
-                         C + (long)d * ldc, 1L, C + d, ldc, X, rows, d, ldx, alpha, beta);
-      CLO_CHECK_LAUNCH("colsum_kernel");
-    }
-    hipLaunchKernelGGL(scale_add_scalar_kernel, dim3(1), dim3(1), 0, st, C + (long)d * ldc + d,
-                       alpha * (float)rows, beta);
-    CLO_CHECK_LAUNCH("scale_add_scalar_kernel");
-  }
+  GemmArgs a{};
+  a.M = dd; a.N = dd; a.K = (int)rows; a.alpha = alpha; a.beta = beta;
+  a.A = X; a.sa_m = 1; a.sa_k = ldx; a.sa_b = 0;   // A = [X | 1]^T : A(m,k) = X[k][m]
+  a.B = X; a.sb_k = ldx; a.sb_n = 1; a.sb_b = 0;
+  a.C = C; a.ldc = ldc; a.sc_b = 0;
+  a.splitk = splitk; a.ws = ws; a.sym = 1;
+  a.ones = ones_col ? 1 : 0;   // the ones column is synthesised by the tile loader
+  int rc = launch_gemm(a, 1, st);
+  if (rc != CLO_OK) return rc;
   return CLO_OK;
 }
 
@@ -494,6 +461,22 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws; a.sym = 0;
+  return launch_gemm(a, 1, st);
+}
+
+// C = beta*C + alpha * X^T X (X row-major [rows][ldx], first d columns), symmetric block raster.
+int launch_syrk_simple(float *C, long ldc, const float *X, long rows, int d, long ldx, float alpha,
+                       float beta, float *ws, long ws_floats, hipStream_t st) {
+  GemmArgs a{};
+  a.M = d; a.N = d; a.K = (int)rows; a.alpha = alpha; a.beta = beta;
+  a.A = X; a.sa_m = 1; a.sa_k = ldx; a.sa_b = 0;
+  a.B = X; a.sb_k = ldx; a.sb_n = 1; a.sb_b = 0;
+  a.C = C; a.ldc = ldc; a.sc_b = 0;
+  long s = clo_gemm_suggest_splitk(d, d, (int)rows, 1);
+  const long per = (long)d * d;
+  if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
+  a.splitk = (int)std::max<long>(1, s);
+  a.ws = ws; a.sym = 1;
   return launch_gemm(a, 1, st);
 }
 }  // namespace clo

@@ -84,7 +84,8 @@ int clo_gemm_sqsum_suggest_splits(int M, int N, int batch);
 /* ------------------------------------------------------------------------- *
  * KFAC factor accumulation: C[d][d] = beta*C + alpha * X^T X for row-major
  * X[rows][ldx] (first d columns used).  If ones_col != 0 the matrix is treated
- * as [X | 1] (joint weight+bias, kfac_math.py:115-116) and C is (d+1)x(d+1).
+ * as [X | 1] (joint weight+bias, kfac_math.py:115-116; the ones are synthesised by the tile
+ * loader, nothing is concatenated) and C is (d+1)x(d+1).
  * Only the upper block-triangle is computed on the MFMA pipe and mirrored.
  * `ws`: split-K workspace as for clo_gemm_f32 (may be NULL when splitk == 1).
  * Replaces einsum("b s i, b s j -> i j") in computers/kfac_hooks.py:350,390.
@@ -92,6 +93,11 @@ int clo_gemm_sqsum_suggest_splits(int M, int N, int batch);
 int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, long ldx,
                        int ones_col, float alpha, float beta,
                        int splitk, float *ws, void *stream);
+
+/* Patch extraction for Conv2d input covariances (kfac_utils.py:78-121: unfold + transpose):
+ * x [B][C][H][W] -> out [B*OH*OW][C*KH*KW], one launch for the whole mini-batch. */
+int clo_im2col_f32(const float *x, float *out, int B, int C, int H, int W, int KH, int KW,
+                   int SH, int SW, int PH, int PW, int DH, int DW, int OH, int OW, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Damped Cholesky inverse of a Kronecker factor (kronecker.py:328-373): the blocked algorithm
@@ -102,6 +108,14 @@ int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, lon
  * ------------------------------------------------------------------------- */
 int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int *status,
                        int pivot_base, void *stream);
+/* Whole inverse in one call: out = (A + damping I)^-1 by the recursive blocked algorithm
+ *   L11,L11^-1 = rec(A11); L21 = A21 L11^-T; S22 -= L21 L21^T; L22,L22^-1 = rec(S22);
+ *   (L^-1)21 = -L22^-1 (L21 L11^-1);   A^-1 = L^-T L^-1
+ * (leaves <= 64 in LDS, everything else GEMM/SYRK on the MFMA pipe).  A is not modified.
+ * ws: clo_cholesky_inverse_ws_floats(n) floats; *status (device int) = 0 or the failing pivot. */
+int clo_cholesky_inverse_f32(const float *A, long lda, float *out, long ldo, int n, float damping,
+                             float *ws, int *status, void *stream);
+long clo_cholesky_inverse_ws_floats(int n);
 
 /* ------------------------------------------------------------------------- *
  * MLP fast path (Sequential of Linear + elementwise activation), one mini-batch,

@@ -286,3 +286,17 @@ def test_cholesky_inverse_not_pd_raises(hip):
     A[40, 40] = 1e-12
     out = linalg_native.damped_cholesky_inverse(A.cuda(), 1e-3)
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("geom", [
+    dict(B=3, C=2, H=8, W=8, k=(3, 3), s=(1, 1), p=(1, 1), d=(1, 1)),
+    dict(B=2, C=3, H=9, W=7, k=(3, 2), s=(2, 1), p=(0, 1), d=(1, 2)),
+    dict(B=5, C=1, H=32, W=32, k=(5, 5), s=(1, 1), p=(0, 0), d=(1, 1)),
+    dict(B=4, C=64, H=8, W=8, k=(3, 3), s=(2, 2), p=(1, 1), d=(1, 1)),
+])
+def test_im2col(hip, geom):
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(geom["B"], geom["C"], geom["H"], geom["W"], generator=g)
+    ref = torch.nn.functional.unfold(x, geom["k"], dilation=geom["d"], padding=geom["p"], stride=geom["s"]).transpose(1, 2)
+    got = hip.im2col(x.cuda(), geom["k"], geom["s"], geom["p"], geom["d"])
+    assert torch.equal(got.cpu(), ref.contiguous())
