@@ -573,25 +573,44 @@ __global__ __launch_bounds__(256) void loss_hessian_kernel(const LossArgs p) {
 // jbase + wave, +8, ... with the W loads of 4 rows in flight.  If JB == 1 the kernel
 // applies dphi_prev and writes delta_prev directly, else bwd_finish_kernel sums the slabs.
 // ------------------------------------------------------------------------------------------
-template <bool VEC, bool OUTER, bool DPREV>
-__global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
+template <bool VEC, bool OUTER, bool DPREV, bool ACCUM>
+__device__ __forceinline__ void bwd_block(
     const float *__restrict__ W, const float *__restrict__ delta,
     const float *__restrict__ a_prev, const float *__restrict__ dphi_prev,
     float *__restrict__ out_W, float *__restrict__ out_b, float *__restrict__ dst, float alpha,
-    float beta, int N, int d_in, int d_out, int rows_per_block, int final_write) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+    float beta, int N, int d_in, int d_out, int rows_per_block, int final_write, int bx, int by,
+    float *smem, const float *__restrict__ dslabs = nullptr, int dnjb = 0,
+    const float *__restrict__ dphi_cur = nullptr) {
   float *s_d = smem;                          // [rows_per_block][NB]
   float *s_red = smem + rows_per_block * NB;  // [BWD_WAVES][NB][CW]   (DPREV), [NB][CW] a_prev (else)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i0 = blockIdx.x * CW;
-  const int jbase = blockIdx.y * rows_per_block;
+  const int i0 = bx * CW;
+  const int jbase = by * rows_per_block;
   const int jend = min(d_out, jbase + rows_per_block);
 
+  // delta[n][jbase ..]: coalesced along j, stored transposed ([row][n]) for broadcast reads
   for (int e = tid; e < rows_per_block * NB; e += 512) {
-    const int jj = e >> 3, n = e & 7;
+    const int n = e / rows_per_block, jj = e - n * rows_per_block;
     const int j = jbase + jj;
-    s_d[e] = (j < d_out && n < N) ? delta[(long)n * d_out + j] : 0.f;
+    float v = 0.f;
+    if (j < d_out && n < N) {
+      if (dslabs) {  // delta = dphi * (sum of the producer's row-range slabs): no finish launch
+        const float *ps = dslabs + (long)n * d_out + j;
+        const long stride = (long)NB * d_out;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int jb = 0;
+        for (; jb + 3 < dnjb; jb += 4) {
+          s0 += ps[(jb + 0) * stride]; s1 += ps[(jb + 1) * stride];
+          s2 += ps[(jb + 2) * stride]; s3 += ps[(jb + 3) * stride];
+        }
+        for (; jb < dnjb; ++jb) s0 += ps[jb * stride];
+        v = ((s0 + s1) + (s2 + s3)) * dphi_cur[(long)n * d_out + j];
+      } else {
+        v = delta[(long)n * d_out + j];
+      }
+    }
+    s_d[jj * NB + n] = v;
   }
   // a_prev[0..7][i0 .. i0+255]: loaded ONCE per block (wave n loads row n) and shared through
   // LDS -- every byte requested from L2/HBM costs the same, so no per-wave re-loads
@@ -620,7 +639,7 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
     if (DPREV) __syncthreads();  // s_red is reused for the cross-wave reduction below
   }
 
-  if (OUTER && out_b && blockIdx.x == 0) {
+  if (OUTER && out_b && bx == 0) {
     for (int jj = tid; jj < jend - jbase; jj += 512) {
       float s = 0.f;
 #pragma unroll
@@ -634,18 +653,16 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
 #pragma unroll
   for (int n = 0; n < NB; ++n) acc[n] = zero4();
 
-  constexpr int P = 4;  // rows in flight per wave
+  constexpr int P = (OUTER && DPREV && ACCUM) ? 4 : 8;  // rows in flight per wave (register budget: 128)
   const bool col_ok = VEC ? (i0 + lane * 4 < d_in) : true;
   for (int j = jbase + wave; j < jend; j += BWD_WAVES * P) {
-    float4 w4[P], old4[P];
+    float4 w4[DPREV ? P : 1], old4[(OUTER && ACCUM) ? P : 1];
 #pragma unroll
     for (int t = 0; t < P; ++t) {
       const int jt = min(j + t * BWD_WAVES, jend - 1);  // clamped: loads stay unconditional
-      w4[t] = zero4();
-      old4[t] = zero4();
-      if (DPREV) w4[t] = load_row4_raw<VEC>(W + (long)jt * d_in, i0, lane, 0, d_in);
-      if (OUTER && beta != 0.f)
-        old4[t] = load_row4_raw<VEC>(out_W + (long)jt * d_in, i0, lane, 0, d_in);
+      if (DPREV) w4[DPREV ? t : 0] = load_row4_raw<VEC>(W + (long)jt * d_in, i0, lane, 0, d_in);
+      if (OUTER && ACCUM)
+        old4[(OUTER && ACCUM) ? t : 0] = load_row4_raw<VEC>(out_W + (long)jt * d_in, i0, lane, 0, d_in);
     }
 #pragma unroll
     for (int t = 0; t < P; ++t) {
@@ -661,8 +678,11 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
             o.x += dn[n] * a[n].x; o.y += dn[n] * a[n].y;
             o.z += dn[n] * a[n].z; o.w += dn[n] * a[n].w;
           }
-          float4 r = make_float4(alpha * o.x + beta * old4[t].x, alpha * o.y + beta * old4[t].y,
-                                 alpha * o.z + beta * old4[t].z, alpha * o.w + beta * old4[t].w);
+          float4 r = make_float4(alpha * o.x, alpha * o.y, alpha * o.z, alpha * o.w);
+          if (ACCUM) {
+            const float4 od = old4[ACCUM ? t : 0];
+            r.x += beta * od.x; r.y += beta * od.y; r.z += beta * od.z; r.w += beta * od.w;
+          }
           float *po = out_W + (long)jt * d_in;
           if (VEC) {
             if (col_ok) *reinterpret_cast<float4 *>(po + i0 + lane * 4) = r;
@@ -678,8 +698,9 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
         if (DPREV) {
 #pragma unroll
           for (int n = 0; n < NB; ++n) {
-            acc[n].x += dn[n] * w4[t].x; acc[n].y += dn[n] * w4[t].y;
-            acc[n].z += dn[n] * w4[t].z; acc[n].w += dn[n] * w4[t].w;
+            const float4 wv = w4[DPREV ? t : 0];
+            acc[n].x += dn[n] * wv.x; acc[n].y += dn[n] * wv.y;
+            acc[n].z += dn[n] * wv.z; acc[n].w += dn[n] * wv.w;
           }
         }
       }
@@ -709,10 +730,63 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
         if (final_write)
           dst[(long)n * d_in + i] = s * dphi_prev[(long)n * d_in + i];
         else
-          dst[((long)blockIdx.y * NB + n) * d_in + i] = s;
+          dst[((long)by * NB + n) * d_in + i] = s;
       }
     }
   }
+}
+
+template <bool VEC, bool OUTER, bool DPREV, bool ACCUM>
+__global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
+    const float *__restrict__ W, const float *__restrict__ delta,
+    const float *__restrict__ a_prev, const float *__restrict__ dphi_prev,
+    float *__restrict__ out_W, float *__restrict__ out_b, float *__restrict__ dst, float alpha,
+    float beta, int N, int d_in, int d_out, int rows_per_block, int final_write) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_block<VEC, OUTER, DPREV, ACCUM>(W, delta, a_prev, dphi_prev, out_W, out_b, dst, alpha, beta, N,
+                                      d_in, d_out, rows_per_block, final_write, blockIdx.x,
+                                      blockIdx.y, smem);
+}
+
+// All parameter-gradient outer products of one matvec in ONE launch (write-only stream):
+// out_W_l = beta out_W_l + delta_l^T a_{l-1} for up to 16 layers.  Measured on MI355X: a sweep
+// that both reads W and writes out_W runs ~1.5x slower than the read-only and the write-only
+// sweep back to back, so the data part (delta_prev) and this part are separate kernels.
+constexpr int OUTER_MAXL = 16;
+constexpr int OUTER_ROWS = 128;  // rows per block (16 per wave)
+struct OuterAllArgs {
+  int nlayers;
+  int first_block[OUTER_MAXL + 1];
+  const float *delta[OUTER_MAXL];
+  const float *a_prev[OUTER_MAXL];
+  float *out_W[OUTER_MAXL];
+  float *out_b[OUTER_MAXL];
+  int d_in[OUTER_MAXL], d_out[OUTER_MAXL], vec[OUTER_MAXL];
+  const float *dslabs[OUTER_MAXL];  // non-null: delta_l = dphi_l * sum of these row-range slabs
+  const float *dphi[OUTER_MAXL];
+  int dnjb[OUTER_MAXL];
+  float alpha, beta;
+  int N;
+};
+
+template <bool ACCUM>
+__global__ __launch_bounds__(512, 4) void outer_all_kernel(const OuterAllArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int l = 0;
+  while (l + 1 < p.nlayers && (int)blockIdx.x >= p.first_block[l + 1]) ++l;
+  const int local = blockIdx.x - p.first_block[l];
+  const int cchunks = (p.d_in[l] + CW - 1) / CW;
+  const int bx = local % cchunks, by = local / cchunks;
+  if (p.vec[l])
+    bwd_block<true, true, false, ACCUM>(nullptr, p.delta[l], p.a_prev[l], nullptr, p.out_W[l],
+                                        p.out_b[l], nullptr, p.alpha, p.beta, p.N, p.d_in[l],
+                                        p.d_out[l], OUTER_ROWS, 0, bx, by, smem, p.dslabs[l],
+                                        p.dnjb[l], p.dphi[l]);
+  else
+    bwd_block<false, true, false, ACCUM>(nullptr, p.delta[l], p.a_prev[l], nullptr, p.out_W[l],
+                                         p.out_b[l], nullptr, p.alpha, p.beta, p.N, p.d_in[l],
+                                         p.d_out[l], OUTER_ROWS, 0, bx, by, smem, p.dslabs[l],
+                                         p.dnjb[l], p.dphi[l]);
 }
 
 __global__ void bwd_finish_kernel(const float *__restrict__ P, const float *__restrict__ dphi_prev,
@@ -730,6 +804,207 @@ __global__ void bwd_finish_kernel(const float *__restrict__ P, const float *__re
     }
     for (; jb < JB; ++jb) s0 += p[jb * stride];
     delta_prev[e] = ((s0 + s1) + (s2 + s3)) * dphi_prev[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// "Head" fusion for a narrow last layer (d_L = C <= 16, identity output, N <= 8): the three tiny,
+// latency-bound launches  fwd(L), loss Hessian, bwd(L)  are folded into the neighbours:
+//   head_fwd_kernel : finish of layer L-1 (slab sum, bias, activation)  +  per-block partial
+//                     products of layer L for the 256 features the block just produced
+//   head_bwd_kernel : merge those partials -> f, J v ; loss Hessian -> delta_L ; backward through
+//                     layer L (out_W_L, out_b_L, delta_{L-1}) for a 256-column chunk per block
+// ------------------------------------------------------------------------------------------
+constexpr int HEAD_CMAX = 16;
+
+struct HeadFwdArgs {
+  const float *part;  // slabs of layer L-1 (nullptr: a/da/dphi already final)
+  int ksplit;
+  const float *b, *Vb;          // bias of layer L-1 and its tangent
+  float *a, *da, *dphi;         // [N][d] outputs of layer L-1 (inputs if part == nullptr)
+  int N, d, act;
+  const float *WL, *VL;         // [C][d] last-layer weight and its tangent
+  int C;
+  float *hp;                    // [N][nblk][2][HEAD_CMAX] partial z_L / dz_L
+};
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs p) {
+  const int tid = threadIdx.x;
+  const int nblk = gridDim.x, n = blockIdx.y;
+  const int j = blockIdx.x * 256 + tid;
+  float av = 0.f, dav = 0.f;
+  if (j < p.d) {
+    const long e = (long)n * p.d + j;
+    if (p.part) {
+      float zz = p.b ? p.b[j] : 0.f, dzz = p.Vb ? p.Vb[j] : 0.f;
+      const float *p0 = p.part + e;
+      const long sstride = 2L * NB * p.d, dzoff = (long)NB * p.d;
+      int sp = 0;
+      for (; sp + 3 < p.ksplit; sp += 4) {
+        const float z0 = p0[(sp + 0) * sstride], z1 = p0[(sp + 1) * sstride];
+        const float z2 = p0[(sp + 2) * sstride], z3 = p0[(sp + 3) * sstride];
+        const float d0 = p0[(sp + 0) * sstride + dzoff], d1 = p0[(sp + 1) * sstride + dzoff];
+        const float d2 = p0[(sp + 2) * sstride + dzoff], d3 = p0[(sp + 3) * sstride + dzoff];
+        zz += (z0 + z1) + (z2 + z3);
+        dzz += (d0 + d1) + (d2 + d3);
+      }
+      for (; sp < p.ksplit; ++sp) {
+        zz += p0[sp * sstride];
+        dzz += p0[sp * sstride + dzoff];
+      }
+      float dphi;
+      av = act_apply(p.act, zz, dphi);
+      dav = dphi * dzz;
+      p.a[e] = av;
+      p.da[e] = dav;
+      p.dphi[e] = dphi;
+    } else {
+      av = p.a[e];
+      dav = p.da[e];
+    }
+  }
+  // partial products of the last layer over this block's 256 features: thread (c, sub) sums 16
+  // features from LDS, then a 16-lane shuffle reduction (short dependency chains)
+  __shared__ float s_av[256], s_dav[256];
+  s_av[tid] = av;
+  s_dav[tid] = dav;
+  __syncthreads();
+  {
+    const int c = tid >> 4, sub = tid & 15;  // 16 classes x 16 sub-ranges
+    float z = 0.f, dz = 0.f;
+    if (c < p.C) {
+      const int jb = blockIdx.x * 256 + sub * 16;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int jj = jb + q;
+        if (jj < p.d) {
+          const float w = p.WL[(long)c * p.d + jj], v = p.VL[(long)c * p.d + jj];
+          const float x = s_av[sub * 16 + q], dx = s_dav[sub * 16 + q];
+          z = fmaf(w, x, z);
+          dz = fmaf(w, dx, fmaf(v, x, dz));
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      z += __shfl_xor(z, off, 64);
+      dz += __shfl_xor(dz, off, 64);
+    }
+    if (sub == 0) {
+      float *o = p.hp + (((long)n * nblk + blockIdx.x) * 2) * HEAD_CMAX + c;
+      o[0] = z;
+      o[HEAD_CMAX] = dz;
+    }
+  }
+}
+
+struct HeadBwdArgs {
+  const float *hp;  // [N][nblk][2][HEAD_CMAX]
+  int nblk;
+  const float *bL, *VbL;        // last-layer bias and its tangent (may be null)
+  int kind;                     // CLO_LOSS_*
+  const float *aux;             // RANK1: [N][rank][C]
+  int aux_rank;
+  float scale;                  // loss scale * alpha
+  const float *WL;              // [C][d]
+  const float *a_prev, *dphi_prev;  // [N][d]
+  float *out_W, *out_b;         // [C][d], [C]
+  float *delta_prev;            // [N][d]
+  float beta;
+  int N, d, C;
+};
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
+  __shared__ float s_f[NB][HEAD_CMAX], s_u[NB][HEAD_CMAX], s_dl[NB][HEAD_CMAX];
+  const int tid = threadIdx.x;
+  const int N = p.N, C = p.C;
+  // ---- merge the head partials: f = b_L + sum_blk hp, u = Vb_L + sum_blk dhp  (every block)
+  if (tid < NB * HEAD_CMAX) {
+    const int n = tid / HEAD_CMAX, c = tid % HEAD_CMAX;
+    float f = 0.f, u = 0.f;
+    if (n < N && c < C) {
+      f = p.bL ? p.bL[c] : 0.f;
+      u = p.VbL ? p.VbL[c] : 0.f;
+      const float *q = p.hp + ((long)n * p.nblk * 2) * HEAD_CMAX + c;
+      for (int k = 0; k < p.nblk; ++k) {
+        f += q[(long)k * 2 * HEAD_CMAX];
+        u += q[((long)k * 2 + 1) * HEAD_CMAX];
+      }
+    }
+    s_f[n][c] = f;
+    s_u[n][c] = u;
+  }
+  __syncthreads();
+  // ---- loss Hessian per sample (C <= 16: one thread per sample)
+  if (tid < NB) {
+    const int n = tid;
+    if (n < N) {
+      if (p.kind == CLO_LOSS_MSE) {
+        for (int c = 0; c < C; ++c) s_dl[n][c] = p.scale * s_u[n][c];
+      } else if (p.kind == CLO_LOSS_BCE) {
+        for (int c = 0; c < C; ++c) {
+          const float sg = 1.f / (1.f + __expf(-s_f[n][c]));
+          s_dl[n][c] = p.scale * sg * (1.f - sg) * s_u[n][c];
+        }
+      } else if (p.kind == CLO_LOSS_CE) {
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, s_f[n][c]);
+        float se = 0.f, spu = 0.f;
+        for (int c = 0; c < C; ++c) {
+          const float e = __expf(s_f[n][c] - mx);
+          se += e;
+          spu += e * s_u[n][c];
+        }
+        const float inv = 1.f / se, pu = spu * inv;
+        for (int c = 0; c < C; ++c) {
+          const float pc = __expf(s_f[n][c] - mx) * inv;
+          s_dl[n][c] = p.scale * pc * (s_u[n][c] - pu);
+        }
+      } else {
+        for (int c = 0; c < C; ++c) s_dl[n][c] = 0.f;
+        for (int m = 0; m < p.aux_rank; ++m) {
+          const float *g = p.aux + ((long)n * p.aux_rank + m) * C;
+          float sdot = 0.f;
+          for (int c = 0; c < C; ++c) sdot += g[c] * s_u[n][c];
+          for (int c = 0; c < C; ++c) s_dl[n][c] += p.scale * g[c] * sdot;
+        }
+      }
+    } else {
+      for (int c = 0; c < C; ++c) s_dl[n][c] = 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- backward through the last layer for column i
+  const int i = blockIdx.x * 256 + tid;
+  if (blockIdx.x == 0 && tid < C && p.out_b) {
+    float sb = 0.f;
+    for (int n = 0; n < N; ++n) sb += s_dl[n][tid];
+    p.out_b[tid] = (p.beta != 0.f ? p.beta * p.out_b[tid] : 0.f) + sb;
+  }
+  if (i < p.d) {
+    float ap[NB], acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      ap[n] = n < N ? p.a_prev[(long)n * p.d + i] : 0.f;
+      acc[n] = 0.f;
+    }
+    for (int c = 0; c < C; ++c) {
+      const float w = p.WL[(long)c * p.d + i];
+      float o = 0.f;
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const float dl = s_dl[n][c];
+        o = fmaf(dl, ap[n], o);
+        acc[n] = fmaf(dl, w, acc[n]);
+      }
+      float *po = p.out_W + (long)c * p.d + i;
+      *po = (p.beta != 0.f ? p.beta * *po : 0.f) + o;
+    }
+    if (p.delta_prev) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        if (n < N) p.delta_prev[(long)n * p.d + i] = acc[n] * p.dphi_prev[(long)n * p.d + i];
+    }
   }
 }
 
@@ -896,7 +1171,7 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
 static int bwd_pass(const float *W, const float *delta, const float *a_prev,
                     const float *dphi_prev, float *out_W, float *out_b, float *delta_prev,
                     float alpha, float beta, int N, int d_in, int d_out, float *ws,
-                    hipStream_t st) {
+                    hipStream_t st, int *leave_slabs_njb = nullptr) {
   const bool outer = out_W != nullptr, dprev = delta_prev != nullptr;
   if (!outer && !dprev) return CLO_OK;
   const int JB = bwd_jb(d_in, d_out, dprev);
@@ -910,25 +1185,35 @@ static int bwd_pass(const float *W, const float *delta, const float *a_prev,
   int rc = CLO_OK;
   // algorithmic bytes: out_W written once (+ read when accumulating), W read once for delta_prev
   ProfScope prof(2, 4.0 * d_in * d_out * ((outer ? (beta != 0.f ? 2 : 1) : 0) + (dprev ? 1 : 0)), st);
-#define CLO_BWD(V, O, D)                                                                        \
+#define CLO_BWD(V, O, D, A)                                                                     \
   do {                                                                                          \
-    rc = set_smem(bwd_fused_kernel<V, O, D>, smem);                                             \
+    rc = set_smem(bwd_fused_kernel<V, O, D, A>, smem);                                          \
     if (rc != CLO_OK) return rc;                                                                \
-    hipLaunchKernelGGL((bwd_fused_kernel<V, O, D>), grid, block, smem, st, W, delta, a_prev,    \
+    hipLaunchKernelGGL((bwd_fused_kernel<V, O, D, A>), grid, block, smem, st, W, delta, a_prev, \
                        dphi_prev, out_W, out_b, dst, alpha, beta, N, d_in, d_out, rpb, fin);    \
   } while (0)
+#define CLO_BWD2(V, O, D)                  \
+  do {                                     \
+    if (outer && beta != 0.f) CLO_BWD(V, O, D, true); \
+    else CLO_BWD(V, O, D, false);          \
+  } while (0)
   if (vec) {
-    if (outer && dprev) CLO_BWD(true, true, true);
-    else if (outer) CLO_BWD(true, true, false);
-    else CLO_BWD(true, false, true);
+    if (outer && dprev) CLO_BWD2(true, true, true);
+    else if (outer) CLO_BWD2(true, true, false);
+    else CLO_BWD(true, false, true, false);
   } else {
-    if (outer && dprev) CLO_BWD(false, true, true);
-    else if (outer) CLO_BWD(false, true, false);
-    else CLO_BWD(false, false, true);
+    if (outer && dprev) CLO_BWD2(false, true, true);
+    else if (outer) CLO_BWD2(false, true, false);
+    else CLO_BWD(false, false, true, false);
   }
+#undef CLO_BWD2
 #undef CLO_BWD
   CLO_CHECK_LAUNCH("bwd_fused_kernel");
   if (prof.on) { prof_end(st); prof.on = false; }
+  if (leave_slabs_njb) {  // the consumer sums the slabs itself (0: delta_prev is already final)
+    *leave_slabs_njb = (dprev && JBe > 1) ? JBe : 0;
+    return CLO_OK;
+  }
   if (dprev && JBe > 1) {
     ProfScope pf(3, 0.0, st);
     hipLaunchKernelGGL(bwd_finish_kernel, dim3(ew_grid((long)N * d_in)), dim3(256), 0, st, ws,
@@ -1043,7 +1328,7 @@ extern "C" long clo_mlp_ggn_ws_floats(int L, const int *dims, int N) {
   long total = 0;
   int dmax = 0;
   for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
-  for (int l = 1; l <= L; ++l) total += 3L * N * dims[l];
+  for (int l = 1; l <= L; ++l) total += 4L * N * dims[l];  // a, da, dphi, delta per layer
   total += 2L * N * dmax;
   long part = 0;
   for (int l = 1; l <= L; ++l) {
@@ -1052,6 +1337,7 @@ extern "C" long clo_mlp_ggn_ws_floats(int L, const int *dims, int N) {
   }
   total += part;
   if (N > SKINNY_MAX_N) total += gemm_ws_floats(N, dmax);
+  else total += (long)NB * (cdiv(dmax, 256) + 1) * 2 * HEAD_CMAX;  // head partials
   return total + 256;
 }
 
@@ -1091,11 +1377,11 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
   // carve the workspace
   float *p = ws;
-  float *a[65], *da[65], *dphi[65];
-  a[0] = const_cast<float *>(X); da[0] = nullptr; dphi[0] = nullptr;
+  float *a[65], *da[65], *dphi[65], *dl[65];
+  a[0] = const_cast<float *>(X); da[0] = nullptr; dphi[0] = nullptr; dl[0] = nullptr;
   for (int l = 1; l <= L; ++l) {
     const long sz = (long)N * dims[l];
-    a[l] = p; p += sz; da[l] = p; p += sz; dphi[l] = p; p += sz;
+    a[l] = p; p += sz; da[l] = p; p += sz; dphi[l] = p; p += sz; dl[l] = p; p += sz;
   }
   float *dl0 = p; p += (long)N * dmax;
   float *dl1 = p; p += (long)N * dmax;
@@ -1113,13 +1399,19 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   const bool last_linear = acts[L - 1] == CLO_ACT_IDENTITY;
   int rc;
   int last_ksplit = 1;
+  // narrow linear head: fold fwd(L) + loss + bwd(L) into the neighbouring launches
+  const bool head = skinny && N <= NB && L >= 2 && last_linear && dims[L] <= HEAD_CMAX;
+  const int Lf = head ? L - 1 : L;  // layers run by the generic forward loop
+  float *hp = nullptr;
+  int head_nblk = 0;
   // ---- forward + JVP
-  for (int l = 1; l <= L; ++l) {
+  for (int l = 1; l <= Lf; ++l) {
     const int di = dims[l - 1], dout = dims[l];
     const float *bl = b ? b[l - 1] : nullptr, *vbl = Vb ? Vb[l - 1] : nullptr;
     if (skinny) {
-      // the last layer's split-K slabs are merged by the loss kernel (single 8-row pass only)
-      const bool defer = l == L && last_linear && N <= NB;
+      // the last layer's split-K slabs are merged by the loss kernel (single 8-row pass only);
+      // with a fused head, layer L-1 leaves its slabs for head_fwd_kernel
+      const bool defer = (l == L && last_linear && N <= NB) || (head && l == Lf);
       for (int n0 = 0; n0 < N; n0 += NB) {
         const int nn = std::min(NB, N - n0);
         rc = fwd_pass(W[l - 1], bl, VW[l - 1], vbl, a[l - 1] + (long)n0 * di,
@@ -1146,18 +1438,92 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
       CLO_CHECK_LAUNCH("fwd_epilogue_kernel");
     }
   }
+  float *dcur, *dnext;
+  int lstart = L;
+  if (head) {
+    const int d = dims[L - 1], C = dims[L];
+    head_nblk = (int)cdiv(d, 256);
+    hp = gws;  // [N][nblk][2][HEAD_CMAX]; the GEMM slab area is unused on the skinny path
+    HeadFwdArgs fa{};
+    fa.part = last_ksplit > 1 ? part : nullptr; fa.ksplit = last_ksplit;
+    fa.b = b ? b[L - 2] : nullptr; fa.Vb = Vb ? Vb[L - 2] : nullptr;
+    fa.a = a[L - 1]; fa.da = da[L - 1]; fa.dphi = dphi[L - 1];
+    fa.N = N; fa.d = d; fa.act = acts[L - 2];
+    fa.WL = W[L - 1]; fa.VL = VW[L - 1]; fa.C = C; fa.hp = hp;
+    {
+      ProfScope pf(3, 0.0, st);
+      hipLaunchKernelGGL(head_fwd_kernel, dim3(head_nblk, N), dim3(256), 0, st, fa);
+      CLO_CHECK_LAUNCH("head_fwd_kernel");
+    }
+    HeadBwdArgs ba{};
+    ba.hp = hp; ba.nblk = head_nblk;
+    ba.bL = b ? b[L - 1] : nullptr; ba.VbL = Vb ? Vb[L - 1] : nullptr;
+    ba.kind = loss_kind; ba.aux = aux; ba.aux_rank = aux_rank; ba.scale = loss_scale * alpha;
+    ba.WL = W[L - 1]; ba.a_prev = a[L - 1]; ba.dphi_prev = dphi[L - 1];
+    ba.out_W = OW[L - 1]; ba.out_b = Ob ? Ob[L - 1] : nullptr; ba.delta_prev = dl[L - 1];
+    ba.beta = beta; ba.N = N; ba.d = d; ba.C = C;
+    {
+      ProfScope pf(1, 4.0 * d * C, st);
+      hipLaunchKernelGGL(head_bwd_kernel, dim3(head_nblk), dim3(256), 0, st, ba);
+      CLO_CHECK_LAUNCH("head_bwd_kernel");
+    }
+    dcur = dl[L - 1]; dnext = dl0;
+    lstart = L - 1;
+  } else {
   // ---- output-space curvature: delta_L = dphi_L * (alpha * s * H u)
   {
     const int C = dims[L];
     const bool merge = last_ksplit > 1;
-    rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], last_linear ? nullptr : dphi[L], dl0, N,
+    float *dL = (skinny && N <= NB) ? dl[L] : dl0;
+    rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], last_linear ? nullptr : dphi[L], dL, N,
                      C, loss_scale * alpha, merge ? part : nullptr, last_ksplit,
                      b ? b[L - 1] : nullptr, Vb ? Vb[L - 1] : nullptr, a[L], da[L], st);
     if (rc != CLO_OK) return rc;
   }
-  // ---- backward
-  float *dcur = dl0, *dnext = dl1;
-  for (int l = L; l >= 1; --l) {
+  dcur = (skinny && N <= NB) ? dl[L] : dl0; dnext = dl1;
+  }
+  // ---- backward, single 8-row pass: data chain (read-only sweeps of W_l) first, then ALL
+  // parameter outer products in one write-only launch
+  if (skinny && N <= NB) {
+    if (lstart > OUTER_MAXL) {
+      set_error("clo_mlp_ggn_matvec: more than %d layers", OUTER_MAXL);
+      return CLO_EUNSUP;
+    }
+    int njb1 = 0;  // > 0: delta_1 is still spread over row-range slabs in `part`
+    for (int l = lstart; l >= 2; --l) {
+      rc = bwd_pass(W[l - 1], dl[l], nullptr, dphi[l - 1], nullptr, nullptr, dl[l - 1], 1.f, 0.f, N,
+                    dims[l - 1], dims[l], part, st, l == 2 ? &njb1 : nullptr);
+      if (rc != CLO_OK) return rc;
+    }
+    if (lstart >= 1) {
+      OuterAllArgs oa{};
+      oa.nlayers = lstart; oa.alpha = 1.f; oa.beta = beta; oa.N = N;
+      int nb = 0;
+      for (int l = 1; l <= lstart; ++l) {
+        const int k = l - 1;
+        oa.first_block[k] = nb;
+        oa.delta[k] = dl[l]; oa.a_prev[k] = a[l - 1];
+        oa.out_W[k] = OW[l - 1]; oa.out_b[k] = Ob ? Ob[l - 1] : nullptr;
+        oa.d_in[k] = dims[l - 1]; oa.d_out[k] = dims[l];
+        oa.vec[k] = vec_ok(dims[l - 1], {a[l - 1], OW[l - 1]}) ? 1 : 0;
+        if (l == 1 && njb1 > 0) { oa.dslabs[k] = part; oa.dnjb[k] = njb1; oa.dphi[k] = dphi[1]; }
+        nb += (int)(cdiv(dims[l - 1], CW) * cdiv(dims[l], OUTER_ROWS));
+      }
+      oa.first_block[lstart] = nb;
+      const size_t smem = (size_t)(OUTER_ROWS * NB + NB * CW) * sizeof(float);
+      double bytes = 0;
+      for (int l = 1; l <= lstart; ++l) bytes += 4.0 * dims[l - 1] * dims[l] * (beta != 0.f ? 2 : 1);
+      ProfScope prof(2, bytes, st);
+      if (beta != 0.f)
+        hipLaunchKernelGGL(outer_all_kernel<true>, dim3(nb), dim3(512), smem, st, oa);
+      else
+        hipLaunchKernelGGL(outer_all_kernel<false>, dim3(nb), dim3(512), smem, st, oa);
+      CLO_CHECK_LAUNCH("outer_all_kernel");
+    }
+    return CLO_OK;
+  }
+  // ---- backward (two 8-row passes / GEMM path): layer by layer
+  for (int l = lstart; l >= 1; --l) {
     const int di = dims[l - 1], dout = dims[l];
     float *obl = Ob ? Ob[l - 1] : nullptr;
     float *dprev = l > 1 ? dnext : nullptr;

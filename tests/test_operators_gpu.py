@@ -266,3 +266,27 @@ def test_trace_estimators_gpu(dev):
     torch.manual_seed(0)
     ests = torch.stack([C.hutchinson_trace(op, 29) for _ in range(200)])
     assert abs(ests.mean() - A.trace()) / A.trace() < 0.05
+
+
+def test_repeated_products_stress(dev):
+    """The split-K / row-range slabs and the activation workspace are reused by every product:
+    300 back-to-back products with changing vectors, each checked through linearity against
+    three reference products (catches stale-buffer / ordering bugs between launches)."""
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(1024, 2688), nn.ReLU(), nn.Linear(2688, 2688), nn.ReLU(), nn.Linear(2688, 10)).to(dev)
+    params = dict(model.named_parameters())
+    X, y = torch.rand(8, 1024, device=dev), torch.rand(8, 10, device=dev)
+    G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X, y)], check_deterministic=False)
+    D = G.shape[1]
+    basis = [torch.rand(D, device=dev) - 0.5 for _ in range(3)]
+    Gb = [G @ b for b in basis]
+    torch.cuda.synchronize()
+    worst = 0.0
+    for it in range(300):
+        c = torch.rand(3, device=dev) - 0.5
+        v = c[0] * basis[0] + c[1] * basis[1] + c[2] * basis[2]
+        ref = c[0] * Gb[0] + c[1] * Gb[1] + c[2] * Gb[2]
+        got = G @ v
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        worst = max(worst, err)
+    assert worst < 5e-4, worst
