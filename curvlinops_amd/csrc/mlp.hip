@@ -414,6 +414,117 @@ __global__ __launch_bounds__(MF_WAVES * 64) void fwd_mfma_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// First-layer variant (no incoming tangent da): the WAVES waves of a block split K among
+// themselves for the SAME RG x 8 features and merge through LDS, so the layer needs neither
+// split-K slabs nor a finish launch.  B = [x ; 0] comes straight from global memory (each wave
+// only touches its own K range of x: 8 rows against the 16 RG weight rows it streams).
+// ------------------------------------------------------------------------------------------
+template <int WAVES, int RG, int U>
+__global__ __launch_bounds__(WAVES * 64) void fwd_mfma_first_kernel(
+    const float *__restrict__ W, const float *__restrict__ b, const float *__restrict__ VW,
+    const float *__restrict__ Vb, const float *__restrict__ a_in, float *__restrict__ a_out,
+    float *__restrict__ da_out, float *__restrict__ dphi_out, int N, int d_in, int d_out, int act,
+    int k_per_wave, int fpb) {
+  // fpb <= RG * 8 features per block (chosen so that the grid fills the CUs evenly); tile rows
+  // past the block's features alias its last row (same address within one load instruction)
+  __shared__ float s_red[WAVES][RG][4][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = lane & 15, s4 = (lane >> 4) * 4;
+  const int kb0 = min(wave * k_per_wave, d_in);
+  const int klen = min(d_in, kb0 + k_per_wave) - kb0;  // multiple of 4, may be 0
+  const int j0 = blockIdx.x * fpb;
+  const int jlast = min(j0 + fpb, d_out) - 1;
+
+  const float *pA[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int row = min(j0 + g * 8 + (idx & 7), jlast);
+    pA[g] = ((idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
+  }
+  // B lanes: columns 0..7 = x rows, columns 8..15 (the absent da) and rows >= N are zero: they
+  // load a valid duplicate address and are masked
+  const int nb = idx & 7;
+  const unsigned bmask = (idx < 8 && nb < N) ? 0xffffffffu : 0u;
+  const float *pB = a_in + (long)min(nb, N - 1) * d_in + kb0 + s4;
+
+  f32x4 acc[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nfull = klen >> 4;
+  int step = 0;
+  for (; step + U <= nfull; step += U) {
+    float4 av[U][RG], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) av[u][g] = ld4(pA[g] + (step + u) * 16);
+      bv[u] = ld4(pB + (step + u) * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float bx = __uint_as_float(__float_as_uint(bv[u].x) & bmask);
+      const float by = __uint_as_float(__float_as_uint(bv[u].y) & bmask);
+      const float bz = __uint_as_float(__float_as_uint(bv[u].z) & bmask);
+      const float bw = __uint_as_float(__float_as_uint(bv[u].w) & bmask);
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].x, bx, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].y, by, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].z, bz, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].w, bw, acc[g], 0, 0, 0);
+      }
+    }
+  }
+  for (; step * 16 < klen; ++step) {  // leftover full steps and the partial one
+    const bool ok = step * 16 + s4 < klen;
+    const unsigned m = ok ? bmask : 0u;
+    const float4 bv = ld4(pB + (ok ? step * 16 : 0));
+    const float bx = __uint_as_float(__float_as_uint(bv.x) & m);
+    const float by = __uint_as_float(__float_as_uint(bv.y) & m);
+    const float bz = __uint_as_float(__float_as_uint(bv.z) & m);
+    const float bw = __uint_as_float(__float_as_uint(bv.w) & m);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const float4 av = ld4(pA[g] + (ok ? step * 16 : 0));
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bx, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, by, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bz, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bw, acc[g], 0, 0, 0);
+    }
+  }
+
+  // ---- merge the waves' K ranges, then the epilogue of fwd_mfma_kernel by wave g for group g
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[wave][g][r][lane] = acc[g][r];
+  __syncthreads();
+  if (wave >= RG) return;
+  const int g = wave;
+  const int q = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += s_red[w][g][r][lane];
+    const float up = __shfl(v, (lane + 24) & 63, 64);    // D[8+i][n]: the VW . x part
+    const float zsrc = __shfl(v, (lane + 56) & 63, 64);  // D[i][n]
+    if (q < 2 && col >= 8) {
+      const int n = col - 8, j = j0 + g * 8 + q * 4 + r;
+      if (n < N && j <= jlast) {
+        float dphi;
+        const float aval = act_apply(act, zsrc + (b ? b[j] : 0.f), dphi);
+        a_out[(long)n * d_out + j] = aval;
+        if (dphi_out) dphi_out[(long)n * d_out + j] = dphi;
+        da_out[(long)n * d_out + j] = dphi * (up + (Vb ? Vb[j] : 0.f));
+      }
+    }
+  }
+}
+
 // Sum the split-K slabs of fwd_jvp_kernel and apply bias + activation.
 __global__ void fwd_finish_kernel(const float *__restrict__ part, int ksplit,
                                   const float *__restrict__ b, const float *__restrict__ Vb,
@@ -832,6 +943,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs p) {
   const int tid = threadIdx.x;
   const int nblk = gridDim.x, n = blockIdx.y;
   const int j = blockIdx.x * 256 + tid;
+  // last-layer operands of the partial product below: issued first, they do not depend on the
+  // slab sum (latency-bound kernel: keep every independent load in flight from the start)
+  const int hc = tid >> 4, hsub = tid & 15;  // 16 classes x 16 sub-ranges
+  const int hjb = blockIdx.x * 256 + hsub * 16;
+  float hw[16], hv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const bool ok = hc < p.C && hjb + q < p.d;
+    const long off = ok ? (long)hc * p.d + hjb + q : 0;
+    hw[q] = p.WL[off];
+    hv[q] = p.VL[off];
+    if (!ok) hw[q] = hv[q] = 0.f;
+  }
   float av = 0.f, dav = 0.f;
   if (j < p.d) {
     const long e = (long)n * p.d + j;
@@ -839,16 +963,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs p) {
       float zz = p.b ? p.b[j] : 0.f, dzz = p.Vb ? p.Vb[j] : 0.f;
       const float *p0 = p.part + e;
       const long sstride = 2L * NB * p.d, dzoff = (long)NB * p.d;
-      int sp = 0;
-      for (; sp + 3 < p.ksplit; sp += 4) {
-        const float z0 = p0[(sp + 0) * sstride], z1 = p0[(sp + 1) * sstride];
-        const float z2 = p0[(sp + 2) * sstride], z3 = p0[(sp + 3) * sstride];
-        const float d0 = p0[(sp + 0) * sstride + dzoff], d1 = p0[(sp + 1) * sstride + dzoff];
-        const float d2 = p0[(sp + 2) * sstride + dzoff], d3 = p0[(sp + 3) * sstride + dzoff];
-        zz += (z0 + z1) + (z2 + z3);
-        dzz += (d0 + d1) + (d2 + d3);
+      // all slabs in flight at once (ksplit <= 16): clamped index + zero weight, no branches
+      float zs[16], ds[16];
+#pragma unroll
+      for (int sp = 0; sp < 16; ++sp) {
+        const int spc = sp < p.ksplit ? sp : 0;
+        zs[sp] = p0[spc * sstride];
+        ds[sp] = p0[spc * sstride + dzoff];
       }
-      for (; sp < p.ksplit; ++sp) {
+#pragma unroll
+      for (int sp = 0; sp < 16; ++sp) {
+        zz += sp < p.ksplit ? zs[sp] : 0.f;
+        dzz += sp < p.ksplit ? ds[sp] : 0.f;
+      }
+      for (int sp = 16; sp < p.ksplit; ++sp) {
         zz += p0[sp * sstride];
         dzz += p0[sp * sstride + dzoff];
       }
@@ -870,27 +998,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs p) {
   s_dav[tid] = dav;
   __syncthreads();
   {
-    const int c = tid >> 4, sub = tid & 15;  // 16 classes x 16 sub-ranges
+    const int c = hc, sub = hsub;
     float z = 0.f, dz = 0.f;
-    if (c < p.C) {
-      const int jb = blockIdx.x * 256 + sub * 16;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int jj = jb + q;
-        if (jj < p.d) {
-          const float w = p.WL[(long)c * p.d + jj], v = p.VL[(long)c * p.d + jj];
-          const float x = s_av[sub * 16 + q], dx = s_dav[sub * 16 + q];
-          z = fmaf(w, x, z);
-          dz = fmaf(w, dx, fmaf(v, x, dz));
-        }
-      }
+    for (int q = 0; q < 16; ++q) {
+      const float x = s_av[sub * 16 + q], dx = s_dav[sub * 16 + q];
+      z = fmaf(hw[q], x, z);
+      dz = fmaf(hw[q], dx, fmaf(hv[q], x, dz));
     }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) {
       z += __shfl_xor(z, off, 64);
       dz += __shfl_xor(dz, off, 64);
     }
-    if (sub == 0) {
+    if (sub == 0 && c < p.C) {
       float *o = p.hp + (((long)n * nblk + blockIdx.x) * 2) * HEAD_CMAX + c;
       o[0] = z;
       o[HEAD_CMAX] = dz;
@@ -918,21 +1039,35 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
   __shared__ float s_f[NB][HEAD_CMAX], s_u[NB][HEAD_CMAX], s_dl[NB][HEAD_CMAX];
   const int tid = threadIdx.x;
   const int N = p.N, C = p.C;
+  // operands of the column phase do not depend on the merge: get them in flight first
+  const int i = blockIdx.x * 256 + tid;
+  const int ic = i < p.d ? i : 0;
+  float ap[NB], dpp[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const long off = (long)(n < N ? n : 0) * p.d + ic;
+    ap[n] = p.a_prev[off];
+    dpp[n] = p.delta_prev ? p.dphi_prev[off] : 0.f;
+    if (n >= N) ap[n] = 0.f;
+  }
   // ---- merge the head partials: f = b_L + sum_blk hp, u = Vb_L + sum_blk dhp  (every block)
-  if (tid < NB * HEAD_CMAX) {
-    const int n = tid / HEAD_CMAX, c = tid % HEAD_CMAX;
-    float f = 0.f, u = 0.f;
+  // thread = (n, which in {z, dz}, c): [2][HEAD_CMAX] is contiguous in hp, 8 slabs in flight
+  {
+    const int n = tid >> 5, r = tid & 31, c = r & (HEAD_CMAX - 1);
+    float acc = 0.f;
     if (n < N && c < C) {
-      f = p.bL ? p.bL[c] : 0.f;
-      u = p.VbL ? p.VbL[c] : 0.f;
-      const float *q = p.hp + ((long)n * p.nblk * 2) * HEAD_CMAX + c;
-      for (int k = 0; k < p.nblk; ++k) {
-        f += q[(long)k * 2 * HEAD_CMAX];
-        u += q[((long)k * 2 + 1) * HEAD_CMAX];
+      const float *bias = (r < HEAD_CMAX) ? p.bL : p.VbL;
+      acc = bias ? bias[c] : 0.f;
+      const float *q = p.hp + ((long)n * p.nblk * 2) * HEAD_CMAX + r;
+      for (int k0 = 0; k0 < p.nblk; k0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = q[(long)min(k0 + k, p.nblk - 1) * 2 * HEAD_CMAX];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (k0 + k < p.nblk) ? t[k] : 0.f;
       }
     }
-    s_f[n][c] = f;
-    s_u[n][c] = u;
+    if (r < HEAD_CMAX) s_f[n][c] = acc; else s_u[n][c] = acc;
   }
   __syncthreads();
   // ---- loss Hessian per sample (C <= 16: one thread per sample)
@@ -975,19 +1110,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
   }
   __syncthreads();
   // ---- backward through the last layer for column i
-  const int i = blockIdx.x * 256 + tid;
   if (blockIdx.x == 0 && tid < C && p.out_b) {
     float sb = 0.f;
     for (int n = 0; n < N; ++n) sb += s_dl[n][tid];
     p.out_b[tid] = (p.beta != 0.f ? p.beta * p.out_b[tid] : 0.f) + sb;
   }
   if (i < p.d) {
-    float ap[NB], acc[NB];
+    float acc[NB];
 #pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      ap[n] = n < N ? p.a_prev[(long)n * p.d + i] : 0.f;
-      acc[n] = 0.f;
-    }
+    for (int n = 0; n < NB; ++n) acc[n] = 0.f;
+#pragma unroll 4
     for (int c = 0; c < C; ++c) {
       const float w = p.WL[(long)c * p.d + i];
       float o = 0.f;
@@ -1003,7 +1135,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
     if (p.delta_prev) {
 #pragma unroll
       for (int n = 0; n < NB; ++n)
-        if (n < N) p.delta_prev[(long)n * p.d + i] = acc[n] * p.dphi_prev[(long)n * p.d + i];
+        if (n < N) p.delta_prev[(long)n * p.d + i] = acc[n] * dpp[n];
     }
   }
 }
@@ -1057,6 +1189,7 @@ static int fwd_ksplit(int d_in, int d_out) {
 // MFMA kernel: a block covers MF_WAVES * MF_RG * 8 features and one K range.  Aim at >= 2 blocks
 // per CU; K ranges are multiples of 32 and at most MF_KB_MAX (LDS).
 constexpr int MF_RG = 2;
+constexpr int MF1_WAVES = 8, MF1_RG = 2, MF1_U = 4;  // fwd_mfma_first_kernel
 static int mfma_kpb(int d_in, int d_out) {
   const long row_blocks = cdiv(d_out, MF_WAVES * MF_RG * 8);
   long ksplit = std::max<long>(1, cdiv(2 * kNumCU, row_blocks));
@@ -1100,6 +1233,34 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
                     bool leave_partials, int *ksplit_out, hipStream_t st) {
   const bool has_v = VW != nullptr, has_da = da_in != nullptr;
   const bool vec = vec_ok(d_in, {W, VW, a_in, da_in});
+  if (vec && N >= 1 && has_v && !has_da && d_in >= 256 && cdiv(d_out, MF1_RG * 8) >= kNumCU / 2) {
+    // ---- first layer: in-block split-K, no slabs, no finish launch
+    if (ksplit_out) *ksplit_out = 1;
+    const int kpw = (int)cdiv(cdiv(d_in, MF1_WAVES), 16) * 16;
+    ProfScope prof(0, 4.0 * d_in * d_out * 2, st);
+    static const int variant = getenv("CLO_MF1") ? atoi(getenv("CLO_MF1")) : 0;
+#define CLO_MF1(WV, RGG, UU)                                                                     \
+  {                                                                                              \
+    const int kpw_ = (int)cdiv(cdiv(d_in, WV), 16) * 16;                                         \
+    const int fpb_ = fenv > 0 ? std::min(fenv, RGG * 8)                                          \
+                              : (int)std::min<long>(RGG * 8, std::max<long>(4, cdiv(d_out, kNumCU))); \
+    hipLaunchKernelGGL((fwd_mfma_first_kernel<WV, RGG, UU>), dim3((unsigned)cdiv(d_out, fpb_)),   \
+                       dim3(WV * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in, \
+                       d_out, act, kpw_, fpb_);                                                  \
+  }
+    static const int fenv = getenv("CLO_MF1_F") ? atoi(getenv("CLO_MF1_F")) : 0;
+    (void)kpw;
+    if (variant == 1) CLO_MF1(8, 2, 8)
+    else if (variant == 2) CLO_MF1(4, 2, 4)
+    else if (variant == 3) CLO_MF1(4, 2, 8)
+    else if (variant == 4) CLO_MF1(8, 1, 8)
+    else if (variant == 5) CLO_MF1(4, 1, 8)
+    else if (variant == 6) CLO_MF1(16, 2, 4)
+    else CLO_MF1(8, 2, 4)
+#undef CLO_MF1
+    CLO_CHECK_LAUNCH("fwd_mfma_first_kernel");
+    return CLO_OK;
+  }
   if (vec && N >= 1 && d_in >= 16) {
     // ---- MFMA path
     int kpb = mfma_kpb(d_in, d_out);

@@ -5,7 +5,7 @@ import torch
 from curvlinops_amd import _hip
 lib = _hip.load()
 st = torch.cuda.current_stream().cuda_stream
-for (di, do, da) in [(2688, 2688, True), (1024, 2688, False)]:
+for (di, do, da) in [(2688, 2688, True), (1024, 2688, False), (1040, 2688, False), (1088, 2688, False), (2048, 2688, False), (2064, 2688, False), (2048, 2688, True), (2064, 2688, True)]:
     nb = 6
     W = [torch.randn(do, di, device="cuda") for _ in range(nb)]
     V = [torch.randn(do, di, device="cuda") for _ in range(nb)]
