@@ -1,0 +1,42 @@
+// Argument block of the fp32 MFMA GEMM engines in gemm.hip (shared with the MLP large-batch path).
+#pragma once
+#include "clo_common.h"
+
+namespace clo {
+
+struct GemmArgs {
+  int M, N, K;
+  float alpha, beta;
+  const float *A;
+  long sa_m, sa_k, sa_b;
+  const float *B;
+  long sb_k, sb_n, sb_b;
+  float *C;
+  long ldc, sc_b;
+  int splitk;
+  int k_per_split;  // multiple of BK
+  float *ws;
+  int sym;  // 1: compute only block-upper triangle, mirror on write (SYRK)
+  int mode_a, mode_b;
+  int tiles_m, tiles_n;
+  int nbatch, batch_per_split;  // SQSUM mode only
+  int ones;  // 1: outer index M-1 of A / N-1 of B is an implicit column of ones ([X | 1])
+  // fused epilogue (single problem only), applied by whichever kernel writes the final C:
+  //   EPI_ACT: v = act(v + e_vec[col]) ; e_out2[row][col] = act'      (e_out2 shares ldc)
+  //   EPI_MUL: v = (v + e_vec[col]) * e_mul[row * ld_mul + col]
+  int epi, e_act;
+  const float *e_vec, *e_mul;
+  long ld_mul;
+  float *e_out2;
+  // second K segment (v2 engine only): for k >= K1 the operands are A2 / B2 (same strides),
+  // i.e. C = A[:, :K1] B[:K1] + A2 B2 with K = K1 + K2 in one pass.  K1 % 32 == 0.
+  const float *A2, *B2;
+  int K1;
+};
+enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2 };
+
+bool gemm_v2_eligible(const GemmArgs &a, int batch);
+int launch_gemm(GemmArgs a, int batch, hipStream_t stream);
+int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st);
+
+}  // namespace clo

@@ -13,6 +13,7 @@
 // Reference call sites this replaces: kronecker.py:141-171 (einsum 'abZ,Aa,Bb->ABZ'),
 // eigh.py:84-105, computers/kfac_hooks.py:350,390 (einsum "b s i, b s j -> i j").
 #include "clo_common.h"
+#include "gemm.h"
 
 namespace clo {
 
@@ -23,24 +24,22 @@ constexpr int LDS_STRIDE = BM + 4;  // floats; 16-byte multiple, breaks power-of
 
 enum LoadMode { MODE_OC_VEC = 0, MODE_KC_VEC = 1, MODE_OC_SCALAR = 2, MODE_KC_SCALAR = 3 };
 
-struct GemmArgs {
-  int M, N, K;
-  float alpha, beta;
-  const float *A;
-  long sa_m, sa_k, sa_b;
-  const float *B;
-  long sb_k, sb_n, sb_b;
-  float *C;
-  long ldc, sc_b;
-  int splitk;
-  int k_per_split;  // multiple of BK
-  float *ws;
-  int sym;  // 1: compute only block-upper triangle, mirror on write (SYRK)
-  int mode_a, mode_b;
-  int tiles_m, tiles_n;
-  int nbatch, batch_per_split;  // SQSUM mode only
-  int ones;  // 1: outer index M-1 of A / N-1 of B is an implicit column of ones ([X | 1])
-};
+
+
+// final value of C[row][col] from the accumulated product `acc`
+__device__ __forceinline__ void store_final(const GemmArgs &p, float *c, int row, int col, float acc,
+                                            float alpha, float beta) {
+  float v = alpha * acc;
+  if (beta != 0.f) v += beta * *c;
+  if (p.epi == EPI_ACT) {
+    float dphi;
+    v = act_apply(p.e_act, v + (p.e_vec ? p.e_vec[col] : 0.f), dphi);
+    if (p.e_out2) p.e_out2[(c - p.C)] = dphi;
+  } else if (p.epi == EPI_MUL) {
+    v = (v + (p.e_vec ? p.e_vec[col] : 0.f)) * p.e_mul[(long)row * p.ld_mul + col];
+  }
+  *c = v;
+}
 
 // Load one [BK x 128] operand tile into 8 registers per thread.
 // Element (o, k) lives at P[o*so + k*sk]; o in [o0, o0+128), k in [k0, k0+16).
@@ -267,6 +266,215 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
         if (row < p.M && col < p.N) {
           float v = alpha * acc[mt][nt][r];
           float *c = C + (long)row * ldc + col;
+          if (!to_ws && p.epi != EPI_NONE) {
+            store_final(p, c, row, col, acc[mt][nt][r], alpha, beta);
+            continue;
+          }
+          if (beta != 0.f) v += beta * *c;
+          *c = v;
+          if (mirror) {
+            float *ct = C + (long)col * ldc + row;
+            float vt = alpha * acc[mt][nt][r];
+            if (beta != 0.f) vt += beta * *ct;
+            *ct = vt;
+          }
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// v2 engine for 16-byte-aligned operands (the common case): operand layouts are template
+// parameters, so the loop body has no mode branches, and a k-contiguous operand keeps its
+// memory order in LDS ([outer][BK + 4]) where ONE ds_read_b128 feeds four MFMAs: the k index a
+// lane supplies is a free permutation as long as A and B agree, so within an 8-k group MFMA
+// m (0..3) takes k = 4 * (lane >> 5) + m on both sides.  Outer-contiguous operands stay k-major
+// ([BK][128 + 4]) and fetch that same k with ds_read_b32.  Loads are unconditional (clamped
+// addresses, results zeroed by select) so hipcc keeps them in flight across the MFMA block.
+// ------------------------------------------------------------------------------------------
+template <bool KC, int BKT, int NTHR = 256>
+struct TileIO {
+  static constexpr int T = 128;
+  static constexpr int LD = KC ? BKT + 4 : T + 4;
+  static constexpr int FLOATS = KC ? T * LD : BKT * LD;
+  static constexpr int NF4 = T * BKT / 4 / NTHR;  // float4 per thread
+  const float *base[NF4];
+  int koff[NF4];  // k offset of the float4 inside the tile
+  int soff[NF4];  // LDS offset (floats)
+
+  // element (o, k) at P[o * so + k * sk]; KC: sk == 1, OC: so == 1.  O % 4 == 0 for OC.
+  __device__ __forceinline__ void init(const float *P, long so, long sk, int o0, int O, int tid) {
+#pragma unroll
+    for (int q = 0; q < NF4; ++q) {
+      const int f = tid + NTHR * q;
+      if (KC) {
+        const int o = f / (BKT / 4), kq = (f % (BKT / 4)) * 4;
+        base[q] = P + (long)min(o0 + o, O - 1) * so;
+        koff[q] = kq;
+        soff[q] = o * LD + kq;
+      } else {
+        const int k = f / (T / 4), oq = (f % (T / 4)) * 4;
+        base[q] = P + min(o0 + oq, O - 4);
+        koff[q] = k;
+        soff[q] = k * LD + oq;
+      }
+    }
+  }
+  // `delta` (floats, wave-uniform) moves the whole tile to the second K segment's operand
+  __device__ __forceinline__ void load(float4 (&r)[NF4], int k0, int Kend, long sk,
+                                       long delta) const {
+#pragma unroll
+    for (int q = 0; q < NF4; ++q) {
+      const int k = k0 + koff[q];
+      if (KC) {
+        const bool ok = k + 3 < Kend;  // K % 4 == 0: all or nothing
+        const float4 v = *reinterpret_cast<const float4 *>(base[q] + delta + (ok ? k : 0));
+        r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const bool ok = k < Kend;
+        const float4 v =
+            *reinterpret_cast<const float4 *>(base[q] + delta + (long)(ok ? k : 0) * sk);
+        r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float *S, const float4 (&r)[NF4]) const {
+#pragma unroll
+    for (int q = 0; q < NF4; ++q) *reinterpret_cast<float4 *>(S + soff[q]) = r[q];
+  }
+  // operand values of this lane for the 8-k group g: v[m] feeds MFMA m
+  static __device__ __forceinline__ float4 frag(const float *S, int outer, int g, int lh) {
+    if (KC) return *reinterpret_cast<const float4 *>(S + outer * LD + g * 8 + 4 * lh);
+    const float *p = S + (g * 8 + 4 * lh) * LD + outer;
+    return make_float4(p[0], p[LD], p[2 * LD], p[3 * LD]);
+  }
+};
+
+// NW = 4: 2x2 waves of 64x64;  NW = 8: 2x4 waves of 64x32 (two waves per SIMD inside ONE block,
+// for grids that cannot put two blocks on every CU)
+template <bool AKC, bool BKC, int BKT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
+  using TA = TileIO<AKC, BKT, NW * 64>;
+  using TB = TileIO<BKC, BKT, NW * 64>;
+  constexpr int NT = NW == 4 ? 2 : 1;   // 32-column MFMA tiles per wave
+  constexpr int WNC = 32 * NT;          // columns per wave
+  extern __shared__ __attribute__((aligned(16))) float lds2[];
+  float *As = lds2;                    // [2][TA::FLOATS]
+  float *Bs = lds2 + 2 * TA::FLOATS;   // [2][TB::FLOATS]
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int lid;
+  {
+    const int b = blockIdx.x;
+    const int q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
+    const int xcd = b % kNumXCD, idx = b / kNumXCD;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  int bm, bn;
+  {
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * p.tiles_n;
+    const int g = lid / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = min(p.tiles_m - first_m, GROUP);
+    const int in_g = lid % per_group;
+    bm = first_m + in_g % gsz;
+    bn = in_g / gsz;
+  }
+  if (p.sym && bn < bm) return;
+
+  const int z = blockIdx.y;
+  const int batch = z / p.splitk, split = z % p.splitk;
+  const int kb = split * p.k_per_split;
+  const int ke = min(p.K, kb + p.k_per_split);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  TA la;
+  TB lb;
+  la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid);
+  lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid);
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (ke - kb + BKT - 1) / BKT;
+  float4 ra[TA::NF4], rb[TB::NF4];
+  // K segments: tile k0 lies in segment 2 iff k0 >= K1 (K1 is a multiple of the tile depth)
+  const int K1 = p.A2 ? p.K1 : p.K;
+  const long dA2 = p.A2 ? (p.A2 - p.A) : 0, dB2 = p.B2 ? (p.B2 - p.B) : 0;
+  if (nk > 0) {
+    const bool s2 = kb >= K1;
+    const int kr = s2 ? kb - K1 : kb, kend = s2 ? ke - K1 : min(ke, K1);
+    la.load(ra, kr, kend, p.sa_k, s2 ? dA2 : 0);
+    lb.load(rb, kr, kend, p.sb_k, s2 ? dB2 : 0);
+    la.store(As, ra);
+    lb.store(Bs, rb);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    // prefetch the next tile (past the end: clamped addresses, zeroed values, never stored)
+    const int k0 = kb + (it + 1) * BKT;
+    {
+      const bool s2 = k0 >= K1;
+      const int kr = s2 ? k0 - K1 : k0, kend = s2 ? ke - K1 : min(ke, K1);
+      la.load(ra, kr, kend, p.sa_k, s2 ? dA2 : 0);
+      lb.load(rb, kr, kend, p.sb_k, s2 ? dB2 : 0);
+    }
+    const float *as = As + cur * TA::FLOATS;
+    const float *bs = Bs + cur * TB::FLOATS;
+#pragma unroll
+    for (int g = 0; g < BKT / 8; ++g) {
+      const float4 a0 = TA::frag(as, wm * 64 + li, g, lh);
+      const float4 a1 = TA::frag(as, wm * 64 + 32 + li, g, lh);
+      const float4 b0 = TB::frag(bs, wn * WNC + li, g, lh);
+      const float4 b1 = NT == 2 ? TB::frag(bs, wn * WNC + 32 + li, g, lh) : b0;
+#define CLO_MM(AX, BX)                                                                             \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b0.BX, acc[0][0], 0, 0, 0);              \
+  if (NT == 2) acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b1.BX, acc[0][NT - 1], 0, 0, 0); \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b0.BX, acc[1][0], 0, 0, 0);              \
+  if (NT == 2) acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b1.BX, acc[1][NT - 1], 0, 0, 0);
+      CLO_MM(x, x) CLO_MM(y, y) CLO_MM(z, z) CLO_MM(w, w)
+#undef CLO_MM
+    }
+    if (it + 1 < nk) {
+      la.store(As + (cur ^ 1) * TA::FLOATS, ra);
+      lb.store(Bs + (cur ^ 1) * TB::FLOATS, rb);
+    }
+    __syncthreads();
+  }
+
+  const bool to_ws = p.splitk > 1;
+  float *C = to_ws ? p.ws + (long)z * p.M * p.N : p.C + (long)batch * p.sc_b;
+  const long ldc = to_ws ? p.N : p.ldc;
+  const float alpha = to_ws ? 1.f : p.alpha;
+  const float beta = to_ws ? 0.f : p.beta;
+  const bool mirror = p.sym && !to_ws && bm != bn;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wn * WNC + nt * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.M && col < p.N) {
+          float v = alpha * acc[mt][nt][r];
+          float *c = C + (long)row * ldc + col;
+          if (!to_ws && p.epi != EPI_NONE) {
+            store_final(p, c, row, col, acc[mt][nt][r], alpha, beta);
+            continue;
+          }
           if (beta != 0.f) v += beta * *c;
           *c = v;
           if (mirror) {
@@ -282,21 +490,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
 // C = alpha * sum_s ws[b][s] + beta * C ; for sym the lower block-triangle of ws was never
 // written, take the transposed element instead.
-__global__ void splitk_reduce_kernel(float *C, long ldc, long sc_b, const float *ws, int M, int N,
-                                     int splitk, float alpha, float beta, int sym) {
-  const long total = (long)M * N;
+__global__ void splitk_reduce_kernel(const GemmArgs p, int splitk) {
+  const long total = (long)p.M * p.N;
   const int b = blockIdx.y;
+  const int N = p.N;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
     const int m = e / N, n = e % N;
     long src = e;
-    if (sym && (n / BN) < (m / BM)) src = (long)n * N + m;
-    float s = 0.f;
-    for (int k = 0; k < splitk; ++k) s += ws[((long)b * splitk + k) * total + src];
-    float *c = C + (long)b * sc_b + (long)m * ldc + n;
-    float v = alpha * s;
-    if (beta != 0.f) v += beta * *c;
-    *c = v;
+    if (p.sym && (n / BN) < (m / BM)) src = (long)n * N + m;
+    const float *w = p.ws + (long)b * splitk * total + src;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < splitk; k += 4) {
+      s0 += w[(k + 0) * total]; s1 += w[(k + 1) * total];
+      s2 += w[(k + 2) * total]; s3 += w[(k + 3) * total];
+    }
+    for (; k < splitk; ++k) s0 += w[k * total];
+    float *c = p.C + (long)b * p.sc_b + (long)m * p.ldc + n;
+    store_final(p, c, m, n, (s0 + s1) + (s2 + s3), p.alpha, p.beta);
   }
 }
 
@@ -305,6 +517,22 @@ static int pick_mode(const float *P, long so, long sk, long sbatch, int batch) {
   if (so == 1) return (sk % 4 == 0 && aligned16(P) && batch_ok) ? MODE_OC_VEC : MODE_OC_SCALAR;
   if (sk == 1) return (so % 4 == 0 && aligned16(P) && batch_ok) ? MODE_KC_VEC : MODE_KC_SCALAR;
   return so <= sk ? MODE_OC_SCALAR : MODE_KC_SCALAR;
+}
+
+// v2 needs float4-complete operands: 16-byte aligned, K % 4 == 0 for k-contiguous operands, the
+// outer extent % 4 == 0 for outer-contiguous ones, and no synthesised ones column.
+bool gemm_v2_eligible(const GemmArgs &a, int batch) {
+  static const int v2_off = getenv("CLO_GEMM_V1") ? atoi(getenv("CLO_GEMM_V1")) : 0;
+  const int ma = pick_mode(a.A, a.sa_m, a.sa_k, a.sa_b, batch);
+  const int mb = pick_mode(a.B, a.sb_n, a.sb_k, a.sb_b, batch);
+  const bool a_vec = ma == MODE_OC_VEC || ma == MODE_KC_VEC;
+  const bool b_vec = mb == MODE_OC_VEC || mb == MODE_KC_VEC;
+  const bool a_kc = ma == MODE_KC_VEC, b_kc = mb == MODE_KC_VEC;
+  const int Kc = a.A2 ? a.K1 : a.K;  // every segment must be float4-complete
+  if (a.A2 && (!aligned16(a.A2) || !aligned16(a.B2))) return false;
+  return !v2_off && a_vec && b_vec && !a.ones && a.K > 0 &&
+         (a_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (a.M % 4 == 0 && a.M >= 4)) &&
+         (b_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (a.N % 4 == 0 && a.N >= 4));
 }
 
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
@@ -322,13 +550,54 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   a.mode_a = pick_mode(a.A, a.sa_m, a.sa_k, a.sa_b, batch);
   a.mode_b = pick_mode(a.B, a.sb_n, a.sb_k, a.sb_b, batch);
   dim3 grid(a.tiles_m * a.tiles_n, batch * a.splitk);
-  hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, a);
-  CLO_CHECK_LAUNCH("gemm_f32_kernel");
+  const bool a_kc = a.mode_a == MODE_KC_VEC, b_kc = a.mode_b == MODE_KC_VEC;
+  const bool v2 = gemm_v2_eligible(a, batch);
+  static const int bk2 = getenv("CLO_GEMM_BK") ? atoi(getenv("CLO_GEMM_BK")) : 32;
+  if (a.A2 && !(v2 && a.K1 % bk2 == 0 && a.K1 > 0 && a.K1 < a.K)) {
+    set_error("clo_gemm: a second K segment needs the aligned engine and K1 %% %d == 0", bk2);
+    return CLO_EUNSUP;
+  }
+  if (v2) {
+    a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), bk2) * bk2;
+    a.splitk = (int)cdiv(a.K, a.k_per_split);
+    grid.y = batch * a.splitk;
+#define CLO_V2(AK, BKC_, BKV, NWV)                                                                   \
+  {                                                                                               \
+    const size_t smem = 2 * (TileIO<AK, BKV>::FLOATS + TileIO<BKC_, BKV>::FLOATS) * sizeof(float); \
+    auto kern = gemm_v2_kernel<AK, BKC_, BKV, NWV>;                                               \
+    if (smem > 64 * 1024) {                                                                       \
+      static bool attr_set = false;                                                               \
+      if (!attr_set) {                                                                            \
+        int rc_ = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),             \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                                (int)smem), "hipFuncSetAttribute");               \
+        if (rc_ != CLO_OK) return rc_;                                                            \
+        attr_set = true;                                                                          \
+      }                                                                                           \
+    }                                                                                             \
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, stream, a);                              \
+  }
+#define CLO_V2L(BKV, NWV)                                \
+  if (a_kc && b_kc) CLO_V2(true, true, BKV, NWV)         \
+  else if (a_kc) CLO_V2(true, false, BKV, NWV)           \
+  else if (b_kc) CLO_V2(false, true, BKV, NWV)           \
+  else CLO_V2(false, false, BKV, NWV)
+    static const int nw_env = getenv("CLO_GEMM_NW") ? atoi(getenv("CLO_GEMM_NW")) : 0;
+    const long nblocks = (long)grid.x * grid.y;
+    const int nw = nw_env ? nw_env : (nblocks < 2L * kNumCU ? 8 : 4);
+    if (bk2 == 32) { if (nw == 8) { CLO_V2L(32, 8) } else { CLO_V2L(32, 4) } }
+    else { if (nw == 8) { CLO_V2L(16, 8) } else { CLO_V2L(16, 4) } }
+#undef CLO_V2L
+#undef CLO_V2
+    CLO_CHECK_LAUNCH("gemm_v2_kernel");
+  } else {
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, a);
+    CLO_CHECK_LAUNCH("gemm_f32_kernel");
+  }
   if (a.splitk > 1) {
     const long total = (long)a.M * a.N;
     dim3 rgrid((unsigned)std::min<long>(cdiv(total, 256), 4096), batch);
-    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a.C, a.ldc, a.sc_b,
-                       a.ws, a.M, a.N, a.splitk, a.alpha, a.beta, a.sym);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a, a.splitk);
     CLO_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return CLO_OK;
@@ -358,8 +627,7 @@ int launch_gemm_sqsum(GemmArgs a, int batch, int splits, hipStream_t stream) {
   if (splits > 1) {
     const long total = (long)a.M * a.N;
     dim3 rgrid((unsigned)std::min<long>(cdiv(total, 256), 4096), 1);
-    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a.C, a.ldc, 0L, a.ws, a.M,
-                       a.N, splits, a.alpha, a.beta, 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a, splits);
     CLO_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return CLO_OK;
@@ -396,13 +664,31 @@ extern "C" int clo_gemm_sqsum_f32(int M, int N, int K, float alpha, const float 
   return launch_gemm_sqsum(a, batch, splits, (hipStream_t)stream);
 }
 
+// Split-K factor from a small cost model (ns): the MFMA phase costs one 128x128 k-slice
+// (32768 flop at 256 flop/clk/CU = 53 ns) per k per block, blocks spread evenly over the CUs, and
+// a split pays the slab round trip ((2s + 1) M N floats at ~3.5 TB/s) plus one more launch.
+namespace clo {
+int suggest_splitk_tiles(long tiles, long K, long MN) {
+  if (tiles <= 0 || K <= 0) return 1;
+  double best = 1e30;
+  int best_s = 1;
+  const long smax = std::min<long>(64, std::max<long>(1, K / 64));
+  for (long s = 1; s <= smax; ++s) {
+    const long kps = cdiv(cdiv(K, s), 16) * 16;
+    const long se = cdiv(K, kps);
+    if (se != s) continue;
+    const double rounds = (double)cdiv(tiles * s, kNumCU);
+    double t = rounds * (kps + 48.0) * 53.0;
+    if (s > 1) t += (2.0 * s + 1.0) * MN * 4.0 / 3500.0 + 4000.0;
+    if (t < best) { best = t; best_s = (int)s; }
+  }
+  return best_s;
+}
+}  // namespace clo
+
 extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
-  const long tiles = cdiv(M, BM) * cdiv(N, BN) * (long)(batch > 0 ? batch : 1);
-  const long ktiles = cdiv(K, BK);
-  if (tiles >= 2 * kNumCU || ktiles < 16) return 1;
-  long s = (2 * kNumCU) / tiles;          // aim at ~2 blocks per CU
-  s = std::min<long>(s, ktiles / 8);      // keep >= 8 k-tiles (128 k) per split
-  return (int)std::max<long>(1, std::min<long>(s, 64));
+  const long b = batch > 0 ? batch : 1;
+  return clo::suggest_splitk_tiles(cdiv(M, BM) * cdiv(N, BN) * b, K, (long)M * N * b);
 }
 
 extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,
@@ -464,6 +750,17 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
   return launch_gemm(a, 1, st);
 }
 
+// Single problem described by `a` (operands, epilogue, optional second K segment); split-K from the
+// cost model, capped by the caller's workspace.
+int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st) {
+  long s = clo_gemm_suggest_splitk(a.M, a.N, a.K, 1);
+  const long per = (long)a.M * a.N;
+  if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
+  a.splitk = (int)std::max<long>(1, s);
+  a.ws = ws;
+  return launch_gemm(a, 1, st);
+}
+
 // C = beta*C + alpha * X^T X (X row-major [rows][ldx], first d columns), symmetric block raster.
 int launch_syrk_simple(float *C, long ldc, const float *X, long rows, int d, long ldx, float alpha,
                        float beta, float *ws, long ws_floats, hipStream_t st) {
@@ -472,7 +769,8 @@ int launch_syrk_simple(float *C, long ldc, const float *X, long rows, int d, lon
   a.A = X; a.sa_m = 1; a.sa_k = ldx; a.sa_b = 0;
   a.B = X; a.sb_k = ldx; a.sb_n = 1; a.sb_b = 0;
   a.C = C; a.ldc = ldc; a.sc_b = 0;
-  long s = clo_gemm_suggest_splitk(d, d, (int)rows, 1);
+  const long td = cdiv(d, BM);
+  long s = suggest_splitk_tiles(td * (td + 1) / 2, rows, (long)d * d);
   const long per = (long)d * d;
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);

@@ -13,12 +13,9 @@
 //   bwd_fused_kernel out_W = beta out_W + alpha delta^T a_prev  (write stream)  and
 //                    delta_prev = dphi_prev * (delta W)         (reads W once), same sweep
 #include "clo_common.h"
+#include "gemm.h"
 
 namespace clo {
-
-int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,
-                       const float *B, long sb_k, long sb_n, float beta, float *C, long ldc,
-                       float *ws, long ws_floats, hipStream_t st);
 
 constexpr int NB = 8;        // batch rows per skinny pass
 constexpr int QN = 1;        // 256-float sub-slices per k-chunk
@@ -1140,39 +1137,126 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
   }
 }
 
-// Elementwise epilogues of the GEMM (large-batch) path.
-__global__ void fwd_epilogue_kernel(float *__restrict__ z_a, float *__restrict__ dz_da,
-                                    float *__restrict__ dphi_out, const float *__restrict__ b,
-                                    const float *__restrict__ Vb, long N, int d_out, int act) {
-  const long total = N * d_out;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long)gridDim.x * blockDim.x) {
-    const int j = e % d_out;
-    float dphi;
-    const float av = act_apply(act, z_a[e] + (b ? b[j] : 0.f), dphi);
-    z_a[e] = av;
-    if (dphi_out) dphi_out[e] = dphi;
-    if (dz_da) dz_da[e] = dphi * (dz_da[e] + (Vb ? Vb[j] : 0.f));
+// ------------------------------------------------------------------------------------------
+// Narrow last layer (C <= 16) for batches beyond one 8-row pass: three small kernels instead of
+// 128-wide GEMM tiles on a 10-column problem.
+// ------------------------------------------------------------------------------------------
+constexpr int HR_ROWS = 4;
+// f[n][c] = b[c] + a[n] . W[c] ;  u[n][c] = Vb[c] + da[n] . W[c] + a[n] . V[c]
+// block = HR_ROWS batch rows, wave w = class c, lanes stride the features.
+template <bool VEC>
+__global__ __launch_bounds__(HEAD_CMAX * 64) void head_rows_fwd_kernel(
+    const float *__restrict__ a, const float *__restrict__ da, const float *__restrict__ W,
+    const float *__restrict__ V, const float *__restrict__ b, const float *__restrict__ Vb,
+    float *__restrict__ f, float *__restrict__ u, int N, int d, int C) {
+  const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (c >= C) return;
+  const int n0 = blockIdx.x * HR_ROWS;
+  float z[HR_ROWS], dz[HR_ROWS];
+#pragma unroll
+  for (int r = 0; r < HR_ROWS; ++r) z[r] = dz[r] = 0.f;
+  const float *w = W + (long)c * d, *v = V + (long)c * d;
+  if (VEC) {  // d % 4 == 0, 16-byte aligned rows: 4 features per lane and trip
+#pragma unroll 2
+    for (int i = lane * 4; i < d; i += 256) {
+      const float4 wi = ld4(w + i), vi = ld4(v + i);
+#pragma unroll
+      for (int r = 0; r < HR_ROWS; ++r) {
+        const long off = (long)min(n0 + r, N - 1) * d + i;
+        const float4 x = ld4(a + off), dx = ld4(da + off);
+        z[r] = fma4(wi, x, z[r]);
+        dz[r] = fma4(wi, dx, fma4(vi, x, dz[r]));
+      }
+    }
+  } else {
+#pragma unroll 2
+    for (int i = lane; i < d; i += 64) {
+      const float wi = w[i], vi = v[i];
+#pragma unroll
+      for (int r = 0; r < HR_ROWS; ++r) {
+        const long off = (long)min(n0 + r, N - 1) * d + i;
+        const float x = a[off], dx = da[off];
+        z[r] = fmaf(wi, x, z[r]);
+        dz[r] = fmaf(wi, dx, fmaf(vi, x, dz[r]));
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < HR_ROWS; ++r) {
+    const float zs = wave_sum(z[r]), dzs = wave_sum(dz[r]);
+    if (lane == 0 && n0 + r < N) {
+      f[(long)(n0 + r) * C + c] = zs + (b ? b[c] : 0.f);
+      u[(long)(n0 + r) * C + c] = dzs + (Vb ? Vb[c] : 0.f);
+    }
   }
 }
-__global__ void mul_inplace_kernel(float *__restrict__ x, const float *__restrict__ m, long n) {
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
-       e += (long)gridDim.x * blockDim.x)
-    x[e] *= m[e];
+
+// delta_prev[n][i] = dphi_prev[n][i] * sum_c dL[n][c] W[c][i]      grid (ceil(d/256), N)
+__global__ __launch_bounds__(256) void head_rows_bwd_kernel(const float *__restrict__ dL,
+                                                            const float *__restrict__ W,
+                                                            const float *__restrict__ dphi_prev,
+                                                            float *__restrict__ delta_prev, int d,
+                                                            int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (i >= d) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) acc = fmaf(dL[(long)n * C + c], W[(long)c * d + i], acc);
+  delta_prev[(long)n * d + i] = acc * dphi_prev[(long)n * d + i];
 }
-__global__ void colsum_small_kernel(float *__restrict__ out, const float *__restrict__ X, long rows,
-                                    int d, float alpha, float beta) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (j < d)
-    for (long r = wave; r < rows; r += 4) s += X[r * d + j];
-  part[wave][lane] = s;
+
+// out[c][j] = beta * out[c][j] + sum_n g[n][c] X[n][j]   (c < C <= 16; g == nullptr: ones, C = 1)
+// block = 64 columns x 8 row groups (one wave each), merged through LDS.  Used for the bias
+// gradients (column sums of delta) and the narrow last layer's weight block.
+constexpr int SO_GROUPS = 8;
+// grid = (ceil(d / 64), NS): with NS > 1 row chunks the block writes its partial sums to
+// slab[chunk][c][j] and small_outer_reduce_kernel finishes.
+template <bool HAS_G>
+__global__ __launch_bounds__(SO_GROUPS * 64) void small_outer_kernel(
+    float *__restrict__ out, const float *__restrict__ g, const float *__restrict__ X, int N, int d,
+    int C, float beta, float *__restrict__ slab) {
+  __shared__ float s_acc[HAS_G ? HEAD_CMAX : 1][SO_GROUPS][64];
+  const int lane = threadIdx.x & 63, grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + lane, jc = min(j, d - 1);
+  const int rows_per = (int)cdiv(N, (int)gridDim.y);
+  const int nb = blockIdx.y * rows_per, ne = min(N, nb + rows_per);
+  float acc[HAS_G ? HEAD_CMAX : 1];
+#pragma unroll
+  for (int c = 0; c < (HAS_G ? HEAD_CMAX : 1); ++c) acc[c] = 0.f;
+#pragma unroll 4
+  for (int n = nb + grp; n < ne; n += SO_GROUPS) {
+    const float x = X[(long)n * d + jc];
+    if (HAS_G) {
+#pragma unroll
+      for (int c = 0; c < HEAD_CMAX; ++c)
+        if (c < C) acc[c] = fmaf(g[(long)n * C + c], x, acc[c]);
+    } else {
+      acc[0] += x;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < (HAS_G ? HEAD_CMAX : 1); ++c) s_acc[c][grp][lane] = acc[c];
   __syncthreads();
-  if (wave == 0 && j < d)
-    out[j] = (beta != 0.f ? beta * out[j] : 0.f) +
-             alpha * (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+  for (int c = grp; c < C; c += SO_GROUPS) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < SO_GROUPS; ++q) t += s_acc[c][q][lane];
+    if (j < d) {
+      if (gridDim.y > 1) {
+        slab[((long)blockIdx.y * C + c) * d + j] = t;
+      } else {
+        float *o = out + (long)c * d + j;
+        *o = (beta != 0.f ? beta * *o : 0.f) + t;
+      }
+    }
+  }
+}
+__global__ void small_outer_reduce_kernel(float *__restrict__ out, const float *__restrict__ slab,
+                                          int ns, long cd, float beta) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= cd) return;
+  float t = 0.f;
+  for (int q = 0; q < ns; ++q) t += slab[q * cd + e];
+  out[e] = (beta != 0.f ? beta * out[e] : 0.f) + t;
 }
 
 static inline unsigned ew_grid(long n) {
@@ -1391,6 +1475,34 @@ static long gemm_ws_floats(int N, int dmax) {
   return 16L * (long)std::max(N, 128) * dmax;
 }
 
+// out[c][j] = beta out + sum_n g[n][c] X[n][j] (g == nullptr: column sums, C = 1); ws >= 16 C d
+static int launch_small_outer(float *out, const float *g, const float *X, int N, int d, int C,
+                              float beta, float *ws, long ws_floats, hipStream_t st) {
+  int ns = (int)std::min<long>(16, cdiv(N, 64));
+  if (!ws || ws_floats < (long)ns * C * d) ns = 1;
+  dim3 grid((unsigned)cdiv(d, 64), (unsigned)ns), block(SO_GROUPS * 64);
+  if (g) hipLaunchKernelGGL(small_outer_kernel<true>, grid, block, 0, st, out, g, X, N, d, C, beta, ws);
+  else hipLaunchKernelGGL(small_outer_kernel<false>, grid, block, 0, st, out, g, X, N, d, C, beta, ws);
+  CLO_CHECK_LAUNCH("small_outer_kernel");
+  if (ns > 1) {
+    const long cd = (long)C * d;
+    hipLaunchKernelGGL(small_outer_reduce_kernel, dim3((unsigned)cdiv(cd, 256)), dim3(256), 0, st, out,
+                       ws, ns, cd, beta);
+    CLO_CHECK_LAUNCH("small_outer_reduce_kernel");
+  }
+  return CLO_OK;
+}
+
+static GemmArgs gemm_problem(int M, int N, int K, const float *A, long sa_m, long sa_k,
+                             const float *B, long sb_k, long sb_n, float beta, float *C, long ldc) {
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.beta = beta;
+  g.A = A; g.sa_m = sa_m; g.sa_k = sa_k;
+  g.B = B; g.sb_k = sb_k; g.sb_n = sb_n;
+  g.C = C; g.ldc = ldc;
+  return g;
+}
+
 static int launch_loss(int kind, const float *f, const float *aux, int aux_rank, const float *u,
                        const float *dphi_last, float *w, int N, int C, float scale,
                        const float *part, int ksplit, const float *b, const float *Vb, float *f_out,
@@ -1561,8 +1673,10 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   int rc;
   int last_ksplit = 1;
   // narrow linear head: fold fwd(L) + loss + bwd(L) into the neighbouring launches
-  const bool head = skinny && N <= NB && L >= 2 && last_linear && dims[L] <= HEAD_CMAX;
-  const int Lf = head ? L - 1 : L;  // layers run by the generic forward loop
+  const bool narrow = L >= 2 && last_linear && dims[L] <= HEAD_CMAX;
+  const bool head = narrow && N <= NB;       // fused into the neighbouring launches
+  const bool head_rows = narrow && N > NB;   // row kernels
+  const int Lf = narrow ? L - 1 : L;  // layers run by the generic forward loop
   float *hp = nullptr;
   int head_nblk = 0;
   // ---- forward + JVP
@@ -1582,21 +1696,32 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
         if (rc != CLO_OK) return rc;
       }
     } else {
-      // Z = A W^T ; dZ = A VW^T (+ dA W^T)
-      rc = launch_gemm_simple(N, dout, di, 1.f, a[l - 1], di, 1, W[l - 1], 1, di, 0.f, a[l], dout,
-                              gws, gws_sz, st);
+      // a_l = act(a W^T + b) with act' as second output; da_l = act' * (a VW^T + da W^T + Vb):
+      // two launches, bias / activation / derivative fused into whichever kernel writes C, the
+      // tangent's two products chained along K in one pass
+      GemmArgs g1 = gemm_problem(N, dout, di, a[l - 1], di, 1, W[l - 1], 1, di, 0.f, a[l], dout);
+      g1.epi = EPI_ACT; g1.e_act = acts[l - 1]; g1.e_vec = bl; g1.e_out2 = dphi[l];
+      rc = launch_gemm_auto(g1, gws, gws_sz, st);
       if (rc != CLO_OK) return rc;
-      rc = launch_gemm_simple(N, dout, di, 1.f, a[l - 1], di, 1, VW[l - 1], 1, di, 0.f, da[l], dout,
-                              gws, gws_sz, st);
-      if (rc != CLO_OK) return rc;
+      GemmArgs g2 = gemm_problem(N, dout, di, a[l - 1], di, 1, VW[l - 1], 1, di, 0.f, da[l], dout);
+      g2.epi = EPI_MUL; g2.e_vec = vbl; g2.e_mul = dphi[l]; g2.ld_mul = dout;
       if (da[l - 1]) {
-        rc = launch_gemm_simple(N, dout, di, 1.f, da[l - 1], di, 1, W[l - 1], 1, di, 1.f, da[l],
-                                dout, gws, gws_sz, st);
-        if (rc != CLO_OK) return rc;
+        GemmArgs gc = g2;
+        gc.K = 2 * di; gc.K1 = di; gc.A2 = da[l - 1]; gc.B2 = W[l - 1];
+        if (di % 32 == 0 && gemm_v2_eligible(gc, 1)) {
+          rc = launch_gemm_auto(gc, gws, gws_sz, st);
+        } else {
+          g2.epi = EPI_NONE;
+          rc = launch_gemm_auto(g2, gws, gws_sz, st);
+          if (rc != CLO_OK) return rc;
+          GemmArgs g3 = gemm_problem(N, dout, di, da[l - 1], di, 1, W[l - 1], 1, di, 1.f, da[l], dout);
+          g3.epi = EPI_MUL; g3.e_vec = vbl; g3.e_mul = dphi[l]; g3.ld_mul = dout;
+          rc = launch_gemm_auto(g3, gws, gws_sz, st);
+        }
+      } else {
+        rc = launch_gemm_auto(g2, gws, gws_sz, st);
       }
-      hipLaunchKernelGGL(fwd_epilogue_kernel, dim3(ew_grid((long)N * dout)), dim3(256), 0, st, a[l],
-                         da[l], dphi[l], bl, vbl, (long)N, dout, acts[l - 1]);
-      CLO_CHECK_LAUNCH("fwd_epilogue_kernel");
+      if (rc != CLO_OK) return rc;
     }
   }
   float *dcur, *dnext;
@@ -1629,6 +1754,31 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
       CLO_CHECK_LAUNCH("head_bwd_kernel");
     }
     dcur = dl[L - 1]; dnext = dl0;
+    lstart = L - 1;
+  } else if (head_rows) {
+    const int d = dims[L - 1], C = dims[L];
+    if (vec_ok(d, {a[L - 1], da[L - 1], W[L - 1], VW[L - 1]}))
+      hipLaunchKernelGGL(head_rows_fwd_kernel<true>, dim3((unsigned)cdiv(N, HR_ROWS)),
+                         dim3(HEAD_CMAX * 64), 0, st, a[L - 1], da[L - 1], W[L - 1], VW[L - 1],
+                         b ? b[L - 1] : nullptr, Vb ? Vb[L - 1] : nullptr, a[L], da[L], N, d, C);
+    else
+      hipLaunchKernelGGL(head_rows_fwd_kernel<false>, dim3((unsigned)cdiv(N, HR_ROWS)),
+                         dim3(HEAD_CMAX * 64), 0, st, a[L - 1], da[L - 1], W[L - 1], VW[L - 1],
+                         b ? b[L - 1] : nullptr, Vb ? Vb[L - 1] : nullptr, a[L], da[L], N, d, C);
+    CLO_CHECK_LAUNCH("head_rows_fwd_kernel");
+    rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], nullptr, dl0, N, C, loss_scale * alpha,
+                     nullptr, 1, nullptr, nullptr, a[L], da[L], st);
+    if (rc != CLO_OK) return rc;
+    rc = launch_small_outer(OW[L - 1], dl0, a[L - 1], N, d, C, beta, gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+    if (Ob && Ob[L - 1]) {
+      rc = launch_small_outer(Ob[L - 1], nullptr, dl0, N, C, 1, beta, nullptr, 0, st);
+      if (rc != CLO_OK) return rc;
+    }
+    hipLaunchKernelGGL(head_rows_bwd_kernel, dim3((unsigned)cdiv(d, 256), N), dim3(256), 0, st, dl0,
+                       W[L - 1], dphi[L - 1], dl1, d, C);
+    CLO_CHECK_LAUNCH("head_rows_bwd_kernel");
+    dcur = dl1; dnext = dl0;
     lstart = L - 1;
   } else {
   // ---- output-space curvature: delta_L = dphi_L * (alpha * s * H u)
@@ -1694,21 +1844,18 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
       if (rc != CLO_OK) return rc;
     } else {
       // out_W = beta out_W + delta^T a_prev
-      rc = launch_gemm_simple(dout, di, N, 1.f, dcur, 1, dout, a[l - 1], di, 1, beta, OW[l - 1], di,
-                              gws, gws_sz, st);
+      GemmArgs go = gemm_problem(dout, di, N, dcur, 1, dout, a[l - 1], di, 1, beta, OW[l - 1], di);
+      rc = launch_gemm_auto(go, gws, gws_sz, st);
       if (rc != CLO_OK) return rc;
       if (obl) {
-        hipLaunchKernelGGL(colsum_small_kernel, dim3((unsigned)cdiv(dout, 64)), dim3(256), 0, st,
-                           obl, dcur, (long)N, dout, 1.f, beta);
-        CLO_CHECK_LAUNCH("colsum_small_kernel");
-      }
-      if (dprev) {
-        rc = launch_gemm_simple(N, di, dout, 1.f, dcur, dout, 1, W[l - 1], di, 1, 0.f, dprev, di, gws,
-                                gws_sz, st);
+        rc = launch_small_outer(obl, nullptr, dcur, N, dout, 1, beta, nullptr, 0, st);
         if (rc != CLO_OK) return rc;
-        hipLaunchKernelGGL(mul_inplace_kernel, dim3(ew_grid((long)N * di)), dim3(256), 0, st, dprev,
-                           dphi[l - 1], (long)N * di);
-        CLO_CHECK_LAUNCH("mul_inplace_kernel");
+      }
+      if (dprev) {  // delta_prev = act'_{l-1} * (delta W)
+        GemmArgs gd = gemm_problem(N, di, dout, dcur, dout, 1, W[l - 1], di, 1, 0.f, dprev, di);
+        gd.epi = EPI_MUL; gd.e_mul = dphi[l - 1]; gd.ld_mul = di;
+        rc = launch_gemm_auto(gd, gws, gws_sz, st);
+        if (rc != CLO_OK) return rc;
       }
     }
     std::swap(dcur, dnext);
