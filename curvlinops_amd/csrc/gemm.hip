@@ -301,9 +301,13 @@ struct TileIO {
   const float *base[NF4];
   int koff[NF4];  // k offset of the float4 inside the tile
   int soff[NF4];  // LDS offset (floats)
+  unsigned one_bits;  // OC + implicit ones column: float4 q starts at that column
 
-  // element (o, k) at P[o * so + k * sk]; KC: sk == 1, OC: so == 1.  O % 4 == 0 for OC.
-  __device__ __forceinline__ void init(const float *P, long so, long sk, int o0, int O, int tid) {
+  // element (o, k) at P[o * so + k * sk]; KC: sk == 1, OC: so == 1.  For OC the extent in memory
+  // (O - ones) is a multiple of 4; outer index O - 1 is the implicit ones column when ones == 1.
+  __device__ __forceinline__ void init(const float *P, long so, long sk, int o0, int O, int tid,
+                                       int ones) {
+    one_bits = 0u;
 #pragma unroll
     for (int q = 0; q < NF4; ++q) {
       const int f = tid + NTHR * q;
@@ -314,7 +318,9 @@ struct TileIO {
         soff[q] = o * LD + kq;
       } else {
         const int k = f / (T / 4), oq = (f % (T / 4)) * 4;
-        base[q] = P + min(o0 + oq, O - 4);
+        const int Oreal = O - ones;
+        base[q] = P + min(o0 + oq, Oreal - 4);
+        if (ones && o0 + oq == Oreal) one_bits |= 1u << q;
         koff[q] = k;
         soff[q] = k * LD + oq;
       }
@@ -332,8 +338,8 @@ struct TileIO {
         r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         const bool ok = k < Kend;
-        const float4 v =
-            *reinterpret_cast<const float4 *>(base[q] + delta + (long)(ok ? k : 0) * sk);
+        float4 v = *reinterpret_cast<const float4 *>(base[q] + delta + (long)(ok ? k : 0) * sk);
+        if ((one_bits >> q) & 1u) v = make_float4(1.f, 0.f, 0.f, 0.f);
         r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -395,8 +401,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
 
   TA la;
   TB lb;
-  la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid);
-  lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid);
+  la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
+  lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid, p.ones);
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -520,7 +526,7 @@ static int pick_mode(const float *P, long so, long sk, long sbatch, int batch) {
 }
 
 // v2 needs float4-complete operands: 16-byte aligned, K % 4 == 0 for k-contiguous operands, the
-// outer extent % 4 == 0 for outer-contiguous ones, and no synthesised ones column.
+// outer extent in memory % 4 == 0 for outer-contiguous ones.
 bool gemm_v2_eligible(const GemmArgs &a, int batch) {
   static const int v2_off = getenv("CLO_GEMM_V1") ? atoi(getenv("CLO_GEMM_V1")) : 0;
   const int ma = pick_mode(a.A, a.sa_m, a.sa_k, a.sa_b, batch);
@@ -530,9 +536,11 @@ bool gemm_v2_eligible(const GemmArgs &a, int batch) {
   const bool a_kc = ma == MODE_KC_VEC, b_kc = mb == MODE_KC_VEC;
   const int Kc = a.A2 ? a.K1 : a.K;  // every segment must be float4-complete
   if (a.A2 && (!aligned16(a.A2) || !aligned16(a.B2))) return false;
-  return !v2_off && a_vec && b_vec && !a.ones && a.K > 0 &&
-         (a_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (a.M % 4 == 0 && a.M >= 4)) &&
-         (b_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (a.N % 4 == 0 && a.N >= 4));
+  if (a.ones && (a_kc || b_kc)) return false;  // the ones column lives in the outer-contiguous loader
+  const int Mr = a.M - a.ones, Nr = a.N - a.ones;   // extents that exist in memory
+  return !v2_off && a_vec && b_vec && a.K > 0 &&
+         (a_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (Mr % 4 == 0 && Mr >= 4)) &&
+         (b_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (Nr % 4 == 0 && Nr >= 4));
 }
 
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {

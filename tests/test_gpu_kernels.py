@@ -85,7 +85,8 @@ def test_gemm_unaligned_views(hip):
     assert rel_err(out.cpu(), A @ B) < TOL
 
 
-@pytest.mark.parametrize("rows,d", [(1, 1), (37, 5), (1000, 26), (4096, 151), (300, 401), (64, 2689), (50000, 27)])
+@pytest.mark.parametrize("rows,d", [(1, 1), (37, 5), (1000, 26), (4096, 151), (300, 401), (64, 2689), (50000, 27),
+                                     (1000, 64), (3000, 576), (70, 1152)])
 @pytest.mark.parametrize("ones", [False, True])
 def test_syrk_accum(hip, rows, d, ones):
     g = torch.Generator().manual_seed(rows + d)
