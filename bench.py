@@ -13,10 +13,11 @@ living in the 256 MiB Infinity Cache; the weights are constant across products, 
 use of the operator.
 
 Extra legs on rank 0 at N = 1 (outside the timed region):
-* ``roofline``: the same steps with the library's HIP-event instrumentation on; the dominant
-  kernel family is ``fwd_jvp_kernel`` (streams W and V of every layer once: 8 B per parameter of
-  the 12 B/parameter a matvec moves algorithmically); achieved = its algorithmic bytes / its
-  summed launch durations, against the 8 TB/s HBM3E peak.
+* ``roofline``: the same steps with the library's HIP-event instrumentation on (events on the
+  launch stream); the dominant kernel family is the forward+JVP weight stream
+  (``fwd_mfma_first_kernel`` + ``fwd_mfma_kernel``: W and V of every layer read once = 8 B per
+  parameter of the 12 B/parameter a matvec moves algorithmically); achieved = its algorithmic
+  bytes / its summed launch durations, against the 8 TB/s HBM3E peak.
 * ``cpu_baseline``: the NumPy oracle (``oracle/mlp_numpy.py``, "port") in float32 on the host
   cores for a bounded number of matvecs of the same workload.
 """
@@ -64,6 +65,20 @@ def pmc_traffic_per_launch(kernel: str):
     if not rows:
         return None
     return sum(k["hbm_bytes"] for k in rows) / len(rows)
+
+
+def rocprof_avg_us(kernels):
+    """Launch-weighted mean duration of `kernels` in the committed rocprofv3 --stats summary."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_n8_bench_kernel_stats.txt")
+    tot = cnt = 0.0
+    try:
+        for line in open(path):
+            f = line.split(None, 4)
+            if len(f) == 5 and not line.startswith("#") and any(k in f[4] for k in kernels):
+                cnt += int(f[0]); tot += float(f[1])
+    except (OSError, ValueError):
+        return None
+    return tot / cnt if cnt else None
 
 
 def cpu_baseline(batch: int, budget_s: float = 12.0) -> dict:
@@ -189,23 +204,31 @@ def main() -> None:
         torch.cuda.synchronize()
         prof = _hip.prof_collect()
         _hip.prof_enable(False)
+        # dominant kernel family: the forward+JVP weight stream (fwd_mfma_first_kernel for layer 1,
+        # fwd_mfma_kernel for the others): reads W and V of every layer exactly once = 8 B/parameter
         fam = max(prof, key=lambda k: prof[k]["ms"])
         r = prof[fam]
-        traffic = pmc_traffic_per_launch({"fwd_jvp": "fwd_mfma_kernel", "bwd_fused": "bwd_fused_kernel"}.get(fam, fam))
+        kernel_names = {"fwd_mfma": ["fwd_mfma_first_kernel", "fwd_mfma_kernel"], "bwd_dprev": ["bwd_fused_kernel"],
+                        "outer_all": ["outer_all_kernel"]}.get(fam, [fam])
+        tr = [pmc_traffic_per_launch(k) for k in kernel_names]
+        traffic = (sum(t for t in tr if t) / max(sum(1 for t in tr if t), 1)) if any(tr) else None
         achieved = r["alg_bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
         kernels_ms = sum(v["ms"] for v in prof.values()) / nprof
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": f"{fam}_kernel",
+            "kernel": " + ".join(kernel_names),
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": "profiles/r01_c2_n8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                              "separate passes, FETCH doubled per the gfx950 note)" if traffic else None,
+                              "separate passes, FETCH doubled per the gfx950 note; mean over the family's launches)" if traffic else None,
             "launches": r["launches"],
             "avg_launch_us": 1e3 * r["ms"] / max(r["launches"], 1),
+            "avg_launch_us_note": "HIP-event interval around each launch on the launch stream: includes the "
+                                  "dispatch latency (~2.5 us) that rocprofv3's kernel durations exclude",
+            "rocprof_avg_kernel_us": rocprof_avg_us(kernel_names),
             "alg_bytes_per_launch": r["alg_bytes"] / max(r["launches"], 1),
             "whole_matvec": {
                 "alg_bytes": 12 * D,

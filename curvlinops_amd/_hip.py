@@ -124,7 +124,8 @@ def prof_collect() -> dict[str, dict[str, float]]:
     cnt = (c_long * 8)()
     by = (ctypes.c_double * 8)()
     _check(load().clo_prof_collect(ms, cnt, by), "clo_prof_collect")
-    names = ["fwd_jvp", "loss_hessian", "bwd_fused", "finish", "gemm", "other", "t6", "t7"]
+    # tags of csrc/clo_common.h:ProfScope as used by mlp.hip
+    names = ["fwd_mfma", "loss_head_bwd", "bwd_dprev", "finish_head_fwd", "outer_all", "other", "t6", "t7"]
     return {n: {"ms": ms[i], "launches": int(cnt[i]), "alg_bytes": by[i]} for i, n in enumerate(names) if cnt[i]}
 
 

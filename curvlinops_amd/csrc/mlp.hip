@@ -1824,7 +1824,7 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
       const size_t smem = (size_t)(OUTER_ROWS * NB + NB * CW) * sizeof(float);
       double bytes = 0;
       for (int l = 1; l <= lstart; ++l) bytes += 4.0 * dims[l - 1] * dims[l] * (beta != 0.f ? 2 : 1);
-      ProfScope prof(2, bytes, st);
+      ProfScope prof(4, bytes, st);
       if (beta != 0.f)
         hipLaunchKernelGGL(outer_all_kernel<true>, dim3(nb), dim3(512), smem, st, oa);
       else

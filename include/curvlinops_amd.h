@@ -44,10 +44,12 @@ int clo_version(void);
 const char *clo_last_error(void);
 
 /* Optional per-kernel timing (HIP events on the launch stream) for the roofline leg of bench.py.
- * clo_prof_collect fills arrays of 8 entries indexed by tag (0 fwd_jvp, 1 loss_hessian,
- * 2 bwd_fused, 3 finish/reduce): summed milliseconds, launch counts, summed algorithmic bytes. */
+ * clo_prof_collect fills arrays of 8 entries indexed by tag (0 forward+JVP weight stream,
+ * 1 loss / head backward, 2 backward data chain, 3 slab finish / head forward, 4 outer products):
+ * summed milliseconds, launch counts, summed algorithmic bytes. */
 int clo_prof_enable(int on);
 int clo_prof_collect(double *ms, long *count, double *alg_bytes);
+
 
 /* ------------------------------------------------------------------------- *
  * Dense fp32 GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32).

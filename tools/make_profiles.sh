@@ -1,0 +1,27 @@
+# Regenerates profiles/r01_* on the GPU box (run via gpurun from the repo root).
+set -x
+R=$PWD; OUT=$R/gpurun_out/profiles; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --no-extras --steps 100 --warmup 10"
+rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o ks -- $CMD > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_ks/ks_results.db $OUT/r01_c2_n8_bench_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-extras --steps 100 --warmup 10  (C2, 8 rows/GPU, 1 GPU)"
+python $R/tools/gap_analysis.py /tmp/p_ks/ks_results.db head_bwd > $OUT/r01_c2_n8_kernel_chain.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- python $R/bench.py --no-extras --steps 50 --warmup 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- python $R/bench.py --no-extras --steps 50 --warmup 5 > /dev/null 2>&1
+python $R/tools/pmc_summary.py /tmp/p_f/f_results.db /tmp/p_w/w_results.db $OUT/r01_c2_n8_pmc_traffic.json $OUT/r01_c2_n8_pmc_traffic.txt "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --no-extras --steps 50 --warmup 5  (C2, 8 rows/GPU)"
+cd $R
+cp $OUT/r01_c2_n8_pmc_traffic.json profiles/   # so that the bench's traffic leg reads the fresh numbers
+python bench.py > $OUT/r01_bench_n1.json 2> $OUT/bench_stderr.txt
+tail -c 3000 $OUT/r01_bench_n1.json
+# large-batch points of the same workload (kernel path only)
+python tools/probe_c2.py 8 128 512 > $OUT/r01_c2_batch_sweep.txt 2>&1
+cd /tmp
+for N in 128 512; do
+  rocprofv3 --kernel-trace --stats -d /tmp/p_n$N -o k -- python $R/tools/probe_c2.py $N > /dev/null 2>&1
+  python $R/tools/prof_summary.py /tmp/p_n$N/k_results.db $OUT/r01_c2_n${N}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python tools/probe_c2.py $N  (C2 GGN matvec, $N rows, kernel path)"
+done
+cd $R
+python benchmarks/bench_kfac.py resnet18 > $OUT/r01_kfac_resnet18_b512.json 2>/dev/null
+python benchmarks/bench_kfac.py lenet > $OUT/r01_kfac_lenet_b1024.json 2>/dev/null
+python tools/probe_gemm.py > $OUT/r01_gemm_f32_shapes.txt 2>&1
+ls -la $OUT
