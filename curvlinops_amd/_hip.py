@@ -75,6 +75,13 @@ _SIGNATURES = {
          c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
     ),
     "clo_mlp_ggn_ws_floats": (c_long, [c_int, POINTER(c_int), c_int]),
+    "clo_mlp_ggn_matmat": (
+        c_int,
+        [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
+         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_long, _PF, c_int,
+         c_int, c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
+    ),
+    "clo_mlp_ggn_matmat_ws_floats": (c_long, [c_int, POINTER(c_int), c_int, c_int]),
     "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
     "clo_transpose_f32": (c_int, [_PF, _PF, c_long, c_long, c_void_p]),
     "clo_rowscale_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_int, c_float, c_void_p]),
@@ -354,7 +361,8 @@ class MLPPlan:
         if ws is None:
             n = load().clo_mlp_ggn_ws_floats(self.L, self.dims, N)
             ws = torch.empty(n, device=device, dtype=torch.float32)
-            self._ws = {key: ws}  # keep only the latest batch size
+            self._ws = {k: v for k, v in self._ws.items() if k[0] == "mm"}  # keep only the latest batch size
+            self._ws[key] = ws
         return ws
 
     # ---- flat fast path: parameters / vectors addressed as base pointer + element offsets ----
@@ -385,6 +393,38 @@ class MLPPlan:
                       loss_kind, aux_ptr, aux_rank, loss_scale, alpha, beta, ws_ptr, stream)
         if rc != 0:
             _check(rc, "clo_mlp_ggn_matvec")
+
+    # ---- K columns at once -------------------------------------------------------------------
+    MATMAT_MAX_K = 64
+
+    def matmat_supported(self, K: int, ldk: int) -> bool:
+        """Shape conditions of ``clo_mlp_ggn_matmat`` (pointer alignment is checked by the library)."""
+        return (K % 4 == 0 and 4 <= K <= self.MATMAT_MAX_K and ldk % 4 == 0
+                and all(d % 4 == 0 for d in self._dims_list[:-1]))
+
+    def matmat_workspace(self, K: int, device) -> Tensor:
+        key = ("mm", K, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            n = load().clo_mlp_ggn_matmat_ws_floats(self.L, self.dims, 8, K)
+            ws = torch.empty(n, device=device, dtype=torch.float32)
+            self._ws[key] = ws
+        return ws
+
+    def ggn_matmat_ptrs(self, vw_ptrs, vb_ptrs, ow_ptrs, ob_ptrs, ldk: int, K: int, X_ptr: int, N: int,
+                        loss_kind: int, loss_scale: float, alpha: float, beta: float, aux_ptr, aux_rank: int,
+                        ws_ptr: int, stream: int) -> None:
+        """``out[.., k] = beta out + alpha (J^T H J) V[.., k]`` for K columns; every ``*_ptrs`` entry is
+        the device address of a layer's ``[d_out][d_in][K]`` (``[d_out][K]``) block with row stride
+        ``ldk`` floats (None = no bias)."""
+        VW, Vb, OW, Ob = self._VW_arr, self._Vb_arr, self._OW_arr, self._Ob_arr
+        for l in range(self.L):
+            VW[l], OW[l], Vb[l], Ob[l] = vw_ptrs[l], ow_ptrs[l], vb_ptrs[l], ob_ptrs[l]
+        rc = load().clo_mlp_ggn_matmat(self.L, self.dims, self.acts, self._W_arr, self._b_arr, VW, Vb, OW, Ob,
+                                       ldk, X_ptr, N, K, loss_kind, aux_ptr, aux_rank, loss_scale, alpha,
+                                       beta, ws_ptr, stream)
+        if rc != 0:
+            _check(rc, "clo_mlp_ggn_matmat")
 
     def ggn_matvec(self, W, b, VW, Vb, OW, Ob, X, loss_kind: int, loss_scale: float, alpha: float,
                    beta: float, aux=None) -> None:

@@ -24,7 +24,9 @@ struct GemmArgs {
   // fused epilogue (single problem only), applied by whichever kernel writes the final C:
   //   EPI_ACT: v = act(v + e_vec[col]) ; e_out2[row][col] = act'      (e_out2 shares ldc)
   //   EPI_MUL: v = (v + e_vec[col]) * e_mul[row * ld_mul + col]
-  int epi, e_act;
+  //   EPI_MUL_T: v = v * e_mul[(col / e_div) * ld_mul + row]   (mask stored sample-major, C is
+  //              feature-major with e_div columns per sample)
+  int epi, e_act, e_div;
   const float *e_vec, *e_mul;
   long ld_mul;
   float *e_out2;
@@ -33,7 +35,7 @@ struct GemmArgs {
   const float *A2, *B2;
   int K1;
 };
-enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2 };
+enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2, EPI_MUL_T = 3 };
 
 bool gemm_v2_eligible(const GemmArgs &a, int batch);
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream);

@@ -37,6 +37,8 @@ __device__ __forceinline__ void store_final(const GemmArgs &p, float *c, int row
     if (p.e_out2) p.e_out2[(c - p.C)] = dphi;
   } else if (p.epi == EPI_MUL) {
     v = (v + (p.e_vec ? p.e_vec[col] : 0.f)) * p.e_mul[(long)row * p.ld_mul + col];
+  } else if (p.epi == EPI_MUL_T) {
+    v *= p.e_mul[(long)(col / p.e_div) * p.ld_mul + row];
   }
   *c = v;
 }

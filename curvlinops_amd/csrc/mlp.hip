@@ -1259,6 +1259,272 @@ __global__ void small_outer_reduce_kernel(float *__restrict__ out, const float *
   out[e] = (beta != 0.f ? beta * out[e] : 0.f) + t;
 }
 
+// ------------------------------------------------------------------------------------------
+// K probe columns at once (reference: vmap over the trailing K axis, _torch_base.py:946-989).
+// The tangent weights keep the reference's K-trailing layout: V_l[j][i][k] at
+// V + ((j * d_in + i) * ldk + k), i.e. the rows of a [D, K] matrix, and so does the result.  Per
+// column the traffic is then 4 D (V) + 4 D (result); W is shared by all columns:
+//   z-path   : a_l, phi'_l once (fwd_mfma kernels without tangent)
+//   kfwd     : dA_l[j][n][k] = phi'[n][j] (sum_i V_l[j][i][k] a[n][i] + (W_l dA_{l-1})[j][n][k] + Vb)
+//              -- streams V_l once; the W_l dA_{l-1} term is a GEMM with N K columns
+//   loss     : per (n, k)
+//   kouter   : out_l[j][i][k] = beta out + sum_n a[n][i] delta_l[j][n][k]   -- streams the result
+//   dprev    : GEMM delta_{l-1} = phi' * (W_l^T delta_l) with N K columns
+// Tangents / deltas are stored feature-major: [d_l][N][K].  N <= 8 rows per pass, K % 4 == 0, K <= 64.
+// ------------------------------------------------------------------------------------------
+constexpr int KC_WAVES = 4;   // waves of a kfwd block: split the contraction among themselves
+constexpr int KC_TPW = 2;     // MFMA tiles per wave
+
+// One MFMA tile = 16 "columns" c = (feature f = c / G, column quad kq = c % G), G = K / 4; lane
+// (c, s = lane >> 4) loads ONE float4 V[j + f][i][4 kq ..] per i and feeds four MFMAs (one per
+// column of the quad), all with the A operand a[n][i].  k-slot s takes i = ib + 4 s + t in step t,
+// so the A operand is one float4 of row n per 16 i.
+template <bool ACC>
+__global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
+    const float *__restrict__ V, long ldk, const float *__restrict__ Vb,
+    const float *__restrict__ a, const float *__restrict__ dphi, float *__restrict__ dA, int N,
+    int K, int d_in, int d_out, int i_per_wave) {
+  __shared__ float s_red[KC_WAVES][KC_TPW][4][4][64];  // [wave][tile][m][r][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, s = lane >> 4;
+  const int G = K >> 2, FPT = 16 / G;        // features per tile
+  const int f = c / G, kq = c - f * G;
+  const bool cvalid = f < FPT;
+  const int j0 = blockIdx.x * FPT * KC_TPW;
+  const int wb = min(wave * i_per_wave, d_in), we = min(d_in, wb + i_per_wave);
+
+  const float *pV[KC_TPW];
+#pragma unroll
+  for (int t = 0; t < KC_TPW; ++t) {
+    const int j = min(j0 + t * FPT + (cvalid ? f : 0), d_out - 1);
+    pV[t] = V + ((long)j * d_in) * ldk + 4 * (cvalid ? kq : 0);
+  }
+  const unsigned bmask = cvalid ? 0xffffffffu : 0u;
+  const int n = c;  // A operand row
+  const unsigned amask = n < N ? 0xffffffffu : 0u;
+  const float *pa = a + (long)min(n, N - 1) * d_in + 4 * s;
+
+  f32x4 acc[KC_TPW][4];
+#pragma unroll
+  for (int t = 0; t < KC_TPW; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ib = wb; ib < we; ib += 16) {
+    const bool aok = ib + 4 * s + 3 < we;   // d_in % 4 == 0 and ranges are multiples of 16
+    float4 av = ld4(pa + (aok ? ib : wb));
+    const unsigned am = aok ? amask : 0u;
+    float4 bv[KC_TPW][4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int i = ib + 4 * s + st;
+      const long off = (long)(i < we ? i : wb) * ldk;
+#pragma unroll
+      for (int t = 0; t < KC_TPW; ++t) bv[t][st] = ld4(pV[t] + off);
+    }
+    const float avs[4] = {__uint_as_float(__float_as_uint(av.x) & am),
+                          __uint_as_float(__float_as_uint(av.y) & am),
+                          __uint_as_float(__float_as_uint(av.z) & am),
+                          __uint_as_float(__float_as_uint(av.w) & am)};
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int t = 0; t < KC_TPW; ++t) {
+        const float4 b = bv[t][st];
+        const float bx = __uint_as_float(__float_as_uint(b.x) & bmask);
+        const float by = __uint_as_float(__float_as_uint(b.y) & bmask);
+        const float bz = __uint_as_float(__float_as_uint(b.z) & bmask);
+        const float bw = __uint_as_float(__float_as_uint(b.w) & bmask);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bx, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], by, acc[t][1], 0, 0, 0);
+        acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bz, acc[t][2], 0, 0, 0);
+        acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bw, acc[t][3], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < KC_TPW; ++t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_red[wave][t][m][r][lane] = acc[t][m][r];
+  __syncthreads();
+  // D layout: row n = 4 (lane >> 4) + r, column c.  Wave w finishes r = w: sums the K ranges and
+  // writes the quad's four columns as one float4.
+  const int r = wave, nn = 4 * s + r;
+  if (!cvalid || nn >= N) return;
+#pragma unroll
+  for (int t = 0; t < KC_TPW; ++t) {
+    const int j = j0 + t * FPT + f;
+    if (j >= d_out) continue;
+    float o[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < KC_WAVES; ++w) v += s_red[w][t][m][r][lane];
+      o[m] = v;
+    }
+    float *dst = dA + ((long)j * N + nn) * K + 4 * kq;
+    if (ACC) {
+      const float4 old = ld4(dst);
+      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+    }
+    if (Vb) {
+      const float4 vb = ld4(Vb + (long)j * ldk + 4 * kq);
+      o[0] += vb.x; o[1] += vb.y; o[2] += vb.z; o[3] += vb.w;
+    }
+    const float dp = dphi ? dphi[(long)nn * d_out + j] : 1.f;
+    *reinterpret_cast<float4 *>(dst) = make_float4(dp * o[0], dp * o[1], dp * o[2], dp * o[3]);
+  }
+}
+
+// aT[i][0..7] = a[n][i] (zero beyond N): the outer-product stream reads 8 samples of one input
+// feature as two float4.
+__global__ void pack_at_kernel(const float *__restrict__ a, float *__restrict__ aT, int N, int d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d * NB) return;
+  const int i = e / NB, n = e % NB;
+  aT[e] = n < N ? a[(long)n * d + i] : 0.f;
+}
+
+// out[j][i][k] = beta out[j][i][k] + sum_n aT[i][n] delta[j][n][k] ; out_b[j][k] likewise with 1.
+// One block per output feature j; lane = (input feature, column quad): a wave instruction stores
+// (64 / G) consecutive rows of K floats = one contiguous run of the result.
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void kouter_stream_kernel(
+    float *__restrict__ out, long ldk, float *__restrict__ out_b, const float *__restrict__ aT,
+    const float *__restrict__ delta, int N, int K, int d_in, float beta) {
+  const int j = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = K >> 2, IPW = 64 / G;  // input features per wave instruction
+  const int io = lane / G, kq = lane - io * G;
+  if (io >= IPW) return;
+  float4 d[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+    d[n] = n < N ? ld4(delta + ((long)j * N + n) * K + 4 * kq) : zero4();
+  if (out_b && wave == 0 && io == 0) {
+    float4 sb = zero4();
+#pragma unroll
+    for (int n = 0; n < NB; ++n) { sb.x += d[n].x; sb.y += d[n].y; sb.z += d[n].z; sb.w += d[n].w; }
+    float *ob = out_b + (long)j * ldk + 4 * kq;
+    if (ACCUM) {
+      const float4 o = ld4(ob);
+      sb.x += beta * o.x; sb.y += beta * o.y; sb.z += beta * o.z; sb.w += beta * o.w;
+    }
+    *reinterpret_cast<float4 *>(ob) = sb;
+  }
+  float *oj = out + (long)j * d_in * ldk + 4 * kq;
+  constexpr int U = 4;
+  const int step = 4 * IPW;  // input features per block trip
+  for (int i0 = wave * IPW + io; i0 < d_in; i0 += U * step) {
+    float4 x0[U], x1[U], old[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u * step, d_in - 1);
+      x0[u] = ld4(aT + (long)i * NB);
+      x1[u] = ld4(aT + (long)i * NB + 4);
+      if (ACCUM) old[u] = ld4(oj + (long)i * ldk);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * step;
+      if (i >= d_in) break;
+      const float xs[NB] = {x0[u].x, x0[u].y, x0[u].z, x0[u].w, x1[u].x, x1[u].y, x1[u].z, x1[u].w};
+      float4 o = ACCUM ? make_float4(beta * old[u].x, beta * old[u].y, beta * old[u].z, beta * old[u].w)
+                       : zero4();
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        o.x = fmaf(xs[n], d[n].x, o.x); o.y = fmaf(xs[n], d[n].y, o.y);
+        o.z = fmaf(xs[n], d[n].z, o.z); o.w = fmaf(xs[n], d[n].w, o.w);
+      }
+      *reinterpret_cast<float4 *>(oj + (long)i * ldk) = o;
+    }
+  }
+}
+
+// delta_L[c][n][k] = phi'_L[n][c] * scale * (H(f_n) u[:, n, k])[c]  in place on u = dA_L.
+// One thread per (n, k); C is small on this path (<= 64).
+constexpr int LC_CMAX = 64;
+__global__ void loss_cols_kernel(int kind, const float *__restrict__ f,
+                                 const float *__restrict__ aux, int aux_rank,
+                                 const float *__restrict__ dphi_last, float *__restrict__ u, int N,
+                                 int K, int C, float scale) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * K) return;
+  const int n = e / K;
+  const long cs = (long)N * K;  // stride between classes
+  float *un = u + e;
+  const float *fn = f + (long)n * C;
+  const float *dp = dphi_last ? dphi_last + (long)n * C : nullptr;
+  if (C <= 16 && kind != CLO_LOSS_RANK1) {
+    // narrow output: everything in registers, all loads issued before the first dependent use
+    float uv[16], fv[16], dv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int cc = c < C ? c : 0;
+      uv[c] = un[cc * cs];
+      fv[c] = fn[cc];
+      dv[c] = dp ? dp[cc] : 1.f;
+    }
+    float mx = -INFINITY, se = 0.f, spu = 0.f;
+    if (kind == CLO_LOSS_CE) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) if (c < C) mx = fmaxf(mx, fv[c]);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) if (c < C) {
+        fv[c] = __expf(fv[c] - mx);
+        se += fv[c];
+        spu += fv[c] * uv[c];
+      }
+    }
+    const float inv = kind == CLO_LOSS_CE ? 1.f / se : 0.f, pu = spu * inv;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < C) {
+      float w;
+      if (kind == CLO_LOSS_MSE) w = uv[c];
+      else if (kind == CLO_LOSS_BCE) { const float sg = 1.f / (1.f + __expf(-fv[c])); w = sg * (1.f - sg) * uv[c]; }
+      else w = fv[c] * inv * (uv[c] - pu);
+      un[c * cs] = scale * w * dv[c];
+    }
+    return;
+  }
+  if (kind == CLO_LOSS_MSE) {
+    for (int c = 0; c < C; ++c) un[c * cs] = scale * un[c * cs] * (dp ? dp[c] : 1.f);
+  } else if (kind == CLO_LOSS_BCE) {
+    for (int c = 0; c < C; ++c) {
+      const float sg = 1.f / (1.f + __expf(-fn[c]));
+      un[c * cs] = scale * sg * (1.f - sg) * un[c * cs] * (dp ? dp[c] : 1.f);
+    }
+  } else if (kind == CLO_LOSS_CE) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, fn[c]);
+    float se = 0.f, spu = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float ex = __expf(fn[c] - mx);
+      se += ex;
+      spu += ex * un[c * cs];
+    }
+    const float inv = 1.f / se, pu = spu * inv;
+    for (int c = 0; c < C; ++c) {
+      const float pc = __expf(fn[c] - mx) * inv;
+      un[c * cs] = scale * pc * (un[c * cs] - pu) * (dp ? dp[c] : 1.f);
+    }
+  } else {  // rank-M: H_n = sum_m g_nm g_nm^T
+    float w[LC_CMAX];
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) w[c] = 0.f;
+    for (int m = 0; m < aux_rank; ++m) {
+      const float *g = aux + ((long)n * aux_rank + m) * C;
+      float sdot = 0.f;
+      for (int c = 0; c < C; ++c) sdot += g[c] * un[c * cs];
+      for (int c = 0; c < C; ++c) w[c] += scale * g[c] * sdot;
+    }
+    for (int c = 0; c < C; ++c) un[c * cs] = w[c] * (dp ? dp[c] : 1.f);
+  }
+}
+
 static inline unsigned ew_grid(long n) {
   return (unsigned)std::max<long>(1, std::min<long>(cdiv(n, 256), kNumCU * 8L));
 }
@@ -1859,6 +2125,161 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
       }
     }
     std::swap(dcur, dnext);
+  }
+  return CLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K columns at once (see the kfwd / kouter kernels above).
+// ------------------------------------------------------------------------------------------
+static long matmat_gemm_ws(int dmax, int K) { return 16L * dmax * NB * K; }
+
+extern "C" long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int K) {
+  (void)N;
+  if (L <= 0 || !dims || K <= 0) return 0;
+  long total = 0;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  for (int l = 1; l <= L; ++l) total += 2L * NB * dims[l] + (long)dims[l] * NB * K;  // a, phi', dA
+  for (int l = 0; l < L; ++l) total += (long)dims[l] * NB;                            // aT
+  long part = 0;
+  for (int l = 1; l <= L; ++l) part = std::max(part, clo_mlp_fwd_ws_floats(NB, dims[l - 1], dims[l]));
+  return total + part + matmat_gemm_ws(dmax, K) + 256;
+}
+
+// out[.., k] = beta out[.., k] + alpha (J^T H J) V[.., k] for K columns.  VW[l] / OW[l] point at
+// element (0, 0, 0) of the [d_out][d_in][K] blocks (column stride 1, row stride ldk floats), Vb[l]
+// / Ob[l] at [d_out][K] blocks with the same ldk.  Requirements (else CLO_EUNSUP): K % 4 == 0,
+// 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0, 16-byte aligned operands.
+extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *const *W,
+                                  const float *const *b, const float *const *VW,
+                                  const float *const *Vb, float *const *OW, float *const *Ob,
+                                  long ldk, const float *X, int N, int K, int loss_kind,
+                                  const float *aux, int aux_rank, float loss_scale, float alpha,
+                                  float beta, float *ws, void *stream) {
+  CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW, "clo_mlp_ggn_matmat: bad layer table");
+  CLO_REQUIRE(N >= 0 && X && ws && K >= 1, "clo_mlp_ggn_matmat: bad batch / workspace / K");
+  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_ggn_matmat: unknown loss kind %d", loss_kind);
+  CLO_REQUIRE(loss_kind != CLO_LOSS_RANK1 || (aux && aux_rank >= 1),
+              "clo_mlp_ggn_matmat: RANK1 needs aux and aux_rank >= 1");
+  bool ok = K % 4 == 0 && K >= 4 && K <= 64 && ldk % 4 == 0 && ldk >= K && aligned16(X) && aligned16(ws);
+  for (int l = 0; l <= L; ++l) CLO_REQUIRE(dims[l] > 0, "clo_mlp_ggn_matmat: dims[%d] <= 0", l);
+  for (int l = 0; l < L; ++l) {
+    CLO_REQUIRE(acts[l] >= 0 && acts[l] <= 3, "clo_mlp_ggn_matmat: unknown activation");
+    CLO_REQUIRE(W[l] && VW[l] && OW[l], "clo_mlp_ggn_matmat: null weight pointer in layer %d", l);
+    ok = ok && dims[l] % 4 == 0 && aligned16(W[l]) && aligned16(VW[l]) && aligned16(OW[l]);
+    if (Vb && Vb[l]) ok = ok && aligned16(Vb[l]);
+    if (Ob && Ob[l]) ok = ok && aligned16(Ob[l]);
+  }
+  if (loss_kind == CLO_LOSS_RANK1 && dims[L] > LC_CMAX) ok = false;
+  if (!ok) {
+    set_error("clo_mlp_ggn_matmat: needs K %% 4 == 0, 4 <= K <= 64, ldk %% 4 == 0, layer inputs %% 4 == 0 "
+              "and 16-byte aligned operands");
+    return CLO_EUNSUP;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  if (N == 0) {  // empty batch: out = beta * out, row by row of the strided blocks
+    if (beta != 1.f)
+      for (int l = 0; l < L; ++l) {
+        const long rows = (long)dims[l] * dims[l + 1];
+        for (int pass = 0; pass < 2; ++pass) {
+          float *o = pass == 0 ? OW[l] : (Ob ? Ob[l] : nullptr);
+          const long r = pass == 0 ? rows : dims[l + 1];
+          if (!o) continue;
+          if (ldk == K) {
+            int rc = clo_axpby_f32(o, o, r * K, 0.f, beta, stream);
+            if (rc != CLO_OK) return rc;
+          } else {
+            for (long q = 0; q < r; ++q) {
+              int rc = clo_axpby_f32(o + q * ldk, o + q * ldk, K, 0.f, beta, stream);
+              if (rc != CLO_OK) return rc;
+            }
+          }
+        }
+      }
+    return CLO_OK;
+  }
+  // carve the workspace
+  float *p = ws;
+  float *a[65], *dphi[65], *dA[65], *aT[65];
+  for (int l = 1; l <= L; ++l) {
+    a[l] = p; p += (long)NB * dims[l];
+    dphi[l] = p; p += (long)NB * dims[l];
+    dA[l] = p; p += (long)dims[l] * NB * K;
+  }
+  for (int l = 0; l < L; ++l) { aT[l] = p; p += (long)dims[l] * NB; }
+  float *part = p;
+  long part_sz = 0;
+  for (int l = 1; l <= L; ++l) part_sz = std::max(part_sz, clo_mlp_fwd_ws_floats(NB, dims[l - 1], dims[l]));
+  p += part_sz;
+  float *gws = p;
+  const long gws_sz = matmat_gemm_ws(dmax, K);
+  const int G = K / 4, FPT = 16 / G;
+  const bool last_linear = acts[L - 1] == CLO_ACT_IDENTITY;
+
+  for (int n0 = 0; n0 < N; n0 += NB) {
+    const int nn = std::min(NB, N - n0);
+    const int NK = nn * K;
+    const float bt = n0 == 0 ? beta : 1.f;
+    a[0] = const_cast<float *>(X) + (long)n0 * dims[0];
+    // ---- forward: z path, tangent GEMM, tangent-weight stream
+    for (int l = 1; l <= L; ++l) {
+      const int di = dims[l - 1], dout = dims[l];
+      int rc = fwd_pass(W[l - 1], b ? b[l - 1] : nullptr, nullptr, nullptr, a[l - 1], nullptr, a[l],
+                        nullptr, dphi[l], nn, di, dout, acts[l - 1], part, false, nullptr, st);
+      if (rc != CLO_OK) return rc;
+      hipLaunchKernelGGL(pack_at_kernel, dim3((unsigned)cdiv((long)di * NB, 256)), dim3(256), 0, st,
+                         a[l - 1], aT[l - 1], nn, di);
+      CLO_CHECK_LAUNCH("pack_at_kernel");
+      if (l >= 2) {  // dA_l = W_l dA_{l-1}   ([dout x di] [di x NK])
+        GemmArgs g = gemm_problem(dout, NK, di, W[l - 1], di, 1, dA[l - 1], NK, 1, 0.f, dA[l], NK);
+        rc = launch_gemm_auto(g, gws, gws_sz, st);
+        if (rc != CLO_OK) return rc;
+      }
+      const int ipw = (int)cdiv(cdiv(di, KC_WAVES), 16) * 16;
+      dim3 grid((unsigned)cdiv(dout, FPT * KC_TPW)), block(KC_WAVES * 64);
+      const float *vb = Vb ? Vb[l - 1] : nullptr;
+      const float *dp = (l == L && last_linear) ? nullptr : dphi[l];
+      ProfScope prof(0, 4.0 * di * dout * K, st);
+      if (l >= 2)
+        hipLaunchKernelGGL(kfwd_stream_kernel<true>, grid, block, 0, st, VW[l - 1], ldk, vb, a[l - 1],
+                           dp, dA[l], nn, K, di, dout, ipw);
+      else
+        hipLaunchKernelGGL(kfwd_stream_kernel<false>, grid, block, 0, st, VW[l - 1], ldk, vb, a[l - 1],
+                           dp, dA[l], nn, K, di, dout, ipw);
+      CLO_CHECK_LAUNCH("kfwd_stream_kernel");
+    }
+    // ---- output-space curvature per (n, k), in place: dA_L becomes delta_L
+    {
+      const float *auxn = aux ? aux + (long)n0 * aux_rank * dims[L] : nullptr;
+      hipLaunchKernelGGL(loss_cols_kernel, dim3((unsigned)cdiv(NK, 64)), dim3(64), 0, st, loss_kind, a[L],
+                         auxn, aux_rank, last_linear ? nullptr : dphi[L], dA[L], nn, K, dims[L],
+                         loss_scale * alpha);
+      CLO_CHECK_LAUNCH("loss_cols_kernel");
+    }
+    // ---- backward: result stream, then the delta GEMM of the next layer down
+    for (int l = L; l >= 1; --l) {
+      const int di = dims[l - 1], dout = dims[l];
+      {
+        ProfScope prof(4, 4.0 * di * dout * K * (bt != 0.f ? 2 : 1), st);
+        float *ob = Ob ? Ob[l - 1] : nullptr;
+        if (bt != 0.f)
+          hipLaunchKernelGGL(kouter_stream_kernel<true>, dim3(dout), dim3(256), 0, st, OW[l - 1], ldk, ob,
+                             aT[l - 1], dA[l], nn, K, di, bt);
+        else
+          hipLaunchKernelGGL(kouter_stream_kernel<false>, dim3(dout), dim3(256), 0, st, OW[l - 1], ldk,
+                             ob, aT[l - 1], dA[l], nn, K, di, bt);
+        CLO_CHECK_LAUNCH("kouter_stream_kernel");
+      }
+      if (l >= 2) {  // delta_{l-1} = phi'_{l-1} * (W_l^T delta_l)   ([di x dout] [dout x NK])
+        GemmArgs g = gemm_problem(di, NK, dout, W[l - 1], 1, di, dA[l], NK, 1, 0.f, dA[l - 1], NK);
+        g.epi = EPI_MUL_T; g.e_mul = dphi[l - 1]; g.ld_mul = di; g.e_div = K;
+        int rc = launch_gemm_auto(g, gws, gws_sz, st);
+        if (rc != CLO_OK) return rc;
+      }
+    }
   }
   return CLO_OK;
 }

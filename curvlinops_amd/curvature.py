@@ -141,6 +141,9 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                 return None
             batches.append((Xn, y, self._get_normalization_factor(X, y)))
         K = M[0].shape[-1]
+        out = self._matmat_native_cols(M, batches, K)
+        if out is not None:
+            return out
         # K-major contiguous copies so that every column is a parameter-shaped contiguous view
         Vk = [m.movedim(-1, 0).contiguous().float() for m in M]
         Ok = [torch.empty_like(v) for v in Vk]
@@ -154,6 +157,50 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                 kind, scale, aux = self._native_batch_args(bi, Xn, y)
                 nat.matvec(V, O, Xn, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0, aux=aux)
         return [o.movedim(0, -1) for o in Ok]
+
+    _NATIVE_COLS_MAX_ROWS = 32  # the K-column kernels run 8-row passes; beyond that GEMMs win
+    _NATIVE_COLS_MIN_K = 8      # below, K matvecs on K-major copies are as fast (measured on C2)
+
+    def _matmat_native_cols(self, M: list[Tensor], batches, K: int) -> list[Tensor] | None:
+        """K >= 4 columns in the reference's K-trailing layout through ``clo_mlp_ggn_matmat`` (the
+        tangent weights and the result are streamed once per column, W is shared); None if the
+        shapes / layout do not qualify."""
+        nat = self._native
+        plan = nat.plan
+        if K < self._NATIVE_COLS_MIN_K or not batches or any(b[0].shape[0] > self._NATIVE_COLS_MAX_ROWS for b in batches):
+            return None
+        # rows of the [D, K] matrix must be float4-complete: K % 4 == 0 (else the column loop runs)
+        if not all(m.is_contiguous() and m.data_ptr() % 16 == 0 for m in M) or not plan.matmat_supported(4, K):
+            return None
+        out = self._alloc_cols_like(M)
+        stream = torch.cuda.current_stream().cuda_stream
+        for k0 in range(0, K, plan.MATMAT_MAX_K):
+            kc = min(plan.MATMAT_MAX_K, K - k0)
+            ws = plan.matmat_workspace(kc, self.device)
+            ptr = lambda lst, i: None if i is None else lst[i].data_ptr() + 4 * k0  # noqa: E731
+            vw = [ptr(M, i) for i in nat.w_idx]
+            vb = [ptr(M, i) for i in nat.b_idx]
+            ow = [ptr(out, i) for i in nat.w_idx]
+            ob = [ptr(out, i) for i in nat.b_idx]
+            for bi, (Xn, y, norm) in enumerate(batches):
+                kind, scale, aux = self._native_batch_args(bi, Xn, y)
+                plan.ggn_matmat_ptrs(vw, vb, ow, ob, K, kc, Xn.data_ptr(), Xn.shape[0], kind, scale, norm,
+                                     0.0 if bi == 0 else 1.0, None if aux is None else aux.data_ptr(),
+                                     1 if aux is None else aux.shape[1], ws.data_ptr(), stream)
+        return out
+
+    @staticmethod
+    def _alloc_cols_like(M: list[Tensor]) -> list[Tensor]:
+        """Result blocks as views of ONE ``[D, K]`` buffer in ``params`` order, so that the flat
+        result the base class builds with ``cat`` is already laid out."""
+        K = M[0].shape[-1]
+        rows = [m.numel() // K for m in M]
+        buf = torch.empty(sum(rows), K, device=M[0].device, dtype=M[0].dtype)
+        out, pos = [], 0
+        for m, r in zip(M, rows):
+            out.append(buf[pos:pos + r].view(m.shape))
+            pos += r
+        return out
 
     # ------------------------------------------------------------------ flat fast path
     def _native_flat_setup(self):

@@ -54,6 +54,20 @@ def _expect_same_shape(old: Tensor, new: Tensor) -> None:
         raise ValueError(f"Shape mismatch: expected {old.shape}, got {new.shape}.")
 
 
+def _adjacent_rows(Y: list[Tensor], sizes: list[int], K: int) -> Tensor | None:
+    """The ``[sum(sizes), K]`` matrix the blocks of ``Y`` already form when they are consecutive row
+    ranges of one contiguous buffer (a producer that wrote its result in place); None otherwise."""
+    base = Y[0]._base
+    if base is None or base.dim() != 2 or base.shape != (sum(sizes), K) or not base.is_contiguous():
+        return None
+    off = base.storage_offset()
+    for y, n in zip(Y, sizes):
+        if y._base is not base or not y.is_contiguous() or y.storage_offset() != off:
+            return None
+        off += n * K
+    return base
+
+
 class PyTorchLinearOperator:
     """Linear operator on tensor-product spaces of PyTorch tensors.
 
@@ -156,7 +170,9 @@ class PyTorchLinearOperator:
         if leading:
             flat = torch.cat([y.reshape(K, n) for y, n in zip(Y, sizes)], dim=1)
         else:
-            flat = torch.cat([y.reshape(n, K) for y, n in zip(Y, sizes)], dim=0)
+            flat = _adjacent_rows(Y, sizes, K)
+            if flat is None:
+                flat = torch.cat([y.reshape(n, K) for y, n in zip(Y, sizes)], dim=0)
         return flat.squeeze(axis) if fmt.is_vector else flat
 
     # ------------------------------------------------------------------ products

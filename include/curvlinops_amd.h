@@ -175,6 +175,21 @@ int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
                        float *ws, void *stream);
 long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
 
+/* K probe columns in one call (reference: vmap over the trailing K axis, _torch_base.py:946-989):
+ *   out[.., k] = beta * out[.., k] + alpha * (J^T H J) V[.., k],   k = 0..K-1
+ * VW[l] / OW[l] point at element (0, 0, 0) of a [d_out][d_in][K] block whose rows (one per weight)
+ * are ldk floats apart -- the rows of the reference's [D, K] matrix; Vb[l] / Ob[l] likewise
+ * [d_out][K].  The tangent weights are streamed once in that layout, W is shared by all columns.
+ * Returns CLO_EUNSUP unless K % 4 == 0, 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0 and all
+ * operands are 16-byte aligned (the caller then loops clo_mlp_ggn_matvec over columns).
+ * ws: clo_mlp_ggn_matmat_ws_floats(L, dims, N, K) floats. */
+long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int K);
+int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *const *W,
+                       const float *const *b, const float *const *VW, const float *const *Vb,
+                       float *const *OW, float *const *Ob, long ldk, const float *X, int N, int K,
+                       int loss_kind, const float *aux, int aux_rank, float loss_scale, float alpha,
+                       float beta, float *ws, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Streaming helpers (HBM-bound).
  * ------------------------------------------------------------------------- */

@@ -263,6 +263,91 @@ def test_ggn_matvec_large_layers(hip, N):
     assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
 
 
+def _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, Vbk, loss_kind, scale, alpha, beta, out0=None,
+                         aux=None, pad=0):
+    """K columns through clo_mlp_ggn_matmat: VWk[l] is [d_out, d_in, K], Vbk[l] is [d_out, K]; `pad`
+    extra columns make the row stride ldk = K + pad differ from K."""
+    plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    dW, db = [dev(W) for W in Ws], [None if b is None else dev(b) for b in bs]
+    plan.bind_params(dW, db)
+    K = VWk[0].shape[-1]
+    ldk = K + pad
+
+    def padded(t, fill):
+        full = torch.full((*t.shape[:-1], ldk), fill, dtype=torch.float32, device="cuda")
+        full[..., :K] = dev(t)
+        return full
+
+    dV = [padded(v, 7.0) for v in VWk]
+    dVb = [None if v is None else padded(v, 7.0) for v in Vbk]
+    if out0 is None:
+        oW = [torch.full_like(v, float("nan")) for v in dV]
+        ob = [None if v is None else torch.full_like(v, float("nan")) for v in dVb]
+    else:
+        oW = [padded(w, 0.0) for w in out0[0]]
+        ob = [None if b is None else padded(b, 0.0) for b in out0[1]]
+    Xd = dev(X)
+    ws = plan.matmat_workspace(K, "cuda")
+    ptr = lambda lst: [None if t is None else t.data_ptr() for t in lst]  # noqa: E731
+    plan.ggn_matmat_ptrs(ptr(dV), ptr(dVb), ptr(oW), ptr(ob), ldk, K, Xd.data_ptr(), Xd.shape[0], loss_kind,
+                         scale, alpha, beta, None if aux is None else aux.data_ptr(),
+                         1 if aux is None else aux.shape[1], ws.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return ([w[..., :K].cpu().numpy() for w in oW],
+            [None if b is None else b[..., :K].cpu().numpy() for b in ob])
+
+
+@pytest.mark.parametrize("loss", ["mse", "ce", "bce"])
+@pytest.mark.parametrize("N,K,pad", [(1, 4, 0), (5, 8, 0), (8, 32, 0), (8, 64, 0), (11, 12, 4), (3, 20, 0), (19, 16, 0)])
+def test_ggn_matmat_columns_vs_oracle(hip, loss, N, K, pad):
+    """K-trailing multi-column kernels (tangent-weight stream, tangent GEMMs, result stream) against the
+    float64 oracle applied column by column; accumulation (beta = 1, alpha = 0.5) included."""
+    g = np.random.default_rng(100 * N + K)
+    dims = [64, 96, 48, 10]
+    acts = ["tanh", "relu", "identity"] if loss != "bce" else ["sigmoid", "tanh", "identity"]
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [g.random(dims[i + 1]) - 0.5 for i in range(3)]
+    VWk = [g.random((*W.shape, K)) - 0.5 for W in Ws]
+    Vbk = [g.random((*b.shape, K)) - 0.5 for b in bs]
+    X = g.random((N, dims[0]))
+    y = g.integers(0, dims[-1], N) if loss == "ce" else g.random((N, dims[-1]))
+    c = O.reduction_factor(loss, "mean", N, dims[-1])
+    scale = (2.0 if loss == "mse" else 1.0) * c
+    out0 = ([g.random(v.shape) for v in VWk], [g.random(v.shape) for v in Vbk])
+    gW, gb = _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, Vbk, LOSS_KIND[loss], scale, 0.5, 1.0,
+                                  out0=out0, pad=pad)
+    for k in range(K):
+        rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", [v[..., k] for v in VWk],
+                                    [v[..., k] for v in Vbk])
+        ref = O.flatten_params([0.5 * r + o[..., k] for r, o in zip(rW, out0[0])],
+                               [0.5 * r + o[..., k] for r, o in zip(rb, out0[1])])
+        got = O.flatten_params([w[..., k] for w in gW], [b[..., k] for b in gb])
+        assert rel_err(got, ref) < 1e-4, k
+
+
+def test_ggn_matmat_columns_c2_width(hip):
+    """C2-like widths (several K ranges per wave, 2688-wide GEMMs) at K = 32, no bias, beta = 0."""
+    g = np.random.default_rng(5)
+    dims, acts, N, K = [256, 672, 672, 10], ["relu", "relu", "identity"], 8, 32
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [None, None, None]
+    VWk = [g.random((*W.shape, K)) - 0.5 for W in Ws]
+    X, y = g.random((N, dims[0])), g.random((N, dims[-1]))
+    scale = 2.0 / (N * dims[-1])
+    gW, _ = _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, [None] * 3, 0, scale, 1.0, 0.0)
+    for k in (0, 13, 31):
+        rW, _ = O.ggn_matvec_batch(Ws, bs, acts, X, y, "mse", "mean", [v[..., k] for v in VWk], [None] * 3)
+        assert rel_err(np.concatenate([w[..., k].ravel() for w in gW]), np.concatenate([r.ravel() for r in rW])) < 1e-4
+
+
+def test_ggn_matmat_unsupported_shapes_report(hip):
+    plan = hip.MLPPlan([6, 4], [0])
+    assert not plan.matmat_supported(8, 8)       # input width not a multiple of 4
+    plan = hip.MLPPlan([8, 4], [0])
+    assert plan.matmat_supported(8, 8) and not plan.matmat_supported(6, 6) and not plan.matmat_supported(128, 128)
+
+
 # ------------------------------------------------------------------------ Cholesky inverse
 @pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 401, 1000])
 def test_cholesky_inverse(hip, n):

@@ -71,6 +71,40 @@ def test_native_matches_autograd_path_on_gpu(dev):
         assert rel_err(a, b.double().cpu().numpy()) < 2e-4
 
 
+def test_native_column_kernels_match_autograd_path_on_gpu(dev):
+    """`A @ M` with K % 4 == 0 columns runs clo_mlp_ggn_matmat (K-trailing, no transposes); same result
+    as the torch.func path, for GGN and EF, several mini-batches (incl. a 2-pass one), K > 64 chunked."""
+    torch.manual_seed(1)
+    model = nn.Sequential(nn.Linear(300, 500), nn.ReLU(), nn.Linear(500, 260), nn.Tanh(), nn.Linear(260, 12)).to(dev)
+    params = dict(model.named_parameters())
+    data = [(torch.rand(8, 300, device=dev), torch.randint(0, 12, (8,), device=dev)),
+            (torch.rand(5, 300, device=dev), torch.randint(0, 12, (5,), device=dev)),
+            (torch.rand(13, 300, device=dev), torch.randint(0, 12, (13,), device=dev))]
+    for cls in (C.GGNLinearOperator, C.EFLinearOperator):
+        nat = cls(model, nn.CrossEntropyLoss(), params, data, check_deterministic=False)
+        ref = cls(model, nn.CrossEntropyLoss(), params, data, check_deterministic=False)
+        ref._native = None
+        for K in (8, 68):
+            V = torch.rand(nat.shape[1], K, device=dev) - 0.5
+            calls = []
+            orig = nat._native.plan.ggn_matmat_ptrs
+            nat._native.plan.ggn_matmat_ptrs = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            a = nat @ V
+            nat._native.plan.ggn_matmat_ptrs = orig
+            assert calls, "the column kernels must have run"
+            Kc = min(K, 8)
+            b = ref @ V[:, :Kc].contiguous()
+            assert rel_err(a[:, :Kc], b.double().cpu().numpy()) < 2e-4
+            # columns are independent: the last one equals a plain matvec
+            assert rel_err(a[:, K - 1], (nat @ V[:, K - 1].contiguous()).double().cpu().numpy()) < 2e-4
+        # tensor-list format in, tensor-list format out
+        V = torch.rand(nat.shape[1], 8, device=dev)
+        shapes = [p.shape for p in params.values()]
+        Vl = [c.reshape(*s, 8) for c, s in zip(V.split([s.numel() for s in shapes]), shapes)]
+        out = nat @ Vl
+        assert rel_err(torch.cat([o.reshape(-1, 8) for o in out]), (nat @ V).double().cpu().numpy()) < 1e-6
+
+
 class TestC2FullSize:
     """BASELINE.json configs[1]: MLP 1024-2688-2688-10 (D = 10 010 122), MSE, GGN."""
 
@@ -109,6 +143,16 @@ class TestC2FullSize:
                                     check_deterministic=False)
         v = torch.rand(one.shape[1], device=dev)
         assert rel_err(split @ v, (one @ v).double().cpu().numpy()) < 2e-4
+
+    def test_columns_vs_matvecs(self, setup):
+        """K = 8 columns at full size through the K-trailing kernels == 8 matvecs."""
+        dev, model, params, X, y = setup
+        G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X[:8], y[:8]), (X[8:11], y[8:11])],
+                                check_deterministic=False)
+        V = torch.rand(G.shape[1], 8, device=dev) - 0.5
+        GV = G @ V
+        for k in (0, 5, 7):
+            assert rel_err(GV[:, k], (G @ V[:, k].contiguous()).double().cpu().numpy()) < 2e-4
 
     def test_against_autograd_path(self, setup):
         dev, model, params, X, y = setup
