@@ -81,6 +81,19 @@ class AllReducedLinearOperator(PyTorchLinearOperator):
         allreduce_tensors_(out, self._group)
         return out
 
+    def __matmul__(self, X):
+        """Flat ``[D]`` / ``[D, K]`` operands: the shard's product through the wrapped operator's own
+        ``@`` (its fast paths included), then ONE in-place all-reduce of the flat result -- no
+        per-parameter views, no pack / unpack copies around the collective."""
+        if isinstance(X, Tensor) and X.dim() in (1, 2):
+            Y = self._op @ X
+            if not Y.is_contiguous():
+                Y = Y.contiguous()
+            if is_distributed():
+                dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self._group)
+            return Y
+        return super().__matmul__(X)
+
     def _adjoint(self) -> "AllReducedLinearOperator":
         return AllReducedLinearOperator(self._op.adjoint(), self._group)
 

@@ -38,6 +38,14 @@ def _worker(rank: int, world: int, port: int, ret):
         local = C.GGNLinearOperator(model, loss, params, mine, num_data=N, check_deterministic=False)
         ok = torch.allclose(AllReducedLinearOperator(local) @ v, full @ v, rtol=1e-10, atol=1e-12)
 
+        # 1-D vector and tensor-list formats take the same collective
+        AR = AllReducedLinearOperator(local)
+        ok &= torch.allclose(AR @ v[:, 0].contiguous(), (full @ v)[:, 0], rtol=1e-10, atol=1e-12)
+        shapes = [p.shape for p in params.values()]
+        vl = [c.reshape(s) for c, s in zip(v[:, 1].split([s.numel() for s in shapes]), shapes)]
+        got = torch.cat([o.flatten() for o in AR @ vl])
+        ok &= torch.allclose(got, (full @ v)[:, 1], rtol=1e-10, atol=1e-12)
+
         # one mini-batch split by rows
         X, y = torch.cat([x for x, _ in data]), torch.cat([t for _, t in data])
         Xr, yr = shard_rows(X, y)
