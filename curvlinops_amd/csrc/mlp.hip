@@ -32,6 +32,28 @@ __device__ __forceinline__ float fma4(const float4 &a, const float4 &b, float ac
 }
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// streamed-once data: non-temporal policy (global_load_dwordx4 ... nt)
+__device__ __forceinline__ float4 ld4nt(const float *p) {
+  typedef float __attribute__((ext_vector_type(4))) v4;
+  const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4nt(float *p, const float4 &v) {
+  typedef float __attribute__((ext_vector_type(4))) v4;
+  __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4 *>(p));
+}
+#ifdef CLO_NT_WEIGHTS
+#define CLO_LDW ld4nt
+#else
+#define CLO_LDW ld4
+#endif
+// the result stream is written once and not read again by the matvec: nt stores (+1 % measured)
+#ifdef CLO_TEMPORAL_STORES
+#define CLO_STW st4
+#else
+#define CLO_STW st4nt
+#endif
 
 // Load the lane's 4 floats of 256-wide sub-slice q of a row (k offset k0).
 // VEC: lane owns 4 consecutive floats (one 16-byte load); scalar: 4 loads strided by 64.
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void fwd_mfma_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int g = 0; g < RG; ++g) av[u][g] = ld4(pA[g] + (step + u) * 16);
+      for (int g = 0; g < RG; ++g) av[u][g] = CLO_LDW(pA[g] + (step + u) * 16);
       bv[u] = ld4(pBs + (step + u) * 16);
     }
 #pragma unroll
@@ -457,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64) void fwd_mfma_first_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int g = 0; g < RG; ++g) av[u][g] = ld4(pA[g] + (step + u) * 16);
+      for (int g = 0; g < RG; ++g) av[u][g] = CLO_LDW(pA[g] + (step + u) * 16);
       bv[u] = ld4(pB + (step + u) * 16);
     }
 #pragma unroll
@@ -793,7 +815,7 @@ __device__ __forceinline__ void bwd_block(
           }
           float *po = out_W + (long)jt * d_in;
           if (VEC) {
-            if (col_ok) *reinterpret_cast<float4 *>(po + i0 + lane * 4) = r;
+            if (col_ok) CLO_STW(po + i0 + lane * 4, r);
           } else {
             const float *pr = reinterpret_cast<const float *>(&r);
 #pragma unroll
@@ -1439,7 +1461,7 @@ __global__ __launch_bounds__(256) void kouter_stream_kernel(
         o.x = fmaf(xs[n], d[n].x, o.x); o.y = fmaf(xs[n], d[n].y, o.y);
         o.z = fmaf(xs[n], d[n].z, o.z); o.w = fmaf(xs[n], d[n].w, o.w);
       }
-      *reinterpret_cast<float4 *>(oj + (long)i * ldk) = o;
+      CLO_STW(oj + (long)i * ldk, o);
     }
   }
 }
