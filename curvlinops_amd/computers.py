@@ -13,6 +13,8 @@ tensors are fp32 on the GPU.
 
 from __future__ import annotations
 
+import os
+
 from collections.abc import Callable, Iterable, MutableMapping
 from contextlib import contextmanager
 from functools import partial
@@ -149,6 +151,46 @@ def _use_params(module: Module, params: dict[str, Tensor]):
         for name, p in module.named_parameters():
             if name in saved:
                 p.data = saved[name]
+
+
+# Factor accumulation (im2col + SYRK) runs on its own HIP stream so that it overlaps the autograd
+# kernels of the layers that follow: the hook only orders it after the producer of its operand.
+_FACTOR_STREAMS: dict = {}
+_OVERLAP = os.environ.get("CLO_KFAC_OVERLAP", "1") != "0"
+
+
+class _factor_stream:
+    """``with _factor_stream(t):`` -- on fp32 GPU tensors, run the body on the per-device factor
+    stream once ``t`` (produced on the current stream) is ready; no-op elsewhere."""
+
+    def __init__(self, t: Tensor):
+        self._on = _OVERLAP and is_native_tensor(t)
+        self._t = t
+
+    def __enter__(self):
+        if not self._on:
+            return self
+        dev = self._t.device
+        side = _FACTOR_STREAMS.get(dev)
+        if side is None:
+            side = _FACTOR_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        side.wait_event(torch.cuda.current_stream(dev).record_event())
+        self._t.record_stream(side)
+        self._ctx = torch.cuda.stream(side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._on:
+            self._ctx.__exit__(*exc)
+        return False
+
+
+def _join_factor_stream(device) -> None:
+    """Make the current stream wait for everything queued on the factor stream."""
+    side = _FACTOR_STREAMS.get(device)
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
 
 
 def _gram_accumulate(store: dict, key, X2d: Tensor, alpha: float, ones_col: bool) -> None:
@@ -288,6 +330,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
                 handles.append(mod.register_forward_pre_hook(partial(self._input_hook, group=group, hyper=hyper, store=A)))
             handles.append(mod.register_forward_hook(partial(self._output_hook, group=group, hyper=hyper, store=G)))
         self._generator = seed_generator(self._generator, self.device, self._seed)
+        self._hooked_outputs = []
         try:
             for X, y in self._loop_over_data(desc="KFAC matrices"):
                 output = self._model_module(X)
@@ -296,6 +339,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
         finally:
             for h in handles:
                 h.remove()
+            _join_factor_stream(self.device)
         if self._distributed:
             from curvlinops_amd.dist import allreduce_tensors_
 
@@ -314,30 +358,40 @@ class HipKFACComputer(EmpiricalRiskMixin):
         grad_outputs = self._grad_outputs_computer(output.detach(), y, self._generator)
         if self._loss_func.reduction == "mean":
             grad_outputs.mul_(1.0 / output.shape[0])
-        module_params = dict(self._model_module.named_parameters())
-        wrt = [module_params[n] for n in self._params]
+        # Differentiate w.r.t. the hooked layer outputs themselves: the tensor hooks see exactly the
+        # output-gradients KFAC needs and autograd never launches a weight-gradient kernel (the
+        # reference differentiates w.r.t. the parameters, kfac_hooks.py:236-289, and discards them).
+        wrt = [o for o in self._hooked_outputs if o.requires_grad]
+        self._hooked_outputs = []
+        if not wrt:
+            module_params = dict(self._model_module.named_parameters())
+            wrt = [module_params[n] for n in self._params]
         V = grad_outputs.shape[0]
         for v in range(V):
-            torch.autograd.grad(output, wrt, grad_outputs=grad_outputs[v], retain_graph=v < V - 1)
+            torch.autograd.grad(output, wrt, grad_outputs=grad_outputs[v], retain_graph=v < V - 1,
+                                allow_unused=True)
 
     def _input_hook(self, module, inputs, group, hyper, store) -> None:
         if len(inputs) != 1:
             raise ValueError("Modules with multiple inputs are not supported.")
-        x = input_to_weight_sharing_format(inputs[0].data.detach(), self._kfac_approx, hyper)
-        shared = x.shape[1]
-        joint = "W" in group and "b" in group
-        _gram_accumulate(store, tuple(group.values()), x.reshape(-1, x.shape[-1]),
-                         1.0 / (self._N_data * shared), ones_col=joint)
+        with _factor_stream(inputs[0]):
+            x = input_to_weight_sharing_format(inputs[0].data.detach(), self._kfac_approx, hyper)
+            shared = x.shape[1]
+            joint = "W" in group and "b" in group
+            _gram_accumulate(store, tuple(group.values()), x.reshape(-1, x.shape[-1]),
+                             1.0 / (self._N_data * shared), ones_col=joint)
 
     def _output_hook(self, module, inputs, output, group, hyper, store) -> None:
         output.register_hook(partial(self._grad_hook, group=group, hyper=hyper, store=store))
+        self._hooked_outputs.append(output)
 
     def _grad_hook(self, grad_output: Tensor, group, hyper, store) -> None:
         g = grad_output.data.detach()
         corr = compute_loss_correction(g.shape[0], self._num_per_example_loss_terms,
                                        self._loss_func.reduction, self._N_data)
-        g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
-        _gram_accumulate(store, tuple(group.values()), g.reshape(-1, g.shape[-1]), corr, ones_col=False)
+        with _factor_stream(g):
+            g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
+            _gram_accumulate(store, tuple(group.values()), g.reshape(-1, g.shape[-1]), corr, ones_col=False)
 
 
 # ------------------------------------------------------------------------------------------
@@ -399,6 +453,7 @@ class HipEKFACComputer(HipKFACComputer):
             mod = self._module_of(group)
             handles.append(mod.register_forward_hook(partial(self._corr_output_hook, group=group, Qa=Qa, Qg=Qg, lam=lam)))
         self._generator = seed_generator(self._generator, self.device, self._seed)
+        self._hooked_outputs = []
         try:
             for X, y in self._loop_over_data(desc="Eigenvalue correction"):
                 output = self._model_module(X)
@@ -415,6 +470,7 @@ class HipEKFACComputer(HipKFACComputer):
 
     def _corr_output_hook(self, module, inputs, output, group, Qa, Qg, lam) -> None:
         output.register_hook(partial(self._corr_grad_hook, module=module, inputs=inputs, group=group, Qa=Qa, Qg=Qg, lam=lam))
+        self._hooked_outputs.append(output)
 
     def _corr_grad_hook(self, grad_output: Tensor, module, inputs, group, Qa, Qg, lam) -> None:
         if len(inputs) != 1:
