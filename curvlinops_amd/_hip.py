@@ -266,11 +266,12 @@ def im2col(x: Tensor, kernel_size, stride, padding, dilation) -> Tensor:
     return out
 
 
-def cholesky_inverse(A: Tensor, damping: float = 0.0) -> Tensor:
-    """``(A + damping I)^-1`` for a symmetric positive definite fp32 GPU matrix (never modifies
-    ``A``): one call into ``clo_cholesky_inverse_f32`` (recursive blocked Cholesky carrying the
-    triangular inverse; leaves in LDS, every O(n^3) step on the MFMA GEMM).  Raises
-    ``RuntimeError`` if the matrix is not positive definite."""
+def cholesky_inverse_async(A: Tensor, damping: float = 0.0) -> tuple[Tensor, Tensor]:
+    """Enqueue ``(A + damping I)^-1`` on the current stream: returns ``(out, status)`` where
+    ``status`` is a device int32 (0 = ok, else the 1-based non-positive pivot) that the caller
+    inspects once the stream has been joined.  One call into ``clo_cholesky_inverse_f32``
+    (recursive blocked Cholesky carrying the triangular inverse; leaves in LDS, every O(n^3) step on
+    the MFMA GEMM); never modifies ``A``."""
     lib = load()
     n = A.shape[0]
     if A.dim() != 2 or A.shape[1] != n:
@@ -278,18 +279,27 @@ def cholesky_inverse(A: Tensor, damping: float = 0.0) -> Tensor:
     if A.stride(-1) != 1 and n > 1:
         A = A.contiguous()
     out = torch.empty(n, n, device=A.device, dtype=torch.float32)
+    status = torch.zeros(1, device=A.device, dtype=torch.int32)
     if n == 0:
-        return out
+        return out, status
     ws = torch.empty(lib.clo_cholesky_inverse_ws_floats(n), device=A.device, dtype=torch.float32)
-    status = torch.empty(1, device=A.device, dtype=torch.int32)
     rc = lib.clo_cholesky_inverse_f32(_p(A), A.stride(0) if n > 1 else 1, _p(out), n, n, damping, _p(ws),
                                       status.data_ptr(), _stream())
     _check(rc, "clo_cholesky_inverse_f32")
+    return out, status
+
+
+def not_pd_error(pivot: int, n: int) -> RuntimeError:
+    return RuntimeError(f"cholesky: the input is not positive-definite (pivot {pivot} of {n} is not positive).")
+
+
+def cholesky_inverse(A: Tensor, damping: float = 0.0) -> Tensor:
+    """Synchronous form of :func:`cholesky_inverse_async`: raises ``RuntimeError`` if the matrix
+    is not positive definite."""
+    out, status = cholesky_inverse_async(A, damping)
     bad = int(status.item())
     if bad:
-        raise RuntimeError(
-            f"cholesky: the input is not positive-definite (pivot {bad} of {n} is not positive)."
-        )
+        raise not_pd_error(bad, A.shape[0])
     return out
 
 

@@ -15,6 +15,7 @@ from collections.abc import Callable, Iterable, MutableMapping
 from torch import Tensor
 from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss, Module, MSELoss
 
+from curvlinops_amd import linalg_native
 from curvlinops_amd.canonical import FromCanonicalLinearOperator, ParamGroup, ToCanonicalLinearOperator
 from curvlinops_amd.computers import HipEKFACComputer, HipKFACComputer
 from curvlinops_amd.enums import FisherType, KFACType
@@ -103,13 +104,15 @@ class KFACLinearOperator(_ChainPyTorchLinearOperator):
         retry_double_precision: bool = True,
     ) -> _ChainPyTorchLinearOperator:
         P, K, PT = self
-        K_inv = BlockDiagonalLinearOperator([
-            block.inverse(
-                damping=damping, use_heuristic_damping=use_heuristic_damping, min_damping=min_damping,
-                use_exact_damping=use_exact_damping, retry_double_precision=retry_double_precision,
-            )
-            for block in K
-        ])
+        # the factors of all blocks are independent: their Cholesky inverses share a pool of streams
+        with linalg_native.concurrent_inverses():
+            K_inv = BlockDiagonalLinearOperator([
+                block.inverse(
+                    damping=damping, use_heuristic_damping=use_heuristic_damping, min_damping=min_damping,
+                    use_exact_damping=use_exact_damping, retry_double_precision=retry_double_precision,
+                )
+                for block in K
+            ])
         return _ChainPyTorchLinearOperator(P, K_inv, PT)
 
 

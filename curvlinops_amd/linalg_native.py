@@ -14,6 +14,7 @@ the diagonal blocks, the MFMA GEMM of ``csrc/gemm.hip`` for every O(n^3) step; d
 
 from __future__ import annotations
 
+from contextlib import contextmanager
 from warnings import warn
 
 import torch
@@ -28,9 +29,92 @@ def _torch_damped_cholesky_inverse(A: Tensor, damping: float) -> Tensor:
     return torch.cholesky_inverse(torch.linalg.cholesky(damped))
 
 
+class _InverseBatch:
+    """Factor inverses are independent dependency-bound chains of small kernels: run them on a few
+    HIP streams at once and inspect all pivot statuses with ONE device read at the end."""
+
+    MIN_SIDE_N = 512
+
+    def __init__(self, num_streams: int):
+        self._num = num_streams
+        self._streams: list = []
+        self._jobs: list = []  # (A, damping, retry, out, status)
+        self._nside = 0
+
+    def submit(self, A: Tensor, damping: float, retry: bool) -> Tensor:
+        if A.shape[0] < self.MIN_SIDE_N:  # tiny factor: a stream hop costs more than it hides
+            out, status = _hip.cholesky_inverse_async(A, damping)
+            self._jobs.append((A, damping, retry, out, status))
+            return out
+        main = torch.cuda.current_stream(A.device)
+        if not self._streams:
+            self._streams = [torch.cuda.Stream(device=A.device) for _ in range(self._num)]
+        side = self._streams[self._nside % self._num]
+        self._nside += 1
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
+            out, status = _hip.cholesky_inverse_async(A, damping)
+        A.record_stream(side)
+        self._jobs.append((A, damping, retry, out, status))
+        return out
+
+    def finish(self) -> None:
+        if not self._jobs:
+            return
+        main = torch.cuda.current_stream(self._jobs[0][0].device)
+        for side in self._streams:
+            main.wait_stream(side)
+        for *_, out, status in self._jobs:
+            out.record_stream(main)
+            status.record_stream(main)
+        bad = torch.cat([j[4] for j in self._jobs]).cpu().tolist()
+        for (A, damping, retry, out, _), pivot in zip(self._jobs, bad):
+            if not pivot:
+                continue
+            error = _hip.not_pd_error(pivot, A.shape[0])
+            if not retry:
+                raise error
+            _warn_retry(A, error)
+            out.copy_(_torch_damped_cholesky_inverse(A.to(torch.float64), damping))
+
+
+_ACTIVE_BATCH: _InverseBatch | None = None
+
+
+@contextmanager
+def concurrent_inverses(num_streams: int = 4):
+    """Inside the block, fp32 GPU calls of :func:`damped_cholesky_inverse` are enqueued on a pool of
+    streams and return immediately; on exit the streams are joined, failed factorisations are
+    redone in float64 into the SAME output tensor (or raise, as in the synchronous form)."""
+    global _ACTIVE_BATCH
+    if _ACTIVE_BATCH is not None:  # nested: the outermost block owns the batch
+        yield
+        return
+    batch = _ACTIVE_BATCH = _InverseBatch(num_streams)
+    try:
+        yield
+    except BaseException:
+        _ACTIVE_BATCH = None
+        torch.cuda.synchronize()
+        raise
+    else:
+        _ACTIVE_BATCH = None
+        batch.finish()
+
+
+def _warn_retry(A: Tensor, error: Exception) -> None:
+    warn(
+        f"Failed to compute Cholesky decomposition in {A.dtype} precision with error {error}. "
+        "Retrying in double precision...",
+        stacklevel=3,
+    )
+
+
 def damped_cholesky_inverse(A: Tensor, damping: float, retry_double_precision: bool = True) -> Tensor:
     """``(A + damping I)^-1`` for symmetric positive definite ``A`` (never modifies ``A``)."""
     native = is_native_tensor(A) and _hip.has("clo_potrf_diag_f32")
+    if native and _ACTIVE_BATCH is not None:
+        return _ACTIVE_BATCH.submit(A, damping, retry_double_precision)
     try:
         if native:
             return _hip.cholesky_inverse(A, damping)

@@ -374,6 +374,39 @@ def test_cholesky_inverse_not_pd_raises(hip):
     assert torch.isfinite(out).all()
 
 
+def test_concurrent_inverses_match_sequential_and_retry(hip):
+    """Inverses enqueued on the stream pool == the synchronous ones; a factor whose fp32 factorisation
+    fails is redone in float64 into the same output tensor (warning), without retry it raises."""
+    import warnings
+
+    from curvlinops_amd import linalg_native
+
+    g = torch.Generator().manual_seed(3)
+    mats = []
+    for n in (5, 64, 130, 257, 700, 33, 1000):
+        X = torch.rand(n + 7, n, generator=g, dtype=torch.float64)
+        mats.append((X.T @ X / n).float().cuda())
+    seq = [linalg_native.damped_cholesky_inverse(A, 1e-3) for A in mats]
+    with linalg_native.concurrent_inverses():
+        par = [linalg_native.damped_cholesky_inverse(A, 1e-3) for A in mats]
+    for a, b in zip(seq, par):
+        assert torch.equal(a, b)
+    # fp32 fails (the damping vanishes next to 1.0f, the 2x2 block stays singular), float64 succeeds
+    bad = torch.eye(70, dtype=torch.float64)
+    bad[40, 41] = bad[41, 40] = 1.0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with linalg_native.concurrent_inverses():
+            outs = [linalg_native.damped_cholesky_inverse(m, 1e-10) for m in (mats[1], bad.float().cuda(), mats[2])]
+    ref = torch.linalg.inv(bad + 1e-10 * torch.eye(70, dtype=torch.float64))
+    assert any("double precision" in str(x.message) for x in w)
+    assert rel_err(outs[1].cpu(), ref) < 1e-3
+    assert rel_err(outs[0].cpu(), torch.linalg.inv(mats[1].double().cpu() + 1e-10 * torch.eye(64, dtype=torch.float64))) < 5e-2
+    with pytest.raises(RuntimeError):
+        with linalg_native.concurrent_inverses():
+            linalg_native.damped_cholesky_inverse(bad.float().cuda(), 1e-10, retry_double_precision=False)
+
+
 @pytest.mark.parametrize("geom", [
     dict(B=3, C=2, H=8, W=8, k=(3, 3), s=(1, 1), p=(1, 1), d=(1, 1)),
     dict(B=2, C=3, H=9, W=7, k=(3, 2), s=(2, 1), p=(0, 1), d=(1, 2)),
