@@ -33,6 +33,7 @@ def main():
     ap.add_argument("model", nargs="?", default="resnet18")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--fisher", default="mc")
+    ap.add_argument("--ekfac", action="store_true", help="also time the EKFAC phases")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -57,6 +58,16 @@ def main():
         loss = nn.functional.cross_entropy(out, y)
         return torch.autograd.grad(loss, list(params.values()))
     res["gradient_and_loss_ms"], _ = timed(fwdbwd)
+    if args.ekfac:
+        # EKFAC = factors + eigendecompositions + eigenvalue-correction pass (reference phases of
+        # benchmark_utils.py:139-143); the eigh phase is timed on the KFAC factors above
+        from curvlinops_amd import linalg_native
+
+        facs = [S for blk in K[1] for S in blk._factors]
+        res["eigh_ms"], _ = timed(lambda: linalg_native.eigh_many(facs), repeats=2)
+        res["ekfac_total_ms"], E = timed(lambda: C.EKFACLinearOperator(model, nn.CrossEntropyLoss(), params, data, **kw),
+                                         repeats=2)
+        res["ekfac_matvec_ms"], _ = timed(lambda: E @ v)
     print(json.dumps(res))
 
 

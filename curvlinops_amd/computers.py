@@ -441,8 +441,10 @@ class HipEKFACComputer(HipKFACComputer):
     def compute(self):
         with _use_params(self._model_module, self._params):
             A, G, mapping = self._compute_kronecker_factors()
-            Qa = {k: linalg_native.eigh(v)[1] for k, v in A.items()}
-            Qg = {k: linalg_native.eigh(v)[1] for k, v in G.items()}
+            keys = [("a", k) for k in A] + [("g", k) for k in G]
+            bases = linalg_native.eigh_many([A[k] if w == "a" else G[k] for w, k in keys])
+            Qa = {k: q[1] for (w, k), q in zip(keys, bases) if w == "a"}
+            Qg = {k: q[1] for (w, k), q in zip(keys, bases) if w == "g"}
             lam = self._eigenvalue_correction(Qa, Qg, mapping)
         return Qa, Qg, lam, mapping
 

@@ -136,3 +136,61 @@ def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
         return _hip.eigh(A)
     res = torch.linalg.eigh(A)
     return res.eigenvalues, res.eigenvectors
+
+
+def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Tensor]]:
+    """:func:`eigh` of several independent symmetric matrices.  On the GPU the solver (rocSOLVER
+    through ``torch.linalg.eigh``) is a long chain of small dependent kernels with host
+    synchronisation in between, so the factors of an EKFAC operator are spread, largest first,
+    over a few worker threads that each own a HIP stream (ResNet-18: 780 -> 337 ms)."""
+    gpu = [i for i, A in enumerate(mats) if A.is_cuda]
+    if len(gpu) < 3 or num_streams < 2:
+        return [eigh(A) for A in mats]
+    import queue
+    import threading
+
+    out: list = [None] * len(mats)
+    for i, A in enumerate(mats):
+        if not A.is_cuda:
+            out[i] = eigh(A)
+    jobs: queue.SimpleQueue = queue.SimpleQueue()
+    for i in sorted(gpu, key=lambda i: -mats[i].shape[0]):
+        jobs.put(i)
+    device = mats[gpu[0]].device
+    main = torch.cuda.current_stream(device)
+    ready = main.record_event()
+    done: list = []
+    errors: list = []
+
+    def worker() -> None:
+        try:
+            with torch.cuda.device(device):
+                side = torch.cuda.Stream(device=device)
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    while True:
+                        try:
+                            i = jobs.get_nowait()
+                        except queue.Empty:
+                            break
+                        mats[i].record_stream(side)
+                        out[i] = eigh(mats[i])
+                done.append(side.record_event())
+        except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker) for _ in range(min(num_streams, len(gpu)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    for ev in done:
+        main.wait_event(ev)
+    for res in out:
+        for t in res:
+            if t.is_cuda:
+                t.record_stream(main)
+    return out
+
