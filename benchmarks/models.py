@@ -64,3 +64,35 @@ def kfac_params(model: nn.Module) -> dict[str, torch.Tensor]:
             for p_name, p in mod.named_parameters(recurse=False):
                 keep[f"{mod_name}.{p_name}" if mod_name else p_name] = p
     return keep
+
+
+class EncoderBlock(nn.Module):
+    """Pre-LN transformer block with explicit (math) attention, so that forward- and reverse-mode
+    `torch.func` transforms apply."""
+
+    def __init__(self, d: int, heads: int, ffn: int):
+        super().__init__()
+        self.h = heads
+        self.ln1, self.ln2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.qkv, self.proj = nn.Linear(d, 3 * d), nn.Linear(d, d)
+        self.fc1, self.fc2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
+
+    def forward(self, x):
+        B, S, d = x.shape
+        q, k, v = self.qkv(self.ln1(x)).view(B, S, 3, self.h, d // self.h).permute(2, 0, 3, 1, 4)
+        att = torch.softmax(q @ k.transpose(-1, -2) / (d // self.h) ** 0.5, dim=-1)
+        x = x + self.proj((att @ v).transpose(1, 2).reshape(B, S, d))
+        return x + self.fc2(torch.nn.functional.gelu(self.fc1(self.ln2(x))))
+
+
+class Encoder(nn.Module):
+    """BASELINE config C5: 12 pre-LN blocks, d = 768, 12 heads, ffn 3072, mean-pool + Linear(768, 10)."""
+
+    def __init__(self, d: int = 768, layers: int = 12, heads: int = 12, ffn: int = 3072, classes: int = 10):
+        super().__init__()
+        self.blocks = nn.Sequential(*[EncoderBlock(d, heads, ffn) for _ in range(layers)])
+        self.ln = nn.LayerNorm(d)
+        self.head = nn.Linear(d, classes)
+
+    def forward(self, x):
+        return self.head(self.ln(self.blocks(x)).mean(dim=1))

@@ -83,6 +83,8 @@ _SIGNATURES = {
     ),
     "clo_mlp_ggn_matmat_ws_floats": (c_long, [c_int, POINTER(c_int), c_int, c_int]),
     "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
+    "clo_dot_ws_bytes": (c_long, []),
+    "clo_dot_f32": (c_int, [_PF, _PF, c_long, c_float, _PF, c_void_p, c_void_p]),
     "clo_transpose_f32": (c_int, [_PF, _PF, c_long, c_long, c_void_p]),
     "clo_rowscale_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_int, c_float, c_void_p]),
     "clo_pack_probes_f32": (c_int, [_PF, c_long, c_long, c_uint64, c_int, c_void_p]),
@@ -458,6 +460,17 @@ def axpby(y: Tensor, x: Tensor, alpha: float, beta: float) -> Tensor:
         raise ValueError("axpby shape mismatch")
     _check(load().clo_axpby_f32(_pc(y), _pc(x), y.numel(), alpha, beta, _stream()), "clo_axpby_f32")
     return y
+
+
+def dot(x: Tensor, y: Tensor, scale: float = 1.0) -> Tensor:
+    """``scale * <x, y>`` of two equally shaped contiguous fp32 GPU tensors as a 0-d tensor."""
+    if x.shape != y.shape:
+        raise ValueError("dot shape mismatch")
+    lib = load()
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.clo_dot_ws_bytes(), device=x.device, dtype=torch.uint8)
+    _check(lib.clo_dot_f32(_pc(x), _pc(y), x.numel(), scale, _pc(out), ws.data_ptr(), _stream()), "clo_dot_f32")
+    return out[0]
 
 
 def transpose(x: Tensor) -> Tensor:

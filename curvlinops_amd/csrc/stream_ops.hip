@@ -152,6 +152,42 @@ __global__ void pack_probes_kernel(float *__restrict__ out, long n, uint64_t see
   }
 }
 
+// <x, y> over n elements: per-block partial sums (float4 loads, fixed grid-stride order), then one
+// block adds the partials in double -- deterministic for a given n, any n (64-bit indices).
+constexpr int DOT_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float *__restrict__ x,
+                                                          const float *__restrict__ y, long n,
+                                                          double *__restrict__ part) {
+  __shared__ double s_w[4];
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0;
+  const long n4 = vec ? n / 4 : 0;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 u = reinterpret_cast<const float4 *>(x)[i], v = reinterpret_cast<const float4 *>(y)[i];
+    a0 = fmaf(u.x, v.x, a0); a1 = fmaf(u.y, v.y, a1); a2 = fmaf(u.z, v.z, a2); a3 = fmaf(u.w, v.w, a3);
+  }
+  double acc = ((double)a0 + a1) + ((double)a2 + a3);
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    acc += (double)x[i] * y[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+__global__ __launch_bounds__(256) void dot_final_kernel(const double *__restrict__ part, int nblocks,
+                                                        float *__restrict__ out, float scale) {
+  __shared__ double s_w[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(scale * ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])));
+}
+
 }  // namespace clo
 
 using namespace clo;
@@ -229,5 +265,21 @@ extern "C" int clo_pack_probes_f32(float *out, long D, long K, uint64_t seed, in
   hipLaunchKernelGGL(pack_probes_kernel, dim3(stream_grid(cdiv(n, 4), 256)), dim3(256), 0,
                      (hipStream_t)stream, out, n, seed, dist);
   CLO_CHECK_LAUNCH("pack_probes_kernel");
+  return CLO_OK;
+}
+
+extern "C" long clo_dot_ws_bytes(void) { return (long)DOT_BLOCKS * sizeof(double); }
+
+// out[0] = scale * <x, y> (n elements, any n >= 0); ws: clo_dot_ws_bytes() bytes.
+extern "C" int clo_dot_f32(const float *x, const float *y, long n, float scale, float *out, void *ws,
+                           void *stream) {
+  CLO_REQUIRE(n >= 0, "clo_dot_f32: negative n");
+  CLO_REQUIRE(out && ws && (n == 0 || (x && y)), "clo_dot_f32: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)std::max<long>(1, std::min<long>(DOT_BLOCKS, cdiv(n, 1024)));
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(blocks), dim3(256), 0, st, x, y, n, (double *)ws);
+  CLO_CHECK_LAUNCH("dot_partial_kernel");
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, (const double *)ws, blocks, out, scale);
+  CLO_CHECK_LAUNCH("dot_final_kernel");
   return CLO_OK;
 }

@@ -14,7 +14,72 @@ from torch import Tensor
 
 from curvlinops_amd import _hip
 from curvlinops_amd.linop import PyTorchLinearOperator
-from curvlinops_amd.utils import assert_divisible_by, assert_is_square, assert_matvecs_subseed_dim
+from curvlinops_amd.utils import assert_divisible_by, assert_is_square, assert_matvecs_subseed_dim, is_native_tensor
+
+_QR_MAX_ELEMS = 2**30  # rocSOLVER / BLAS index with 32-bit ints: keep every library call below 2^31
+
+
+def frobenius_inner(X: Tensor, Y: Tensor) -> Tensor:
+    """``sum_ij X_ij Y_ij`` (the reference's ``einsum("ij,ij", X, Y)``).  fp32 GPU blocks use the
+    64-bit-indexed streaming kernel ``clo_dot_f32`` (one pass over both operands, no temporary);
+    ``[D, K]`` blocks with ``D K >= 2^31`` (C5) are beyond what the BLAS-backed einsum accepts."""
+    if is_native_tensor(X) and is_native_tensor(Y) and X.is_contiguous() and Y.is_contiguous():
+        return _hip.dot(X, Y)
+    return torch.einsum("ij,ij", X, Y)
+
+
+_GRAM_MIN_ELEMS = 2**22  # above this, fp32 GPU blocks use the GEMM-rich Gram route
+
+
+def _gram_orthonormal_basis(X: Tensor, rel_tol: float = 1e-5) -> Tensor:
+    """Orthonormal basis of range(X) for a very tall fp32 GPU block from two Gram passes
+    (``Q = X V diag(lambda)^-1/2`` with ``X^T X = V diag(lambda) V^T`` solved in float64, then once
+    more on ``Q`` to push the loss of orthogonality from sqrt(eps) to eps).  Everything O(m) is a
+    SYRK / GEMM on the matrix pipe (Householder QR of an [85M, 32] block takes seconds in the
+    vendor solver, this takes tens of milliseconds).  Directions whose singular value is below
+    ``sqrt(rel_tol)`` of the largest are numerically indistinguishable from zero in a float32 Gram
+    matrix and are dropped, so the result has ``r <= n`` columns -- Hutch++ is exact for ANY
+    orthonormal ``Q`` (trace on range(Q) + Hutchinson on the complement), a smaller basis only
+    moves work to the stochastic part."""
+    Q = X if X.is_contiguous() else X.contiguous()
+    for it in range(2):
+        n = Q.shape[1]
+        gram = torch.empty(n, n, device=Q.device, dtype=torch.float32)
+        _hip.syrk_accum(gram, Q, alpha=1.0, beta=0.0)
+        lam, V = torch.linalg.eigh(gram.double())
+        keep = lam > lam.max() * (rel_tol if it == 0 else 1e-12)
+        if not bool(keep.any()):
+            return torch.zeros(Q.shape[0], 1, device=Q.device, dtype=Q.dtype)
+        T = (V[:, keep] / lam[keep].sqrt()).float().contiguous()
+        Q = _hip.gemm(Q, T)
+    return Q
+
+
+def orthonormal_basis(X: Tensor) -> Tensor:
+    """``Q`` of the reduced QR factorisation of a tall ``[m, n]`` matrix (``meyer2020hutch.py:93``).
+    Above ``2^30`` elements the factorisation is done as TSQR -- Householder QR of row chunks, QR of
+    the stacked triangular factors, one small GEMM per chunk -- which is as stable as the direct
+    call, works for rank-deficient inputs, and keeps every library call within 32-bit indexing."""
+    m, n = X.shape
+    if is_native_tensor(X) and m * n >= _GRAM_MIN_ELEMS and m >= 64 * n:
+        return _gram_orthonormal_basis(X)
+    if m * n <= _QR_MAX_ELEMS or m <= 2 * n:
+        return torch.linalg.qr(X)[0]
+    rows = max(2 * n, _QR_MAX_ELEMS // n)
+    bounds = list(range(0, m, rows)) + [m]
+    if len(bounds) > 2 and bounds[-1] - bounds[-2] < n:  # last chunk too short for a reduced QR
+        bounds.pop(-2)
+    Qs, Rs = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        q, r = torch.linalg.qr(X[lo:hi])
+        Qs.append(q)
+        Rs.append(r)
+    Q2 = torch.linalg.qr(torch.cat(Rs, dim=0))[0]
+    out = torch.empty_like(X)
+    for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        torch.matmul(Qs[i], Q2[i * n : (i + 1) * n], out=out[lo:hi])
+        Qs[i] = None
+    return out
 
 
 def rademacher(dim: int, device, dtype) -> Tensor:
@@ -50,7 +115,7 @@ def hutchinson_trace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distri
     dim = assert_is_square(A)
     assert_matvecs_subseed_dim(A, num_matvecs)
     G = random_matrix(dim, num_matvecs, distribution, A.device, A.dtype) if probes is None else probes
-    return torch.einsum("ij,ij", G, A @ G) / num_matvecs
+    return frobenius_inner(G, A @ G) / num_matvecs
 
 
 def hutchpp_trace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribution: str = "rademacher",
@@ -63,9 +128,9 @@ def hutchpp_trace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribut
     N = num_matvecs // 3
     dev, dt = A.device, A.dtype
     S = random_matrix(dim, N, distribution, dev, dt) if probes is None else probes[0]
-    Q, _ = torch.linalg.qr(A @ S)
-    tr_range = torch.einsum("ji,ji", Q, A @ Q)
+    Q = orthonormal_basis(A @ S)
+    tr_range = frobenius_inner(Q, A @ Q)
     G = random_matrix(dim, N, distribution, dev, dt) if probes is None else probes[1]
     AG = A @ (G - Q @ (Q.T @ G))
     AG = AG - Q @ (Q.T @ AG)
-    return tr_range + torch.einsum("ij,ij", G, AG) / N
+    return tr_range + frobenius_inner(G, AG) / N

@@ -205,6 +205,13 @@ int clo_rowscale_f32(float *y, const float *x, const float *s, long rows, long K
  * from a counter-based Philox4x32-10 stream keyed by (seed, element index). */
 int clo_pack_probes_f32(float *out, long D, long K, uint64_t seed, int dist, void *stream);
 
+/* out[0] = scale * <x, y> over n fp32 elements (Frobenius inner product of two packed [D, K] blocks:
+ * the reductions of trace/hutchinson.py:75 and trace/meyer2020hutch.py:95-102).  64-bit indexing
+ * (D * K >= 2^31 is the C5 regime where BLAS-backed reductions refuse), double accumulation of the
+ * block partials, deterministic.  ws: clo_dot_ws_bytes() bytes of device memory. */
+long clo_dot_ws_bytes(void);
+int clo_dot_f32(const float *x, const float *y, long n, float scale, float *out, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,18 @@ def test_axpby_transpose_rowscale(hip):
     assert torch.allclose(hip.rowscale(x.cuda(), s.cuda(), True, 0.5).cpu(), x / (s[:, None] + 0.5), atol=1e-6)
 
 
+@pytest.mark.parametrize("n", [0, 1, 3, 1000, 4097, 1 << 20, (1 << 22) + 5])
+def test_dot_kernel(hip, n):
+    g = torch.Generator().manual_seed(n)
+    x, y = torch.rand(n + 1, generator=g) - 0.5, torch.rand(n + 1, generator=g) - 0.5
+    ref = float(x[:n].double() @ y[:n].double())
+    got = float(hip.dot(x[:n].cuda(), y[:n].cuda(), scale=0.5))
+    assert abs(got - 0.5 * ref) <= 1e-5 * max(1.0, abs(ref))
+    if n:  # unaligned views take the scalar path
+        xu, yu = x.cuda()[1:], y.cuda()[1:]
+        assert abs(float(hip.dot(xu, yu)) - float(x[1:].double() @ y[1:].double())) <= 1e-5 * max(1.0, abs(ref))
+
+
 def test_pack_probes(hip):
     P = hip.pack_probes(100001, 3, 1234, "rademacher", "cuda")
     assert P.shape == (100001, 3)

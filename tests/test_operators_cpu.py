@@ -288,3 +288,34 @@ def test_trace_estimators_with_injected_probes():
         C.hutchinson_trace(op, 30)
     with pytest.raises(ValueError):
         C.hutchinson_trace(op, 5, "cauchy")
+
+
+def test_tsqr_orthonormal_basis_matches_direct_qr(monkeypatch):
+    """Chunked TSQR (used above 2^30 elements) spans the same space as the direct QR, has orthonormal
+    columns also for rank-deficient input, and leaves the Hutch++ estimate unchanged."""
+    import curvlinops_amd.trace as T
+
+    g = torch.Generator().manual_seed(0)
+    X = torch.rand(1000, 6, generator=g, dtype=torch.float64)
+    Qd = torch.linalg.qr(X)[0]
+    monkeypatch.setattr(T, "_QR_MAX_ELEMS", 600)  # chunks of 100 rows, last one merged if short
+    Q = T.orthonormal_basis(X)
+    assert Q.shape == X.shape
+    assert torch.allclose(Q.T @ Q, torch.eye(6, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(Q @ (Q.T @ X), X, atol=1e-10)                 # span(Q) contains span(X)
+    assert torch.allclose(Q @ Q.T, Qd @ Qd.T, atol=1e-10)               # same projector as the direct QR
+    Xr = X[:, :2] @ torch.rand(2, 6, generator=g, dtype=torch.float64)  # rank 2
+    Qr = T.orthonormal_basis(Xr)
+    assert torch.allclose(Qr.T @ Qr, torch.eye(6, dtype=torch.float64), atol=1e-10)
+    assert torch.allclose(Qr @ (Qr.T @ Xr), Xr, atol=1e-10)
+    # ragged tail: 1003 rows -> last chunk of 3 rows (< n) is merged into its predecessor
+    Xt = torch.rand(1003, 6, generator=g, dtype=torch.float64)
+    Qt = T.orthonormal_basis(Xt)
+    assert torch.allclose(Qt @ (Qt.T @ Xt), Xt, atol=1e-10)
+    A = torch.rand(1000, 1000, generator=g, dtype=torch.float64)
+    A = A @ A.T
+    S, G = torch.rand(1000, 6, generator=g, dtype=torch.float64), torch.rand(1000, 6, generator=g, dtype=torch.float64)
+    chunked = T.hutchpp_trace(A, 18, probes=(S, G))
+    monkeypatch.setattr(T, "_QR_MAX_ELEMS", 2**30)
+    assert torch.allclose(chunked, T.hutchpp_trace(A, 18, probes=(S, G)), rtol=1e-10)
+

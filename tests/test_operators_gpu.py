@@ -334,3 +334,31 @@ def test_repeated_products_stress(dev):
         err = ((got - ref).abs().max() / ref.abs().max()).item()
         worst = max(worst, err)
     assert worst < 5e-4, worst
+
+
+def test_gram_orthonormal_basis_gpu(dev):
+    """The Gram route used for very tall fp32 blocks: orthonormal to fp32 accuracy, spans range(X)
+    (full-rank and rank-deficient), and Hutch++ built on it agrees with the float64 reference."""
+    import curvlinops_amd.trace as T
+
+    g = torch.Generator().manual_seed(0)
+    X = (torch.rand(300_000, 16, generator=g, dtype=torch.float64) - 0.5) * torch.logspace(0, -2, 16, dtype=torch.float64)
+    Xd = X.float().to(dev)
+    Q = T.orthonormal_basis(Xd)
+    assert Q.shape == (300_000, 16)
+    assert (Q.T.double() @ Q.double() - torch.eye(16, device=dev, dtype=torch.float64)).abs().max() < 1e-5
+    resid = Xd.double() - Q.double() @ (Q.T.double() @ Xd.double())
+    assert resid.abs().max() / Xd.abs().max() < 1e-4
+    Xr = (X[:, :3] @ torch.rand(3, 16, generator=g, dtype=torch.float64)).float().to(dev)  # rank 3
+    Qr = T.orthonormal_basis(Xr)
+    assert Qr.shape[1] == 3
+    assert (Xr.double() - Qr.double() @ (Qr.T.double() @ Xr.double())).abs().max() / Xr.abs().max() < 1e-4
+    # Hutch++ on a dense PSD matrix: same estimate as float64 torch with the same probes
+    n = 300_000 // 64
+    B = torch.rand(n, 40, generator=g, dtype=torch.float64)
+    A = B @ B.T
+    S, G = torch.rand(n, 8, generator=g, dtype=torch.float64) - 0.5, torch.rand(n, 8, generator=g, dtype=torch.float64) - 0.5
+    ref = T.hutchpp_trace(A, 24, probes=(S, G))
+    got = T.hutchpp_trace(A.float().to(dev), 24, probes=(S.float().to(dev), G.float().to(dev)))
+    assert abs(float(got) - float(ref)) / abs(float(ref)) < 1e-3
+

@@ -25,3 +25,8 @@ python benchmarks/bench_kfac.py resnet18 > $OUT/r01_kfac_resnet18_b512.json 2>/d
 python benchmarks/bench_kfac.py lenet > $OUT/r01_kfac_lenet_b1024.json 2>/dev/null
 python tools/probe_gemm.py > $OUT/r01_gemm_f32_shapes.txt 2>&1
 ls -la $OUT
+cd $R
+python benchmarks/bench_kfac.py resnet18 --ekfac > $OUT/r01_kfac_resnet18_b512.json 2>/dev/null
+python benchmarks/bench_general.py resnet18 > $OUT/r01_general_resnet18_b512.json 2>/dev/null
+python benchmarks/bench_general.py encoder > $OUT/r01_general_encoder_c5.json 2>/dev/null
+python tools/probe_cols.py 8 32 64 > $OUT/r01_c2_columns.txt 2>&1
