@@ -409,9 +409,9 @@ class MLPPlan:
     # ---- K columns at once -------------------------------------------------------------------
     MATMAT_MAX_K = 64
 
-    def matmat_supported(self, K: int, ldk: int) -> bool:
+    def matmat_supported(self, K: int, ldk: int, aux_rank: int = 1) -> bool:
         """Shape conditions of ``clo_mlp_ggn_matmat`` (pointer alignment is checked by the library)."""
-        return (K % 4 == 0 and 4 <= K <= self.MATMAT_MAX_K and ldk % 4 == 0
+        return (K % 4 == 0 and 4 <= K <= self.MATMAT_MAX_K and ldk % 4 == 0 and aux_rank <= 16
                 and all(d % 4 == 0 for d in self._dims_list[:-1]))
 
     def matmat_workspace(self, K: int, device) -> Tensor:

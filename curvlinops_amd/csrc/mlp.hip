@@ -1467,8 +1467,8 @@ __global__ __launch_bounds__(256) void kouter_stream_kernel(
 }
 
 // delta_L[c][n][k] = phi'_L[n][c] * scale * (H(f_n) u[:, n, k])[c]  in place on u = dA_L.
-// One thread per (n, k); C is small on this path (<= 64).
-constexpr int LC_CMAX = 64;
+// One thread per (n, k).
+constexpr int LC_RMAX = 16;  // rank-M curvature: at most 16 backpropagated vectors per sample
 __global__ void loss_cols_kernel(int kind, const float *__restrict__ f,
                                  const float *__restrict__ aux, int aux_rank,
                                  const float *__restrict__ dphi_last, float *__restrict__ u, int N,
@@ -1533,17 +1533,25 @@ __global__ void loss_cols_kernel(int kind, const float *__restrict__ f,
       const float pc = __expf(fn[c] - mx) * inv;
       un[c * cs] = scale * pc * (un[c * cs] - pu) * (dp ? dp[c] : 1.f);
     }
-  } else {  // rank-M: H_n = sum_m g_nm g_nm^T
-    float w[LC_CMAX];
-#pragma unroll 1
-    for (int c = 0; c < C; ++c) w[c] = 0.f;
-    for (int m = 0; m < aux_rank; ++m) {
-      const float *g = aux + ((long)n * aux_rank + m) * C;
-      float sdot = 0.f;
-      for (int c = 0; c < C; ++c) sdot += g[c] * un[c * cs];
-      for (int c = 0; c < C; ++c) w[c] += scale * g[c] * sdot;
+  } else {  // rank-M: H_n = sum_m g_nm g_nm^T, M <= LC_RMAX: all <g_m, u> first, then overwrite u
+    float sd[LC_RMAX];
+#pragma unroll
+    for (int m = 0; m < LC_RMAX; ++m) {
+      sd[m] = 0.f;
+      if (m < aux_rank) {
+        const float *g = aux + ((long)n * aux_rank + m) * C;
+        float sdot = 0.f;
+        for (int c = 0; c < C; ++c) sdot += g[c] * un[c * cs];
+        sd[m] = scale * sdot;
+      }
     }
-    for (int c = 0; c < C; ++c) un[c * cs] = w[c] * (dp ? dp[c] : 1.f);
+    for (int c = 0; c < C; ++c) {
+      float w = 0.f;
+#pragma unroll
+      for (int m = 0; m < LC_RMAX; ++m)
+        if (m < aux_rank) w += aux[((long)n * aux_rank + m) * C + c] * sd[m];
+      un[c * cs] = w * (dp ? dp[c] : 1.f);
+    }
   }
 }
 
@@ -2193,7 +2201,7 @@ extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const
     if (Vb && Vb[l]) ok = ok && aligned16(Vb[l]);
     if (Ob && Ob[l]) ok = ok && aligned16(Ob[l]);
   }
-  if (loss_kind == CLO_LOSS_RANK1 && dims[L] > LC_CMAX) ok = false;
+  if (loss_kind == CLO_LOSS_RANK1 && aux_rank > LC_RMAX) ok = false;
   if (!ok) {
     set_error("clo_mlp_ggn_matmat: needs K %% 4 == 0, 4 <= K <= 64, ldk %% 4 == 0, layer inputs %% 4 == 0 "
               "and 16-byte aligned operands");

@@ -180,8 +180,8 @@ long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
  * VW[l] / OW[l] point at element (0, 0, 0) of a [d_out][d_in][K] block whose rows (one per weight)
  * are ldk floats apart -- the rows of the reference's [D, K] matrix; Vb[l] / Ob[l] likewise
  * [d_out][K].  The tangent weights are streamed once in that layout, W is shared by all columns.
- * Returns CLO_EUNSUP unless K % 4 == 0, 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0 and all
- * operands are 16-byte aligned (the caller then loops clo_mlp_ggn_matvec over columns).
+ * Returns CLO_EUNSUP unless K % 4 == 0, 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0, aux_rank
+ * <= 16 and all operands are 16-byte aligned (the caller then loops clo_mlp_ggn_matvec over columns).
  * ws: clo_mlp_ggn_matmat_ws_floats(L, dims, N, K) floats. */
 long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int K);
 int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *const *W,

@@ -362,3 +362,16 @@ def test_gram_orthonormal_basis_gpu(dev):
     got = T.hutchpp_trace(A.float().to(dev), 24, probes=(S.float().to(dev), G.float().to(dev)))
     assert abs(float(got) - float(ref)) / abs(float(ref)) < 1e-3
 
+
+
+def test_randomised_native_vs_autograd(dev):
+    """40 random MLPs (1-4 layers, aligned and odd widths, all activations / losses / reductions,
+    1-3 mini-batches of 1..70 rows, vectors and K-column blocks): native kernels == torch.func path."""
+    import os, sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_native
+
+    worst, failures = fuzz_native.run(seed=11, ncase=40)
+    assert not failures, failures
+    assert worst < 1e-4
