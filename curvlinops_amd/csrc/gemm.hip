@@ -562,7 +562,7 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   dim3 grid(a.tiles_m * a.tiles_n, batch * a.splitk);
   const bool a_kc = a.mode_a == MODE_KC_VEC, b_kc = a.mode_b == MODE_KC_VEC;
   const bool v2 = gemm_v2_eligible(a, batch);
-  static const int bk2 = getenv("CLO_GEMM_BK") ? atoi(getenv("CLO_GEMM_BK")) : 32;
+  constexpr int bk2 = 32;
   if (a.A2 && !(v2 && a.K1 % bk2 == 0 && a.K1 > 0 && a.K1 < a.K)) {
     set_error("clo_gemm: a second K segment needs the aligned engine and K1 %% %d == 0", bk2);
     return CLO_EUNSUP;
@@ -592,11 +592,9 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   else if (a_kc) CLO_V2(true, false, BKV, NWV)           \
   else if (b_kc) CLO_V2(false, true, BKV, NWV)           \
   else CLO_V2(false, false, BKV, NWV)
-    static const int nw_env = getenv("CLO_GEMM_NW") ? atoi(getenv("CLO_GEMM_NW")) : 0;
+    // 8 waves (two per SIMD inside one block) when the grid cannot put two blocks on every CU
     const long nblocks = (long)grid.x * grid.y;
-    const int nw = nw_env ? nw_env : (nblocks < 2L * kNumCU ? 8 : 4);
-    if (bk2 == 32) { if (nw == 8) { CLO_V2L(32, 8) } else { CLO_V2L(32, 4) } }
-    else { if (nw == 8) { CLO_V2L(16, 8) } else { CLO_V2L(16, 4) } }
+    if (nblocks < 2L * kNumCU) { CLO_V2L(32, 8) } else { CLO_V2L(32, 4) }
 #undef CLO_V2L
 #undef CLO_V2
     CLO_CHECK_LAUNCH("gemm_v2_kernel");

@@ -1617,27 +1617,12 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
     // ---- first layer: in-block split-K, no slabs, no finish launch
     if (ksplit_out) *ksplit_out = 1;
     const int kpw = (int)cdiv(cdiv(d_in, MF1_WAVES), 16) * 16;
+    // features per block: fill the CUs evenly (11 for d_out = 2688), at most one RG x 8 tile group
+    const int fpb = (int)std::min<long>(MF1_RG * 8, std::max<long>(4, cdiv(d_out, kNumCU)));
     ProfScope prof(0, 4.0 * d_in * d_out * 2, st);
-    static const int variant = getenv("CLO_MF1") ? atoi(getenv("CLO_MF1")) : 0;
-#define CLO_MF1(WV, RGG, UU)                                                                     \
-  {                                                                                              \
-    const int kpw_ = (int)cdiv(cdiv(d_in, WV), 16) * 16;                                         \
-    const int fpb_ = fenv > 0 ? std::min(fenv, RGG * 8)                                          \
-                              : (int)std::min<long>(RGG * 8, std::max<long>(4, cdiv(d_out, kNumCU))); \
-    hipLaunchKernelGGL((fwd_mfma_first_kernel<WV, RGG, UU>), dim3((unsigned)cdiv(d_out, fpb_)),   \
-                       dim3(WV * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in, \
-                       d_out, act, kpw_, fpb_);                                                  \
-  }
-    static const int fenv = getenv("CLO_MF1_F") ? atoi(getenv("CLO_MF1_F")) : 0;
-    (void)kpw;
-    if (variant == 1) CLO_MF1(8, 2, 8)
-    else if (variant == 2) CLO_MF1(4, 2, 4)
-    else if (variant == 3) CLO_MF1(4, 2, 8)
-    else if (variant == 4) CLO_MF1(8, 1, 8)
-    else if (variant == 5) CLO_MF1(4, 1, 8)
-    else if (variant == 6) CLO_MF1(16, 2, 4)
-    else CLO_MF1(8, 2, 4)
-#undef CLO_MF1
+    hipLaunchKernelGGL((fwd_mfma_first_kernel<MF1_WAVES, MF1_RG, MF1_U>), dim3((unsigned)cdiv(d_out, fpb)),
+                       dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in,
+                       d_out, act, kpw, fpb);
     CLO_CHECK_LAUNCH("fwd_mfma_first_kernel");
     return CLO_OK;
   }
