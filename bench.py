@@ -123,14 +123,14 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
 
     import curvlinops_amd as C
     from curvlinops_amd import _hip

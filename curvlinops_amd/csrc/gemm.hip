@@ -294,12 +294,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 // ([BK][128 + 4]) and fetch that same k with ds_read_b32.  Loads are unconditional (clamped
 // addresses, results zeroed by select) so hipcc keeps them in flight across the MFMA block.
 // ------------------------------------------------------------------------------------------
-template <bool KC, int BKT, int NTHR = 256>
+template <bool KC, int BKT, int NTHR, int T>
 struct TileIO {
-  static constexpr int T = 128;
   static constexpr int LD = KC ? BKT + 4 : T + 4;
   static constexpr int FLOATS = KC ? T * LD : BKT * LD;
-  static constexpr int NF4 = T * BKT / 4 / NTHR;  // float4 per thread
+  static constexpr int F4 = T * BKT / 4;                    // float4 per tile
+  static constexpr int NF4 = (F4 + NTHR - 1) / NTHR;        // float4 per thread
+  // a tile with fewer float4 than threads: the surplus threads repeat the work of thread f % F4
+  // (same load, same LDS store) instead of branching around the loads
   const float *base[NF4];
   int koff[NF4];  // k offset of the float4 inside the tile
   int soff[NF4];  // LDS offset (floats)
@@ -312,7 +314,7 @@ struct TileIO {
     one_bits = 0u;
 #pragma unroll
     for (int q = 0; q < NF4; ++q) {
-      const int f = tid + NTHR * q;
+      const int f = (tid + NTHR * q) % F4;
       if (KC) {
         const int o = f / (BKT / 4), kq = (f % (BKT / 4)) * 4;
         base[q] = P + (long)min(o0 + o, O - 1) * so;
@@ -358,14 +360,19 @@ struct TileIO {
   }
 };
 
-// NW = 4: 2x2 waves of 64x64;  NW = 8: 2x4 waves of 64x32 (two waves per SIMD inside ONE block,
-// for grids that cannot put two blocks on every CU)
-template <bool AKC, bool BKC, int BKT, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
-  using TA = TileIO<AKC, BKT, NW * 64>;
-  using TB = TileIO<BKC, BKT, NW * 64>;
-  constexpr int NT = NW == 4 ? 2 : 1;   // 32-column MFMA tiles per wave
-  constexpr int WNC = 32 * NT;          // columns per wave
+// Block tile BMt x BNt, WVM x WVN waves, each wave (BMt / WVM) x (BNt / WVN) in 32x32 MFMA tiles:
+//   128 x 128, 2 x 2 waves of 64x64 : large grids
+//   128 x 128, 2 x 4 waves of 64x32 : two waves per SIMD inside ONE block, for grids that cannot put
+//                                     two blocks on every CU
+//    64 x 256, 1 x 8 waves of 64x32 ; 32 x 256, 1 x 8 waves of 32x32 : few rows (M <= 64 / 32): no
+//                                     MFMA work on padding rows, the B operand streams once
+template <bool AKC, bool BKC, int BKT, int BMt, int BNt, int WVM, int WVN>
+__global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
+  constexpr int NW = WVM * WVN;
+  constexpr int WM = BMt / WVM, WNC = BNt / WVN;  // rows / columns per wave
+  constexpr int MT = WM / 32, NT = WNC / 32;      // MFMA tiles per wave
+  using TA = TileIO<AKC, BKT, NW * 64, BMt>;
+  using TB = TileIO<BKC, BKT, NW * 64, BNt>;
   extern __shared__ __attribute__((aligned(16))) float lds2[];
   float *As = lds2;                    // [2][TA::FLOATS]
   float *Bs = lds2 + 2 * TA::FLOATS;   // [2][TB::FLOATS]
@@ -397,18 +404,18 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
   const int ke = min(p.K, kb + p.k_per_split);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
+  const int wm = wave / WVN, wn = wave % WVN;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = bm * BM, n0 = bn * BN;
+  const int m0 = bm * BMt, n0 = bn * BNt;
 
   TA la;
   TB lb;
   la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
   lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid, p.ones);
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -443,16 +450,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
     const float *bs = Bs + cur * TB::FLOATS;
 #pragma unroll
     for (int g = 0; g < BKT / 8; ++g) {
-      const float4 a0 = TA::frag(as, wm * 64 + li, g, lh);
-      const float4 a1 = TA::frag(as, wm * 64 + 32 + li, g, lh);
-      const float4 b0 = TB::frag(bs, wn * WNC + li, g, lh);
-      const float4 b1 = NT == 2 ? TB::frag(bs, wn * WNC + 32 + li, g, lh) : b0;
-#define CLO_MM(AX, BX)                                                                             \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b0.BX, acc[0][0], 0, 0, 0);              \
-  if (NT == 2) acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b1.BX, acc[0][NT - 1], 0, 0, 0); \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b0.BX, acc[1][0], 0, 0, 0);              \
-  if (NT == 2) acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b1.BX, acc[1][NT - 1], 0, 0, 0);
-      CLO_MM(x, x) CLO_MM(y, y) CLO_MM(z, z) CLO_MM(w, w)
+      float4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = TA::frag(as, wm * WM + i * 32 + li, g, lh);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = TB::frag(bs, wn * WNC + j * 32 + li, g, lh);
+#define CLO_MM(E)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].E, bf[j].E, acc[i][j], 0, 0, 0);
+      CLO_MM(x) CLO_MM(y) CLO_MM(z) CLO_MM(w)
 #undef CLO_MM
     }
     if (it + 1 < nk) {
@@ -469,13 +475,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
   const float beta = to_ws ? 0.f : p.beta;
   const bool mirror = p.sym && !to_ws && bm != bn;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = n0 + wn * WNC + nt * 32 + li;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < p.M && col < p.N) {
           float v = alpha * acc[mt][nt][r];
           float *c = C + (long)row * ldc + col;
@@ -527,6 +533,15 @@ static int pick_mode(const float *P, long so, long sk, long sbatch, int batch) {
   return so <= sk ? MODE_OC_SCALAR : MODE_KC_SCALAR;
 }
 
+// Tile configuration of the v2 engine: few-row problems (the batch dimension of the mid-size MLP
+// path) get 32- / 64-row tiles so that no MFMA work is spent on padding rows.
+struct V2Config { int bm, bn, bk; };
+static V2Config v2_config(int M, int sym) {
+  if (!sym && M <= 32) return {32, 256, 16};
+  if (!sym && M <= 64) return {64, 256, 16};
+  return {128, 128, 32};
+}
+
 // v2 needs float4-complete operands: 16-byte aligned, K % 4 == 0 for k-contiguous operands, the
 // outer extent in memory % 4 == 0 for outer-contiguous ones.
 bool gemm_v2_eligible(const GemmArgs &a, int batch) {
@@ -568,13 +583,18 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
     return CLO_EUNSUP;
   }
   if (v2) {
-    a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), bk2) * bk2;
+    const V2Config cfg = v2_config(a.M, a.sym);
+    a.tiles_m = (int)cdiv(a.M, cfg.bm);
+    a.tiles_n = (int)cdiv(a.N, cfg.bn);
+    a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), cfg.bk) * cfg.bk;
     a.splitk = (int)cdiv(a.K, a.k_per_split);
-    grid.y = batch * a.splitk;
-#define CLO_V2(AK, BKC_, BKV, NWV)                                                                   \
+    grid = dim3(a.tiles_m * a.tiles_n, batch * a.splitk);
+#define CLO_V2(AK, BKC_, BKV, BMV, BNV, WM_, WN_)                                                 \
   {                                                                                               \
-    const size_t smem = 2 * (TileIO<AK, BKV>::FLOATS + TileIO<BKC_, BKV>::FLOATS) * sizeof(float); \
-    auto kern = gemm_v2_kernel<AK, BKC_, BKV, NWV>;                                               \
+    constexpr int nthr = WM_ * WN_ * 64;                                                          \
+    const size_t smem =                                                                           \
+        2 * (TileIO<AK, BKV, nthr, BMV>::FLOATS + TileIO<BKC_, BKV, nthr, BNV>::FLOATS) * sizeof(float); \
+    auto kern = gemm_v2_kernel<AK, BKC_, BKV, BMV, BNV, WM_, WN_>;                                \
     if (smem > 64 * 1024) {                                                                       \
       static bool attr_set = false;                                                               \
       if (!attr_set) {                                                                            \
@@ -585,16 +605,19 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
         attr_set = true;                                                                          \
       }                                                                                           \
     }                                                                                             \
-    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, stream, a);                              \
+    hipLaunchKernelGGL(kern, grid, dim3(nthr), smem, stream, a);                                  \
   }
-#define CLO_V2L(BKV, NWV)                                \
-  if (a_kc && b_kc) CLO_V2(true, true, BKV, NWV)         \
-  else if (a_kc) CLO_V2(true, false, BKV, NWV)           \
-  else if (b_kc) CLO_V2(false, true, BKV, NWV)           \
-  else CLO_V2(false, false, BKV, NWV)
-    // 8 waves (two per SIMD inside one block) when the grid cannot put two blocks on every CU
+#define CLO_V2L(BKV, BMV, BNV, WM_, WN_)                                \
+  if (a_kc && b_kc) CLO_V2(true, true, BKV, BMV, BNV, WM_, WN_)         \
+  else if (a_kc) CLO_V2(true, false, BKV, BMV, BNV, WM_, WN_)           \
+  else if (b_kc) CLO_V2(false, true, BKV, BMV, BNV, WM_, WN_)           \
+  else CLO_V2(false, false, BKV, BMV, BNV, WM_, WN_)
     const long nblocks = (long)grid.x * grid.y;
-    if (nblocks < 2L * kNumCU) { CLO_V2L(32, 8) } else { CLO_V2L(32, 4) }
+    if (cfg.bm == 32) { CLO_V2L(16, 32, 256, 1, 8) }
+    else if (cfg.bm == 64) { CLO_V2L(16, 64, 256, 1, 8) }
+    // 8 waves (two per SIMD inside one block) when the grid cannot put two blocks on every CU
+    else if (nblocks < 2L * kNumCU) { CLO_V2L(32, 128, 128, 2, 4) }
+    else { CLO_V2L(32, 128, 128, 2, 2) }
 #undef CLO_V2L
 #undef CLO_V2
     CLO_CHECK_LAUNCH("gemm_v2_kernel");
@@ -676,17 +699,18 @@ extern "C" int clo_gemm_sqsum_f32(int M, int N, int K, float alpha, const float 
 // (32768 flop at 256 flop/clk/CU = 53 ns) per k per block, blocks spread evenly over the CUs, and
 // a split pays the slab round trip ((2s + 1) M N floats at ~3.5 TB/s) plus one more launch.
 namespace clo {
-int suggest_splitk_tiles(long tiles, long K, long MN) {
+// tile_scale = block tile area / (128 x 128): MFMA time per k of one block
+int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale) {
   if (tiles <= 0 || K <= 0) return 1;
   double best = 1e30;
   int best_s = 1;
   const long smax = std::min<long>(64, std::max<long>(1, K / 64));
   for (long s = 1; s <= smax; ++s) {
-    const long kps = cdiv(cdiv(K, s), 16) * 16;
+    const long kps = cdiv(cdiv(K, s), 32) * 32;
     const long se = cdiv(K, kps);
     if (se != s) continue;
     const double rounds = (double)cdiv(tiles * s, kNumCU);
-    double t = rounds * (kps + 48.0) * 53.0;
+    double t = rounds * (kps * tile_scale + 48.0) * 53.0;
     if (s > 1) t += (2.0 * s + 1.0) * MN * 4.0 / 3500.0 + 4000.0;
     if (t < best) { best = t; best_s = (int)s; }
   }
@@ -696,7 +720,9 @@ int suggest_splitk_tiles(long tiles, long K, long MN) {
 
 extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
   const long b = batch > 0 ? batch : 1;
-  return clo::suggest_splitk_tiles(cdiv(M, BM) * cdiv(N, BN) * b, K, (long)M * N * b);
+  const V2Config cfg = v2_config(M, 0);
+  return clo::suggest_splitk_tiles(cdiv(M, cfg.bm) * cdiv(N, cfg.bn) * b, K, (long)M * N * b,
+                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0));
 }
 
 extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,
@@ -778,7 +804,7 @@ int launch_syrk_simple(float *C, long ldc, const float *X, long rows, int d, lon
   a.B = X; a.sb_k = ldx; a.sb_n = 1; a.sb_b = 0;
   a.C = C; a.ldc = ldc; a.sc_b = 0;
   const long td = cdiv(d, BM);
-  long s = suggest_splitk_tiles(td * (td + 1) / 2, rows, (long)d * d);
+  long s = suggest_splitk_tiles(td * (td + 1) / 2, rows, (long)d * d, 1.0);
   const long per = (long)d * d;
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
