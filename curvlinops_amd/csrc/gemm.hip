@@ -502,6 +502,156 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused forward + JVP tile of the large-batch MLP path: ONE pass over W and V per layer,
+//   Z  = A W^T            -> a  = act(Z + b),  phi' = act'(Z + b)
+//   dZ = A V^T + dA W^T   -> da = phi' * (dZ + Vb)
+// All four operands are k-contiguous (activations [N][d_in], weights [d_out][d_in]); three MFMA
+// products per fragment pair, two accumulator sets.  Split-K writes both sets to slabs
+// ws[split][2][N][d_out]; fwd3_reduce_kernel then applies the epilogue.
+// ------------------------------------------------------------------------------------------
+struct Fwd3Args {
+  const float *A, *dA;   // [N][d_in], dA may be null (first layer)
+  const float *W, *V;    // [d_out][d_in]
+  const float *b, *Vb;   // [d_out] or null
+  float *a, *da, *dphi;  // [N][d_out]
+  float *ws;             // split-K slabs
+  int N, d_in, d_out, act;
+  int splitk, k_per_split, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void fwd3_finish(const Fwd3Args &p, int row, int col, float z, float dz) {
+  float dphi;
+  const long e = (long)row * p.d_out + col;
+  p.a[e] = act_apply(p.act, z + (p.b ? p.b[col] : 0.f), dphi);
+  p.dphi[e] = dphi;
+  p.da[e] = dphi * (dz + (p.Vb ? p.Vb[col] : 0.f));
+}
+
+template <int BKT, int BMt, int BNt, int WVM, int WVN, bool HAS_DA>
+__global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_fwd3_kernel(const Fwd3Args p) {
+  constexpr int NW = WVM * WVN;
+  constexpr int WM = BMt / WVM, WNC = BNt / WVN;
+  constexpr int MT = WM / 32, NT = WNC / 32;
+  using TA = TileIO<true, BKT, NW * 64, BMt>;
+  using TB = TileIO<true, BKT, NW * 64, BNt>;
+  extern __shared__ __attribute__((aligned(16))) float lds3[];
+  constexpr int STAGE = (HAS_DA ? 2 : 1) * TA::FLOATS + 2 * TB::FLOATS;
+  // stage layout: [A][dA][W][V]
+  const int tile = blockIdx.x;
+  const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+  const int split = blockIdx.y;
+  const int kb = split * p.k_per_split, ke = min(p.d_in, kb + p.k_per_split);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WVN, wn = wave % WVN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = bm * BMt, n0 = bn * BNt;
+
+  TA la;
+  TB lb;
+  la.init(p.A, p.d_in, 1, m0, p.N, tid, 0);
+  lb.init(p.W, p.d_in, 1, n0, p.d_out, tid, 0);
+  const long dDA = HAS_DA ? (p.dA - p.A) : 0, dV = p.V - p.W;
+
+  f32x16 accz[MT][NT], accd[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accz[i][j][r] = accd[i][j][r] = 0.f;
+
+  const int nk = (ke - kb + BKT - 1) / BKT;
+  float4 ra[TA::NF4], rda[HAS_DA ? TA::NF4 : 1], rw[TB::NF4], rv[TB::NF4];
+  auto load_all = [&](int k0) {
+    la.load(ra, k0, ke, 1, 0);
+    if constexpr (HAS_DA) la.load(rda, k0, ke, 1, dDA);
+    lb.load(rw, k0, ke, 1, 0);
+    lb.load(rv, k0, ke, 1, dV);
+  };
+  auto store_all = [&](float *S) {
+    la.store(S, ra);
+    if constexpr (HAS_DA) la.store(S + TA::FLOATS, rda);
+    lb.store(S + (HAS_DA ? 2 : 1) * TA::FLOATS, rw);
+    lb.store(S + (HAS_DA ? 2 : 1) * TA::FLOATS + TB::FLOATS, rv);
+  };
+  if (nk > 0) {
+    load_all(kb);
+    store_all(lds3);
+  }
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    load_all(kb + (it + 1) * BKT);
+    const float *S = lds3 + cur * STAGE;
+    const float *as = S, *das = S + TA::FLOATS;
+    const float *wsm = S + (HAS_DA ? 2 : 1) * TA::FLOATS, *vsm = wsm + TB::FLOATS;
+#pragma unroll
+    for (int g = 0; g < BKT / 8; ++g) {
+      float4 af[MT], daf[MT], wf[NT], vf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        af[i] = TA::frag(as, wm * WM + i * 32 + li, g, lh);
+        if (HAS_DA) daf[i] = TA::frag(das, wm * WM + i * 32 + li, g, lh);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        wf[j] = TB::frag(wsm, wn * WNC + j * 32 + li, g, lh);
+        vf[j] = TB::frag(vsm, wn * WNC + j * 32 + li, g, lh);
+      }
+#define CLO_M3(E)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) {  \
+    accz[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].E, wf[j].E, accz[i][j], 0, 0, 0);      \
+    accd[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].E, vf[j].E, accd[i][j], 0, 0, 0);      \
+    if (HAS_DA)                                                                                    \
+      accd[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(daf[i].E, wf[j].E, accd[i][j], 0, 0, 0);   \
+  }
+      CLO_M3(x) CLO_M3(y) CLO_M3(z) CLO_M3(w)
+#undef CLO_M3
+    }
+    if (it + 1 < nk) store_all(lds3 + (cur ^ 1) * STAGE);
+    __syncthreads();
+  }
+  const bool to_ws = p.splitk > 1;
+  const long MN = (long)p.N * p.d_out;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wn * WNC + nt * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.N && col < p.d_out) {
+          if (to_ws) {
+            float *w = p.ws + (long)split * 2 * MN + (long)row * p.d_out + col;
+            w[0] = accz[mt][nt][r];
+            w[MN] = accd[mt][nt][r];
+          } else {
+            fwd3_finish(p, row, col, accz[mt][nt][r], accd[mt][nt][r]);
+          }
+        }
+      }
+    }
+}
+
+__global__ void fwd3_reduce_kernel(const Fwd3Args p) {
+  const long MN = (long)p.N * p.d_out;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < MN;
+       e += (long)gridDim.x * blockDim.x) {
+    const float *w = p.ws + e;
+    float z0 = 0.f, z1 = 0.f, d0 = 0.f, d1 = 0.f;
+    int s = 0;
+    for (; s + 1 < p.splitk; s += 2) {
+      z0 += w[(2L * s) * MN]; d0 += w[(2L * s + 1) * MN];
+      z1 += w[(2L * s + 2) * MN]; d1 += w[(2L * s + 3) * MN];
+    }
+    for (; s < p.splitk; ++s) { z0 += w[(2L * s) * MN]; d0 += w[(2L * s + 1) * MN]; }
+    fwd3_finish(p, (int)(e / p.d_out), (int)(e % p.d_out), z0 + z1, d0 + d1);
+  }
+}
+
 // C = alpha * sum_s ws[b][s] + beta * C ; for sym the lower block-triangle of ws was never
 // written, take the transposed element instead.
 __global__ void splitk_reduce_kernel(const GemmArgs p, int splitk) {
@@ -793,6 +943,67 @@ int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st) {
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws;
   return launch_gemm(a, 1, st);
+}
+
+// Fused forward + JVP of one Linear layer for a batch of N rows (see gemm_fwd3_kernel).  Needs
+// d_in % 4 == 0 and 16-byte aligned operands (returns CLO_EUNSUP otherwise: the caller then runs the
+// separate GEMMs); ws_floats bounds the split-K slabs.
+int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float *V, const float *b,
+                    const float *Vb, float *a, float *da, float *dphi, int N, int d_in, int d_out,
+                    int act, float *ws, long ws_floats, hipStream_t st) {
+  const bool ok = d_in % 4 == 0 && aligned16(A) && aligned16(W) && aligned16(V) && (!dA || aligned16(dA));
+  if (!ok) {
+    set_error("launch_mlp_fwd3: unaligned operands");
+    return CLO_EUNSUP;
+  }
+  Fwd3Args p{};
+  p.A = A; p.dA = dA; p.W = W; p.V = V; p.b = b; p.Vb = Vb; p.a = a; p.da = da; p.dphi = dphi;
+  p.ws = ws; p.N = N; p.d_in = d_in; p.d_out = d_out; p.act = act;
+  const int bm = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
+  const int bn = bm == 128 ? 64 : 128;
+  constexpr int bk = 16;
+  p.tiles_m = (int)cdiv(N, bm);
+  p.tiles_n = (int)cdiv(d_out, bn);
+  const long tiles = (long)p.tiles_m * p.tiles_n, MN = (long)N * d_out;
+  // three products per tile: 1.5x the MFMA time of a plain tile of the same area
+  long s = suggest_splitk_tiles(tiles, d_in, 2 * MN, 1.5 * bm * bn / (128.0 * 128.0));
+  if (MN > 0) s = std::min<long>(s, ws ? ws_floats / (2 * MN) : 1);
+  s = std::max<long>(1, s);
+  p.k_per_split = (int)cdiv(cdiv(d_in, s), bk) * bk;
+  p.splitk = (int)cdiv(d_in, p.k_per_split);
+  dim3 grid((unsigned)tiles, (unsigned)p.splitk);
+#define CLO_F3(BMV, BNV, WM_, WN_, DA_)                                                            \
+  {                                                                                                \
+    constexpr int nthr = WM_ * WN_ * 64;                                                           \
+    const size_t smem = 2 * ((DA_ ? 2 : 1) * TileIO<true, bk, nthr, BMV>::FLOATS +                 \
+                             2 * TileIO<true, bk, nthr, BNV>::FLOATS) * sizeof(float);             \
+    auto kern = gemm_fwd3_kernel<bk, BMV, BNV, WM_, WN_, DA_>;                                     \
+    if (smem > 64 * 1024) {                                                                        \
+      static bool attr_set = false;                                                                \
+      if (!attr_set) {                                                                             \
+        int rc_ = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),              \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                                (int)smem), "hipFuncSetAttribute");                \
+        if (rc_ != CLO_OK) return rc_;                                                             \
+        attr_set = true;                                                                           \
+      }                                                                                            \
+    }                                                                                              \
+    hipLaunchKernelGGL(kern, grid, dim3(nthr), smem, st, p);                                       \
+  }
+#define CLO_F3L(BMV, BNV, WM_, WN_) \
+  if (dA) CLO_F3(BMV, BNV, WM_, WN_, true) else CLO_F3(BMV, BNV, WM_, WN_, false)
+  if (bm == 32) { CLO_F3L(32, 128, 1, 4) }
+  else if (bm == 64) { CLO_F3L(64, 128, 2, 4) }
+  else { CLO_F3L(128, 64, 2, 2) }
+#undef CLO_F3L
+#undef CLO_F3
+  CLO_CHECK_LAUNCH("gemm_fwd3_kernel");
+  if (p.splitk > 1) {
+    hipLaunchKernelGGL(fwd3_reduce_kernel, dim3((unsigned)std::min<long>(cdiv(MN, 256), 4096)), dim3(256),
+                       0, st, p);
+    CLO_CHECK_LAUNCH("fwd3_reduce_kernel");
+  }
+  return CLO_OK;
 }
 
 // C = beta*C + alpha * X^T X (X row-major [rows][ldx], first d columns), symmetric block raster.

@@ -1749,7 +1749,9 @@ static int bwd_pass(const float *W, const float *delta, const float *a_prev,
   return CLO_OK;
 }
 
-constexpr int SKINNY_MAX_N = 16;  // up to two 8-row passes; above that the MFMA GEMM path wins
+constexpr int LAYER_MAX_N = 16;  // the per-layer entry points run up to two 8-row passes
+constexpr int SKINNY_MAX_N = 8;  // whole-network matvec: one 8-row streaming pass; above that the
+                                 // GEMM engine (32-row tiles, fused forward) is faster (measured)
 
 static long gemm_ws_floats(int N, int dmax) {
   // split-K partial slabs for the widest product of the large-batch path
@@ -1820,8 +1822,8 @@ extern "C" int clo_mlp_fwd_jvp_layer(const float *W, const float *b, const float
   CLO_REQUIRE(act >= 0 && act <= 3, "clo_mlp_fwd_jvp_layer: unknown activation %d", act);
   CLO_REQUIRE(W && a_in && a_out, "clo_mlp_fwd_jvp_layer: null operand");
   CLO_REQUIRE(!(VW || da_in) || da_out, "clo_mlp_fwd_jvp_layer: da_out required for a JVP");
-  CLO_REQUIRE(N <= SKINNY_MAX_N, "clo_mlp_fwd_jvp_layer: N=%d > %d, use clo_mlp_ggn_matvec", N,
-              SKINNY_MAX_N);
+  CLO_REQUIRE(N <= LAYER_MAX_N, "clo_mlp_fwd_jvp_layer: N=%d > %d, use clo_mlp_ggn_matvec", N,
+              LAYER_MAX_N);
   hipStream_t st = (hipStream_t)stream;
   for (int n0 = 0; n0 < N; n0 += NB) {
     const int nn = std::min(NB, N - n0);
@@ -1853,8 +1855,8 @@ extern "C" int clo_mlp_bwd_layer(const float *W, const float *delta, const float
                                  float *delta_prev, float alpha, float beta, int N, int d_in,
                                  int d_out, float *ws, void *stream) {
   CLO_REQUIRE(N >= 0 && d_in > 0 && d_out > 0, "clo_mlp_bwd_layer: bad sizes");
-  CLO_REQUIRE(N <= SKINNY_MAX_N, "clo_mlp_bwd_layer: N=%d > %d, use clo_mlp_ggn_matvec", N,
-              SKINNY_MAX_N);
+  CLO_REQUIRE(N <= LAYER_MAX_N, "clo_mlp_bwd_layer: N=%d > %d, use clo_mlp_ggn_matvec", N,
+              LAYER_MAX_N);
   CLO_REQUIRE(delta && (!out_W || a_prev), "clo_mlp_bwd_layer: null operand");
   CLO_REQUIRE(!delta_prev || (W && dphi_prev && ws),
               "clo_mlp_bwd_layer: delta_prev needs W, dphi_prev, ws");
@@ -1977,9 +1979,14 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
         if (rc != CLO_OK) return rc;
       }
     } else {
-      // a_l = act(a W^T + b) with act' as second output; da_l = act' * (a VW^T + da W^T + Vb):
-      // two launches, bias / activation / derivative fused into whichever kernel writes C, the
-      // tangent's two products chained along K in one pass
+      // unaligned operands: a_l = act(a W^T + b) with act' as second output; da_l = act' * (a VW^T +
+      // da W^T + Vb): two launches, bias / activation / derivative fused into whichever kernel
+      // writes C, the tangent's two products chained along K in one pass
+      // preferred: one fused pass over W_l and V_l (three MFMA products per tile, gemm_fwd3_kernel)
+      rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], bl, vbl, a[l], da[l], dphi[l], N, di,
+                           dout, acts[l - 1], gws, gws_sz, st);
+      if (rc == CLO_OK) continue;
+      if (rc != CLO_EUNSUP) return rc;
       GemmArgs g1 = gemm_problem(N, dout, di, a[l - 1], di, 1, W[l - 1], 1, di, 0.f, a[l], dout);
       g1.epi = EPI_ACT; g1.e_act = acts[l - 1]; g1.e_vec = bl; g1.e_out2 = dphi[l];
       rc = launch_gemm_auto(g1, gws, gws_sz, st);
