@@ -850,7 +850,9 @@ extern "C" int clo_gemm_sqsum_f32(int M, int N, int K, float alpha, const float 
 // a split pays the slab round trip ((2s + 1) M N floats at ~3.5 TB/s) plus one more launch.
 namespace clo {
 // tile_scale = block tile area / (128 x 128): MFMA time per k of one block
-int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale) {
+// waves = waves per block: with fewer than two waves per SIMD resident on a CU nothing hides a
+// wave's barrier / LDS stalls (measured ~1.5x the MFMA time)
+int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale, int waves) {
   if (tiles <= 0 || K <= 0) return 1;
   double best = 1e30;
   int best_s = 1;
@@ -860,7 +862,8 @@ int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale) {
     const long se = cdiv(K, kps);
     if (se != s) continue;
     const double rounds = (double)cdiv(tiles * s, kNumCU);
-    double t = rounds * (kps * tile_scale + 48.0) * 53.0;
+    const double resident = (double)waves * std::min<double>(2.0, rounds);
+    double t = rounds * (kps * tile_scale + 48.0) * 53.0 * (resident >= 8.0 ? 1.0 : 1.5);
     if (s > 1) t += (2.0 * s + 1.0) * MN * 4.0 / 3500.0 + 4000.0;
     if (t < best) { best = t; best_s = (int)s; }
   }
@@ -872,7 +875,7 @@ extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
   const long b = batch > 0 ? batch : 1;
   const V2Config cfg = v2_config(M, 0);
   return clo::suggest_splitk_tiles(cdiv(M, cfg.bm) * cdiv(N, cfg.bn) * b, K, (long)M * N * b,
-                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0));
+                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0), 8);
 }
 
 extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,
@@ -965,8 +968,9 @@ int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float
   p.tiles_m = (int)cdiv(N, bm);
   p.tiles_n = (int)cdiv(d_out, bn);
   const long tiles = (long)p.tiles_m * p.tiles_n, MN = (long)N * d_out;
-  // three products per tile: 1.5x the MFMA time of a plain tile of the same area
-  long s = suggest_splitk_tiles(tiles, d_in, 2 * MN, 1.5 * bm * bn / (128.0 * 128.0));
+  // two or three products per tile: the MFMA time of a plain tile of the same area times that
+  long s = suggest_splitk_tiles(tiles, d_in, 2 * MN, (dA ? 3.0 : 2.0) * bm * bn / (128.0 * 128.0),
+                                bm == 64 ? 8 : 4);
   if (MN > 0) s = std::min<long>(s, ws ? ws_floats / (2 * MN) : 1);
   s = std::max<long>(1, s);
   p.k_per_split = (int)cdiv(cdiv(d_in, s), bk) * bk;
@@ -1015,7 +1019,7 @@ int launch_syrk_simple(float *C, long ldc, const float *X, long rows, int d, lon
   a.B = X; a.sb_k = ldx; a.sb_n = 1; a.sb_b = 0;
   a.C = C; a.ldc = ldc; a.sc_b = 0;
   const long td = cdiv(d, BM);
-  long s = suggest_splitk_tiles(td * (td + 1) / 2, rows, (long)d * d, 1.0);
+  long s = suggest_splitk_tiles(td * (td + 1) / 2, rows, (long)d * d, 1.0, 8);
   const long per = (long)d * d;
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
