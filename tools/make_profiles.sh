@@ -14,7 +14,7 @@ cp $OUT/r01_c2_n8_pmc_traffic.json profiles/   # so that the bench's traffic leg
 python bench.py > $OUT/r01_bench_n1.json 2> $OUT/bench_stderr.txt
 tail -c 3000 $OUT/r01_bench_n1.json
 # large-batch points of the same workload (kernel path only)
-python tools/probe_c2.py 8 128 512 > $OUT/r01_c2_batch_sweep.txt 2>&1
+python tools/probe_c2.py 1 8 9 16 32 64 128 256 512 1024 > $OUT/r01_c2_batch_sweep.txt 2>&1
 cd /tmp
 for N in 128 512; do
   rocprofv3 --kernel-trace --stats -d /tmp/p_n$N -o k -- python $R/tools/probe_c2.py $N > /dev/null 2>&1
