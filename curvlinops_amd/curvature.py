@@ -110,6 +110,14 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if self._NATIVE_KIND == "ggn":
             kind, scale = loss_kind_and_scale(self._loss_func, N, C)
             return kind, scale, None
+        if self._NATIVE_KIND == "mc":
+            # MC-GGN: H_n = (1/c) sum_m g'_nm g'_nm^T with would-be gradients drawn from the model's
+            # likelihood (ggn.py:100-168).  Drawn HERE, once per mini-batch and product, from the
+            # global RNG that GGNLinearOperator._matmat seeds -- the same draws as the autograd path.
+            with torch.no_grad():
+                g = self._mc_sampler(self._model_func(self._params, X), y)  # [N, M, C]
+            c = {"mean": float(N), "sum": 1.0}[self._loss_func.reduction]
+            return _hip.LOSS_RANK1, 1.0 / c, g.reshape(N, g.shape[1], C).contiguous()
         # empirical Fisher: H_n = (1/c) g_n g_n^T with g_n the UNREDUCED per-sample gradient
         # of the loss w.r.t. the prediction (gradient_moments.py:48-87); params are fixed, so
         # g_n is cached per batch.
@@ -141,7 +149,9 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                 return None
             batches.append((Xn, y, self._get_normalization_factor(X, y)))
         K = M[0].shape[-1]
-        out = self._matmat_native_cols(M, batches, K)
+        # per-batch curvature arguments ONCE per product and in data order (MC draws its samples here)
+        bargs = [self._native_batch_args(bi, Xn, y) for bi, (Xn, y, _) in enumerate(batches)]
+        out = self._matmat_native_cols(M, batches, bargs, K)
         if out is not None:
             return out
         # K-major contiguous copies so that every column is a parameter-shaped contiguous view
@@ -154,14 +164,14 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             V = [v[k] for v in Vk]
             O = [o[k] for o in Ok]
             for bi, (Xn, y, norm) in enumerate(batches):
-                kind, scale, aux = self._native_batch_args(bi, Xn, y)
+                kind, scale, aux = bargs[bi]
                 nat.matvec(V, O, Xn, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0, aux=aux)
         return [o.movedim(0, -1) for o in Ok]
 
     _NATIVE_COLS_MAX_ROWS = 32  # the K-column kernels run 8-row passes; beyond that GEMMs win
     _NATIVE_COLS_MIN_K = 8      # below, K matvecs on K-major copies are as fast (measured on C2)
 
-    def _matmat_native_cols(self, M: list[Tensor], batches, K: int) -> list[Tensor] | None:
+    def _matmat_native_cols(self, M: list[Tensor], batches, bargs, K: int) -> list[Tensor] | None:
         """K >= 4 columns in the reference's K-trailing layout through ``clo_mlp_ggn_matmat`` (the
         tangent weights and the result are streamed once per column, W is shared); None if the
         shapes / layout do not qualify."""
@@ -170,7 +180,8 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if K < self._NATIVE_COLS_MIN_K or not batches or any(b[0].shape[0] > self._NATIVE_COLS_MAX_ROWS for b in batches):
             return None
         # rows of the [D, K] matrix must be float4-complete: K % 4 == 0 (else the column loop runs)
-        if not all(m.is_contiguous() and m.data_ptr() % 16 == 0 for m in M) or not plan.matmat_supported(4, K):
+        rank = max([1] + [a[2].shape[1] for a in bargs if a[2] is not None])
+        if not all(m.is_contiguous() and m.data_ptr() % 16 == 0 for m in M) or not plan.matmat_supported(4, K, rank):
             return None
         out = self._alloc_cols_like(M)
         stream = torch.cuda.current_stream().cuda_stream
@@ -183,7 +194,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             ow = [ptr(out, i) for i in nat.w_idx]
             ob = [ptr(out, i) for i in nat.b_idx]
             for bi, (Xn, y, norm) in enumerate(batches):
-                kind, scale, aux = self._native_batch_args(bi, Xn, y)
+                kind, scale, aux = bargs[bi]
                 plan.ggn_matmat_ptrs(vw, vb, ow, ob, K, kc, Xn.data_ptr(), Xn.shape[0], kind, scale, norm,
                                      0.0 if bi == 0 else 1.0, None if aux is None else aux.data_ptr(),
                                      1 if aux is None else aux.shape[1], ws.data_ptr(), stream)
@@ -395,7 +406,9 @@ class GGNLinearOperator(CurvatureLinearOperator):
                 )
             self.FIXED_DATA_ORDER = True
             self._seed = seed
-            self._NATIVE_KIND = None  # sampled curvature: autograd path (RNG parity with torch)
+            self._NATIVE_KIND = "mc"  # rank-M output curvature from sampled would-be gradients
+            self._mc_sampler = vmap(make_grad_output_fn(loss_func, FisherType.MC, mc_samples), (0, 0),
+                                    randomness="different")
         super().__init__(
             model_func, loss_func, params, data, progressbar=progressbar,
             check_deterministic=check_deterministic, num_data=num_data, batch_size_fn=batch_size_fn,

@@ -105,6 +105,32 @@ def test_native_column_kernels_match_autograd_path_on_gpu(dev):
         assert rel_err(torch.cat([o.reshape(-1, 8) for o in out]), (nat @ V).double().cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("loss", ["ce", "mse", "bce"])
+def test_native_mc_ggn_matches_autograd_path_on_gpu(dev, loss):
+    """MC-GGN (sampled would-be gradients, ggn.py:100-168) on the native kernels: the samples are
+    drawn from the same seeded global RNG in the same order, so both paths agree to fp32 accuracy --
+    vectors, a K-column block (column kernels) and a batch beyond 8 rows (GEMM engine)."""
+    torch.manual_seed(2)
+    model = nn.Sequential(nn.Linear(40, 64), nn.Tanh(), nn.Linear(64, 12)).to(dev)
+    params = dict(model.named_parameters())
+    lossf = {"ce": nn.CrossEntropyLoss(), "mse": nn.MSELoss(), "bce": nn.BCEWithLogitsLoss(reduction="sum")}[loss]
+    def target(n):
+        return torch.randint(0, 12, (n,), device=dev) if loss == "ce" else torch.rand(n, 12, device=dev)
+    data = [(torch.rand(n, 40, device=dev), target(n)) for n in (8, 3, 20)]
+    nat = C.GGNLinearOperator(model, lossf, params, data, check_deterministic=False, mc_samples=3, seed=123)
+    ref = C.GGNLinearOperator(model, lossf, params, data, check_deterministic=False, mc_samples=3, seed=123)
+    assert nat.uses_native_kernels
+    ref._native = None
+    v = torch.rand(nat.shape[1], device=dev) - 0.5
+    assert rel_err(nat @ v, (ref @ v).double().cpu().numpy()) < 2e-4
+    V = torch.rand(nat.shape[1], 8, device=dev) - 0.5
+    assert rel_err(nat @ V, (ref @ V).double().cpu().numpy()) < 2e-4
+    # deterministic for a fixed seed, different for another
+    assert torch.equal(nat @ v, nat @ v)
+    other = C.GGNLinearOperator(model, lossf, params, data, check_deterministic=False, mc_samples=3, seed=7)
+    assert not torch.allclose(other @ v, nat @ v)
+
+
 class TestC2FullSize:
     """BASELINE.json configs[1]: MLP 1024-2688-2688-10 (D = 10 010 122), MSE, GGN."""
 
