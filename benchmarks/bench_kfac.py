@@ -50,6 +50,25 @@ def main():
     res["kfac_factors_ms"], K = timed(lambda: C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, data, **kw))
     v = torch.rand(K.shape[1], device=dev)
     res["kfac_matvec_ms"], _ = timed(lambda: K @ v)
+    # algorithmic work: matvec = sum_l 2 (d_out^2 d_in' + d_out d_in'^2) flop; factor
+    # build = sum_l 2 B S_l (d_in'^2 + d_out^2) flop with S_l recovered from a forward pass
+    blocks = [[S.shape[0] for S in blk._factors] for blk in K[1]]
+    mv_flops = sum(2.0 * (b[0] ** 2 * b[1] + b[0] * b[1] ** 2) for b in blocks if len(b) == 2)
+    res["kfac_matvec_tflops"] = mv_flops / (res["kfac_matvec_ms"] * 1e-3) / 1e12
+    rows = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, rows=rows: rows.__setitem__(mod, o.numel() // (o.shape[0] * o.shape[1])))
+             for m in model.modules() if isinstance(m, (nn.Conv2d, nn.Linear))]
+    with torch.no_grad():
+        model(X[:2])
+    for h in hooks:
+        h.remove()
+    build_flops = 0.0
+    for m, S in rows.items():
+        d_out = m.weight.shape[0]
+        d_in = m.weight[0].numel() + (1 if m.bias is not None else 0)
+        build_flops += 2.0 * B * S * (d_in**2 + d_out**2)
+    res["factor_build_gflop"] = build_flops / 1e9
+    res["factor_build_tflops_incl_autograd"] = build_flops / (res["kfac_factors_ms"] * 1e-3) / 1e12
     res["cholesky_inverse_ms"], Kinv = timed(lambda: K.inverse(damping=1e-3), repeats=2)
     res["inverse_matvec_ms"], _ = timed(lambda: Kinv @ v)
     # forward+backward alone (host-framework time that any backend pays)

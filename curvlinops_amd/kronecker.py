@@ -294,11 +294,43 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         _expect_same_dtype(old, value)
         self._blocks[index] = value
 
+    _POOL_STREAMS = 4
+    _pool: dict = {}
+
     def _matmat(self, X: list[Tensor]) -> list[Tensor]:
         parts = split_list(X, [len(B._in_shape) for B in self._blocks])
+        if len(self._blocks) >= 4 and all(is_native_tensor(x) for x in X):
+            return self._matmat_concurrent(parts)
         out: list[Tensor] = []
         for B, xs in zip(self._blocks, parts):
             out.extend(B._matmat(xs))
+        return out
+
+    def _matmat_concurrent(self, parts: list[list[Tensor]]) -> list[Tensor]:
+        """The blocks are independent and individually too small to fill 256 CUs (a ResNet-18 KFAC
+        product is 21 blocks of two GEMMs each): spread them over a few HIP streams and join."""
+        dev = parts[0][0].device
+        pool = BlockDiagonalLinearOperator._pool.get(dev)
+        if pool is None:
+            pool = BlockDiagonalLinearOperator._pool[dev] = [torch.cuda.Stream(device=dev)
+                                                             for _ in range(self._POOL_STREAMS)]
+        main = torch.cuda.current_stream(dev)
+        ready = main.record_event()
+        for side in pool:
+            side.wait_event(ready)
+        out: list[Tensor] = []
+        # largest blocks first on each stream would balance better; program order keeps it simple
+        for i, (B, xs) in enumerate(zip(self._blocks, parts)):
+            side = pool[i % len(pool)]
+            with torch.cuda.stream(side):
+                ys = B._matmat(xs)
+            for t in (*xs, *ys):
+                t.record_stream(side)
+            out.extend(ys)
+        for side in pool:
+            main.wait_stream(side)
+        for t in out:
+            t.record_stream(main)
         return out
 
     def _adjoint(self) -> "BlockDiagonalLinearOperator":
