@@ -82,6 +82,13 @@ _SIGNATURES = {
          c_int, c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
     ),
     "clo_mlp_ggn_matmat_ws_floats": (c_long, [c_int, POINTER(c_int), c_int, c_int]),
+    "clo_mlp_hessian_matvec": (
+        c_int,
+        [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
+         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _PF, c_int, _PF,
+         c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
+    ),
+    "clo_mlp_hessian_ws_floats": (c_long, [c_int, POINTER(c_int), c_int]),
     "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
     "clo_dot_ws_bytes": (c_long, []),
     "clo_dot_f32": (c_int, [_PF, _PF, c_long, c_float, _PF, c_void_p, c_void_p]),
@@ -373,7 +380,7 @@ class MLPPlan:
         if ws is None:
             n = load().clo_mlp_ggn_ws_floats(self.L, self.dims, N)
             ws = torch.empty(n, device=device, dtype=torch.float32)
-            self._ws = {k: v for k, v in self._ws.items() if k[0] == "mm"}  # keep only the latest batch size
+            self._ws = {k: v for k, v in self._ws.items() if k[0] in ("mm", "hess")}  # keep only the latest batch size
             self._ws[key] = ws
         return ws
 
@@ -437,6 +444,31 @@ class MLPPlan:
                                        beta, ws_ptr, stream)
         if rc != 0:
             _check(rc, "clo_mlp_ggn_matmat")
+
+    def hessian_supported(self) -> bool:
+        """Shape conditions of ``clo_mlp_hessian_matvec`` (alignment is checked by the library)."""
+        return all(d % 4 == 0 for d in self._dims_list[:-1])
+
+    def hessian_matvec(self, W, b, VW, Vb, OW, Ob, X, G, loss_kind: int, loss_scale: float, alpha: float,
+                       beta: float, aux=None) -> None:
+        """``out = beta out + alpha H v`` (exact Hessian, R-operator on the GEMM engine); ``G`` is the
+        gradient of the reduced mini-batch loss w.r.t. the model output, ``[N, C]``."""
+        lib = load()
+        N = X.shape[0]
+        key = ("hess", N, str(X.device))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.empty(lib.clo_mlp_hessian_ws_floats(self.L, self.dims, N), device=X.device,
+                             dtype=torch.float32)
+            self._ws = {k: v for k, v in self._ws.items() if k[0] != "hess"}
+            self._ws[key] = ws
+        rank = 1 if aux is None else (aux.shape[1] if aux.dim() == 3 else 1)
+        rc = lib.clo_mlp_hessian_matvec(
+            self.L, self.dims, self.acts, self._ptr_array(W), self._ptr_array(b),
+            self._ptr_array(VW), self._ptr_array(Vb), self._ptr_array(OW), self._ptr_array(Ob),
+            _pc(X), N, _pc(G), loss_kind, _pc(aux), rank, loss_scale, alpha, beta, _pc(ws), _stream(),
+        )
+        _check(rc, "clo_mlp_hessian_matvec")
 
     def ggn_matvec(self, W, b, VW, Vb, OW, Ob, X, loss_kind: int, loss_scale: float, alpha: float,
                    beta: float, aux=None) -> None:

@@ -1555,6 +1555,42 @@ __global__ void loss_cols_kernel(int kind, const float *__restrict__ f,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact Hessian-vector product of an MLP (hessian.py:13-69) by the R-operator: next to the tangent
+// forward pass (a_l, da_l, phi'_l) it backpropagates the true gradient signal d_l = dL/dz_l AND its
+// directional derivative Rd_l:
+//   dA      = d_l W_l                       (signal at the previous activation)
+//   T       = Rd_l W_l + d_l V_l
+//   d_{l-1}  = phi'_{l-1} * dA
+//   Rd_{l-1} = (phi'' dz)_{l-1} * dA + phi'_{l-1} * T,   phi'' dz from (a, da): 0 for ReLU / identity,
+//             -2 a da for tanh, (1 - 2a) da for the sigmoid
+//   out_W_l = beta out_W_l + Rd_l^T a_{l-1} + d_l^T da_{l-1},   out_b_l = beta out_b_l + sum_n Rd_l
+// All products run on the GEMM engine; this kernel is the elementwise combine.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_second_times_dz(int act, float a, float da) {
+  if (act == CLO_ACT_TANH) return -2.f * a * da;
+  if (act == CLO_ACT_SIGMOID) return (1.f - 2.f * a) * da;
+  return 0.f;
+}
+// d = dphi * dA ; Rd = act''dz * dA + dphi * T      (T == nullptr: treated as given in Rd itself)
+__global__ void hess_combine_kernel(const float *__restrict__ dA, const float *__restrict__ T,
+                                    const float *__restrict__ a, const float *__restrict__ da,
+                                    const float *__restrict__ dphi, float *__restrict__ d,
+                                    float *__restrict__ Rd, long n, int act) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long)gridDim.x * blockDim.x) {
+    const float g = dA[e], ph = dphi[e];
+    const float t = T ? T[e] : Rd[e];
+    Rd[e] = act_second_times_dz(act, a[e], da[e]) * g + ph * t;
+    d[e] = ph * g;
+  }
+}
+__global__ void scale_copy_kernel(float *__restrict__ y, const float *__restrict__ x, long n, float s) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long)gridDim.x * blockDim.x)
+    y[e] = s * x[e];
+}
+
 static inline unsigned ew_grid(long n) {
   return (unsigned)std::max<long>(1, std::min<long>(cdiv(n, 256), kNumCU * 8L));
 }
@@ -2302,6 +2338,121 @@ extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const
         if (rc != CLO_OK) return rc;
       }
     }
+  }
+  return CLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Hessian-vector product (see hess_combine_kernel).
+// ------------------------------------------------------------------------------------------
+extern "C" long clo_mlp_hessian_ws_floats(int L, const int *dims, int N) {
+  if (L <= 0 || !dims || N < 0) return 0;
+  long total = 0;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  for (int l = 1; l <= L; ++l) total += 3L * N * dims[l];  // a, da, phi'
+  total += 6L * N * dmax;                                  // d, Rd (ping/pong), dA, T
+  return total + gemm_ws_floats(N, dmax) + 256;
+}
+
+// out = beta out + alpha H v for one mini-batch.  G [N][C]: gradient of the (reduced) mini-batch
+// loss w.r.t. the model output; loss_kind / aux / loss_scale describe its Hessian as in
+// clo_mlp_ggn_matvec.  Needs dims[0..L-1] % 4 == 0 and 16-byte aligned operands (CLO_EUNSUP
+// otherwise).
+extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, const float *const *W,
+                                      const float *const *b, const float *const *VW,
+                                      const float *const *Vb, float *const *OW, float *const *Ob,
+                                      const float *X, int N, const float *G, int loss_kind,
+                                      const float *aux, int aux_rank, float loss_scale, float alpha,
+                                      float beta, float *ws, void *stream) {
+  CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW, "clo_mlp_hessian_matvec: bad layer table");
+  CLO_REQUIRE(N >= 1 && X && G && ws, "clo_mlp_hessian_matvec: bad batch / gradient / workspace");
+  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_hessian_matvec: unknown loss kind %d", loss_kind);
+  bool ok = aligned16(X) && aligned16(ws);
+  for (int l = 0; l <= L; ++l) CLO_REQUIRE(dims[l] > 0, "clo_mlp_hessian_matvec: dims[%d] <= 0", l);
+  for (int l = 0; l < L; ++l) {
+    CLO_REQUIRE(acts[l] >= 0 && acts[l] <= 3, "clo_mlp_hessian_matvec: unknown activation");
+    CLO_REQUIRE(W[l] && VW[l] && OW[l], "clo_mlp_hessian_matvec: null weight pointer in layer %d", l);
+    ok = ok && dims[l] % 4 == 0 && aligned16(W[l]) && aligned16(VW[l]);
+  }
+  if (!ok) {
+    set_error("clo_mlp_hessian_matvec: needs layer inputs %% 4 == 0 and 16-byte aligned operands");
+    return CLO_EUNSUP;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  float *p = ws;
+  float *a[65], *da[65], *dphi[65];
+  a[0] = const_cast<float *>(X); da[0] = nullptr; dphi[0] = nullptr;
+  for (int l = 1; l <= L; ++l) {
+    const long sz = (long)N * dims[l];
+    a[l] = p; p += sz; da[l] = p; p += sz; dphi[l] = p; p += sz;
+  }
+  const long nd = (long)N * dmax;
+  float *d0 = p, *d1 = p + nd, *R0 = p + 2 * nd, *R1 = p + 3 * nd, *dAb = p + 4 * nd, *Tb = p + 5 * nd;
+  p += 6 * nd;
+  float *gws = p;
+  const long gws_sz = gemm_ws_floats(N, dmax);
+  int rc;
+  // ---- tangent forward pass, one fused launch per layer
+  for (int l = 1; l <= L; ++l) {
+    rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
+                         Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l],
+                         acts[l - 1], gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+  }
+  // ---- output layer: dA = alpha G, T = alpha s H(f) Jv  ->  d_L, Rd_L
+  const int C = dims[L];
+  const long nc = (long)N * C;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(ew_grid(nc)), dim3(256), 0, st, dAb, G, nc, alpha);
+  CLO_CHECK_LAUNCH("scale_copy_kernel");
+  rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], nullptr, Tb, N, C, loss_scale * alpha, nullptr, 1,
+                   nullptr, nullptr, a[L], da[L], st);
+  if (rc != CLO_OK) return rc;
+  float *dcur = d0, *dnext = d1, *Rcur = R0, *Rnext = R1;
+  hipLaunchKernelGGL(hess_combine_kernel, dim3(ew_grid(nc)), dim3(256), 0, st, dAb, Tb, a[L], da[L], dphi[L],
+                     dcur, Rcur, nc, acts[L - 1]);
+  CLO_CHECK_LAUNCH("hess_combine_kernel");
+  // ---- backward
+  for (int l = L; l >= 1; --l) {
+    const int di = dims[l - 1], dout = dims[l];
+    // out_W = beta out_W + Rd^T a_prev (+ d^T da_prev)
+    GemmArgs go = gemm_problem(dout, di, N, Rcur, 1, dout, a[l - 1], di, 1, beta, OW[l - 1], di);
+    rc = launch_gemm_auto(go, gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+    if (da[l - 1]) {
+      GemmArgs g2 = gemm_problem(dout, di, N, dcur, 1, dout, da[l - 1], di, 1, 1.f, OW[l - 1], di);
+      rc = launch_gemm_auto(g2, gws, gws_sz, st);
+      if (rc != CLO_OK) return rc;
+    }
+    if (Ob && Ob[l - 1]) {
+      rc = launch_small_outer(Ob[l - 1], nullptr, Rcur, N, dout, 1, beta, nullptr, 0, st);
+      if (rc != CLO_OK) return rc;
+    }
+    if (l == 1) break;
+    // dA = d W_l ;  T = Rd W_l + d V_l
+    GemmArgs ga = gemm_problem(N, di, dout, dcur, dout, 1, W[l - 1], di, 1, 0.f, dAb, di);
+    rc = launch_gemm_auto(ga, gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+    GemmArgs gt = gemm_problem(N, di, dout, Rcur, dout, 1, W[l - 1], di, 1, 0.f, Tb, di);
+    GemmArgs gc = gt;
+    gc.K = 2 * dout; gc.K1 = dout; gc.A2 = dcur; gc.B2 = VW[l - 1];
+    if (dout % 32 == 0 && gemm_v2_eligible(gc, 1)) {
+      rc = launch_gemm_auto(gc, gws, gws_sz, st);
+    } else {
+      rc = launch_gemm_auto(gt, gws, gws_sz, st);
+      if (rc != CLO_OK) return rc;
+      GemmArgs gv = gemm_problem(N, di, dout, dcur, dout, 1, VW[l - 1], di, 1, 1.f, Tb, di);
+      rc = launch_gemm_auto(gv, gws, gws_sz, st);
+    }
+    if (rc != CLO_OK) return rc;
+    const long ne = (long)N * di;
+    hipLaunchKernelGGL(hess_combine_kernel, dim3(ew_grid(ne)), dim3(256), 0, st, dAb, Tb, a[l - 1],
+                       da[l - 1], dphi[l - 1], dnext, Rnext, ne, acts[l - 2]);
+    CLO_CHECK_LAUNCH("hess_combine_kernel");
+    std::swap(dcur, dnext);
+    std::swap(Rcur, Rnext);
   }
   return CLO_OK;
 }

@@ -98,7 +98,10 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if structure is None or loss_kind_and_scale(self._loss_func, 1, 1) is None:
             return
         _hip.load()  # a GPU fp32 MLP must run natively: fail loudly if the library is absent
-        self._native = NativeMLP(structure, self._params)
+        native = NativeMLP(structure, self._params)
+        if self._NATIVE_KIND == "hessian" and not native.plan.hessian_supported():
+            return  # layer widths not float4-complete: the R-operator kernels do not apply
+        self._native = native
 
     @property
     def uses_native_kernels(self) -> bool:
@@ -110,6 +113,17 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if self._NATIVE_KIND == "ggn":
             kind, scale = loss_kind_and_scale(self._loss_func, N, C)
             return kind, scale, None
+        if self._NATIVE_KIND == "hessian":
+            # exact Hessian: besides the loss Hessian (as for the GGN) the R-operator backward needs
+            # the gradient of the reduced mini-batch loss w.r.t. the prediction, G [N, C]
+            kind, scale = loss_kind_and_scale(self._loss_func, N, C)
+            G = self._native_aux.get(idx)
+            if G is None:
+                with torch.enable_grad():
+                    f = self._model_func(self._params, X).detach().requires_grad_(True)
+                    (G,) = torch.autograd.grad(self._loss_func(f, y), f)
+                G = self._native_aux[idx] = G.contiguous()
+            return kind, scale, G
         if self._NATIVE_KIND == "mc":
             # MC-GGN: H_n = (1/c) sum_m g'_nm g'_nm^T with would-be gradients drawn from the model's
             # likelihood (ggn.py:100-168).  Drawn HERE, once per mini-batch and product, from the
@@ -165,7 +179,10 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             O = [o[k] for o in Ok]
             for bi, (Xn, y, norm) in enumerate(batches):
                 kind, scale, aux = bargs[bi]
-                nat.matvec(V, O, Xn, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0, aux=aux)
+                if self._NATIVE_KIND == "hessian":
+                    nat.hessian_matvec(V, O, Xn, aux, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0)
+                else:
+                    nat.matvec(V, O, Xn, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0, aux=aux)
         return [o.movedim(0, -1) for o in Ok]
 
     _NATIVE_COLS_MAX_ROWS = 32  # the K-column kernels run 8-row passes; beyond that GEMMs win
@@ -177,7 +194,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         shapes / layout do not qualify."""
         nat = self._native
         plan = nat.plan
-        if K < self._NATIVE_COLS_MIN_K or not batches or any(b[0].shape[0] > self._NATIVE_COLS_MAX_ROWS for b in batches):
+        if self._NATIVE_KIND == "hessian" or K < self._NATIVE_COLS_MIN_K or not batches or any(b[0].shape[0] > self._NATIVE_COLS_MAX_ROWS for b in batches):
             return None
         # rows of the [D, K] matrix must be float4-complete: K % 4 == 0 (else the column loop runs)
         rank = max([1] + [a[2].shape[1] for a in bargs if a[2] is not None])
@@ -221,7 +238,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if cached is not False:
             return cached
         self._native_flat = None
-        if self._native is None or not isinstance(self._data, (list, tuple)):
+        if self._native is None or self._NATIVE_KIND == "hessian" or not isinstance(self._data, (list, tuple)):
             return None
         batches = []
         for bi, (X, y) in enumerate(self._data):
@@ -367,6 +384,7 @@ class HessianLinearOperator(CurvatureLinearOperator):
     """Hessian of the empirical risk, ``c sum_n nabla^2_theta l(f(x_n), y_n)``."""
 
     SELF_ADJOINT: bool = True
+    _NATIVE_KIND = "hessian"
 
     def _init_mp(self) -> None:
         self._vp = make_batch_hessian_vector_product(self._model_func, self._loss_func)

@@ -137,3 +137,14 @@ class NativeMLP:
         OW = [out[i] for i in self.w_idx]
         Ob = [None if i is None else out[i] for i in self.b_idx]
         self.plan.ggn_matvec(self.W, self.b, VW, Vb, OW, Ob, X, loss_kind, loss_scale, alpha, beta, aux=aux)
+
+    def hessian_matvec(self, V: list[Tensor], out: list[Tensor], X: Tensor, G: Tensor, loss_kind: int,
+                       loss_scale: float, alpha: float, beta: float) -> None:
+        """``out = beta*out + alpha * H V`` (exact Hessian) for one mini-batch; ``G`` = gradient of the
+        reduced mini-batch loss w.r.t. the model output."""
+        VW = [V[i] for i in self.w_idx]
+        Vb = [None if i is None else V[i] for i in self.b_idx]
+        OW = [out[i] for i in self.w_idx]
+        Ob = [None if i is None else out[i] for i in self.b_idx]
+        self.plan.hessian_matvec(self.W, self.b, VW, Vb, OW, Ob, X, G, loss_kind, loss_scale, alpha, beta)
+

@@ -183,6 +183,20 @@ long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
  * Returns CLO_EUNSUP unless K % 4 == 0, 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0, aux_rank
  * <= 16 and all operands are 16-byte aligned (the caller then loops clo_mlp_ggn_matvec over columns).
  * ws: clo_mlp_ggn_matmat_ws_floats(L, dims, N, K) floats. */
+/* Exact Hessian-vector product of the mini-batch loss for an MLP (reference hessian.py:13-69:
+ * jvp of the gradient), computed by the R-operator: tangent forward pass, then backpropagation of
+ * the gradient signal AND its directional derivative; every product on the MFMA GEMM engine.
+ *   G [N][C]   gradient of the (reduced) mini-batch loss w.r.t. the model output f
+ *   loss_kind / aux / aux_rank / loss_scale: the loss Hessian w.r.t. f as in clo_mlp_ggn_matvec
+ * out = beta * out + alpha * H v.  Returns CLO_EUNSUP unless dims[0..L-1] % 4 == 0 and the operands
+ * are 16-byte aligned.  ws: clo_mlp_hessian_ws_floats(L, dims, N) floats. */
+long clo_mlp_hessian_ws_floats(int L, const int *dims, int N);
+int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, const float *const *W,
+                           const float *const *b, const float *const *VW, const float *const *Vb,
+                           float *const *OW, float *const *Ob, const float *X, int N, const float *G,
+                           int loss_kind, const float *aux, int aux_rank, float loss_scale, float alpha,
+                           float beta, float *ws, void *stream);
+
 long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int K);
 int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *const *W,
                        const float *const *b, const float *const *VW, const float *const *Vb,
