@@ -81,6 +81,37 @@ def rocprof_avg_us(kernels):
     return tot / cnt if cnt else None
 
 
+def other_points(model, params, device, D: int) -> dict:
+    """Untimed-region extras on the same network (not the headline): larger mini-batches (MFMA-bound
+    regime of SURVEY 8d) and a K = 32 probe block through the K-column kernels."""
+    import curvlinops_amd as C
+
+    def us_per_call(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / n
+
+    out = {}
+    v = torch.rand(D, device=device)
+    for rows in (128, 512):
+        X, y = torch.rand(rows, DIMS[0], device=device), torch.rand(rows, DIMS[3], device=device)
+        G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X, y)], check_deterministic=False)
+        us = us_per_call(lambda: G @ v, 20)
+        out[f"rows{rows}"] = {"us_per_matvec": us, "alg_tflops": 10.0 * rows * D / us / 1e6,
+                              "frac_of_f32_mfma_peak": 10.0 * rows * D / us / 1e6 / 157.3}
+    X, y = torch.rand(8, DIMS[0], device=device), torch.rand(8, DIMS[3], device=device)
+    G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X, y)], check_deterministic=False)
+    V = torch.rand(D, 32, device=device)
+    us = us_per_call(lambda: G @ V, 4)
+    out["k32_columns_rows8"] = {"us_per_column": us / 32, "columns_per_s": 32e6 / us,
+                                "alg_bytes_per_column": 8 * D, "achieved_GBps": 8 * D * 32 / us / 1e3}
+    return out
+
+
 def cpu_baseline(batch: int, budget_s: float = 12.0) -> dict:
     """Time the float32 NumPy oracle on the host cores for a bounded number of matvecs."""
     from oracle import mlp_numpy as O
@@ -239,6 +270,7 @@ def main() -> None:
             "per_family_ms_per_matvec": {k: v["ms"] / nprof for k, v in prof.items()},
         }
         result["cpu_baseline"] = cpu_baseline(args.batch)
+        result["other_points"] = other_points(model, params, device, D)
 
     if rank == 0:
         print(json.dumps(result))
