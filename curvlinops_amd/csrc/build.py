@@ -15,7 +15,7 @@ CSRC = Path(__file__).resolve().parent
 LIB_DIR = CSRC.parent / "lib"
 LIB_PATH = LIB_DIR / "libclo_hip.so"
 SOURCES = ["gemm.hip", "mlp.hip", "stream_ops.hip", "linalg.hip", "conv.hip"]
-HEADERS = ["clo_common.h", "../../include/curvlinops_amd.h"]
+HEADERS = ["clo_common.h", "gemm.h", "../../include/curvlinops_amd.h"]
 
 
 def _hipcc() -> str:
@@ -38,23 +38,33 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not _stale():
         return LIB_PATH
     LIB_DIR.mkdir(exist_ok=True)
-    srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
-    cmd = [
-        _hipcc(),
-        "--offload-arch=gfx950",
-        "-O3",
-        "-std=c++17",
-        "-fPIC",
-        "-shared",
-        "-o",
-        str(LIB_PATH),
-        *srcs,
-    ]
+    srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    obj_dir = LIB_DIR / "obj"
+    obj_dir.mkdir(exist_ok=True)
+
+    def compile_one(src: Path) -> Path:
+        obj = obj_dir / (src.stem + ".o")
+        cmd = [_hipcc(), *flags, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n{res.stdout}\n{res.stderr}")
+        return obj
+
+    # the translation units are independent: compile them side by side, then link
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
+    shutil.rmtree(obj_dir, ignore_errors=True)
     return LIB_PATH
 
 
