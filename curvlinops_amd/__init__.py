@@ -16,6 +16,7 @@ from curvlinops_amd.curvature import (
     HessianLinearOperator,
 )
 from curvlinops_amd.enums import FisherType, KFACType
+from curvlinops_amd.jacobian import JacobianLinearOperator, TransposedJacobianLinearOperator
 from curvlinops_amd.kfac import EKFACLinearOperator, KFACLinearOperator
 from curvlinops_amd.kronecker import (
     BlockDiagonalLinearOperator,
@@ -31,6 +32,8 @@ __all__ = [
     "HessianLinearOperator",
     "GGNLinearOperator",
     "EFLinearOperator",
+    "JacobianLinearOperator",
+    "TransposedJacobianLinearOperator",
     "KFACLinearOperator",
     "EKFACLinearOperator",
     "KroneckerProductLinearOperator",

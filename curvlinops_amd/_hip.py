@@ -89,6 +89,17 @@ _SIGNATURES = {
          c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
     ),
     "clo_mlp_hessian_ws_floats": (c_long, [c_int, POINTER(c_int), c_int]),
+    "clo_mlp_jac_ws_floats": (c_long, [c_int, POINTER(c_int), c_int]),
+    "clo_mlp_jvp": (
+        c_int,
+        [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+         POINTER(c_void_p), _PF, c_int, _PF, _PF, c_void_p],
+    ),
+    "clo_mlp_vjp": (
+        c_int,
+        [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+         POINTER(c_void_p), _PF, c_int, _PF, c_float, c_float, _PF, c_void_p],
+    ),
     "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
     "clo_dot_ws_bytes": (c_long, []),
     "clo_dot_f32": (c_int, [_PF, _PF, c_long, c_float, _PF, c_void_p, c_void_p]),
@@ -380,7 +391,7 @@ class MLPPlan:
         if ws is None:
             n = load().clo_mlp_ggn_ws_floats(self.L, self.dims, N)
             ws = torch.empty(n, device=device, dtype=torch.float32)
-            self._ws = {k: v for k, v in self._ws.items() if k[0] in ("mm", "hess")}  # keep only the latest batch size
+            self._ws = {k: v for k, v in self._ws.items() if k[0] in ("mm", "hess", "jac")}  # keep only the latest batch size
             self._ws[key] = ws
         return ws
 
@@ -444,6 +455,31 @@ class MLPPlan:
                                        beta, ws_ptr, stream)
         if rc != 0:
             _check(rc, "clo_mlp_ggn_matmat")
+
+    def _jac_workspace(self, N: int, device) -> Tensor:
+        key = ("jac", N, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.empty(load().clo_mlp_jac_ws_floats(self.L, self.dims, N), device=device, dtype=torch.float32)
+            self._ws = {k: v for k, v in self._ws.items() if k[0] != "jac"}
+            self._ws[key] = ws
+        return ws
+
+    def jvp(self, W, b, VW, Vb, X, out: Tensor) -> None:
+        """``out[n, c] = (J v)[n, c]`` for one mini-batch (``out`` contiguous ``[N, d_L]``)."""
+        N = X.shape[0]
+        rc = load().clo_mlp_jvp(self.L, self.dims, self.acts, self._ptr_array(W), self._ptr_array(b),
+                                self._ptr_array(VW), self._ptr_array(Vb), _pc(X), N, _pc(out),
+                                _pc(self._jac_workspace(N, X.device)), _stream())
+        _check(rc, "clo_mlp_jvp")
+
+    def vjp(self, W, b, OW, Ob, X, U: Tensor, alpha: float, beta: float) -> None:
+        """``out = beta out + alpha J^T U`` for one mini-batch, ``U`` contiguous ``[N, d_L]``."""
+        N = X.shape[0]
+        rc = load().clo_mlp_vjp(self.L, self.dims, self.acts, self._ptr_array(W), self._ptr_array(b),
+                                self._ptr_array(OW), self._ptr_array(Ob), _pc(X), N, _pc(U), alpha, beta,
+                                _pc(self._jac_workspace(N, X.device)), _stream())
+        _check(rc, "clo_mlp_vjp")
 
     def hessian_supported(self) -> bool:
         """Shape conditions of ``clo_mlp_hessian_matvec`` (alignment is checked by the library)."""

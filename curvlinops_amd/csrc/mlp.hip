@@ -1585,6 +1585,12 @@ __global__ void hess_combine_kernel(const float *__restrict__ dA, const float *_
     d[e] = ph * g;
   }
 }
+__global__ void mask_scale_kernel(float *__restrict__ y, const float *__restrict__ x,
+                                  const float *__restrict__ m, long n, float s) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long)gridDim.x * blockDim.x)
+    y[e] = s * x[e] * m[e];
+}
 __global__ void scale_copy_kernel(float *__restrict__ y, const float *__restrict__ x, long n, float s) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (long)gridDim.x * blockDim.x)
@@ -2453,6 +2459,117 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
     CLO_CHECK_LAUNCH("hess_combine_kernel");
     std::swap(dcur, dnext);
     std::swap(Rcur, Rnext);
+  }
+  return CLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Jacobian / transposed-Jacobian products of an MLP (reference jacobian.py:14-358): the forward +
+// JVP half and the VJP half of the GGN product, exposed on their own.
+// ------------------------------------------------------------------------------------------
+extern "C" long clo_mlp_jac_ws_floats(int L, const int *dims, int N) {
+  if (L <= 0 || !dims || N < 0) return 0;
+  long total = 0;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  for (int l = 1; l <= L; ++l) total += 3L * N * dims[l];
+  return total + 2L * N * dmax + gemm_ws_floats(N, dmax) + 256;
+}
+
+// JV[n][c] = (J_theta f(x_n) v)[c]: tangent forward pass (one fused launch per layer).  Needs
+// dims[0..L-1] % 4 == 0 and 16-byte aligned operands (CLO_EUNSUP otherwise).
+extern "C" int clo_mlp_jvp(int L, const int *dims, const int *acts, const float *const *W,
+                           const float *const *b, const float *const *VW, const float *const *Vb,
+                           const float *X, int N, float *JV, float *ws, void *stream) {
+  CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW, "clo_mlp_jvp: bad layer table");
+  CLO_REQUIRE(N >= 1 && X && JV && ws, "clo_mlp_jvp: bad batch / output / workspace");
+  bool ok = aligned16(X) && aligned16(ws);
+  for (int l = 0; l < L; ++l) {
+    CLO_REQUIRE(dims[l] > 0 && dims[l + 1] > 0 && acts[l] >= 0 && acts[l] <= 3, "clo_mlp_jvp: bad layer %d", l);
+    CLO_REQUIRE(W[l] && VW[l], "clo_mlp_jvp: null weight pointer in layer %d", l);
+    ok = ok && dims[l] % 4 == 0 && aligned16(W[l]) && aligned16(VW[l]);
+  }
+  if (!ok) {
+    set_error("clo_mlp_jvp: needs layer inputs %% 4 == 0 and 16-byte aligned operands");
+    return CLO_EUNSUP;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  float *p = ws;
+  float *a[65], *da[65], *dphi[65];
+  a[0] = const_cast<float *>(X); da[0] = nullptr;
+  for (int l = 1; l <= L; ++l) {
+    const long sz = (long)N * dims[l];
+    a[l] = p; p += sz; da[l] = p; p += sz; dphi[l] = p; p += sz;
+  }
+  da[L] = JV;
+  p += 2L * N * dmax;
+  float *gws = p;
+  const long gws_sz = gemm_ws_floats(N, dmax);
+  for (int l = 1; l <= L; ++l) {
+    int rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
+                             Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l],
+                             acts[l - 1], gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+  }
+  return CLO_OK;
+}
+
+// out = beta out + alpha J^T U for U [N][d_L]: plain forward pass (activations and their
+// derivatives), then the backward chain on the GEMM engine.  Any widths / alignment.
+extern "C" int clo_mlp_vjp(int L, const int *dims, const int *acts, const float *const *W,
+                           const float *const *b, float *const *OW, float *const *Ob, const float *X,
+                           int N, const float *U, float alpha, float beta, float *ws, void *stream) {
+  CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && OW, "clo_mlp_vjp: bad layer table");
+  CLO_REQUIRE(N >= 1 && X && U && ws, "clo_mlp_vjp: bad batch / cotangent / workspace");
+  for (int l = 0; l < L; ++l) {
+    CLO_REQUIRE(dims[l] > 0 && dims[l + 1] > 0 && acts[l] >= 0 && acts[l] <= 3, "clo_mlp_vjp: bad layer %d", l);
+    CLO_REQUIRE(W[l] && OW[l], "clo_mlp_vjp: null weight pointer in layer %d", l);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  float *p = ws;
+  float *a[65], *dphi[65];
+  a[0] = const_cast<float *>(X);
+  for (int l = 1; l <= L; ++l) {
+    const long sz = (long)N * dims[l];
+    a[l] = p; p += sz; p += sz; dphi[l] = p; p += sz;  // (the da slot of the shared layout stays unused)
+  }
+  float *dcur = p, *dnext = p + (long)N * dmax;
+  p += 2L * N * dmax;
+  float *gws = p;
+  const long gws_sz = gemm_ws_floats(N, dmax);
+  int rc;
+  for (int l = 1; l <= L; ++l) {
+    const int di = dims[l - 1], dout = dims[l];
+    GemmArgs g = gemm_problem(N, dout, di, a[l - 1], di, 1, W[l - 1], 1, di, 0.f, a[l], dout);
+    g.epi = EPI_ACT; g.e_act = acts[l - 1]; g.e_vec = b ? b[l - 1] : nullptr; g.e_out2 = dphi[l];
+    rc = launch_gemm_auto(g, gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+  }
+  // delta_L = alpha * phi'_L * U
+  {
+    const long nc = (long)N * dims[L];
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(ew_grid(nc)), dim3(256), 0, st, dcur, U, dphi[L], nc, alpha);
+    CLO_CHECK_LAUNCH("mask_scale_kernel");
+  }
+  for (int l = L; l >= 1; --l) {
+    const int di = dims[l - 1], dout = dims[l];
+    GemmArgs go = gemm_problem(dout, di, N, dcur, 1, dout, a[l - 1], di, 1, beta, OW[l - 1], di);
+    rc = launch_gemm_auto(go, gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+    if (Ob && Ob[l - 1]) {
+      rc = launch_small_outer(Ob[l - 1], nullptr, dcur, N, dout, 1, beta, nullptr, 0, st);
+      if (rc != CLO_OK) return rc;
+    }
+    if (l == 1) break;
+    GemmArgs gd = gemm_problem(N, di, dout, dcur, dout, 1, W[l - 1], di, 1, 0.f, dnext, di);
+    gd.epi = EPI_MUL; gd.e_mul = dphi[l - 1]; gd.ld_mul = di;
+    rc = launch_gemm_auto(gd, gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+    std::swap(dcur, dnext);
   }
   return CLO_OK;
 }

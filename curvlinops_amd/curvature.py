@@ -238,8 +238,9 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if cached is not False:
             return cached
         self._native_flat = None
-        if self._native is None or self._NATIVE_KIND == "hessian" or not isinstance(self._data, (list, tuple)):
-            return None
+        if (self._native is None or self._NATIVE_KIND not in ("ggn", "ef")
+                or not isinstance(self._data, (list, tuple))):
+            return None  # the flat path is the whole-network GGN-type kernel only
         batches = []
         for bi, (X, y) in enumerate(self._data):
             if not (isinstance(X, Tensor) and X.device == self.device and y.device == self.device):

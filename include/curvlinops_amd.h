@@ -183,6 +183,19 @@ long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
  * Returns CLO_EUNSUP unless K % 4 == 0, 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0, aux_rank
  * <= 16 and all operands are 16-byte aligned (the caller then loops clo_mlp_ggn_matvec over columns).
  * ws: clo_mlp_ggn_matmat_ws_floats(L, dims, N, K) floats. */
+/* Jacobian and transposed-Jacobian products of an MLP (reference jacobian.py:14-358): the
+ * forward+JVP half and the VJP half of the GGN product.
+ *   clo_mlp_jvp: JV [N][d_L] = J v          (CLO_EUNSUP unless dims[0..L-1] % 4 == 0, aligned)
+ *   clo_mlp_vjp: out = beta out + alpha J^T U,  U [N][d_L]     (any widths)
+ * ws: clo_mlp_jac_ws_floats(L, dims, N) floats for either. */
+long clo_mlp_jac_ws_floats(int L, const int *dims, int N);
+int clo_mlp_jvp(int L, const int *dims, const int *acts, const float *const *W, const float *const *b,
+                const float *const *VW, const float *const *Vb, const float *X, int N, float *JV,
+                float *ws, void *stream);
+int clo_mlp_vjp(int L, const int *dims, const int *acts, const float *const *W, const float *const *b,
+                float *const *OW, float *const *Ob, const float *X, int N, const float *U, float alpha,
+                float beta, float *ws, void *stream);
+
 /* Exact Hessian-vector product of the mini-batch loss for an MLP (reference hessian.py:13-69:
  * jvp of the gradient), computed by the R-operator: tangent forward pass, then backpropagation of
  * the gradient signal AND its directional derivative; every product on the MFMA GEMM engine.

@@ -99,6 +99,45 @@ def gen_mlp(curvlinops):
     print("mlp_curvature.npz:", len(out), "arrays")
 
 
+def gen_jacobian(curvlinops):
+    """Jacobian / transposed-Jacobian products (jacobian.py:14-358) on the MLP cases above (same
+    seeds => same nets and data as mlp_curvature.npz; inputs are stored again for self-containment)."""
+    out = {}
+    for idx, (name, dims, acts, bias, loss, red, bsz) in enumerate(MLP_CASES):
+        if dims[0] > 64:
+            continue  # fixture size
+        gen = torch.Generator().manual_seed(1000 + idx)
+        torch.manual_seed(1000 + idx)
+        model = build_mlp(dims, acts, bias)
+        for p in model.parameters():
+            p.data += 0.01 * torch.rand(p.shape, generator=gen)
+        data = make_data(gen, bsz, dims[0], dims[-1], loss)
+        params = dict(model.named_parameters())
+        D = sum(p.numel() for p in params.values())
+        g2 = torch.Generator().manual_seed(5000 + idx)
+        V = torch.rand(D, 3, generator=g2)
+        N = sum(bsz)
+        U = torch.rand(N * dims[-1], 2, generator=g2)
+        rec = {"dims": np.array(dims), "acts": np.array(acts), "bias": np.array(bias), "V": V.numpy(),
+               "U": U.numpy(), "num_batches": np.array(len(data))}
+        for i, (X, y) in enumerate(data):
+            rec[f"X{i}"] = X.numpy()
+            rec[f"y{i}"] = y.numpy()
+        for k, p in params.items():
+            rec[f"param:{k}"] = p.detach().numpy()
+        J = curvlinops.JacobianLinearOperator(model, params, data)
+        JT = curvlinops.TransposedJacobianLinearOperator(model, params, data)
+        rec["J_V"] = (J @ V).detach().numpy()
+        rec["J_v"] = (J @ V[:, 0]).detach().numpy()
+        rec["JT_U"] = (JT @ U).detach().numpy()
+        rec["JT_u"] = (JT @ U[:, 0]).detach().numpy()
+        rec["Jadj_U"] = (J.adjoint() @ U).detach().numpy()
+        for k, val in rec.items():
+            out[f"{name}/{k}"] = val
+    np.savez_compressed(OUT / "jacobian.npz", **out)
+    print("jacobian.npz:", len(out), "arrays")
+
+
 def gen_linops(curvlinops):
     """Kronecker / eigendecomposed / block-diagonal / canonical-converter known answers."""
     from curvlinops.blockdiagonal import BlockDiagonalLinearOperator
@@ -169,9 +208,11 @@ def main():
     import curvlinops
 
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["mlp", "linops", "kfac", "trace"]
+    which = sys.argv[1:] or ["mlp", "jacobian", "linops", "kfac", "trace"]
     if "mlp" in which:
         gen_mlp(curvlinops)
+    if "jacobian" in which:
+        gen_jacobian(curvlinops)
     if "linops" in which:
         gen_linops(curvlinops)
     if "kfac" in which:

@@ -127,6 +127,20 @@ def _vjp(Ws, bs, a, d1, w_out):
     return gW, gb
 
 
+def jacobian_matvec_batch(Ws, bs, acts, X, vWs, vbs):
+    """Mini-batch Jacobian applied to a parameter-space vector: ``[N, C]`` (jacobian.py:33-51)."""
+    a, d1, _ = forward(Ws, bs, acts, X)
+    da, _ = _jvp(Ws, bs, acts, a, d1, vWs, vbs)
+    return da[-1]
+
+
+def jacobian_t_matvec_batch(Ws, bs, acts, X, U):
+    """Transposed mini-batch Jacobian applied to an output-space vector ``U [N, C]``
+    (jacobian.py:77-98): parameter-shaped results."""
+    a, d1, _ = forward(Ws, bs, acts, X)
+    return _vjp(Ws, bs, a, d1, U)
+
+
 def ggn_matvec_batch(Ws, bs, acts, X, y, loss, reduction, vWs, vbs):
     """Mini-batch GGN-vector product (ggn.py:41-72)."""
     a, d1, _ = forward(Ws, bs, acts, X)
