@@ -134,8 +134,9 @@ class EmpiricalRiskMixin:
         plist = list(self._params.values())
         for X, y in self._loop_over_data(desc="batch_prediction_loss_gradient"):
             if self._loss_func is None:
-                with torch.no_grad():
-                    yield (X, y), self._model_func(self._params, X).detach(), None, None
+                with torch.no_grad():  # (never yield inside: the grad mode would leak to the caller)
+                    pred = self._model_func(self._params, X).detach()
+                yield (X, y), pred, None, None
                 continue
             with enable_requires_grad(plist):
                 pred = self._model_func(self._params, X)
