@@ -15,7 +15,13 @@ from curvlinops_amd.curvature import (
     GGNLinearOperator,
     HessianLinearOperator,
 )
+from curvlinops_amd.diag import DiagonalLinearOperator
 from curvlinops_amd.enums import FisherType, KFACType
+from curvlinops_amd.inverse import (
+    CGInverseLinearOperator,
+    LSMRInverseLinearOperator,
+    NeumannInverseLinearOperator,
+)
 from curvlinops_amd.jacobian import JacobianLinearOperator, TransposedJacobianLinearOperator
 from curvlinops_amd.kfac import EKFACLinearOperator, KFACLinearOperator
 from curvlinops_amd.kronecker import (
@@ -34,6 +40,10 @@ __all__ = [
     "EFLinearOperator",
     "JacobianLinearOperator",
     "TransposedJacobianLinearOperator",
+    "DiagonalLinearOperator",
+    "CGInverseLinearOperator",
+    "LSMRInverseLinearOperator",
+    "NeumannInverseLinearOperator",
     "KFACLinearOperator",
     "EKFACLinearOperator",
     "KroneckerProductLinearOperator",

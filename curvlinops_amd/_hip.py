@@ -103,6 +103,8 @@ _SIGNATURES = {
     "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
     "clo_dot_ws_bytes": (c_long, []),
     "clo_dot_f32": (c_int, [_PF, _PF, c_long, c_float, _PF, c_void_p, c_void_p]),
+    "clo_cg_update_f32": (c_int, [_PF, _PF, _PF, _PF, c_long, _PF, _PF, _PF, c_void_p, c_void_p]),
+    "clo_cg_direction_f32": (c_int, [_PF, _PF, c_long, _PF, _PF, c_void_p]),
     "clo_transpose_f32": (c_int, [_PF, _PF, c_long, c_long, c_void_p]),
     "clo_rowscale_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_int, c_float, c_void_p]),
     "clo_pack_probes_f32": (c_int, [_PF, c_long, c_long, c_uint64, c_int, c_void_p]),

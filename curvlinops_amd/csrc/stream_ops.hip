@@ -188,6 +188,53 @@ __global__ __launch_bounds__(256) void dot_final_kernel(const double *__restrict
   if (threadIdx.x == 0) out[0] = (float)(scale * ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])));
 }
 
+// ---- fused vector updates of conjugate gradients (single right-hand side) --------------------
+// x += a p ; r -= a ap ; partial sums of r.r      with a = rz / pap read from device scalars
+__global__ __launch_bounds__(256) void cg_update_kernel(float *__restrict__ x, float *__restrict__ r,
+                                                        const float *__restrict__ p,
+                                                        const float *__restrict__ ap, long n,
+                                                        const float *__restrict__ rz,
+                                                        const float *__restrict__ pap,
+                                                        double *__restrict__ part) {
+  __shared__ double s_w[4];
+  const float den = pap[0];
+  const float a = fabsf(den) > 1e-30f ? rz[0] / den : 0.f;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(r) |
+                     reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(ap)) & 15u) == 0;
+  const long n4 = vec ? n / 4 : 0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 pv = reinterpret_cast<const float4 *>(p)[i], av = reinterpret_cast<const float4 *>(ap)[i];
+    float4 xv = reinterpret_cast<float4 *>(x)[i], rv = reinterpret_cast<float4 *>(r)[i];
+    xv.x = fmaf(a, pv.x, xv.x); xv.y = fmaf(a, pv.y, xv.y); xv.z = fmaf(a, pv.z, xv.z); xv.w = fmaf(a, pv.w, xv.w);
+    rv.x = fmaf(-a, av.x, rv.x); rv.y = fmaf(-a, av.y, rv.y); rv.z = fmaf(-a, av.z, rv.z); rv.w = fmaf(-a, av.w, rv.w);
+    reinterpret_cast<float4 *>(x)[i] = xv;
+    reinterpret_cast<float4 *>(r)[i] = rv;
+    s0 = fmaf(rv.x, rv.x, s0); s1 = fmaf(rv.y, rv.y, s1); s2 = fmaf(rv.z, rv.z, s2); s3 = fmaf(rv.w, rv.w, s3);
+  }
+  double acc = ((double)s0 + s1) + ((double)s2 + s3);
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    x[i] = fmaf(a, p[i], x[i]);
+    const float rv = fmaf(-a, ap[i], r[i]);
+    r[i] = rv;
+    acc += (double)rv * rv;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+// p = z + (num / den) p
+__global__ void cg_direction_kernel(float *__restrict__ p, const float *__restrict__ z, long n,
+                                    const float *__restrict__ num, const float *__restrict__ den) {
+  const float d = den[0];
+  const float b = fabsf(d) > 1e-30f ? num[0] / d : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    p[i] = fmaf(b, p[i], z[i]);
+}
+
 }  // namespace clo
 
 using namespace clo;
@@ -281,5 +328,33 @@ extern "C" int clo_dot_f32(const float *x, const float *y, long n, float scale, 
   CLO_CHECK_LAUNCH("dot_partial_kernel");
   hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, (const double *)ws, blocks, out, scale);
   CLO_CHECK_LAUNCH("dot_final_kernel");
+  return CLO_OK;
+}
+
+// One conjugate-gradient update for a single right-hand side, step size from DEVICE scalars (no host
+// round trip):  a = rz / pap;  x += a p;  r -= a ap;  rr_out[0] = <r, r>.   ws: clo_dot_ws_bytes().
+extern "C" int clo_cg_update_f32(float *x, float *r, const float *p, const float *ap, long n,
+                                 const float *rz, const float *pap, float *rr_out, void *ws,
+                                 void *stream) {
+  CLO_REQUIRE(n >= 0, "clo_cg_update_f32: negative n");
+  CLO_REQUIRE(rz && pap && rr_out && ws && (n == 0 || (x && r && p && ap)), "clo_cg_update_f32: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)std::max<long>(1, std::min<long>(DOT_BLOCKS, cdiv(n, 1024)));
+  hipLaunchKernelGGL(cg_update_kernel, dim3(blocks), dim3(256), 0, st, x, r, p, ap, n, rz, pap, (double *)ws);
+  CLO_CHECK_LAUNCH("cg_update_kernel");
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, (const double *)ws, blocks, rr_out, 1.f);
+  CLO_CHECK_LAUNCH("dot_final_kernel");
+  return CLO_OK;
+}
+
+// New search direction p = z + (num / den) p with num, den device scalars (beta = rz_new / rz_old).
+extern "C" int clo_cg_direction_f32(float *p, const float *z, long n, const float *num, const float *den,
+                                    void *stream) {
+  CLO_REQUIRE(n >= 0, "clo_cg_direction_f32: negative n");
+  if (n == 0) return CLO_OK;
+  CLO_REQUIRE(p && z && num && den, "clo_cg_direction_f32: null pointer");
+  hipLaunchKernelGGL(cg_direction_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, z, n,
+                     num, den);
+  CLO_CHECK_LAUNCH("cg_direction_kernel");
   return CLO_OK;
 }

@@ -251,6 +251,13 @@ class _SumPyTorchLinearOperator(PyTorchLinearOperator):
     def _matmat(self, X: list[Tensor]) -> list[Tensor]:
         return [a + b for a, b in zip(self._A._matmat(X), self._B._matmat(X))]
 
+    def __matmul__(self, X):
+        # flat operands go through the summands' own `@` (and thus their fast paths), not through
+        # the tensor-list detour
+        if isinstance(X, Tensor) and X.dim() in (1, 2):
+            return (self._A @ X).add_(self._B @ X)
+        return super().__matmul__(X)
+
     def _adjoint(self) -> "_SumPyTorchLinearOperator":
         return _SumPyTorchLinearOperator(self._A.adjoint(), self._B.adjoint())
 
@@ -273,6 +280,11 @@ class _ScalePyTorchLinearOperator(PyTorchLinearOperator):
 
     def _matmat(self, X: list[Tensor]) -> list[Tensor]:
         return [self._scalar * y for y in self._A._matmat(X)]
+
+    def __matmul__(self, X):
+        if isinstance(X, Tensor) and X.dim() in (1, 2):
+            return (self._A @ X).mul_(self._scalar)
+        return super().__matmul__(X)
 
     def _adjoint(self) -> "_ScalePyTorchLinearOperator":
         return _ScalePyTorchLinearOperator(self._A.adjoint(), self._scalar)

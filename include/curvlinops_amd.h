@@ -239,6 +239,16 @@ int clo_pack_probes_f32(float *out, long D, long K, uint64_t seed, int dist, voi
 long clo_dot_ws_bytes(void);
 int clo_dot_f32(const float *x, const float *y, long n, float scale, float *out, void *ws, void *stream);
 
+/* Fused vector updates of conjugate gradients for one right-hand side (the consumer of the matvec in
+ * reference inverse.py:54-140); step sizes are formed on the device from the scalars the previous
+ * kernels left there, so an iteration needs no host synchronisation:
+ *   clo_cg_update_f32   : a = rz / pap;  x += a p;  r -= a ap;  rr_out[0] = <r, r>   (ws as clo_dot)
+ *   clo_cg_direction_f32: p = z + (num / den) p */
+int clo_cg_update_f32(float *x, float *r, const float *p, const float *ap, long n, const float *rz,
+                      const float *pap, float *rr_out, void *ws, void *stream);
+int clo_cg_direction_f32(float *p, const float *z, long n, const float *num, const float *den,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif
