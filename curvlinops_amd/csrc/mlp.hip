@@ -1294,31 +1294,32 @@ __global__ void small_outer_reduce_kernel(float *__restrict__ out, const float *
 //   dprev    : GEMM delta_{l-1} = phi' * (W_l^T delta_l) with N K columns
 // Tangents / deltas are stored feature-major: [d_l][N][K].  N <= 8 rows per pass, K % 4 == 0, K <= 64.
 // ------------------------------------------------------------------------------------------
-constexpr int KC_WAVES = 4;   // waves of a kfwd block: split the contraction among themselves
-constexpr int KC_TPW = 2;     // MFMA tiles per wave
+constexpr int KC_WAVES = 8;   // waves of a kfwd block: split the contraction among themselves
+                              // (1 tile x 8 waves measured best among {1,2,3,4} tiles x {1,2,4,8} waves)
+constexpr int KC_TPW = 1;     // MFMA tiles per wave (1 measured best: more, smaller blocks)
 
 // One MFMA tile = 16 "columns" c = (feature f = c / G, column quad kq = c % G), G = K / 4; lane
 // (c, s = lane >> 4) loads ONE float4 V[j + f][i][4 kq ..] per i and feeds four MFMAs (one per
 // column of the quad), all with the A operand a[n][i].  k-slot s takes i = ib + 4 s + t in step t,
 // so the A operand is one float4 of row n per 16 i.
-template <bool ACC>
-__global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
+template <bool ACC, int TPW, int KW>
+__global__ __launch_bounds__(KW * 64) void kfwd_stream_kernel(
     const float *__restrict__ V, long ldk, const float *__restrict__ Vb,
     const float *__restrict__ a, const float *__restrict__ dphi, float *__restrict__ dA, int N,
     int K, int d_in, int d_out, int i_per_wave) {
-  __shared__ float s_red[KC_WAVES][KC_TPW][4][4][64];  // [wave][tile][m][r][lane]
+  __shared__ float s_red[KW][TPW][4][4][64];  // [wave][tile][m][r][lane]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, s = lane >> 4;
   const int G = K >> 2, FPT = 16 / G;        // features per tile
   const int f = c / G, kq = c - f * G;
   const bool cvalid = f < FPT;
-  const int j0 = blockIdx.x * FPT * KC_TPW;
+  const int j0 = blockIdx.x * FPT * TPW;
   const int wb = min(wave * i_per_wave, d_in), we = min(d_in, wb + i_per_wave);
 
-  const float *pV[KC_TPW];
+  const float *pV[TPW];
 #pragma unroll
-  for (int t = 0; t < KC_TPW; ++t) {
+  for (int t = 0; t < TPW; ++t) {
     const int j = min(j0 + t * FPT + (cvalid ? f : 0), d_out - 1);
     pV[t] = V + ((long)j * d_in) * ldk + 4 * (cvalid ? kq : 0);
   }
@@ -1327,9 +1328,9 @@ __global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
   const unsigned amask = n < N ? 0xffffffffu : 0u;
   const float *pa = a + (long)min(n, N - 1) * d_in + 4 * s;
 
-  f32x4 acc[KC_TPW][4];
+  f32x4 acc[TPW][4];
 #pragma unroll
-  for (int t = 0; t < KC_TPW; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1337,13 +1338,13 @@ __global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
     const bool aok = ib + 4 * s + 3 < we;   // d_in % 4 == 0 and ranges are multiples of 16
     float4 av = ld4(pa + (aok ? ib : wb));
     const unsigned am = aok ? amask : 0u;
-    float4 bv[KC_TPW][4];
+    float4 bv[TPW][4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int i = ib + 4 * s + st;
       const long off = (long)(i < we ? i : wb) * ldk;
 #pragma unroll
-      for (int t = 0; t < KC_TPW; ++t) bv[t][st] = ld4(pV[t] + off);
+      for (int t = 0; t < TPW; ++t) bv[t][st] = ld4(pV[t] + off);
     }
     const float avs[4] = {__uint_as_float(__float_as_uint(av.x) & am),
                           __uint_as_float(__float_as_uint(av.y) & am),
@@ -1352,7 +1353,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
-      for (int t = 0; t < KC_TPW; ++t) {
+      for (int t = 0; t < TPW; ++t) {
         const float4 b = bv[t][st];
         const float bx = __uint_as_float(__float_as_uint(b.x) & bmask);
         const float by = __uint_as_float(__float_as_uint(b.y) & bmask);
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
       }
   }
 #pragma unroll
-  for (int t = 0; t < KC_TPW; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1373,10 +1374,12 @@ __global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
   __syncthreads();
   // D layout: row n = 4 (lane >> 4) + r, column c.  Wave w finishes r = w: sums the K ranges and
   // writes the quad's four columns as one float4.
-  const int r = wave, nn = 4 * s + r;
-  if (!cvalid || nn >= N) return;
+  if (!cvalid) return;
+  for (int r = wave; r < 4; r += KW) {
+  const int nn = 4 * s + r;
+  if (nn >= N) continue;
 #pragma unroll
-  for (int t = 0; t < KC_TPW; ++t) {
+  for (int t = 0; t < TPW; ++t) {
     const int j = j0 + t * FPT + f;
     if (j >= d_out) continue;
     float o[4];
@@ -1384,7 +1387,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
     for (int m = 0; m < 4; ++m) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < KC_WAVES; ++w) v += s_red[w][t][m][r][lane];
+      for (int w = 0; w < KW; ++w) v += s_red[w][t][m][r][lane];
       o[m] = v;
     }
     float *dst = dA + ((long)j * N + nn) * K + 4 * kq;
@@ -1398,6 +1401,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void kfwd_stream_kernel(
     }
     const float dp = dphi ? dphi[(long)nn * d_out + j] : 1.f;
     *reinterpret_cast<float4 *>(dst) = make_float4(dp * o[0], dp * o[1], dp * o[2], dp * o[3]);
+  }
   }
 }
 
@@ -2308,11 +2312,11 @@ extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const
       const float *dp = (l == L && last_linear) ? nullptr : dphi[l];
       ProfScope prof(0, 4.0 * di * dout * K, st);
       if (l >= 2)
-        hipLaunchKernelGGL(kfwd_stream_kernel<true>, grid, block, 0, st, VW[l - 1], ldk, vb, a[l - 1],
-                           dp, dA[l], nn, K, di, dout, ipw);
+        hipLaunchKernelGGL((kfwd_stream_kernel<true, KC_TPW, KC_WAVES>), grid, block, 0, st, VW[l - 1], ldk, vb,
+                           a[l - 1], dp, dA[l], nn, K, di, dout, ipw);
       else
-        hipLaunchKernelGGL(kfwd_stream_kernel<false>, grid, block, 0, st, VW[l - 1], ldk, vb, a[l - 1],
-                           dp, dA[l], nn, K, di, dout, ipw);
+        hipLaunchKernelGGL((kfwd_stream_kernel<false, KC_TPW, KC_WAVES>), grid, block, 0, st, VW[l - 1], ldk, vb,
+                           a[l - 1], dp, dA[l], nn, K, di, dout, ipw);
       CLO_CHECK_LAUNCH("kfwd_stream_kernel");
     }
     // ---- output-space curvature per (n, k), in place: dA_L becomes delta_L
