@@ -30,7 +30,7 @@ from curvlinops_amd.kronecker import (
     KroneckerProductLinearOperator,
 )
 from curvlinops_amd.linop import PyTorchLinearOperator
-from curvlinops_amd.trace import hutchinson_trace, hutchpp_trace
+from curvlinops_amd.trace import hutchinson_diag, hutchinson_squared_fro, hutchinson_trace, hutchpp_trace
 
 __all__ = [
     "PyTorchLinearOperator",
@@ -55,4 +55,6 @@ __all__ = [
     "KFACType",
     "hutchinson_trace",
     "hutchpp_trace",
+    "hutchinson_diag",
+    "hutchinson_squared_fro",
 ]

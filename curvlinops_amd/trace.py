@@ -134,3 +134,30 @@ def hutchpp_trace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribut
     AG = A @ (G - Q @ (Q.T @ G))
     AG = AG - Q @ (Q.T @ AG)
     return tr_range + frobenius_inner(G, AG) / N
+
+
+def hutchinson_diag(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribution: str = "rademacher",
+                    probes: Tensor | None = None) -> Tensor:
+    """Hutchinson estimator of the diagonal, ``mean_k g_k * (A g_k)`` (reference
+    ``diagonal/hutchinson.py``); probes packed as for the trace estimators."""
+    dim = assert_is_square(A)
+    assert_matvecs_subseed_dim(A, num_matvecs)
+    G = random_matrix(dim, num_matvecs, distribution, A.device, A.dtype) if probes is None else probes
+    return (G * (A @ G)).sum(dim=1) / num_matvecs
+
+
+def hutchinson_squared_fro(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribution: str = "rademacher",
+                           probes: Tensor | None = None) -> Tensor:
+    """Hutchinson estimator of the squared Frobenius norm, ``mean_k ||A g_k||^2`` (reference
+    ``norm/hutchinson.py``); a wide matrix is applied through its transpose."""
+    if len(A.shape) != 2:
+        raise ValueError(f"A must be a matrix. Got shape {A.shape}.")
+    dim = min(A.shape)
+    if num_matvecs >= dim:
+        raise ValueError(f"num_matvecs ({num_matvecs}) must be less than the minimum dimension of A.")
+    if A.shape[1] > A.shape[0]:
+        A = A.T if isinstance(A, Tensor) else A.adjoint()
+    G = random_matrix(dim, num_matvecs, distribution, A.device, A.dtype) if probes is None else probes
+    AG = A @ G
+    return frobenius_inner(AG, AG) / num_matvecs
+

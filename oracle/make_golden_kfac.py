@@ -155,6 +155,20 @@ def gen_trace(curvlinops, OUT):
             out[f"{dist}/hutchpp"] = M.hutchpp_trace(op, 24, dist).numpy()
         finally:
             H.random_vector, M.random_vector = orig_h, orig_m
+        # diagonal and squared-Frobenius-norm estimators replay the same pool from its start
+        import curvlinops.diagonal.hutchinson as DH
+        import curvlinops.norm.hutchinson as NH
+
+        orig_d, orig_n = DH.random_vector, NH.random_vector
+        DH.random_vector = replay
+        NH.random_vector = replay
+        try:
+            state["i"] = 0
+            out[f"{dist}/hutch_diag"] = DH.hutchinson_diag(op, 12, dist).numpy()
+            state["i"] = 0
+            out[f"{dist}/hutch_fro2"] = NH.hutchinson_squared_fro(op, 12, dist).numpy()
+        finally:
+            DH.random_vector, NH.random_vector = orig_d, orig_n
         out[f"{dist}/pool"] = pool.numpy()
     np.savez_compressed(OUT / "trace.npz", **{f"t/{k}": v for k, v in out.items()})
     print("trace.npz:", len(out), "arrays")

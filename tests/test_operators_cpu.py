@@ -279,6 +279,8 @@ def test_trace_estimators_with_injected_probes():
         assert rel_err(C.hutchinson_trace(op, 12, dist, probes=pool[:, :12]), rec[f"{dist}/hutch"]) < TOL
         got = C.hutchpp_trace(op, 24, dist, probes=(pool[:, :8], pool[:, 8:16]))
         assert rel_err(got, rec[f"{dist}/hutchpp"]) < TOL
+        assert rel_err(C.hutchinson_diag(op, 12, dist, probes=pool[:, :12]), rec[f"{dist}/hutch_diag"]) < TOL
+        assert rel_err(C.hutchinson_squared_fro(op, 12, dist, probes=pool[:, :12]), rec[f"{dist}/hutch_fro2"]) < TOL
     torch.manual_seed(0)
     est = C.hutchinson_trace(op, 29)
     assert abs(est - A.trace()) / A.trace() < 0.5

@@ -335,6 +335,9 @@ def test_trace_estimators_gpu(dev):
         assert rel_err(C.hutchinson_trace(op, 12, dist, probes=pool[:, :12].contiguous()), rec[f"{dist}/hutch"]) < TOL
         got = C.hutchpp_trace(op, 24, dist, probes=(pool[:, :8].contiguous(), pool[:, 8:16].contiguous()))
         assert rel_err(got, rec[f"{dist}/hutchpp"]) < 1e-3
+        p12 = pool[:, :12].contiguous()
+        assert rel_err(C.hutchinson_diag(op, 12, dist, probes=p12), rec[f"{dist}/hutch_diag"]) < TOL
+        assert rel_err(C.hutchinson_squared_fro(op, 12, dist, probes=p12), rec[f"{dist}/hutch_fro2"]) < TOL
     torch.manual_seed(0)
     ests = torch.stack([C.hutchinson_trace(op, 29) for _ in range(200)])
     assert abs(ests.mean() - A.trace()) / A.trace() < 0.05
