@@ -39,6 +39,10 @@ def main():
     torch.manual_seed(0)
     if args.model == "lenet":
         model, shape, B = lenet5(), (1, 32, 32), args.batch or 1024
+    elif args.model == "encoder":  # 12-layer d = 768 encoder (C5 net): Linear layers with weight sharing
+        from benchmarks.models import Encoder
+
+        model, shape, B = Encoder(), (128, 768), args.batch or 8
     else:
         model, shape, B = ResNet18(), (3, 32, 32), args.batch or 512
     model = model.to(dev).eval()
@@ -56,7 +60,11 @@ def main():
     mv_flops = sum(2.0 * (b[0] ** 2 * b[1] + b[0] * b[1] ** 2) for b in blocks if len(b) == 2)
     res["kfac_matvec_tflops"] = mv_flops / (res["kfac_matvec_ms"] * 1e-3) / 1e12
     rows = {}
-    hooks = [m.register_forward_hook(lambda mod, i, o, rows=rows: rows.__setitem__(mod, o.numel() // (o.shape[0] * o.shape[1])))
+    def shared_positions(mod, o):  # spatial positions of a conv output, sequence positions of a linear one
+        feat = o.shape[1] if isinstance(mod, nn.Conv2d) else o.shape[-1]
+        return o.numel() // (o.shape[0] * feat)
+
+    hooks = [m.register_forward_hook(lambda mod, i, o, rows=rows: rows.__setitem__(mod, shared_positions(mod, o)))
              for m in model.modules() if isinstance(m, (nn.Conv2d, nn.Linear))]
     with torch.no_grad():
         model(X[:2])

@@ -30,3 +30,4 @@ python benchmarks/bench_kfac.py resnet18 --ekfac > $OUT/r01_kfac_resnet18_b512.j
 python benchmarks/bench_general.py resnet18 > $OUT/r01_general_resnet18_b512.json 2>/dev/null
 python benchmarks/bench_general.py encoder > $OUT/r01_general_encoder_c5.json 2>/dev/null
 python tools/probe_cols.py 8 32 64 > $OUT/r01_c2_columns.txt 2>&1
+python benchmarks/bench_kfac.py encoder > $OUT/r01_kfac_encoder_b8.json 2>/dev/null
