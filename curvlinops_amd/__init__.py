@@ -17,6 +17,7 @@ from curvlinops_amd.curvature import (
 )
 from curvlinops_amd.diag import DiagonalLinearOperator
 from curvlinops_amd.enums import FisherType, KFACType
+from curvlinops_amd.ggn_diagonal import GGNDiagonalLinearOperator
 from curvlinops_amd.inverse import (
     CGInverseLinearOperator,
     LSMRInverseLinearOperator,
@@ -41,6 +42,7 @@ __all__ = [
     "JacobianLinearOperator",
     "TransposedJacobianLinearOperator",
     "DiagonalLinearOperator",
+    "GGNDiagonalLinearOperator",
     "CGInverseLinearOperator",
     "LSMRInverseLinearOperator",
     "NeumannInverseLinearOperator",

@@ -403,25 +403,29 @@ def compute_eigenvalue_correction(g: Tensor, Qg: Tensor, a: Tensor | None, Qa: T
 
     ``g``: ``[V, B, S, d_out]``; ``a``: ``[B, S, d_in]`` (reference
     ``computers/ekfac_hooks.py:25-238`` -- both of its strategies compute this quantity)."""
-    if (a is None) != (Qa is None):
+    identity = Qg is None  # no rotation at all: squared per-example gradients (the GGN diagonal)
+    if not identity and (a is None) != (Qa is None):
         raise ValueError(f"Both (a, aaT_eigvecs) must be None or Tensor. Got {(type(a), type(Qa))}.")
     V, B, S, d1 = g.shape
-    native = is_native_tensor(g) and is_native_tensor(Qg)
+    native = is_native_tensor(g) and (identity or is_native_tensor(Qg))
     if a is None:
         gs = g.sum(dim=2).reshape(V * B, d1)
-        rot = _hip.gemm(gs.contiguous(), Qg) if native else gs @ Qg
-        return rot.square_().sum(dim=0)
+        rot = gs if identity else (_hip.gemm(gs.contiguous(), Qg) if native else gs @ Qg)
+        return rot.square().sum(dim=0)
     d2 = a.shape[-1]
     if native:
-        g_rot = _hip.gemm(g.reshape(V * B * S, d1).contiguous(), Qg).view(V, B, S, d1)
-        a_rot = _hip.gemm(a.reshape(B * S, d2).contiguous(), Qa).view(B, S, d2)
+        if identity:
+            g_rot, a_rot = g.contiguous(), a.contiguous()
+        else:
+            g_rot = _hip.gemm(g.reshape(V * B * S, d1).contiguous(), Qg).view(V, B, S, d1)
+            a_rot = _hip.gemm(a.reshape(B * S, d2).contiguous(), Qa).view(B, S, d2)
         out = torch.zeros(d1, d2, device=g.device, dtype=torch.float32)
         for v in range(V):
             # per-example products P_n = g_rot_n^T a_rot_n, squared and summed over n, fused
             _hip.gemm_sqsum(g_rot[v].transpose(1, 2), a_rot, out, beta=1.0)
         return out
-    g_rot = g @ Qg
-    a_rot = a @ Qa
+    g_rot = g if identity else g @ Qg
+    a_rot = a if identity else a @ Qa
     per_example = torch.einsum("vnsi,nsj->vnij", g_rot, a_rot)
     return per_example.square_().sum(dim=(0, 1))
 
@@ -489,8 +493,39 @@ class HipEKFACComputer(HipKFACComputer):
         corr = compute_loss_correction(batch_size, self._num_per_example_loss_terms,
                                        self._loss_func.reduction, self._N_data)
         key = tuple(group.values())
-        upd = compute_eigenvalue_correction(g, Qg[key], a, Qa.get(key)).mul_(corr)
+        if Qg is None:  # identity bases (GGN diagonal)
+            upd = compute_eigenvalue_correction(g, None, a, None).mul_(corr)
+        else:
+            upd = compute_eigenvalue_correction(g, Qg[key], a, Qa.get(key)).mul_(corr)
         if key in lam:
             lam[key].add_(upd)
         else:
             lam[key] = upd
+
+
+class HipGGNDiagonalComputer(HipEKFACComputer):
+    """Diagonal of the GGN / type-2 Fisher (reference ``computers/ggn_diagonal.py:21-232``) for nets
+    whose parameters all belong to ``Linear`` / ``Conv2d`` layers: the EKFAC eigenvalue sweep with
+    identity bases, i.e. ``sum_{v,n} (sum_s g_vns a_ns^T)^2`` per layer on the fused
+    ``clo_gemm_sqsum_f32`` kernel -- no per-example gradients are materialised."""
+
+    def compute(self) -> dict[str, Tensor]:
+        with _use_params(self._model_module, self._params):
+            mapping = self.compute_parameter_groups(self._params, self._model_module, False)
+            lam = self._eigenvalue_correction(None, None, mapping)
+        out: dict[str, Tensor] = {}
+        for group in mapping:
+            val = lam[tuple(group.values())]
+            if "W" in group:
+                W = self._params[group["W"]]
+                if "b" in group:
+                    out[group["b"]] = val[:, -1].contiguous()
+                    val = val[:, :-1]
+                out[group["W"]] = val.reshape(W.shape)
+            else:
+                out[group["b"]] = val
+        missing = [n for n in self._params if n not in out]
+        if missing:
+            raise NotImplementedError(f"Parameters outside Linear / Conv2d layers: {missing}.")
+        return {n: out[n] for n in self._params}
+

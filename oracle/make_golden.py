@@ -138,6 +138,48 @@ def gen_jacobian(curvlinops):
     print("jacobian.npz:", len(out), "arrays")
 
 
+def gen_ggn_diagonal(curvlinops):
+    """Exact GGN diagonal (ggn_diagonal.py / computers/ggn_diagonal.py) on small MLPs and a CNN."""
+    out = {}
+    cases = [(i, c) for i, c in enumerate(MLP_CASES) if c[1][0] <= 64]
+    for idx, (name, dims, acts, bias, loss, red, bsz) in cases:
+        gen = torch.Generator().manual_seed(1000 + idx)
+        torch.manual_seed(1000 + idx)
+        model = build_mlp(dims, acts, bias)
+        for p in model.parameters():
+            p.data += 0.01 * torch.rand(p.shape, generator=gen)
+        data = make_data(gen, bsz, dims[0], dims[-1], loss)
+        params = dict(model.named_parameters())
+        op = curvlinops.GGNDiagonalLinearOperator(model, LOSS[loss](reduction=red), params, data)
+        rec = {"dims": np.array(dims), "acts": np.array(acts), "bias": np.array(bias), "loss": np.array(loss),
+               "reduction": np.array(red), "num_batches": np.array(len(data)), "kind": np.array("mlp"),
+               "diag": torch.cat([d.flatten() for d in op._diagonal]).detach().numpy()}
+        for i, (X, y) in enumerate(data):
+            rec[f"X{i}"], rec[f"y{i}"] = X.numpy(), y.numpy()
+        for k, p in params.items():
+            rec[f"param:{k}"] = p.detach().numpy()
+        for k, val in rec.items():
+            out[f"{name}/{k}"] = val
+    # a small CNN: conv (padding, stride) -> relu -> flatten -> linear, CE mean
+    gen = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    model = nn.Sequential(nn.Conv2d(2, 3, 3, padding=1, stride=2), nn.ReLU(), nn.Flatten(start_dim=-3),
+                          nn.Linear(3 * 3 * 3, 4))
+    data = [(torch.rand(B, 2, 6, 6, generator=gen), torch.randint(0, 4, (B,), generator=gen)) for B in (3, 5)]
+    params = dict(model.named_parameters())
+    op = curvlinops.GGNDiagonalLinearOperator(model, nn.CrossEntropyLoss(), params, data)
+    rec = {"kind": np.array("cnn"), "num_batches": np.array(2),
+           "diag": torch.cat([d.flatten() for d in op._diagonal]).detach().numpy()}
+    for i, (X, y) in enumerate(data):
+        rec[f"X{i}"], rec[f"y{i}"] = X.numpy(), y.numpy()
+    for k, p in params.items():
+        rec[f"param:{k}"] = p.detach().numpy()
+    for k, val in rec.items():
+        out[f"cnn_ce_mean/{k}"] = val
+    np.savez_compressed(OUT / "ggn_diagonal.npz", **out)
+    print("ggn_diagonal.npz:", len(out), "arrays")
+
+
 def gen_linops(curvlinops):
     """Kronecker / eigendecomposed / block-diagonal / canonical-converter known answers."""
     from curvlinops.blockdiagonal import BlockDiagonalLinearOperator
@@ -208,11 +250,13 @@ def main():
     import curvlinops
 
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["mlp", "jacobian", "linops", "kfac", "trace"]
+    which = sys.argv[1:] or ["mlp", "jacobian", "ggn_diagonal", "linops", "kfac", "trace"]
     if "mlp" in which:
         gen_mlp(curvlinops)
     if "jacobian" in which:
         gen_jacobian(curvlinops)
+    if "ggn_diagonal" in which:
+        gen_ggn_diagonal(curvlinops)
     if "linops" in which:
         gen_linops(curvlinops)
     if "kfac" in which:
