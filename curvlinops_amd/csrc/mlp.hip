@@ -369,23 +369,40 @@ __global__ __launch_bounds__(MF_WAVES * 64) void fwd_mfma_kernel(
   constexpr int U = 2;  // steps per load group
   const int nfull = klen >> 4;
   int step = 0;
-  for (; step + U <= nfull; step += U) {
-    float4 av[U][RG], bv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int g = 0; g < RG; ++g) av[u][g] = CLO_LDW(pA[g] + (step + u) * 16);
-      bv[u] = ld4(pBs + (step + u) * 16);
-    }
+  // two register buffers: the weight loads of group g + 1 are in flight while group g feeds the MFMAs
+  struct Group { float4 av[U][RG]; };
+  auto load = [&](Group &gr, int st0) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
+      for (int g = 0; g < RG; ++g) gr.av[u][g] = CLO_LDW(pA[g] + (st0 + u) * 16);
+  };
+  auto mma = [&](const Group &gr, int st0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float4 bv = ld4(pBs + (st0 + u) * 16);
+#pragma unroll
       for (int g = 0; g < RG; ++g) {
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].x, bv[u].x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].y, bv[u].y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].z, bv[u].z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].w, bv[u].w, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr.av[u][g].x, bv.x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr.av[u][g].y, bv.y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr.av[u][g].z, bv.z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr.av[u][g].w, bv.w, acc[g], 0, 0, 0);
       }
+    }
+  };
+  {
+    Group ga, gb;
+    const int ngroups = nfull / U;
+    if (ngroups > 0) load(ga, 0);
+    int gi = 0;
+    for (; gi + 1 < ngroups; gi += 2) {
+      load(gb, (gi + 1) * U);
+      mma(ga, gi * U);
+      if (gi + 2 < ngroups) load(ga, (gi + 2) * U);
+      mma(gb, (gi + 1) * U);
+    }
+    if (gi < ngroups) mma(ga, gi * U);
+    step = ngroups * U;
   }
   // remaining full steps and the partial one: B is zero beyond klen, A only needs a valid address
   for (; step * 16 < klen; ++step) {
@@ -1307,6 +1324,8 @@ __global__ __launch_bounds__(KW * 64) void kfwd_stream_kernel(
     const float *__restrict__ V, long ldk, const float *__restrict__ Vb,
     const float *__restrict__ a, const float *__restrict__ dphi, float *__restrict__ dA, int N,
     int K, int d_in, int d_out, int i_per_wave) {
+  // PERSISTENT: the grid is ~2 blocks per CU (the occupancy at which a read stream peaks on this
+  // part, profiles/r01_ubench_read_stream.txt) and every block walks feature tiles tb, tb + grid, ...
   __shared__ float s_red[KW][TPW][4][4][64];  // [wave][tile][m][r][lane]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1314,94 +1333,111 @@ __global__ __launch_bounds__(KW * 64) void kfwd_stream_kernel(
   const int G = K >> 2, FPT = 16 / G;        // features per tile
   const int f = c / G, kq = c - f * G;
   const bool cvalid = f < FPT;
-  const int j0 = blockIdx.x * FPT * TPW;
   const int wb = min(wave * i_per_wave, d_in), we = min(d_in, wb + i_per_wave);
-
-  const float *pV[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int j = min(j0 + t * FPT + (cvalid ? f : 0), d_out - 1);
-    pV[t] = V + ((long)j * d_in) * ldk + 4 * (cvalid ? kq : 0);
-  }
   const unsigned bmask = cvalid ? 0xffffffffu : 0u;
   const int n = c;  // A operand row
   const unsigned amask = n < N ? 0xffffffffu : 0u;
   const float *pa = a + (long)min(n, N - 1) * d_in + 4 * s;
+  const int ntb = (int)cdiv(d_out, FPT * TPW);
 
-  f32x4 acc[TPW][4];
+  struct Group { float4 av; float4 bv[TPW][4]; };
+  for (int tb = blockIdx.x; tb < ntb; tb += gridDim.x) {
+    const int j0 = tb * FPT * TPW;
+    const float *pV[TPW];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int ib = wb; ib < we; ib += 16) {
-    const bool aok = ib + 4 * s + 3 < we;   // d_in % 4 == 0 and ranges are multiples of 16
-    float4 av = ld4(pa + (aok ? ib : wb));
-    const unsigned am = aok ? amask : 0u;
-    float4 bv[TPW][4];
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int i = ib + 4 * s + st;
-      const long off = (long)(i < we ? i : wb) * ldk;
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) bv[t][st] = ld4(pV[t] + off);
+    for (int t = 0; t < TPW; ++t) {
+      const int j = min(j0 + t * FPT + (cvalid ? f : 0), d_out - 1);
+      pV[t] = V + ((long)j * d_in) * ldk + 4 * (cvalid ? kq : 0);
     }
-    const float avs[4] = {__uint_as_float(__float_as_uint(av.x) & am),
-                          __uint_as_float(__float_as_uint(av.y) & am),
-                          __uint_as_float(__float_as_uint(av.z) & am),
-                          __uint_as_float(__float_as_uint(av.w) & am)};
+    f32x4 acc[TPW][4];
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        const float4 b = bv[t][st];
-        const float bx = __uint_as_float(__float_as_uint(b.x) & bmask);
-        const float by = __uint_as_float(__float_as_uint(b.y) & bmask);
-        const float bz = __uint_as_float(__float_as_uint(b.z) & bmask);
-        const float bw = __uint_as_float(__float_as_uint(b.w) & bmask);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bx, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], by, acc[t][1], 0, 0, 0);
-        acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bz, acc[t][2], 0, 0, 0);
-        acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bw, acc[t][3], 0, 0, 0);
+      for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](Group &g, int ib) {  // the 16 input features ib .. ib + 15 (clamped: values masked)
+      const bool aok = ib + 4 * s + 3 < we;
+      g.av = ld4(pa + (aok ? ib : wb));
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int i = ib + 4 * s + st;
+        const long off = (long)(i < we ? i : wb) * ldk;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) g.bv[t][st] = ld4(pV[t] + off);
       }
-  }
+    };
+    auto mma = [&](const Group &g, int ib) {
+      const unsigned am = (ib + 4 * s + 3 < we) ? amask : 0u;
+      const float avs[4] = {__uint_as_float(__float_as_uint(g.av.x) & am),
+                            __uint_as_float(__float_as_uint(g.av.y) & am),
+                            __uint_as_float(__float_as_uint(g.av.z) & am),
+                            __uint_as_float(__float_as_uint(g.av.w) & am)};
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
+      for (int st = 0; st < 4; ++st)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_red[wave][t][m][r][lane] = acc[t][m][r];
-  __syncthreads();
-  // D layout: row n = 4 (lane >> 4) + r, column c.  Wave w finishes r = w: sums the K ranges and
-  // writes the quad's four columns as one float4.
-  if (!cvalid) return;
-  for (int r = wave; r < 4; r += KW) {
-  const int nn = 4 * s + r;
-  if (nn >= N) continue;
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int j = j0 + t * FPT + f;
-    if (j >= d_out) continue;
-    float o[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < KW; ++w) v += s_red[w][t][m][r][lane];
-      o[m] = v;
+        for (int t = 0; t < TPW; ++t) {
+          const float4 b = g.bv[t][st];
+          const float bx = __uint_as_float(__float_as_uint(b.x) & bmask);
+          const float by = __uint_as_float(__float_as_uint(b.y) & bmask);
+          const float bz = __uint_as_float(__float_as_uint(b.z) & bmask);
+          const float bw = __uint_as_float(__float_as_uint(b.w) & bmask);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bx, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], by, acc[t][1], 0, 0, 0);
+          acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bz, acc[t][2], 0, 0, 0);
+          acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bw, acc[t][3], 0, 0, 0);
+        }
+    };
+    // two register buffers: the loads of group g + 1 are in flight while group g feeds the MFMAs
+    Group ga, gb;
+    if (wb < we) load(ga, wb);
+    for (int ib = wb; ib < we; ib += 32) {
+      if (ib + 16 < we) load(gb, ib + 16);
+      mma(ga, ib);
+      if (ib + 16 < we) {
+        if (ib + 32 < we) load(ga, ib + 32);
+        mma(gb, ib + 16);
+      }
     }
-    float *dst = dA + ((long)j * N + nn) * K + 4 * kq;
-    if (ACC) {
-      const float4 old = ld4(dst);
-      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[wave][t][m][r][lane] = acc[t][m][r];
+    __syncthreads();
+    // D layout: row n = 4 (lane >> 4) + r, column c.  Wave w finishes r = w: sums the K ranges and
+    // writes the quad's four columns as one float4.
+    if (cvalid) {
+      for (int r = wave; r < 4; r += KW) {
+        const int nn = 4 * s + r;
+        if (nn >= N) continue;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int j = j0 + t * FPT + f;
+          if (j >= d_out) continue;
+          float o[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < KW; ++w) v += s_red[w][t][m][r][lane];
+            o[m] = v;
+          }
+          float *dst = dA + ((long)j * N + nn) * K + 4 * kq;
+          if (ACC) {
+            const float4 old = ld4(dst);
+            o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+          }
+          if (Vb) {
+            const float4 vb = ld4(Vb + (long)j * ldk + 4 * kq);
+            o[0] += vb.x; o[1] += vb.y; o[2] += vb.z; o[3] += vb.w;
+          }
+          const float dp = dphi ? dphi[(long)nn * d_out + j] : 1.f;
+          *reinterpret_cast<float4 *>(dst) = make_float4(dp * o[0], dp * o[1], dp * o[2], dp * o[3]);
+        }
+      }
     }
-    if (Vb) {
-      const float4 vb = ld4(Vb + (long)j * ldk + 4 * kq);
-      o[0] += vb.x; o[1] += vb.y; o[2] += vb.z; o[3] += vb.w;
-    }
-    const float dp = dphi ? dphi[(long)nn * d_out + j] : 1.f;
-    *reinterpret_cast<float4 *>(dst) = make_float4(dp * o[0], dp * o[1], dp * o[2], dp * o[3]);
-  }
+    __syncthreads();  // s_red is reused by the next tile
   }
 }
 
@@ -2307,7 +2343,8 @@ extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const
         if (rc != CLO_OK) return rc;
       }
       const int ipw = (int)cdiv(cdiv(di, KC_WAVES), 16) * 16;
-      dim3 grid((unsigned)cdiv(dout, FPT * KC_TPW)), block(KC_WAVES * 64);
+      static const int kc_bpc = getenv("CLO_KC_BPC") ? atoi(getenv("CLO_KC_BPC")) : 4;
+      dim3 grid((unsigned)std::min<long>(cdiv(dout, FPT * KC_TPW), (long)kc_bpc * kNumCU)), block(KC_WAVES * 64);
       const float *vb = Vb ? Vb[l - 1] : nullptr;
       const float *dp = (l == L && last_linear) ? nullptr : dphi[l];
       ProfScope prof(0, 4.0 * di * dout * K, st);
