@@ -31,7 +31,14 @@ from curvlinops_amd.kronecker import (
     KroneckerProductLinearOperator,
 )
 from curvlinops_amd.linop import PyTorchLinearOperator
-from curvlinops_amd.trace import hutchinson_diag, hutchinson_squared_fro, hutchinson_trace, hutchpp_trace
+from curvlinops_amd.trace import (
+    hutchinson_diag,
+    hutchinson_squared_fro,
+    hutchinson_trace,
+    hutchpp_trace,
+    xdiag,
+    xtrace,
+)
 
 __all__ = [
     "PyTorchLinearOperator",
@@ -59,4 +66,6 @@ __all__ = [
     "hutchpp_trace",
     "hutchinson_diag",
     "hutchinson_squared_fro",
+    "xtrace",
+    "xdiag",
 ]

@@ -161,3 +161,56 @@ def hutchinson_squared_fro(A: Tensor | PyTorchLinearOperator, num_matvecs: int, 
     AG = A @ G
     return frobenius_inner(AG, AG) / num_matvecs
 
+
+def _leave_one_out_vectors(R: Tensor) -> Tensor:
+    """Columns ``s_i`` with ``Q_i Q_i^T = Q (I - s_i s_i^T) Q^T`` for the bases ``Q_i`` one would get
+    from the QR factorisation without the i-th test vector (Epperly et al. 2024)."""
+    RT_inv = torch.linalg.inv(R.T)
+    return RT_inv / (RT_inv**2).sum(0) ** 0.5
+
+
+def xtrace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribution: str = "rademacher",
+           probes: Tensor | None = None) -> Tensor:
+    """XTrace (Epperly, Tropp & Webber 2024; reference ``trace/epperly2024xtrace.py``): exchangeable
+    leave-one-out combination of a low-rank trace and Hutchinson on the complement.  The loop over
+    test vectors of the reference is evaluated for all of them at once (three small GEMMs)."""
+    dim = assert_is_square(A)
+    assert_matvecs_subseed_dim(A, num_matvecs)
+    assert_divisible_by(num_matvecs, 2, "num_matvecs")
+    N = num_matvecs // 2
+    W = random_matrix(dim, N, distribution, A.device, A.dtype) if probes is None else probes
+    A_W = A @ W
+    Q, R = torch.linalg.qr(A_W)
+    A_Q = A @ Q
+    QT_A_Q = Q.T @ A_Q
+    S = _leave_one_out_vectors(R)
+    traces = QT_A_Q.trace() - torch.einsum("ij,ik,kj->j", S, QT_A_Q, S)
+    # (I - Q_i Q_i^T) A (I - Q_i Q_i^T) w_i for all i; deflation = v - <s_i, v> s_i column by column
+    def deflate(V: Tensor) -> Tensor:
+        return V - S * (S * V).sum(0)
+
+    A_P_W = A_W - A_Q @ deflate(Q.T @ W)
+    PT_A_P_W = A_P_W - Q @ deflate(Q.T @ A_P_W)
+    return (traces + (W * PT_A_P_W).sum(0)).mean()
+
+
+def xdiag(A: Tensor | PyTorchLinearOperator, num_matvecs: int, probes: Tensor | None = None) -> Tensor:
+    """XDiag (reference ``diagonal/epperly2024xtrace.py``; Rademacher test vectors): the diagonal
+    counterpart of :func:`xtrace`.  Needs products with ``A^T`` (``Q^T A``)."""
+    dim = assert_is_square(A)
+    assert_matvecs_subseed_dim(A, num_matvecs)
+    assert_divisible_by(num_matvecs, 2, "num_matvecs")
+    N = num_matvecs // 2
+    W = random_matrix(dim, N, "rademacher", A.device, A.dtype) if probes is None else probes
+    A_W = A @ W
+    Q, R = torch.linalg.qr(A_W)
+    QT_A = Q.T @ A
+    S = _leave_one_out_vectors(R)
+    diagonal = (Q * QT_A.T).sum(1) - ((Q @ S) * (QT_A.T @ S)).sum(1) / N
+
+    def deflate(V: Tensor) -> Tensor:
+        return V - S * (S * V).sum(0)
+
+    A_comp_W = A_W - Q @ deflate(QT_A @ W)
+    return diagonal + (W * A_comp_W / W**2).sum(1) / N
+

@@ -169,6 +169,20 @@ def gen_trace(curvlinops, OUT):
             out[f"{dist}/hutch_fro2"] = NH.hutchinson_squared_fro(op, 12, dist).numpy()
         finally:
             DH.random_vector, NH.random_vector = orig_d, orig_n
+        import curvlinops.diagonal.epperly2024xtrace as XD
+        import curvlinops.trace.epperly2024xtrace as XT
+
+        orig_xt, orig_xd = XT.random_vector, XD.random_vector
+        XT.random_vector = replay
+        XD.random_vector = replay
+        try:
+            state["i"] = 0
+            out[f"{dist}/xtrace"] = XT.xtrace(op, 16, dist).numpy()
+            if dist == "rademacher":
+                state["i"] = 0
+                out[f"{dist}/xdiag"] = XD.xdiag(op, 16).numpy()
+        finally:
+            XT.random_vector, XD.random_vector = orig_xt, orig_xd
         out[f"{dist}/pool"] = pool.numpy()
     np.savez_compressed(OUT / "trace.npz", **{f"t/{k}": v for k, v in out.items()})
     print("trace.npz:", len(out), "arrays")

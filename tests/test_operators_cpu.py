@@ -281,6 +281,9 @@ def test_trace_estimators_with_injected_probes():
         assert rel_err(got, rec[f"{dist}/hutchpp"]) < TOL
         assert rel_err(C.hutchinson_diag(op, 12, dist, probes=pool[:, :12]), rec[f"{dist}/hutch_diag"]) < TOL
         assert rel_err(C.hutchinson_squared_fro(op, 12, dist, probes=pool[:, :12]), rec[f"{dist}/hutch_fro2"]) < TOL
+        assert rel_err(C.xtrace(op, 16, dist, probes=pool[:, :8]), rec[f"{dist}/xtrace"]) < 1e-8
+        if dist == "rademacher":
+            assert rel_err(C.xdiag(op, 16, probes=pool[:, :8]), rec[f"{dist}/xdiag"]) < 1e-8
     torch.manual_seed(0)
     est = C.hutchinson_trace(op, 29)
     assert abs(est - A.trace()) / A.trace() < 0.5
