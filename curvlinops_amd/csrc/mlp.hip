@@ -1,17 +1,23 @@
-// MLP fast path for GGN-type curvature-vector products (ggn.py:41-72 of the reference).
+// Curvature-vector products of fully-connected nets (reference ggn.py:17-168, hessian.py:13-69,
+// gradient_moments.py:15-87, jacobian.py:14-358) without autograd.  Entry points at the end of the file:
 //
-// For mini-batches of up to 8 rows per pass the per-layer products are GEMV-shaped and
-// HBM-bound.  The kernels stream every weight matrix exactly once per pass with 16-byte
-// per-lane coalesced loads issued a whole k-chunk ahead of use (8 KiB in flight per
-// wave), keep the tiny activations in LDS / registers, and reduce with wavefront shuffles.
-// Larger batches go through the MFMA GEMM (gemm.hip).
-//
-//   fwd_jvp_kernel   z = a W^T + b, dz = da W^T + a VW^T + Vb, activation + derivative;
-//                    lanes split k, a wave owns 2 output features, 8 waves per block,
-//                    optional split-K over blocks for narrow layers
-//   loss_hessian     w = s * H(f) u per sample (also merges split-K slabs of the last layer)
-//   bwd_fused_kernel out_W = beta out_W + alpha delta^T a_prev  (write stream)  and
-//                    delta_prev = dphi_prev * (delta W)         (reads W once), same sweep
+//   clo_mlp_ggn_matvec      GGN / empirical Fisher / MC-GGN, one probe vector
+//     N <= 8 rows  : six streaming launches that read W and V once (HBM-bound regime)
+//       fwd_mfma_first_kernel  layer 1 forward + JVP, in-block split-K (no slabs)
+//       fwd_mfma_kernel        other layers, 16x16x4 f32 MFMA tiles, split-K slabs
+//       head_fwd_kernel        slab sum + partial products of a narrow last layer
+//       head_bwd_kernel        loss Hessian + backward through the last layer
+//       bwd_fused_kernel       data chain delta_{l-1} = phi' * (delta_l W_l), read-only sweep
+//       outer_all_kernel       all layers' out_W = beta out_W + delta^T a in one write-only launch
+//       (fwd_jvp_kernel, fwd_finish_kernel, bwd_finish_kernel, loss_hessian_kernel: unaligned
+//        operands, wide heads, deeper nets)
+//     N > 8 rows   : GEMM engine of gemm.hip (fused forward gemm_fwd3_kernel, epilogue-fused
+//                    backward GEMMs) + head_rows_* / small_outer_* for narrow layers and biases
+//   clo_mlp_ggn_matmat      K probe columns in the reference's K-trailing layout
+//       kfwd_stream_kernel, kouter_stream_kernel, loss_cols_kernel, pack_at_kernel
+//   clo_mlp_hessian_matvec  exact Hessian by the R-operator (hess_combine_kernel + GEMMs)
+//   clo_mlp_jvp / clo_mlp_vjp  the two halves on their own (Jacobian operators)
+//   clo_mlp_fwd_jvp_layer / clo_mlp_bwd_layer / clo_loss_hessian_apply  per-layer building blocks
 #include "clo_common.h"
 #include "gemm.h"
 
