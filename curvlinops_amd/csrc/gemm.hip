@@ -1,17 +1,20 @@
 // fp32 GEMM / SYRK on the gfx950 f32 MFMA pipe (v_mfma_f32_32x32x2_f32).
 //
-// Block tile 128x128x16, 256 threads = 4 waves in a 2x2 arrangement, each wave owns a
-// 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator registers).  Both operand
-// tiles are staged in LDS k-major ([k][outer], row stride 132 floats) so that the MFMA
-// operand fetch (lane l needs element (outer = l&31, k = l>>5)) is a conflict-free
-// ds_read_b32 whatever the global layout was; the global->LDS copy goes through
-// registers, is coalesced for either "outer-contiguous" or "k-contiguous" operands and
-// is software-pipelined one tile ahead of the MFMAs (double-buffered LDS, one barrier per
-// k-tile).  f32 MFMA issues at 64 cycles per instruction, so LDS bandwidth is irrelevant;
-// the design goal is simply to keep the matrix pipe fed while HBM/L2 latency is hidden.
+// Three kernels share GemmArgs (gemm.h):
+//   gemm_v2_kernel    16-byte aligned operands (the hot path): operand layouts are template
+//                     parameters; k-contiguous operands keep their memory order in LDS and one
+//                     ds_read_b128 feeds four MFMAs; tiles 128x128 (4 or 8 waves), 64x256, 32x256;
+//                     fused epilogues, second K segment, implicit ones column, symmetric output
+//   gemm_fwd3_kernel  fused forward + JVP of the large-batch MLP path (three products per tile)
+//   gemm_f32_kernel   v1: runtime layout modes and scalar loads for unaligned operands; also the
+//                     squared-accumulate variant of the EKFAC eigenvalue correction
+// All stage both operand tiles in double-buffered LDS through registers one tile ahead of the
+// MFMAs (one barrier per k-tile), use an XCD-aware grouped raster, and split K into deterministic
+// slabs chosen by a small cost model (suggest_splitk_tiles).
 //
 // Reference call sites this replaces: kronecker.py:141-171 (einsum 'abZ,Aa,Bb->ABZ'),
-// eigh.py:84-105, computers/kfac_hooks.py:350,390 (einsum "b s i, b s j -> i j").
+// eigh.py:84-105, computers/kfac_hooks.py:350,390 (einsum "b s i, b s j -> i j"),
+// computers/ekfac_hooks.py:206-236.
 #include "clo_common.h"
 #include "gemm.h"
 
