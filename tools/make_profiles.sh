@@ -31,3 +31,8 @@ python benchmarks/bench_general.py resnet18 > $OUT/r01_general_resnet18_b512.jso
 python benchmarks/bench_general.py encoder > $OUT/r01_general_encoder_c5.json 2>/dev/null
 python tools/probe_cols.py 8 32 64 > $OUT/r01_c2_columns.txt 2>&1
 python benchmarks/bench_kfac.py encoder > $OUT/r01_kfac_encoder_b8.json 2>/dev/null
+# practical read / write stream ceilings of this GPU (size, occupancy, nt, LDS-DMA)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/stream2_bench tools/ubench/stream2.hip && /tmp/stream2_bench > $OUT/r01_ubench_read_stream.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/stream3_bench tools/ubench/stream3.hip && /tmp/stream3_bench > $OUT/r01_ubench_write_stream.txt
+python tools/probe_hessian.py > $OUT/r01_c2_hessian.txt 2>/dev/null
+python tools/probe_cg.py > $OUT/r01_c2_cg.txt 2>/dev/null
