@@ -79,6 +79,9 @@ def main():
     res["factor_build_tflops_incl_autograd"] = build_flops / (res["kfac_factors_ms"] * 1e-3) / 1e12
     res["cholesky_inverse_ms"], Kinv = timed(lambda: K.inverse(damping=1e-3), repeats=2)
     res["inverse_matvec_ms"], _ = timed(lambda: Kinv @ v)
+    if args.model == "lenet":  # BASELINE C3 also asks for the heuristic and exact damping variants
+        res["inverse_heuristic_ms"], _ = timed(lambda: K.inverse(damping=1e-3, use_heuristic_damping=True), repeats=2)
+        res["inverse_exact_ms"], _ = timed(lambda: K.inverse(damping=1e-3, use_exact_damping=True), repeats=2)
     # forward+backward alone (host-framework time that any backend pays)
     def fwdbwd():
         out = model(X)

@@ -36,3 +36,4 @@ python benchmarks/bench_kfac.py encoder > $OUT/r01_kfac_encoder_b8.json 2>/dev/n
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/stream3_bench tools/ubench/stream3.hip && /tmp/stream3_bench > $OUT/r01_ubench_write_stream.txt
 python tools/probe_hessian.py > $OUT/r01_c2_hessian.txt 2>/dev/null
 python tools/probe_cg.py > $OUT/r01_c2_cg.txt 2>/dev/null
+python benchmarks/bench_kfac.py lenet --fisher type-2 > $OUT/r01_kfac_lenet_b1024_type2.json 2>/dev/null
