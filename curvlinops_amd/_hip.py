@@ -100,6 +100,9 @@ _SIGNATURES = {
         [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
          POINTER(c_void_p), _PF, c_int, _PF, c_float, c_float, _PF, c_void_p],
     ),
+    "clo_gram_tall_supported": (c_int, [c_long, c_int, c_int]),
+    "clo_gram_tall_ws_floats": (c_long, [c_long, c_int, c_int]),
+    "clo_gram_tall_f32": (c_int, [_PF, c_long, _PF, c_long, c_int, c_long, c_int, c_float, c_float, _PF, c_void_p]),
     "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
     "clo_dot_ws_bytes": (c_long, []),
     "clo_dot_f32": (c_int, [_PF, _PF, c_long, c_float, _PF, c_void_p, c_void_p]),
@@ -264,10 +267,17 @@ def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones
     dd = d + (1 if ones_col else 0)
     if C.shape != (dd, dd) or C.stride(1) != 1:
         raise ValueError(f"C must be [{dd},{dd}] row-major, got {tuple(C.shape)}")
+    ldx = X.stride(0) if rows > 1 else max(d, 1)
+    if splitk is None and lib.clo_gram_tall_supported(rows, d, int(ones_col)):
+        # tall and skinny (conv-layer factors, Hutch++ Gram passes): the streaming Gram kernel
+        ws = torch.empty(lib.clo_gram_tall_ws_floats(rows, d, int(ones_col)), device=X.device, dtype=torch.float32)
+        rc = lib.clo_gram_tall_f32(_p(C), C.stride(0), _p(X), rows, d, ldx, int(ones_col), alpha, beta, _p(ws),
+                                   _stream())
+        _check(rc, "clo_gram_tall_f32")
+        return C
     if splitk is None:
         splitk = lib.clo_gemm_suggest_splitk(dd, dd, rows, 1)
     ws = torch.empty(splitk * dd * dd, device=X.device, dtype=torch.float32) if splitk > 1 else None
-    ldx = X.stride(0) if rows > 1 else max(d, 1)
     rc = lib.clo_syrk_accum_f32(_p(C), C.stride(0), _p(X), rows, d, ldx, int(ones_col), alpha, beta,
                                 splitk, _p(ws), _stream())
     _check(rc, "clo_syrk_accum_f32")

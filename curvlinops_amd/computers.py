@@ -361,15 +361,50 @@ class HipKFACComputer(EmpiricalRiskMixin):
         # Differentiate w.r.t. the hooked layer outputs themselves: the tensor hooks see exactly the
         # output-gradients KFAC needs and autograd never launches a weight-gradient kernel (the
         # reference differentiates w.r.t. the parameters, kfac_hooks.py:236-289, and discards them).
-        wrt = [o for o in self._hooked_outputs if o.requires_grad]
+        hooked = [(o, cb) for o, cb in self._hooked_outputs if o.requires_grad]
         self._hooked_outputs = []
+        wrt = [o for o, _ in hooked]
         if not wrt:
             module_params = dict(self._model_module.named_parameters())
             wrt = [module_params[n] for n in self._params]
         V = grad_outputs.shape[0]
+        if self._manual_callbacks and hooked:
+            # V > 1 vectors per datum (type-2, several MC samples): ONE batched backward pass instead
+            # of V sequential ones; the callbacks then see the V slices of every layer's gradient
+            try:
+                grads = torch.autograd.grad(output, wrt, grad_outputs=grad_outputs, is_grads_batched=True,
+                                            allow_unused=True, retain_graph=True)
+                for (_, cb), g in zip(hooked, grads):
+                    if g is not None:
+                        cb(g, stacked=True)  # [V, B, ...]: one accumulation for all V vectors
+                return
+            except RuntimeError:
+                pass  # an op without a batching rule: fall back to V sequential passes
+            for v in range(V):
+                grads = torch.autograd.grad(output, wrt, grad_outputs=grad_outputs[v], retain_graph=v < V - 1,
+                                            allow_unused=True)
+                for (_, cb), g in zip(hooked, grads):
+                    if g is not None:
+                        cb(g)
+            return
         for v in range(V):
             torch.autograd.grad(output, wrt, grad_outputs=grad_outputs[v], retain_graph=v < V - 1,
                                 allow_unused=True)
+
+    @property
+    def _manual_callbacks(self) -> bool:
+        """More than one backpropagated vector per datum: gradients are taken by one batched
+        ``autograd.grad`` and handed to the callbacks afterwards (tensor hooks would fire inside
+        ``vmap`` with batched tensors); with a single vector the tensor hooks fire DURING the
+        backward pass, which lets the factor stream overlap it."""
+        if self._fisher_type == FisherType.MC:
+            return self._mc_samples > 1
+        return self._fisher_type == FisherType.TYPE2
+
+    def _track_output(self, output: Tensor, callback) -> None:
+        if not self._manual_callbacks:
+            output.register_hook(callback)
+        self._hooked_outputs.append((output, callback))
 
     def _input_hook(self, module, inputs, group, hyper, store) -> None:
         if len(inputs) != 1:
@@ -382,12 +417,14 @@ class HipKFACComputer(EmpiricalRiskMixin):
                              1.0 / (self._N_data * shared), ones_col=joint)
 
     def _output_hook(self, module, inputs, output, group, hyper, store) -> None:
-        output.register_hook(partial(self._grad_hook, group=group, hyper=hyper, store=store))
-        self._hooked_outputs.append(output)
+        self._track_output(output, partial(self._grad_hook, group=group, hyper=hyper, store=store))
 
-    def _grad_hook(self, grad_output: Tensor, group, hyper, store) -> None:
+    def _grad_hook(self, grad_output: Tensor, group, hyper, store, stacked: bool = False) -> None:
         g = grad_output.data.detach()
-        corr = compute_loss_correction(g.shape[0], self._num_per_example_loss_terms,
+        batch_size = g.shape[1] if stacked else g.shape[0]
+        if stacked:  # [V, B, ...] -> [V B, ...]: the V vectors are just more rows of the Gram matrix
+            g = g.flatten(0, 1)
+        corr = compute_loss_correction(batch_size, self._num_per_example_loss_terms,
                                        self._loss_func.reduction, self._N_data)
         with _factor_stream(g):
             g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
@@ -475,16 +512,20 @@ class HipEKFACComputer(HipKFACComputer):
         return lam
 
     def _corr_output_hook(self, module, inputs, output, group, Qa, Qg, lam) -> None:
-        output.register_hook(partial(self._corr_grad_hook, module=module, inputs=inputs, group=group, Qa=Qa, Qg=Qg, lam=lam))
-        self._hooked_outputs.append(output)
+        self._track_output(output, partial(self._corr_grad_hook, module=module, inputs=inputs, group=group,
+                                           Qa=Qa, Qg=Qg, lam=lam))
 
-    def _corr_grad_hook(self, grad_output: Tensor, module, inputs, group, Qa, Qg, lam) -> None:
+    def _corr_grad_hook(self, grad_output: Tensor, module, inputs, group, Qa, Qg, lam, stacked: bool = False) -> None:
         if len(inputs) != 1:
             raise ValueError("Modules with multiple inputs are not supported.")
         g = grad_output.data.detach()
-        batch_size = g.shape[0]
         hyper = _conv_hyperparams(module)
-        g = grad_to_weight_sharing_format(g, KFACType.EXPAND, hyper).unsqueeze(0)
+        if stacked:  # [V, B, ...]: format every vector, keep the leading V axis
+            batch_size = g.shape[1]
+            g = torch.stack([grad_to_weight_sharing_format(gv, KFACType.EXPAND, hyper) for gv in g])
+        else:
+            batch_size = g.shape[0]
+            g = grad_to_weight_sharing_format(g, KFACType.EXPAND, hyper).unsqueeze(0)
         a = None
         if "W" in group:
             a = input_to_weight_sharing_format(inputs[0].data.detach(), KFACType.EXPAND, hyper)

@@ -1,0 +1,241 @@
+// Tall-skinny Gram matrices  C = beta C + alpha [X | 1]^T [X | 1]  with rows >> d, d + 1 <= 128.
+//
+// KFAC's factors of convolution layers (G_l: d_out = 6 ... 128 columns against B * H * W rows;
+// A_1: C_in k^2 + 1 = 26 ... 28 columns), the Gram passes of the Hutch++ range basis ([85M, 32]) --
+// reference computers/kfac_hooks.py:350,390 (einsum "b s i, b s j -> i j"), trace/meyer2020hutch.py:93.
+// The 128 x 128 tile engine of gemm.hip spends its MFMAs on padding there and can only split K into 64
+// slabs; this kernel instead streams X exactly once, linearly, at the HBM rate:
+//
+//   * persistent blocks (a few per CU) walk row chunks b, b + grid, ...; a chunk is staged in LDS as
+//     [rows][P] (P = d + 1 padded to 16 / 32 / 64 / 96 / 128) with 16-byte global loads;
+//   * the chunk's rows are the K dimension of v_mfma_f32_16x16x4 (P = 16) or 32x32x2 tiles; both
+//     operands of a tile are columns of the SAME LDS rows, so a diagonal tile needs one ds_read_b32
+//     per MFMA;  P <= 64: the four waves split the rows and hold all upper tiles; P > 64: wave w owns
+//     tile row w;
+//   * per-block partial Grams go to slabs, a small second kernel sums them (fixed order:
+//     deterministic), applies alpha / beta and mirrors the lower triangle.
+#include "clo_common.h"
+
+namespace clo {
+
+using f32x4g = __attribute__((ext_vector_type(4))) float;
+using f32x16g = __attribute__((ext_vector_type(16))) float;
+
+constexpr int GT_THREADS = 256;
+constexpr int GT_LDS_FLOATS = 8192;  // 32 KiB staging area per block
+// rows per chunk for a padded width P: a multiple of 8 (four waves x an even count)
+constexpr int gram_rc(int P) { return (GT_LDS_FLOATS / P) / 8 * 8; }
+
+struct GramArgs {
+  const float *X;
+  long rows, ldx;
+  int d, ones, dd;
+  float *slab;  // [grid][dd][dd] (upper tiles only are written)
+  int vec;      // 16-byte loads allowed
+};
+
+// Stage rows [r0, r0 + RC) of [X | 1] into S[RC][P]; rows beyond `rows` and columns >= dd are zero.
+template <int P, int RC>
+__device__ __forceinline__ void gram_stage(const GramArgs &p, long r0, float *S, int tid) {
+  const int d = p.d;
+  if (p.vec) {
+    const int q4 = d >> 2;
+    for (int e = tid; e < RC * q4; e += GT_THREADS) {
+      const int r = e / q4, q = e - r * q4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + r < p.rows) v = *reinterpret_cast<const float4 *>(p.X + (r0 + r) * p.ldx + 4 * q);
+      *reinterpret_cast<float4 *>(S + r * P + 4 * q) = v;
+    }
+  } else {
+    for (int e = tid; e < RC * d; e += GT_THREADS) {
+      const int r = e / d, c = e - r * d;
+      S[r * P + c] = (r0 + r < p.rows) ? p.X[(r0 + r) * p.ldx + c] : 0.f;
+    }
+  }
+  const int npad = P - d;
+  for (int e = tid; e < RC * npad; e += GT_THREADS) {
+    const int r = e / npad, c = d + (e - r * npad);
+    S[r * P + c] = (p.ones && c == d && r0 + r < p.rows) ? 1.f : 0.f;
+  }
+}
+
+// P = 16: one 16x16x4 tile, four waves split the rows of the chunk.
+__global__ __launch_bounds__(GT_THREADS) void gram16_kernel(const GramArgs p) {
+  constexpr int P = 16, RC = gram_rc(P);  // 512 rows per chunk
+  __shared__ __attribute__((aligned(16))) float S[GT_LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, ks = lane >> 4;
+  f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+  const long nchunks = cdiv(p.rows, (long)RC);
+  for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    gram_stage<P, RC>(p, c * RC, S, tid);
+    __syncthreads();
+    const float *s = S + (wave * (RC / 4) + ks) * P + i;
+#pragma unroll 8
+    for (int r = 0; r < RC / 4; r += 4) {
+      const float a = s[r * P];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // cross-wave sum through LDS; D layout: row = 4 (lane >> 4) + r, col = lane & 15
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(wave * 16 + 4 * ks + r) * 16 + i] = acc[r];
+  __syncthreads();
+  const int e = tid;  // 256 threads = 16 x 16 entries
+  const int row = e >> 4, col = e & 15;
+  const float v = S[row * 16 + col] + S[(16 + row) * 16 + col] + S[(32 + row) * 16 + col] + S[(48 + row) * 16 + col];
+  if (row < p.dd && col < p.dd) p.slab[(long)blockIdx.x * p.dd * p.dd + row * p.dd + col] = v;
+}
+
+// P = 32 T: T x T tiles of 32 x 32 (upper triangle computed).  T <= 2: waves split the rows and hold
+// every upper tile; T >= 3: wave w owns tile row w over all rows of the chunk.
+template <int T>
+__global__ __launch_bounds__(GT_THREADS) void gram32_kernel(const GramArgs p) {
+  constexpr int P = 32 * T, RC = gram_rc(P);
+  constexpr bool KSPLIT = T <= 2;
+  constexpr int NT = KSPLIT ? T * (T + 1) / 2 : T;  // accumulator tiles per wave
+  __shared__ __attribute__((aligned(16))) float S[GT_LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, ks = lane >> 5;
+  f32x16g acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const long nchunks = cdiv(p.rows, (long)RC);
+  for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    gram_stage<P, RC>(p, c * RC, S, tid);
+    __syncthreads();
+    if (KSPLIT) {
+      const float *s = S + (wave * (RC / 4) + ks) * P + i;
+#pragma unroll 4
+      for (int r = 0; r < RC / 4; r += 2) {
+        float x[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[t] = s[r * P + 32 * t];
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+          for (int b = a; b < T; ++b, ++k)
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[a], x[b], acc[k], 0, 0, 0);
+      }
+    } else if (wave < T) {
+      const float *s = S + ks * P + i;
+#pragma unroll 2
+      for (int r = 0; r < RC; r += 2) {
+        const float xa = s[r * P + 32 * wave];
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+          if (b < wave) continue;  // (uniform per wave)
+          const float xb = s[r * P + 32 * b];
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, xb, acc[b], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- write the block's partial Gram.  D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float *out = p.slab + (long)blockIdx.x * p.dd * p.dd;
+  if (KSPLIT) {
+    // sum the four waves' tiles through LDS, one tile at a time (4 x 4 KiB)
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = a; b < T; ++b, ++k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * ks;
+          S[wave * 1024 + row * 32 + i] = acc[k][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 1024; e += GT_THREADS) {
+          const int row = 32 * a + (e >> 5), col = 32 * b + (e & 31);
+          if (row < p.dd && col < p.dd) out[row * p.dd + col] = (S[e] + S[1024 + e]) + (S[2048 + e] + S[3072 + e]);
+        }
+        __syncthreads();
+      }
+  } else if (wave < T) {
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      if (b < wave) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * ks, col = 32 * b + i;
+        if (row < p.dd && col < p.dd) out[row * p.dd + col] = acc[b][r];
+      }
+    }
+  }
+}
+
+// C = beta C + alpha sum_b slab[b]; the slabs hold the upper 32-wide tiles, the rest is mirrored.
+__global__ void gram_reduce_kernel(float *__restrict__ C, long ldc, const float *__restrict__ slab,
+                                   int nslab, int dd, int tile, float alpha, float beta) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= dd * dd) return;
+  const int row = e / dd, col = e - row * dd;
+  const bool upper = (row / tile) <= (col / tile);
+  const long src = upper ? (long)row * dd + col : (long)col * dd + row;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long st = (long)dd * dd;
+  int b = 0;
+  for (; b + 3 < nslab; b += 4) {
+    s0 += slab[b * st + src]; s1 += slab[(b + 1) * st + src];
+    s2 += slab[(b + 2) * st + src]; s3 += slab[(b + 3) * st + src];
+  }
+  for (; b < nslab; ++b) s0 += slab[b * st + src];
+  float *c = C + (long)row * ldc + col;
+  *c = (beta != 0.f ? beta * *c : 0.f) + alpha * ((s0 + s1) + (s2 + s3));
+}
+
+static int gram_grid(long rows, int P) {
+  const long nchunks = cdiv(rows, (long)gram_rc(P));
+  return (int)std::max<long>(1, std::min<long>(nchunks, 4L * kNumCU));
+}
+static int gram_pad(int dd) { return dd <= 16 ? 16 : 32 * (int)cdiv(dd, 32); }
+
+}  // namespace clo
+
+using namespace clo;
+
+// Worth it when the matrix is tall: rows >= 32 (d + 1) and d + 1 <= 128.
+extern "C" int clo_gram_tall_supported(long rows, int d, int ones_col) {
+  const int dd = d + (ones_col ? 1 : 0);
+  return dd >= 1 && dd <= 128 && rows >= 32L * dd;
+}
+extern "C" long clo_gram_tall_ws_floats(long rows, int d, int ones_col) {
+  const int dd = d + (ones_col ? 1 : 0);
+  if (dd < 1 || dd > 128) return 0;
+  return (long)gram_grid(rows, gram_pad(dd)) * dd * dd;
+}
+
+// C = beta C + alpha [X | 1]^T [X | 1]   (X row-major [rows][ldx], first d columns; C [dd][ldc]).
+extern "C" int clo_gram_tall_f32(float *C, long ldc, const float *X, long rows, int d, long ldx,
+                                 int ones_col, float alpha, float beta, float *ws, void *stream) {
+  const int dd = d + (ones_col ? 1 : 0);
+  CLO_REQUIRE(d >= 0 && rows >= 0 && dd >= 1 && dd <= 128, "clo_gram_tall_f32: needs 1 <= d + ones <= 128");
+  CLO_REQUIRE(ldc >= dd && ldx >= d, "clo_gram_tall_f32: leading dimensions too small");
+  CLO_REQUIRE(C && ws && (X || rows == 0 || d == 0), "clo_gram_tall_f32: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = gram_pad(dd);
+  GramArgs a{};
+  a.X = X; a.rows = rows; a.ldx = ldx; a.d = d; a.ones = ones_col ? 1 : 0; a.dd = dd; a.slab = ws;
+  a.vec = (d % 4 == 0 && ldx % 4 == 0 && aligned16(X)) ? 1 : 0;
+  const int grid = gram_grid(rows, P);
+  switch (P) {
+    case 16: hipLaunchKernelGGL(gram16_kernel, dim3(grid), dim3(GT_THREADS), 0, st, a); break;
+    case 32: hipLaunchKernelGGL(gram32_kernel<1>, dim3(grid), dim3(GT_THREADS), 0, st, a); break;
+    case 64: hipLaunchKernelGGL(gram32_kernel<2>, dim3(grid), dim3(GT_THREADS), 0, st, a); break;
+    case 96: hipLaunchKernelGGL(gram32_kernel<3>, dim3(grid), dim3(GT_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL(gram32_kernel<4>, dim3(grid), dim3(GT_THREADS), 0, st, a); break;
+  }
+  CLO_CHECK_LAUNCH("gram_kernel");
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)cdiv(dd * dd, 256)), dim3(256), 0, st, C, ldc, ws, grid,
+                     dd, P == 16 ? 16 : 32, alpha, beta);
+  CLO_CHECK_LAUNCH("gram_reduce_kernel");
+  return CLO_OK;
+}

@@ -101,6 +101,16 @@ int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, lon
 int clo_im2col_f32(const float *x, float *out, int B, int C, int H, int W, int KH, int KW,
                    int SH, int SW, int PH, int PW, int DH, int DW, int OH, int OW, void *stream);
 
+/* Tall-skinny Gram matrix C = beta C + alpha [X | 1]^T [X | 1] for rows >> d, d + ones_col <= 128 (KFAC
+ * factors of convolution layers: G_l with few output channels against B*H*W rows, A_1 with C_in k^2 + 1
+ * columns; the Gram passes of the Hutch++ range basis).  X is streamed once, linearly; per-block
+ * partial Grams are summed in a fixed order.  clo_gram_tall_supported: whether this beats the tiled
+ * SYRK (rows >= 32 (d + ones), d + ones <= 128).  ws: clo_gram_tall_ws_floats floats. */
+int clo_gram_tall_supported(long rows, int d, int ones_col);
+long clo_gram_tall_ws_floats(long rows, int d, int ones_col);
+int clo_gram_tall_f32(float *C, long ldc, const float *X, long rows, int d, long ldx, int ones_col,
+                      float alpha, float beta, float *ws, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Damped Cholesky inverse of a Kronecker factor (kronecker.py:328-373): the blocked algorithm
  * (panel solve, trailing update, triangular inverse, L^-T L^-1) runs on clo_gemm_f32; this entry

@@ -103,6 +103,30 @@ def test_syrk_accum(hip, rows, d, ones):
         assert torch.equal(C, C.T)
 
 
+@pytest.mark.parametrize("rows,d,ones", [(100_000, 6, False), (100_003, 6, True), (5000, 33, True), (20_000, 100, False),
+                                         (9000, 127, True), (9000, 128, False), (4096, 16, False), (700, 15, True),
+                                         (300_000, 32, False), (12_345, 64, True)])
+def test_gram_tall_kernel(hip, rows, d, ones):
+    """The streaming tall-skinny Gram kernel (every padded width 16 / 32 / 64 / 96 / 128, vector and
+    scalar loaders, ragged last chunk, strided rows, accumulation) against float64."""
+    lib = hip.load()
+    assert lib.clo_gram_tall_supported(rows, d, int(ones))
+    g = torch.Generator().manual_seed(rows + d)
+    Xbig = torch.rand(rows, d + 4, generator=g, dtype=torch.float64) - 0.3
+    for X in (Xbig[:, :d].contiguous(), Xbig[:, :d]):          # contiguous and strided rows
+        Xa = torch.cat([X, torch.ones(rows, 1, dtype=torch.float64)], 1) if ones else X
+        dd = Xa.shape[1]
+        C0 = torch.rand(dd, dd, generator=g, dtype=torch.float64)
+        C0 = C0 + C0.T
+        for beta in (0.0, 1.0):
+            C = C0.float().cuda()
+            hip.syrk_accum(C, X.float().cuda() if X.is_contiguous() else Xbig.float().cuda()[:, :d], alpha=0.5,
+                           beta=beta, ones_col=ones)
+            ref = 0.5 * Xa.T @ Xa + beta * C0
+            assert rel_err(C.cpu(), ref) < TOL
+            assert torch.equal(C, C.T)
+
+
 def test_syrk_splitk_and_strided_rows(hip):
     g = torch.Generator().manual_seed(5)
     big = torch.rand(9000, 40, generator=g, dtype=torch.float64)
