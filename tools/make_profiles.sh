@@ -37,3 +37,4 @@ python benchmarks/bench_kfac.py encoder > $OUT/r01_kfac_encoder_b8.json 2>/dev/n
 python tools/probe_hessian.py > $OUT/r01_c2_hessian.txt 2>/dev/null
 python tools/probe_cg.py > $OUT/r01_c2_cg.txt 2>/dev/null
 python benchmarks/bench_kfac.py lenet --fisher type-2 > $OUT/r01_kfac_lenet_b1024_type2.json 2>/dev/null
+python tools/probe_syrk_skinny.py > $OUT/r01_gram_tall_shapes.txt 2>/dev/null
