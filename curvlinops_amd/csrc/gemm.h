@@ -19,6 +19,7 @@ struct GemmArgs {
   int sym;  // 1: compute only block-upper triangle, mirror on write (SYRK)
   int mode_a, mode_b;
   int tiles_m, tiles_n;
+  int tbm, tbn;  // block tile extents of the engine that runs (set by launch_gemm)
   int nbatch, batch_per_split;  // SQSUM mode only
   int ones;  // 1: outer index M-1 of A / N-1 of B is an implicit column of ones ([X | 1])
   // fused epilogue (single problem only), applied by whichever kernel writes the final C:
@@ -34,8 +35,14 @@ struct GemmArgs {
   // i.e. C = A[:, :K1] B[:K1] + A2 B2 with K = K1 + K2 in one pass.  K1 % 32 == 0.
   const float *A2, *B2;
   int K1;
+  // triangular-operand hint (v2 engine; other engines ignore it, the skipped products are zeros):
+  // per output tile only the k range that can be nonzero is visited
+  //   TRI_KGE_M: A(m, k) == 0 for k < m     TRI_KLT_M: A(m, k) == 0 for k > m
+  //   TRI_KGE_N: B(k, n) == 0 for k < n     TRI_KLT_N: B(k, n) == 0 for k > n
+  int tri;
 };
 enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2, EPI_MUL_T = 3 };
+enum { TRI_KGE_M = 1, TRI_KLT_M = 2, TRI_KGE_N = 4, TRI_KLT_N = 8 };
 
 bool gemm_v2_eligible(const GemmArgs &a, int batch);
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream);

@@ -403,13 +403,22 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
 
   const int z = blockIdx.y;
   const int batch = z / p.splitk, split = z % p.splitk;
-  const int kb = split * p.k_per_split;
-  const int ke = min(p.K, kb + p.k_per_split);
+  const int m0 = bm * BMt, n0 = bn * BNt;
+  int kb = split * p.k_per_split;
+  int ke = min(p.K, kb + p.k_per_split);
+  if (p.tri) {  // triangular operands: visit only the k range of this tile that can be nonzero
+    int lo = 0, hi = p.K;
+    if (p.tri & TRI_KGE_M) lo = max(lo, m0);
+    if (p.tri & TRI_KGE_N) lo = max(lo, n0);
+    if (p.tri & TRI_KLT_M) hi = min(hi, m0 + BMt);
+    if (p.tri & TRI_KLT_N) hi = min(hi, n0 + BNt);
+    kb = max(kb, lo & ~(BKT - 1));
+    ke = min(ke, hi);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WVN, wn = wave % WVN;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = bm * BMt, n0 = bn * BNt;
 
   TA la;
   TB lb;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (ke - kb + BKT - 1) / BKT;
+  const int nk = ke > kb ? (ke - kb + BKT - 1) / BKT : 0;
   float4 ra[TA::NF4], rb[TB::NF4];
   // K segments: tile k0 lies in segment 2 iff k0 >= K1 (K1 is a multiple of the tile depth)
   const int K1 = p.A2 ? p.K1 : p.K;
@@ -665,7 +674,7 @@ __global__ void splitk_reduce_kernel(const GemmArgs p, int splitk) {
        e += (long)gridDim.x * blockDim.x) {
     const int m = e / N, n = e % N;
     long src = e;
-    if (p.sym && (n / BN) < (m / BM)) src = (long)n * N + m;
+    if (p.sym && (n / p.tbn) < (m / p.tbm)) src = (long)n * N + m;
     const float *w = p.ws + (long)b * splitk * total + src;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
@@ -688,8 +697,16 @@ static int pick_mode(const float *P, long so, long sk, long sbatch, int batch) {
 
 // Tile configuration of the v2 engine: few-row problems (the batch dimension of the mid-size MLP
 // path) get 32- / 64-row tiles so that no MFMA work is spent on padding rows.
+//  64 x  64, 2 x 2 waves, k tiles of 64: tiny problems (a handful of tiles, short K), where one
+//                                     block's k loop is a chain of memory round trips (~1.3 us
+//                                     each whatever the tile depth): smaller tiles on more CUs,
+//                                     4x deeper k tiles (Cholesky recursion, small-network layers)
 struct V2Config { int bm, bn, bk; };
-static V2Config v2_config(int M, int sym) {
+static V2Config v2_config(int M, int N, long batch, int sym, bool allow_small = true) {
+  // (few-row problems keep their 32- / 64-row tiles unless they are tiny)
+  static const long small_max = getenv("CLO_GEMM_SMALL_MAX") ? atol(getenv("CLO_GEMM_SMALL_MAX")) : 1024L * 1024L;
+  const long area = (long)M * N * batch;
+  if (allow_small && (area <= 256L * 256L || (area <= small_max && (M > 64 || sym)))) return {64, 64, 64};
   if (!sym && M <= 32) return {32, 256, 16};
   if (!sym && M <= 64) return {64, 256, 16};
   return {128, 128, 32};
@@ -716,6 +733,7 @@ bool gemm_v2_eligible(const GemmArgs &a, int batch) {
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   a.tiles_m = (int)cdiv(a.M, BM);
   a.tiles_n = (int)cdiv(a.N, BN);
+  a.tbm = BM; a.tbn = BN;
   if (a.splitk < 1) a.splitk = 1;
   const int ktiles = (int)cdiv(a.K, BK);
   if (a.splitk > ktiles) a.splitk = ktiles > 0 ? ktiles : 1;
@@ -736,9 +754,10 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
     return CLO_EUNSUP;
   }
   if (v2) {
-    const V2Config cfg = v2_config(a.M, a.sym);
+    const V2Config cfg = v2_config(a.M, a.N, batch, a.sym, !a.A2 || a.K1 % 64 == 0);
     a.tiles_m = (int)cdiv(a.M, cfg.bm);
     a.tiles_n = (int)cdiv(a.N, cfg.bn);
+    a.tbm = cfg.bm; a.tbn = cfg.bn;
     a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), cfg.bk) * cfg.bk;
     a.splitk = (int)cdiv(a.K, a.k_per_split);
     grid = dim3(a.tiles_m * a.tiles_n, batch * a.splitk);
@@ -766,7 +785,8 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   else if (b_kc) CLO_V2(false, true, BKV, BMV, BNV, WM_, WN_)           \
   else CLO_V2(false, false, BKV, BMV, BNV, WM_, WN_)
     const long nblocks = (long)grid.x * grid.y;
-    if (cfg.bm == 32) { CLO_V2L(16, 32, 256, 1, 8) }
+    if (cfg.bk == 64) { CLO_V2L(64, 64, 64, 2, 2) }
+    else if (cfg.bm == 32) { CLO_V2L(16, 32, 256, 1, 8) }
     else if (cfg.bm == 64) { CLO_V2L(16, 64, 256, 1, 8) }
     // 8 waves (two per SIMD inside one block) when the grid cannot put two blocks on every CU
     else if (nblocks < 2L * kNumCU) { CLO_V2L(32, 128, 128, 2, 4) }
@@ -792,6 +812,7 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
 int launch_gemm_sqsum(GemmArgs a, int batch, int splits, hipStream_t stream) {
   a.tiles_m = (int)cdiv(a.M, BM);
   a.tiles_n = (int)cdiv(a.N, BN);
+  a.tbm = BM; a.tbn = BN;
   a.nbatch = batch;
   splits = std::max(1, std::min(splits, batch));
   a.batch_per_split = (int)cdiv(batch, splits);
@@ -876,9 +897,9 @@ int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale, int wav
 
 extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
   const long b = batch > 0 ? batch : 1;
-  const V2Config cfg = v2_config(M, 0);
+  const V2Config cfg = v2_config(M, N, b, 0);
   return clo::suggest_splitk_tiles(cdiv(M, cfg.bm) * cdiv(N, cfg.bn) * b, K, (long)M * N * b,
-                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0), 8);
+                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0), cfg.bk == 64 ? 4 : 8);
 }
 
 extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,

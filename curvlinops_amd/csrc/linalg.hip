@@ -16,46 +16,168 @@ constexpr int PNB = 64;
 // to A (may alias Ain); also writes Linv = L^-1 (lower triangular, zeros above the diagonal).
 // *status is set to the 1-based pivot index if a non-positive pivot is met.
 //
-// ONE wavefront (barriers are free), lane i owns row i.  Left-looking: column k of L is
-//   L[i][k] = (S[i][k] - sum_{j<k} L[i][j] L[k][j]) / L[k][k]
-// with L[i][j] read from the lane's own LDS row (stride 65: conflict-free) and L[k][j] a broadcast
-// read; the triangular inverse is forward substitution with lane c owning column c of L^-1.
-// ~2 x 2016 LDS-fed FMAs per lane instead of 64 x 3 workgroup barriers.
+// A leaf sits on the critical path of the whole inverse (one per 64 rows of a factor), so its wall
+// time is what matters.  ONE wavefront (barriers are free), the block in LDS, blocked by 16:
+//   * 16 x 16 diagonal blocks: factor + triangular inverse in REGISTERS, lane i holds row i, fully
+//     unrolled so every index is static; pivots and the other rows' column entries arrive by
+//     v_readlane (an SGPR operand of the FMA): right-looking s_i[j] -= l_ik l_jk, then column-oriented
+//     forward substitution for X = L^-1 (lane c owns column c).  ~1000 instructions: unrolling the
+//     full 64 x 64 block the same way is 10x that, and a single wave running 80 KB of cold
+//     straight-line code is instruction-fetch bound (measured 65 us); LDS loops with dynamic
+//     indices instead wait ~650 ns per step on ds_read latency (83 us).
+//   * everything else on v_mfma_f32_16x16x4_f32: the panel L_ik = S_ik X_kk^T, the trailing update
+//     S_ij -= L_ik L_jk^T, and the off-diagonal blocks of the inverse
+//     X_ij = -X_ii sum_{j <= k < i} L_ik X_kj.  All products are of the form P Q^T with both
+//     operands row-major in LDS (one ds_read_b128 per lane feeds four MFMAs), so X is kept in
+//     both orientations.
+constexpr int PLD = PNB + 4;  // LDS row stride in floats: rows stay 16-byte aligned
+constexpr int PSB = 16;       // sub-block
+constexpr int TLD = PSB + 4;
+
+__device__ __forceinline__ float read_lane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+using lf32x4 = __attribute__((ext_vector_type(4))) float;
+
+// acc += P Q^T for 16 x 16 blocks given as per-lane fragments (row lane & 15, k = 4 (lane >> 4) ..+3)
+__device__ __forceinline__ lf32x4 mm16(const float4 a, const float4 b, lf32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  return acc;
+}
+
 __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long ldin, float *A,
                                                         long lda, int nb, float *__restrict__ Linv,
                                                         long ldinv, int *__restrict__ status,
                                                         int pivot_base) {
-  __shared__ float S[PNB][PNB + 1];   // becomes L (lower triangle)
-  __shared__ float XT[PNB][PNB + 1];  // XT[c][i] = (L^-1)[i][c]
+  __shared__ __attribute__((aligned(16))) float S[PNB * PLD];   // becomes L (lower blocks)
+  __shared__ __attribute__((aligned(16))) float X[PNB * PLD];   // L^-1
+  __shared__ __attribute__((aligned(16))) float XT[PNB * PLD];  // (L^-1)^T
+  __shared__ __attribute__((aligned(16))) float TT[PSB * TLD];  // transposed 16 x 16 scratch
   const int lane = threadIdx.x;
-  for (int j = 0; j < nb; ++j)
-    S[lane][j] = lane < nb ? Ain[(long)lane * ldin + j] : 0.f;
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    float acc = S[lane][k];
-#pragma unroll 4
-    for (int j = 0; j < k; ++j) acc = fmaf(-S[lane][j], S[k][j], acc);
-    const float d = __shfl(acc, k, 64);
-    if (!(d > 0.f)) {  // uniform; also catches NaN
-      if (lane == 0) *status = pivot_base + k + 1;
-      return;
+  const int idx = lane & 15, s4 = (lane >> 4) * 4;
+  // coalesced load (lane = column); rows / columns beyond nb: identity
+  {
+    float v[PNB];  // all 64 loads in flight: one memory round trip
+    const int cl = min(lane, nb - 1);
+#pragma unroll
+    for (int r = 0; r < PNB; ++r) v[r] = Ain[(long)min(r, nb - 1) * ldin + cl];
+#pragma unroll
+    for (int r = 0; r < PNB; ++r) {
+      S[r * PLD + lane] = (r < nb && lane < nb) ? v[r] : ((r == lane) ? 1.f : 0.f);
+      X[r * PLD + lane] = 0.f;
+      XT[r * PLD + lane] = 0.f;
     }
-    const float inv = rsqrtf(d);
-    __syncthreads();
-    if (lane >= k && lane < nb) S[lane][k] = (lane == k) ? d * inv : acc * inv;
-    __syncthreads();
-  }
-  // forward substitution for column c = lane of X = L^-1
-  for (int i = 0; i < nb; ++i) {
-    float acc = (lane == i) ? 1.f : 0.f;
-#pragma unroll 4
-    for (int k = 0; k < i; ++k) acc = fmaf(-S[i][k], XT[lane][k], acc);
-    XT[lane][i] = (i < lane || lane >= nb) ? 0.f : acc / S[i][i];
   }
   __syncthreads();
-  if (lane < nb) {
-    for (int j = 0; j <= lane; ++j) A[(long)lane * lda + j] = S[lane][j];
-    for (int c = 0; c < nb; ++c) Linv[(long)lane * ldinv + c] = XT[c][lane];
+
+  auto frag = [&](const float *M, int r0, int c0) {
+    return *reinterpret_cast<const float4 *>(M + (r0 + idx) * PLD + c0 + s4);
+  };
+  // D layout of the MFMA: acc[r] is element (s4 + r, idx) of the 16 x 16 result
+  auto store = [&](float *M, int r0, int c0, const lf32x4 d, float scale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[(r0 + s4 + r) * PLD + c0 + idx] = scale * d[r];
+  };
+  auto store_t = [&](float *M, int ld, int r0, int c0, const lf32x4 d, float scale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[(r0 + idx) * ld + c0 + s4 + r] = scale * d[r];
+  };
+
+#pragma unroll 1
+  for (int kb = 0; kb < PNB / PSB; ++kb) {
+    const int o = kb * PSB;
+    {  // ---- diagonal block in registers: every group of 16 lanes runs the same rows
+      float s[PSB], x[PSB];
+      const float *src = S + (o + idx) * PLD + o;
+#pragma unroll
+      for (int q = 0; q < PSB / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
+        s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
+      }
+      float my_inv = 1.f;
+#pragma unroll
+      for (int k = 0; k < PSB; ++k) {
+        const float d = read_lane(s[k], k);
+        if (!(d > 0.f)) {  // uniform; also catches NaN (padding rows have d == 1)
+          if (lane == 0) *status = pivot_base + o + k + 1;
+          return;
+        }
+        const float inv = rsqrtf(d);
+        const float l = (idx == k) ? d * inv : s[k] * inv;
+        if (idx == k) my_inv = inv;
+        s[k] = l;
+#pragma unroll
+        for (int j = k + 1; j < PSB; ++j) s[j] = fmaf(-l, read_lane(l, j), s[j]);
+      }
+#pragma unroll
+      for (int r = 0; r < PSB; ++r) x[r] = (r == idx) ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < PSB; ++i) {
+        const float xi = x[i] * read_lane(my_inv, i);
+        x[i] = xi;  // X[i][idx]
+#pragma unroll
+        for (int r = i + 1; r < PSB; ++r) x[r] = fmaf(-read_lane(s[i], r), xi, x[r]);
+      }
+      if (lane < PSB) {
+        float *dst = S + (o + idx) * PLD + o;
+        float *xt = XT + (o + idx) * PLD + o;
+#pragma unroll
+        for (int j = 0; j < PSB; ++j) {
+          dst[j] = (j <= idx) ? s[j] : 0.f;
+          X[(o + j) * PLD + o + idx] = x[j];
+          xt[j] = x[j];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- panel: L_ik = S_ik X_kk^T
+    {
+      const float4 b = frag(X, o, o);
+      for (int ib = kb + 1; ib < PNB / PSB; ++ib) {
+        const float4 a = frag(S, ib * PSB, o);
+        const lf32x4 d = mm16(a, b, lf32x4{0.f, 0.f, 0.f, 0.f});
+        store(S, ib * PSB, o, d, 1.f);
+      }
+    }
+    __syncthreads();
+    // ---- trailing update: S_ij -= L_ik L_jk^T (lower blocks)
+    for (int ib = kb + 1; ib < PNB / PSB; ++ib) {
+      const float4 a = frag(S, ib * PSB, o);
+      for (int jb = kb + 1; jb <= ib; ++jb) {
+        const float4 b = frag(S, jb * PSB, o);
+        const lf32x4 d = mm16(a, b, lf32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(ib * PSB + s4 + r) * PLD + jb * PSB + idx] -= d[r];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- off-diagonal blocks of X = L^-1, column block by column block
+#pragma unroll 1
+  for (int jb = 0; jb < PNB / PSB - 1; ++jb)
+#pragma unroll 1
+    for (int ib = jb + 1; ib < PNB / PSB; ++ib) {
+      lf32x4 t{0.f, 0.f, 0.f, 0.f};
+      for (int k = jb; k < ib; ++k)  // (L_ik X_kj)[i][n] = sum_kk L_ik[i][kk] XT_jk[n][kk]
+        t = mm16(frag(S, ib * PSB, k * PSB), frag(XT, jb * PSB, k * PSB), t);
+      store_t(TT, TLD, 0, 0, t, 1.f);
+      __syncthreads();
+      const float4 tb = *reinterpret_cast<const float4 *>(TT + idx * TLD + s4);
+      const lf32x4 d = mm16(frag(X, ib * PSB, ib * PSB), tb, lf32x4{0.f, 0.f, 0.f, 0.f});
+      store(X, ib * PSB, jb * PSB, d, -1.f);
+      store_t(XT, PLD, jb * PSB, ib * PSB, d, -1.f);
+      __syncthreads();
+    }
+
+  // coalesced stores (lane = column): L lower triangle, L^-1 with its zeros
+  for (int r = 0; r < nb; ++r) {
+    if (lane <= r) A[(long)r * lda + lane] = S[r * PLD + lane];
+    if (lane < nb) Linv[(long)r * ldinv + lane] = X[r * PLD + lane];
   }
 }
 
@@ -72,11 +194,9 @@ __global__ void chol_init_kernel(const float *__restrict__ A, long lda, float *_
   }
 }
 
-int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,
-                       const float *B, long sb_k, long sb_n, float beta, float *C, long ldc,
-                       float *ws, long ws_floats, hipStream_t st);
-int launch_syrk_simple(float *C, long ldc, const float *X, long rows, int d, long ldx, float alpha,
-                       float beta, float *ws, long ws_floats, hipStream_t st);
+}  // namespace clo
+#include "gemm.h"
+namespace clo {
 
 struct CholCtx {
   float *S, *L, *Li, *T, *G;
@@ -103,19 +223,28 @@ static int chol_rec(const CholCtx &c, int o, int m) {
   if (rc != CLO_OK) return rc;
   const float *L11i = c.Li + a * n + a;
   float *L21 = c.L + b * n + a;
-  // L21 = S21 * L11i^T      (B(k,n) = L11i[n][k])
-  rc = launch_gemm_simple(m2, m1, m1, 1.f, c.S + b * n + a, n, 1, L11i, 1, n, 0.f, L21, n, c.G, c.gws, c.st);
+  // one product on the GEMM engine; `tri` names the triangular operand so that only the k range
+  // of each tile that can be nonzero is visited, `sym` computes the block-upper triangle and mirrors
+  auto gemm = [&](int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k, const float *B,
+                  long sb_k, long sb_n, float beta, float *C, long ldc, int tri, int sym) {
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+    g.A = A; g.sa_m = sa_m; g.sa_k = sa_k; g.B = B; g.sb_k = sb_k; g.sb_n = sb_n;
+    g.C = C; g.ldc = ldc; g.tri = tri; g.sym = sym;
+    return launch_gemm_auto(g, c.G, c.gws, c.st);
+  };
+  // L21 = S21 * L11i^T      (B(k,n) = L11i[n][k], zero for k > n)
+  rc = gemm(m2, m1, m1, 1.f, c.S + b * n + a, n, 1, L11i, 1, n, 0.f, L21, n, TRI_KLT_N, 0);
   if (rc != CLO_OK) return rc;
-  // S22 -= L21 * L21^T
-  rc = launch_gemm_simple(m2, m2, m1, -1.f, L21, n, 1, L21, 1, n, 1.f, c.S + b * n + b, n, c.G, c.gws, c.st);
+  // S22 -= L21 * L21^T      (symmetric: half the tiles, mirrored)
+  rc = gemm(m2, m2, m1, -1.f, L21, n, 1, L21, 1, n, 1.f, c.S + b * n + b, n, 0, 1);
   if (rc != CLO_OK) return rc;
   rc = chol_rec(c, b, m2);
   if (rc != CLO_OK) return rc;
-  // T = L21 * L11i ; Li21 = -L22i * T
-  rc = launch_gemm_simple(m2, m1, m1, 1.f, L21, n, 1, L11i, n, 1, 0.f, c.T, m1, c.G, c.gws, c.st);
+  // T = L21 * L11i (B(k,n) = L11i[k][n], zero for k < n) ; Li21 = -L22i * T (A(m,k) zero for k > m)
+  rc = gemm(m2, m1, m1, 1.f, L21, n, 1, L11i, n, 1, 0.f, c.T, m1, TRI_KGE_N, 0);
   if (rc != CLO_OK) return rc;
-  return launch_gemm_simple(m2, m1, m2, -1.f, c.Li + b * n + b, n, 1, c.T, m1, 1, 0.f, c.Li + b * n + a, n,
-                            c.G, c.gws, c.st);
+  return gemm(m2, m1, m2, -1.f, c.Li + b * n + b, n, 1, c.T, m1, 1, 0.f, c.Li + b * n + a, n, TRI_KLT_M, 0);
 }
 
 }  // namespace clo
@@ -148,8 +277,12 @@ extern "C" int clo_cholesky_inverse_f32(const float *A, long lda, float *out, lo
   CLO_CHECK_LAUNCH("chol_init_kernel");
   rc = chol_rec(c, 0, n);
   if (rc != CLO_OK) return rc;
-  // A^-1 = Li^T Li
-  return launch_syrk_simple(out, ldo, c.Li, n, n, n, 1.f, 0.f, c.G, c.gws, st);
+  // A^-1 = Li^T Li: A(m,k) = Li[k][m] and B(k,n) = Li[k][n] are zero for k < m / k < n
+  GemmArgs g{};
+  g.M = n; g.N = n; g.K = n; g.alpha = 1.f; g.beta = 0.f;
+  g.A = c.Li; g.sa_m = 1; g.sa_k = n; g.B = c.Li; g.sb_k = n; g.sb_n = 1;
+  g.C = out; g.ldc = ldo; g.sym = 1; g.tri = TRI_KGE_M | TRI_KGE_N;
+  return launch_gemm_auto(g, c.G, c.gws, st);
 }
 
 extern "C" int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int *status,
