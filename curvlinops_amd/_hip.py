@@ -304,21 +304,30 @@ def cholesky_inverse_async(A: Tensor, damping: float = 0.0) -> tuple[Tensor, Ten
     inspects once the stream has been joined.  One call into ``clo_cholesky_inverse_f32``
     (recursive blocked Cholesky carrying the triangular inverse; leaves in LDS, every O(n^3) step on
     the MFMA GEMM); never modifies ``A``."""
-    lib = load()
     n = A.shape[0]
     if A.dim() != 2 or A.shape[1] != n:
         raise ValueError(f"expected a square matrix, got {tuple(A.shape)}")
-    if A.stride(-1) != 1 and n > 1:
-        A = A.contiguous()
     out = torch.empty(n, n, device=A.device, dtype=torch.float32)
     status = torch.zeros(1, device=A.device, dtype=torch.int32)
+    cholesky_inverse_into(A, damping, out, status)
+    return out, status
+
+
+def cholesky_inverse_into(A: Tensor, damping: float, out: Tensor, status: Tensor) -> None:
+    """:func:`cholesky_inverse_async` into caller-provided ``out`` ([n, n] contiguous float32) and
+    ``status`` (device int32), on the calling thread's current stream.  The whole chain of launches
+    happens inside ONE foreign call (the GIL is released), so several host threads can drive
+    independent factors concurrently."""
+    lib = load()
+    n = A.shape[0]
     if n == 0:
-        return out, status
+        return
+    if A.stride(-1) != 1 and n > 1:
+        A = A.contiguous()
     ws = torch.empty(lib.clo_cholesky_inverse_ws_floats(n), device=A.device, dtype=torch.float32)
     rc = lib.clo_cholesky_inverse_f32(_p(A), A.stride(0) if n > 1 else 1, _p(out), n, n, damping, _p(ws),
                                       status.data_ptr(), _stream())
     _check(rc, "clo_cholesky_inverse_f32")
-    return out, status
 
 
 def not_pd_error(pivot: int, n: int) -> RuntimeError:

@@ -34,6 +34,13 @@ constexpr int PLD = PNB + 4;  // LDS row stride in floats: rows stay 16-byte ali
 constexpr int PSB = 16;       // sub-block
 constexpr int TLD = PSB + 4;
 
+#ifdef CLO_POTRF_DBG
+__device__ long long potrf_dbg[16];
+#define CLO_TICK(i) if (lane == 0) potrf_dbg[i] = wall_clock64();
+#else
+#define CLO_TICK(i)
+#endif
+
 __device__ __forceinline__ float read_lane(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -73,6 +80,7 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
     }
   }
   __syncthreads();
+  CLO_TICK(1)
 
   auto frag = [&](const float *M, int r0, int c0) {
     return *reinterpret_cast<const float4 *>(M + (r0 + idx) * PLD + c0 + s4);
@@ -99,19 +107,23 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
         s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
       }
       float my_inv = 1.f;
+      int bad = 0;  // first non-positive pivot (1-based), kept as data: no exits inside the chain
 #pragma unroll
       for (int k = 0; k < PSB; ++k) {
         const float d = read_lane(s[k], k);
-        if (!(d > 0.f)) {  // uniform; also catches NaN (padding rows have d == 1)
-          if (lane == 0) *status = pivot_base + o + k + 1;
-          return;
-        }
-        const float inv = rsqrtf(d);
+        // uniform; false for NaN too (padding rows have d == 1).  A bad pivot poisons the rest of
+        // the block with NaNs, which nobody reads: the kernel leaves right after the chain.
+        bad = (bad == 0 && !(d > 0.f)) ? k + 1 : bad;
+        const float inv = __builtin_amdgcn_rsqf(d);
         const float l = (idx == k) ? d * inv : s[k] * inv;
         if (idx == k) my_inv = inv;
         s[k] = l;
 #pragma unroll
         for (int j = k + 1; j < PSB; ++j) s[j] = fmaf(-l, read_lane(l, j), s[j]);
+      }
+      if (bad) {  // uniform
+        if (lane == 0) *status = pivot_base + o + bad;
+        return;
       }
 #pragma unroll
       for (int r = 0; r < PSB; ++r) x[r] = (r == idx) ? 1.f : 0.f;
@@ -134,6 +146,7 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
       }
     }
     __syncthreads();
+    if (kb == 0) { CLO_TICK(2) }
     // ---- panel: L_ik = S_ik X_kk^T
     {
       const float4 b = frag(X, o, o);
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
       }
     }
     __syncthreads();
+    if (kb == 0) { CLO_TICK(3) }
     // ---- trailing update: S_ij -= L_ik L_jk^T (lower blocks)
     for (int ib = kb + 1; ib < PNB / PSB; ++ib) {
       const float4 a = frag(S, ib * PSB, o);
@@ -155,7 +169,9 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
       }
     }
     __syncthreads();
+    if (kb == 0) { CLO_TICK(4) }
   }
+  CLO_TICK(5)
 
   // ---- off-diagonal blocks of X = L^-1, column block by column block
 #pragma unroll 1
@@ -174,11 +190,19 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
       __syncthreads();
     }
 
+  CLO_TICK(6)
   // coalesced stores (lane = column): L lower triangle, L^-1 with its zeros
-  for (int r = 0; r < nb; ++r) {
-    if (lane <= r) A[(long)r * lda + lane] = S[r * PLD + lane];
-    if (lane < nb) Linv[(long)r * ldinv + lane] = X[r * PLD + lane];
+  if (lane < nb) {
+    const float *sp = S + lane, *xp = X + lane;
+    float *ap = A + lane, *lp = Linv + lane;
+#pragma unroll 8
+    for (int r = 0; r < nb; ++r) {
+      const float lv = sp[r * PLD], xv = xp[r * PLD];
+      lp[(long)r * ldinv] = xv;
+      if (lane <= r) ap[(long)r * lda] = lv;
+    }
   }
+  CLO_TICK(7)
 }
 
 // S = A + damping * I ; L = 0 ; Li = 0

@@ -30,43 +30,78 @@ def _torch_damped_cholesky_inverse(A: Tensor, damping: float) -> Tensor:
 
 
 class _InverseBatch:
-    """Factor inverses are independent dependency-bound chains of small kernels: run them on a few
-    HIP streams at once and inspect all pivot statuses with ONE device read at the end."""
+    """Factor inverses are independent dependency-bound chains of small kernels (a few hundred
+    launches for a 4608 x 4608 factor), limited as much by the host's launch rate as by the GPU.
+    The jobs are collected, then driven largest-first by a few worker threads that each own a HIP
+    stream (one foreign call per factor, GIL released), and all pivot statuses are inspected with
+    ONE device read at the end."""
 
-    MIN_SIDE_N = 512
+    MIN_THREADED = 3     # fewer jobs than this: run them inline on the caller's stream
+    MIN_TOTAL_N = 2048   # ... as are batches of tiny factors (LeNet-5: threads cost more than they hide)
 
     def __init__(self, num_streams: int):
         self._num = num_streams
-        self._streams: list = []
         self._jobs: list = []  # (A, damping, retry, out, status)
-        self._nside = 0
 
     def submit(self, A: Tensor, damping: float, retry: bool) -> Tensor:
-        if A.shape[0] < self.MIN_SIDE_N:  # tiny factor: a stream hop costs more than it hides
-            out, status = _hip.cholesky_inverse_async(A, damping)
-            self._jobs.append((A, damping, retry, out, status))
-            return out
-        main = torch.cuda.current_stream(A.device)
-        if not self._streams:
-            self._streams = [torch.cuda.Stream(device=A.device) for _ in range(self._num)]
-        side = self._streams[self._nside % self._num]
-        self._nside += 1
-        side.wait_event(main.record_event())
-        with torch.cuda.stream(side):
-            out, status = _hip.cholesky_inverse_async(A, damping)
-        A.record_stream(side)
+        n = A.shape[0]
+        out = torch.empty(n, n, device=A.device, dtype=torch.float32)
+        status = torch.zeros(1, device=A.device, dtype=torch.int32)
         self._jobs.append((A, damping, retry, out, status))
         return out
+
+    def _run(self) -> None:
+        jobs = self._jobs
+        if (len(jobs) < self.MIN_THREADED or self._num < 2
+                or sum(j[0].shape[0] for j in jobs) < self.MIN_TOTAL_N):
+            for A, damping, _, out, status in jobs:
+                _hip.cholesky_inverse_into(A, damping, out, status)
+            return
+        import queue
+        import threading
+
+        device = jobs[0][0].device
+        main = torch.cuda.current_stream(device)
+        ready = main.record_event()
+        todo: queue.SimpleQueue = queue.SimpleQueue()
+        for j in sorted(range(len(jobs)), key=lambda j: -jobs[j][0].shape[0]):
+            todo.put(j)
+        done: list = []
+        errors: list = []
+
+        def worker() -> None:
+            try:
+                with torch.cuda.device(device):
+                    side = torch.cuda.Stream(device=device)
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        while True:
+                            try:
+                                j = todo.get_nowait()
+                            except queue.Empty:
+                                break
+                            A, damping, _, out, status = jobs[j]
+                            for t in (A, out, status):
+                                t.record_stream(side)
+                            _hip.cholesky_inverse_into(A, damping, out, status)
+                    done.append(side.record_event())
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker) for _ in range(min(self._num, len(jobs)))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for ev in done:
+            main.wait_event(ev)
+        if errors:
+            raise errors[0]
 
     def finish(self) -> None:
         if not self._jobs:
             return
-        main = torch.cuda.current_stream(self._jobs[0][0].device)
-        for side in self._streams:
-            main.wait_stream(side)
-        for *_, out, status in self._jobs:
-            out.record_stream(main)
-            status.record_stream(main)
+        self._run()
         bad = torch.cat([j[4] for j in self._jobs]).cpu().tolist()
         for (A, damping, retry, out, _), pivot in zip(self._jobs, bad):
             if not pivot:
@@ -90,7 +125,8 @@ def concurrent_inverses(num_streams: int = 4):
     if _ACTIVE_BATCH is not None:  # nested: the outermost block owns the batch
         yield
         return
-    batch = _ACTIVE_BATCH = _InverseBatch(num_streams)
+    import os
+    batch = _ACTIVE_BATCH = _InverseBatch(int(os.environ.get("CLO_INV_STREAMS", num_streams)))
     try:
         yield
     except BaseException:

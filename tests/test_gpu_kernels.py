@@ -441,6 +441,13 @@ def test_concurrent_inverses_match_sequential_and_retry(hip):
     with pytest.raises(RuntimeError):
         with linalg_native.concurrent_inverses():
             linalg_native.damped_cholesky_inverse(bad.float().cuda(), 1e-10, retry_double_precision=False)
+    # the same inside a batch large enough for the worker threads
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with linalg_native.concurrent_inverses():
+            outs = [linalg_native.damped_cholesky_inverse(m, 1e-10) for m in [*mats, bad.float().cuda()]]
+    assert any("double precision" in str(x.message) for x in w)
+    assert rel_err(outs[-1].cpu(), ref) < 1e-3
 
 
 @pytest.mark.parametrize("geom", [
