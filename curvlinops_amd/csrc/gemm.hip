@@ -986,26 +986,29 @@ int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float
   Fwd3Args p{};
   p.A = A; p.dA = dA; p.W = W; p.V = V; p.b = b; p.Vb = Vb; p.a = a; p.da = da; p.dphi = dphi;
   p.ws = ws; p.N = N; p.d_in = d_in; p.d_out = d_out; p.act = act;
-  const int bm = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
-  const int bn = bm == 128 ? 64 : 128;
-  constexpr int bk = 16;
+  // tiny layers (small networks): one block's k loop is a chain of memory round trips, so small
+  // tiles on more CUs with 64-deep k steps (as v2_config does for plain products)
+  const bool tiny = (long)N * d_out <= 256L * 256L;
+  const int bm = tiny ? 32 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128));
+  const int bn = tiny ? 64 : (bm == 128 ? 64 : 128);
+  const int bk = tiny ? 64 : 16;
   p.tiles_m = (int)cdiv(N, bm);
   p.tiles_n = (int)cdiv(d_out, bn);
   const long tiles = (long)p.tiles_m * p.tiles_n, MN = (long)N * d_out;
   // two or three products per tile: the MFMA time of a plain tile of the same area times that
   long s = suggest_splitk_tiles(tiles, d_in, 2 * MN, (dA ? 3.0 : 2.0) * bm * bn / (128.0 * 128.0),
-                                bm == 64 ? 8 : 4);
+                                tiny ? 2 : (bm == 64 ? 8 : 4));
   if (MN > 0) s = std::min<long>(s, ws ? ws_floats / (2 * MN) : 1);
   s = std::max<long>(1, s);
   p.k_per_split = (int)cdiv(cdiv(d_in, s), bk) * bk;
   p.splitk = (int)cdiv(d_in, p.k_per_split);
   dim3 grid((unsigned)tiles, (unsigned)p.splitk);
-#define CLO_F3(BMV, BNV, WM_, WN_, DA_)                                                            \
+#define CLO_F3(BKV, BMV, BNV, WM_, WN_, DA_)                                                       \
   {                                                                                                \
     constexpr int nthr = WM_ * WN_ * 64;                                                           \
-    const size_t smem = 2 * ((DA_ ? 2 : 1) * TileIO<true, bk, nthr, BMV>::FLOATS +                 \
-                             2 * TileIO<true, bk, nthr, BNV>::FLOATS) * sizeof(float);             \
-    auto kern = gemm_fwd3_kernel<bk, BMV, BNV, WM_, WN_, DA_>;                                     \
+    const size_t smem = 2 * ((DA_ ? 2 : 1) * TileIO<true, BKV, nthr, BMV>::FLOATS +                \
+                             2 * TileIO<true, BKV, nthr, BNV>::FLOATS) * sizeof(float);            \
+    auto kern = gemm_fwd3_kernel<BKV, BMV, BNV, WM_, WN_, DA_>;                                    \
     if (smem > 64 * 1024) {                                                                        \
       static bool attr_set = false;                                                                \
       if (!attr_set) {                                                                             \
@@ -1018,11 +1021,12 @@ int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float
     }                                                                                              \
     hipLaunchKernelGGL(kern, grid, dim3(nthr), smem, st, p);                                       \
   }
-#define CLO_F3L(BMV, BNV, WM_, WN_) \
-  if (dA) CLO_F3(BMV, BNV, WM_, WN_, true) else CLO_F3(BMV, BNV, WM_, WN_, false)
-  if (bm == 32) { CLO_F3L(32, 128, 1, 4) }
-  else if (bm == 64) { CLO_F3L(64, 128, 2, 4) }
-  else { CLO_F3L(128, 64, 2, 2) }
+#define CLO_F3L(BKV, BMV, BNV, WM_, WN_) \
+  if (dA) CLO_F3(BKV, BMV, BNV, WM_, WN_, true) else CLO_F3(BKV, BMV, BNV, WM_, WN_, false)
+  if (tiny) { CLO_F3L(64, 32, 64, 1, 2) }
+  else if (bm == 32) { CLO_F3L(16, 32, 128, 1, 4) }
+  else if (bm == 64) { CLO_F3L(16, 64, 128, 2, 4) }
+  else { CLO_F3L(16, 128, 64, 2, 2) }
 #undef CLO_F3L
 #undef CLO_F3
   CLO_CHECK_LAUNCH("gemm_fwd3_kernel");
