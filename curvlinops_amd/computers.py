@@ -483,7 +483,14 @@ class HipEKFACComputer(HipKFACComputer):
         with _use_params(self._model_module, self._params):
             A, G, mapping = self._compute_kronecker_factors()
             keys = [("a", k) for k in A] + [("g", k) for k in G]
-            bases = linalg_native.eigh_many([A[k] if w == "a" else G[k] for w, k in keys])
+            mats = [A[k] if w == "a" else G[k] for w, k in keys]
+            if self._distributed:
+                # identical factors on every rank: shard the eigendecompositions by factor
+                from curvlinops_amd.dist import sharded_factor_map
+
+                bases = sharded_factor_map(mats, linalg_native.eigh_many, lambda n: [(n,), (n, n)])
+            else:
+                bases = linalg_native.eigh_many(mats)
             Qa = {k: q[1] for (w, k), q in zip(keys, bases) if w == "a"}
             Qg = {k: q[1] for (w, k), q in zip(keys, bases) if w == "g"}
             lam = self._eigenvalue_correction(Qa, Qg, mapping)

@@ -65,6 +65,7 @@ class KFACLinearOperator(_ChainPyTorchLinearOperator):
         K, mapping = self._compute_canonical_op(computer)
         P, PT = self._build_converters(computer, mapping)
         super().__init__(P, K, PT)
+        self._distributed = distributed
 
     @staticmethod
     def _compute_canonical_op(computer) -> tuple[BlockDiagonalLinearOperator, list[ParamGroup]]:
@@ -104,8 +105,9 @@ class KFACLinearOperator(_ChainPyTorchLinearOperator):
         retry_double_precision: bool = True,
     ) -> _ChainPyTorchLinearOperator:
         P, K, PT = self
-        # the factors of all blocks are independent: their Cholesky inverses share a pool of streams
-        with linalg_native.concurrent_inverses():
+        # the factors of all blocks are independent: their Cholesky inverses run concurrently (and,
+        # for a data-parallel operator whose factors are replicated, sharded over the ranks)
+        with linalg_native.concurrent_inverses(distributed=getattr(self, "_distributed", False)):
             K_inv = BlockDiagonalLinearOperator([
                 block.inverse(
                     damping=damping, use_heuristic_damping=use_heuristic_damping, min_damping=min_damping,

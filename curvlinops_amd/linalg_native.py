@@ -34,38 +34,58 @@ class _InverseBatch:
     launches for a 4608 x 4608 factor), limited as much by the host's launch rate as by the GPU.
     The jobs are collected, then driven largest-first by a few worker threads that each own a HIP
     stream (one foreign call per factor, GIL released), and all pivot statuses are inspected with
-    ONE device read at the end."""
+    ONE device read at the end.
+
+    ``distributed=True`` (factors replicated on every rank, as after the KFAC factor all-reduce):
+    the jobs are additionally sharded over the ranks, largest-first, and the inverses exchanged
+    with one packed broadcast per owner (``dist.partition_by_cost``)."""
 
     MIN_THREADED = 3     # fewer jobs than this: run them inline on the caller's stream
     MIN_TOTAL_N = 2048   # ... as are batches of tiny factors (LeNet-5: threads cost more than they hide)
 
-    def __init__(self, num_streams: int):
+    def __init__(self, num_streams: int, distributed: bool = False):
         self._num = num_streams
-        self._jobs: list = []  # (A, damping, retry, out, status)
+        self.distributed = distributed
+        self._jobs: list = []  # [A, damping, retry, out, status (device int32 | None), error]
 
     def submit(self, A: Tensor, damping: float, retry: bool) -> Tensor:
         n = A.shape[0]
-        out = torch.empty(n, n, device=A.device, dtype=torch.float32)
-        status = torch.zeros(1, device=A.device, dtype=torch.int32)
-        self._jobs.append((A, damping, retry, out, status))
+        native = is_native_tensor(A)
+        out = torch.empty(n, n, device=A.device, dtype=A.dtype)
+        status = torch.zeros(1, device=A.device, dtype=torch.int32) if native else None
+        self._jobs.append([A, damping, retry, out, status, None])
         return out
 
-    def _run(self) -> None:
-        jobs = self._jobs
-        if (len(jobs) < self.MIN_THREADED or self._num < 2
-                or sum(j[0].shape[0] for j in jobs) < self.MIN_TOTAL_N):
-            for A, damping, _, out, status in jobs:
-                _hip.cholesky_inverse_into(A, damping, out, status)
+    @staticmethod
+    def _run_job(job: list) -> None:
+        A, damping, _, out, status, _ = job
+        if status is not None:
+            _hip.cholesky_inverse_into(A, damping, out, status)
+            return
+        try:  # non-native tensors (CPU, float64): the torch path, failure kept for the retry logic
+            out.copy_(_torch_damped_cholesky_inverse(A, damping))
+        except RuntimeError as error:
+            job[5] = error
+
+    def _run(self, jobs: list) -> None:
+        native = [j for j in jobs if j[4] is not None]
+        for job in jobs:
+            if job[4] is None:
+                self._run_job(job)
+        if (len(native) < self.MIN_THREADED or self._num < 2
+                or sum(j[0].shape[0] for j in native) < self.MIN_TOTAL_N):
+            for job in native:
+                self._run_job(job)
             return
         import queue
         import threading
 
-        device = jobs[0][0].device
+        device = native[0][0].device
         main = torch.cuda.current_stream(device)
         ready = main.record_event()
         todo: queue.SimpleQueue = queue.SimpleQueue()
-        for j in sorted(range(len(jobs)), key=lambda j: -jobs[j][0].shape[0]):
-            todo.put(j)
+        for job in sorted(native, key=lambda j: -j[0].shape[0]):
+            todo.put(job)
         done: list = []
         errors: list = []
 
@@ -77,18 +97,17 @@ class _InverseBatch:
                     with torch.cuda.stream(side):
                         while True:
                             try:
-                                j = todo.get_nowait()
+                                job = todo.get_nowait()
                             except queue.Empty:
                                 break
-                            A, damping, _, out, status = jobs[j]
-                            for t in (A, out, status):
+                            for t in (job[0], job[3], job[4]):
                                 t.record_stream(side)
-                            _hip.cholesky_inverse_into(A, damping, out, status)
+                            self._run_job(job)
                     done.append(side.record_event())
             except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
                 errors.append(e)
 
-        threads = [threading.Thread(target=worker) for _ in range(min(self._num, len(jobs)))]
+        threads = [threading.Thread(target=worker) for _ in range(min(self._num, len(native)))]
         for t in threads:
             t.start()
         for t in threads:
@@ -99,39 +118,87 @@ class _InverseBatch:
             raise errors[0]
 
     def finish(self) -> None:
-        if not self._jobs:
+        jobs = self._jobs
+        if not jobs:
             return
-        self._run()
-        bad = torch.cat([j[4] for j in self._jobs]).cpu().tolist()
-        for (A, damping, retry, out, _), pivot in zip(self._jobs, bad):
-            if not pivot:
+        from curvlinops_amd import dist as cdist
+
+        sharded = self.distributed and cdist.is_distributed()
+        if sharded:
+            import torch.distributed as tdist
+
+            owner = cdist.partition_by_cost([float(j[0].shape[0]) ** 3 for j in jobs], tdist.get_world_size())
+            rank = tdist.get_rank()
+            mine = [j for j, o in zip(jobs, owner) if o == rank]
+        else:
+            mine = jobs
+        self._run(mine)
+        # failures of this rank's jobs: retry in float64 or remember the error
+        native = [j for j in mine if j[4] is not None]
+        if native:
+            for job, pivot in zip(native, torch.cat([j[4] for j in native]).cpu().tolist()):
+                if pivot:
+                    job[5] = _hip.not_pd_error(pivot, job[0].shape[0])
+        fatal = None
+        for job in mine:
+            A, damping, retry, out, _, error = job
+            if error is None:
                 continue
-            error = _hip.not_pd_error(pivot, A.shape[0])
-            if not retry:
-                raise error
+            if not retry or A.dtype == torch.float64:
+                fatal = fatal or error
+                continue
             _warn_retry(A, error)
             out.copy_(_torch_damped_cholesky_inverse(A.to(torch.float64), damping))
+        if sharded:
+            flag = torch.tensor([1.0 if fatal is not None else 0.0], device=jobs[0][0].device)
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
+            if fatal is None and float(flag) > 0:
+                fatal = RuntimeError("cholesky: a factor owned by another rank is not positive-definite.")
+        if fatal is not None:
+            raise fatal
+        if sharded:
+            world = tdist.get_world_size()
+            for r in range(world):
+                theirs = [j for j, o in zip(jobs, owner) if o == r]
+                if not theirs:
+                    continue
+                ref = theirs[0][3]
+                if r == rank:
+                    flat = torch.cat([j[3].reshape(-1).to(ref.dtype) for j in theirs])
+                else:
+                    flat = torch.empty(sum(j[3].numel() for j in theirs), device=ref.device, dtype=ref.dtype)
+                tdist.broadcast(flat, src=r)
+                if r != rank:
+                    off = 0
+                    for j in theirs:
+                        n = j[3].numel()
+                        j[3].copy_(flat[off : off + n].view_as(j[3]))
+                        off += n
 
 
 _ACTIVE_BATCH: _InverseBatch | None = None
 
 
 @contextmanager
-def concurrent_inverses(num_streams: int = 4):
-    """Inside the block, fp32 GPU calls of :func:`damped_cholesky_inverse` are enqueued on a pool of
-    streams and return immediately; on exit the streams are joined, failed factorisations are
-    redone in float64 into the SAME output tensor (or raise, as in the synchronous form)."""
+def concurrent_inverses(num_streams: int = 4, distributed: bool = False):
+    """Inside the block, fp32 GPU calls of :func:`damped_cholesky_inverse` are collected and return
+    their (still empty) output tensors immediately; on exit the factors are inverted concurrently
+    (worker threads with their own streams), failed factorisations are redone in float64 into the
+    SAME output tensor (or raise, as in the synchronous form).  ``distributed=True``: the factors
+    are replicated on all ranks of the default process group and the work is sharded by factor."""
     global _ACTIVE_BATCH
     if _ACTIVE_BATCH is not None:  # nested: the outermost block owns the batch
         yield
         return
     import os
-    batch = _ACTIVE_BATCH = _InverseBatch(int(os.environ.get("CLO_INV_STREAMS", num_streams)))
+
+    batch = _ACTIVE_BATCH = _InverseBatch(int(os.environ.get("CLO_INV_STREAMS", num_streams)), distributed)
     try:
         yield
     except BaseException:
         _ACTIVE_BATCH = None
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         raise
     else:
         _ACTIVE_BATCH = None
@@ -149,7 +216,7 @@ def _warn_retry(A: Tensor, error: Exception) -> None:
 def damped_cholesky_inverse(A: Tensor, damping: float, retry_double_precision: bool = True) -> Tensor:
     """``(A + damping I)^-1`` for symmetric positive definite ``A`` (never modifies ``A``)."""
     native = is_native_tensor(A) and _hip.has("clo_potrf_diag_f32")
-    if native and _ACTIVE_BATCH is not None:
+    if _ACTIVE_BATCH is not None and (native or _ACTIVE_BATCH.distributed):
         return _ACTIVE_BATCH.submit(A, damping, retry_double_precision)
     try:
         if native:
