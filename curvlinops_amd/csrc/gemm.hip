@@ -664,6 +664,33 @@ __global__ void fwd3_reduce_kernel(const Fwd3Args p) {
   }
 }
 
+// Tiny products with operands the aligned engine cannot take (e.g. the 10-class head of a small
+// network: K = 10 or M = 10): one thread per output element, the k loop straight from global memory
+// (the operands are a few KB and stay in L2).  One short launch instead of the v1 tile kernel's
+// latency chain (~15 us for a single 128x128 tile).
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(const GemmArgs p) {
+  const long total = (long)p.M * p.N;
+  const int b = blockIdx.y;
+  const float *A = p.A + (long)b * p.sa_b, *B = p.B + (long)b * p.sb_b;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int m = e / p.N, n = e % p.N;
+    if (p.sym && n < m) continue;
+    const float *a = A + (long)m * p.sa_m, *bb = B + (long)n * p.sb_n;
+    const bool one_a = p.ones && m == p.M - 1, one_b = p.ones && n == p.N - 1;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < p.K; k += 2) {
+      s0 = fmaf(one_a ? 1.f : a[(long)k * p.sa_k], one_b ? 1.f : bb[(long)k * p.sb_k], s0);
+      s1 = fmaf(one_a ? 1.f : a[(long)(k + 1) * p.sa_k], one_b ? 1.f : bb[(long)(k + 1) * p.sb_k], s1);
+    }
+    if (k < p.K) s0 = fmaf(one_a ? 1.f : a[(long)k * p.sa_k], one_b ? 1.f : bb[(long)k * p.sb_k], s0);
+    const float acc = s0 + s1;
+    float *c = p.C + (long)b * p.sc_b + (long)m * p.ldc + n;
+    store_final(p, c, m, n, acc, p.alpha, p.beta);
+    if (p.sym && n != m) store_final(p, p.C + (long)b * p.sc_b + (long)n * p.ldc + m, n, m, acc, p.alpha, p.beta);
+  }
+}
+
 // C = alpha * sum_s ws[b][s] + beta * C ; for sym the lower block-triangle of ws was never
 // written, take the transposed element instead.
 __global__ void splitk_reduce_kernel(const GemmArgs p, int splitk) {
@@ -794,6 +821,11 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
 #undef CLO_V2L
 #undef CLO_V2
     CLO_CHECK_LAUNCH("gemm_v2_kernel");
+  } else if (!a.A2 && (long)a.M * a.N * batch <= 128L * 128L && (long)a.M * a.N * a.K * batch <= (1L << 19)) {
+    a.splitk = 1;
+    const long total = (long)a.M * a.N;
+    hipLaunchKernelGGL(gemm_tiny_kernel, dim3((unsigned)cdiv(total, 256), batch), dim3(256), 0, stream, a);
+    CLO_CHECK_LAUNCH("gemm_tiny_kernel");
   } else {
     hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, a);
     CLO_CHECK_LAUNCH("gemm_f32_kernel");

@@ -38,3 +38,6 @@ python tools/probe_hessian.py > $OUT/r01_c2_hessian.txt 2>/dev/null
 python tools/probe_cg.py > $OUT/r01_c2_cg.txt 2>/dev/null
 python benchmarks/bench_kfac.py lenet --fisher type-2 > $OUT/r01_kfac_lenet_b1024_type2.json 2>/dev/null
 python tools/probe_syrk_skinny.py > $OUT/r01_gram_tall_shapes.txt 2>/dev/null
+python tools/probe_c1.py 2>/dev/null | grep -v amdgpu > $OUT/r01_c1_matvec.txt
+python tools/probe_chol.py 2>/dev/null | grep -v amdgpu > $OUT/r01_cholesky_inverse_sizes.txt
+python tools/probe_mlp_zoo.py 2>/dev/null | grep -v amdgpu > $OUT/r01_mlp_shapes.txt
