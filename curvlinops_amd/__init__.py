@@ -25,6 +25,7 @@ from curvlinops_amd.inverse import (
 )
 from curvlinops_amd.jacobian import JacobianLinearOperator, TransposedJacobianLinearOperator
 from curvlinops_amd.kfac import EKFACLinearOperator, KFACLinearOperator
+from curvlinops_amd.kfoc import KFOCLinearOperator
 from curvlinops_amd.kronecker import (
     BlockDiagonalLinearOperator,
     EighDecomposedLinearOperator,
@@ -55,6 +56,7 @@ __all__ = [
     "NeumannInverseLinearOperator",
     "KFACLinearOperator",
     "EKFACLinearOperator",
+    "KFOCLinearOperator",
     "KroneckerProductLinearOperator",
     "EighDecomposedLinearOperator",
     "BlockDiagonalLinearOperator",

@@ -250,7 +250,7 @@ def main():
     import curvlinops
 
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["mlp", "jacobian", "ggn_diagonal", "linops", "kfac", "trace"]
+    which = sys.argv[1:] or ["mlp", "jacobian", "ggn_diagonal", "linops", "kfac", "trace", "kfoc"]
     if "mlp" in which:
         gen_mlp(curvlinops)
     if "jacobian" in which:
@@ -267,6 +267,10 @@ def main():
         from make_golden_kfac import gen_trace
 
         gen_trace(curvlinops, OUT)
+    if "kfoc" in which:
+        from make_golden_kfac import gen_kfoc
+
+        gen_kfoc(curvlinops, OUT)
 
 
 if __name__ == "__main__":

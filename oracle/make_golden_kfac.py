@@ -186,3 +186,42 @@ def gen_trace(curvlinops, OUT):
         out[f"{dist}/pool"] = pool.numpy()
     np.savez_compressed(OUT / "trace.npz", **{f"t/{k}": v for k, v in out.items()})
     print("trace.npz:", len(out), "arrays")
+
+
+KFOC_CASES = [
+    # name, model factory, input shape, C, loss, reduction, batch
+    ("mlp_mse_mean", lambda: mlp([7, 9, 6, 3]), (7,), 3, "mse", "mean", 12),
+    ("mlp_ce_mean", lambda: mlp([7, 9, 6, 4], act=nn.Tanh), (7,), 4, "ce", "mean", 10),
+    ("mlp_bce_sum_nobias", lambda: mlp([6, 8, 3], bias=False), (6,), 3, "bce", "sum", 9),
+    ("cnn_ce_mean", cnn, (2, 8, 8), 5, "ce", "mean", 6),
+]
+
+
+def gen_kfoc(curvlinops, OUT):
+    """KFOC (type-2: deterministic) on a single batch: the dense operator, which does not depend on
+    the sign ARPACK happens to return for a singular pair, and its product with fixed vectors."""
+    out = {}
+    for idx, (name, factory, in_shape, C, loss, red, B) in enumerate(KFOC_CASES):
+        gen = torch.Generator().manual_seed(900 + idx)
+        torch.manual_seed(900 + idx)
+        model = factory()
+        for p in model.parameters():
+            p.data += 0.01 * torch.rand(p.shape, generator=gen)
+        (X, y), = _data(gen, [B], in_shape, C, loss, False)
+        params = dict(model.named_parameters())
+        D = sum(p.numel() for p in params.values())
+        V = torch.rand(D, 2, generator=gen)
+        rec = {"loss": np.array(loss), "reduction": np.array(red), "V": V.numpy(), "X": X.numpy(),
+               "y": y.numpy(), "in_shape": np.array(in_shape), "C": np.array(C)}
+        for k, p in params.items():
+            rec[f"param:{k}"] = p.detach().numpy()
+        for sep in (True, False):
+            K = curvlinops.KFOCLinearOperator(model, LOSS[loss](reduction=red), params, [(X, y)],
+                                              fisher_type="type-2", separate_weight_and_bias=sep)
+            tag = "sep" if sep else "joint"
+            rec[f"{tag}/dense"] = (K @ torch.eye(D)).detach().numpy()
+            rec[f"{tag}/KV"] = (K @ V).detach().numpy()
+        for k, val in rec.items():
+            out[f"{name}/{k}"] = val
+    np.savez_compressed(OUT / "kfoc.npz", **out)
+    print("kfoc.npz:", len(out), "arrays")
