@@ -729,11 +729,12 @@ static int pick_mode(const float *P, long so, long sk, long sbatch, int batch) {
 //                                     each whatever the tile depth): smaller tiles on more CUs,
 //                                     4x deeper k tiles (Cholesky recursion, small-network layers)
 struct V2Config { int bm, bn, bk; };
-static V2Config v2_config(int M, int N, long batch, int sym, bool allow_small = true) {
+static V2Config v2_config(int M, int N, int K, long batch, int sym, bool allow_small = true) {
   // (few-row problems keep their 32- / 64-row tiles unless they are tiny)
   static const long small_max = getenv("CLO_GEMM_SMALL_MAX") ? atol(getenv("CLO_GEMM_SMALL_MAX")) : 1024L * 1024L;
   const long area = (long)M * N * batch;
-  if (allow_small && (area <= 256L * 256L || (area <= small_max && (M > 64 || sym)))) return {64, 64, 64};
+  if (allow_small && ((area <= 256L * 256L && K <= 1024) || (area <= small_max && (M > 64 || sym))))
+    return {64, 64, 64};
   if (!sym && M <= 32) return {32, 256, 16};
   if (!sym && M <= 64) return {64, 256, 16};
   return {128, 128, 32};
@@ -781,7 +782,7 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
     return CLO_EUNSUP;
   }
   if (v2) {
-    const V2Config cfg = v2_config(a.M, a.N, batch, a.sym, !a.A2 || a.K1 % 64 == 0);
+    const V2Config cfg = v2_config(a.M, a.N, a.K, batch, a.sym, !a.A2 || a.K1 % 64 == 0);
     a.tiles_m = (int)cdiv(a.M, cfg.bm);
     a.tiles_n = (int)cdiv(a.N, cfg.bn);
     a.tbm = cfg.bm; a.tbn = cfg.bn;
@@ -927,11 +928,17 @@ int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale, int wav
 }
 }  // namespace clo
 
-extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
-  const long b = batch > 0 ? batch : 1;
-  const V2Config cfg = v2_config(M, N, b, 0);
+// `aligned`: the v2 engine will take the problem (its tile configuration applies); otherwise the
+// v1 kernel with its fixed 128 x 128 tiles runs
+static int suggest_splitk_for(int M, int N, int K, long b, bool aligned) {
+  const V2Config cfg = aligned ? v2_config(M, N, K, b, 0) : V2Config{128, 128, 32};
   return clo::suggest_splitk_tiles(cdiv(M, cfg.bm) * cdiv(N, cfg.bn) * b, K, (long)M * N * b,
                                    (double)cfg.bm * cfg.bn / (128.0 * 128.0), cfg.bk == 64 ? 4 : 8);
+}
+
+extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
+  // without the operands: float4-complete extents are taken as "aligned"
+  return suggest_splitk_for(M, N, K, batch > 0 ? batch : 1, M % 4 == 0 && N % 4 == 0 && K % 4 == 0);
 }
 
 extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,
@@ -985,7 +992,7 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
   a.A = A; a.sa_m = sa_m; a.sa_k = sa_k; a.sa_b = 0;
   a.B = B; a.sb_k = sb_k; a.sb_n = sb_n; a.sb_b = 0;
   a.C = C; a.ldc = ldc; a.sc_b = 0;
-  long s = clo_gemm_suggest_splitk(M, N, K, 1);
+  long s = suggest_splitk_for(M, N, K, 1, gemm_v2_eligible(a, 1));
   const long per = (long)M * N;
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
@@ -996,7 +1003,7 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
 // Single problem described by `a` (operands, epilogue, optional second K segment); split-K from the
 // cost model, capped by the caller's workspace.
 int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st) {
-  long s = clo_gemm_suggest_splitk(a.M, a.N, a.K, 1);
+  long s = suggest_splitk_for(a.M, a.N, a.K, 1, gemm_v2_eligible(a, 1));
   const long per = (long)a.M * a.N;
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
@@ -1020,7 +1027,7 @@ int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float
   p.ws = ws; p.N = N; p.d_in = d_in; p.d_out = d_out; p.act = act;
   // tiny layers (small networks): one block's k loop is a chain of memory round trips, so small
   // tiles on more CUs with 64-deep k steps (as v2_config does for plain products)
-  const bool tiny = (long)N * d_out <= 256L * 256L;
+  const bool tiny = (long)N * d_out <= 256L * 256L && d_in <= 1024;
   const int bm = tiny ? 32 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128));
   const int bn = tiny ? 64 : (bm == 128 ? 64 : 128);
   const int bk = tiny ? 64 : 16;
