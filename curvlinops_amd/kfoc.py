@@ -40,7 +40,6 @@ from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss, Module, MSELoss
 from curvlinops_amd import _hip
 from curvlinops_amd.computers import (
     HipKFACComputer,
-    ParamGroup,
     ParamGroupKey,
     _conv_hyperparams,
     _use_params,
