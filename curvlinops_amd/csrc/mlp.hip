@@ -636,9 +636,9 @@ struct LossArgs {
   float *w;             // [N][C] result
   int C;
   float scale;
-  // optional split-K slabs of the last (identity-activation) layer: part[s][2][NB][C]
+  // optional split-K slabs of the last (identity-activation) layer: part[s][2][part_rows][C]
   const float *part;
-  int ksplit;
+  int ksplit, part_rows;
   const float *b, *Vb;
   float *f_out, *u_out;
 };
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void loss_hessian_kernel(const LossArgs p) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float zz = p.b ? p.b[c] : 0.f, dzz = p.Vb ? p.Vb[c] : 0.f;
       const float *q0 = p.part + (long)n * C + c;
-      const long sstride = 2L * NB * C, dzoff = (long)NB * C;
+      const long sstride = 2L * p.part_rows * C, dzoff = (long)p.part_rows * C;
       int s = 0;
       for (; s + 3 < p.ksplit; s += 4) {
         const float z0 = q0[(s + 0) * sstride], z1 = q0[(s + 1) * sstride];
@@ -1189,21 +1189,26 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
 constexpr int HR_ROWS = 4;
 // f[n][c] = b[c] + a[n] . W[c] ;  u[n][c] = Vb[c] + da[n] . W[c] + a[n] . V[c]
 // block = HR_ROWS batch rows, wave w = class c, lanes stride the features.
+// grid.y > 1: few rows would leave the chip to a handful of blocks walking all of d, so the
+// features are split over grid.y and the raw partial sums go to part[split][2][N][C]
+// (loss_hessian_kernel adds them up together with the biases, as it does for the 8-row chain).
 template <bool VEC>
 __global__ __launch_bounds__(HEAD_CMAX * 64) void head_rows_fwd_kernel(
     const float *__restrict__ a, const float *__restrict__ da, const float *__restrict__ W,
     const float *__restrict__ V, const float *__restrict__ b, const float *__restrict__ Vb,
-    float *__restrict__ f, float *__restrict__ u, int N, int d, int C) {
+    float *__restrict__ f, float *__restrict__ u, int N, int d, int C, int d_per_split,
+    float *__restrict__ part) {
   const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (c >= C) return;
   const int n0 = blockIdx.x * HR_ROWS;
+  const int i0 = blockIdx.y * d_per_split, i1 = min(d, i0 + d_per_split);
   float z[HR_ROWS], dz[HR_ROWS];
 #pragma unroll
   for (int r = 0; r < HR_ROWS; ++r) z[r] = dz[r] = 0.f;
   const float *w = W + (long)c * d, *v = V + (long)c * d;
   if (VEC) {  // d % 4 == 0, 16-byte aligned rows: 4 features per lane and trip
 #pragma unroll 2
-    for (int i = lane * 4; i < d; i += 256) {
+    for (int i = i0 + lane * 4; i < i1; i += 256) {
       const float4 wi = ld4(w + i), vi = ld4(v + i);
 #pragma unroll
       for (int r = 0; r < HR_ROWS; ++r) {
@@ -1215,7 +1220,7 @@ __global__ __launch_bounds__(HEAD_CMAX * 64) void head_rows_fwd_kernel(
     }
   } else {
 #pragma unroll 2
-    for (int i = lane; i < d; i += 64) {
+    for (int i = i0 + lane; i < i1; i += 64) {
       const float wi = w[i], vi = v[i];
 #pragma unroll
       for (int r = 0; r < HR_ROWS; ++r) {
@@ -1230,8 +1235,14 @@ __global__ __launch_bounds__(HEAD_CMAX * 64) void head_rows_fwd_kernel(
   for (int r = 0; r < HR_ROWS; ++r) {
     const float zs = wave_sum(z[r]), dzs = wave_sum(dz[r]);
     if (lane == 0 && n0 + r < N) {
-      f[(long)(n0 + r) * C + c] = zs + (b ? b[c] : 0.f);
-      u[(long)(n0 + r) * C + c] = dzs + (Vb ? Vb[c] : 0.f);
+      if (gridDim.y > 1) {
+        float *pz = part + ((long)blockIdx.y * 2 * N + (n0 + r)) * C + c;
+        pz[0] = zs;
+        pz[(long)N * C] = dzs;
+      } else {
+        f[(long)(n0 + r) * C + c] = zs + (b ? b[c] : 0.f);
+        u[(long)(n0 + r) * C + c] = dzs + (Vb ? Vb[c] : 0.f);
+      }
     }
   }
 }
@@ -1877,10 +1888,11 @@ static GemmArgs gemm_problem(int M, int N, int K, const float *A, long sa_m, lon
 static int launch_loss(int kind, const float *f, const float *aux, int aux_rank, const float *u,
                        const float *dphi_last, float *w, int N, int C, float scale,
                        const float *part, int ksplit, const float *b, const float *Vb, float *f_out,
-                       float *u_out, hipStream_t st) {
+                       float *u_out, hipStream_t st, int part_rows = NB) {
   LossArgs a{};
   a.kind = kind; a.f = f; a.aux = aux; a.aux_rank = aux_rank; a.u = u; a.dphi_last = dphi_last;
-  a.w = w; a.C = C; a.scale = scale; a.part = part; a.ksplit = ksplit; a.b = b; a.Vb = Vb;
+  a.w = w; a.C = C; a.scale = scale; a.part = part; a.ksplit = ksplit; a.part_rows = part_rows;
+  a.b = b; a.Vb = Vb;
   a.f_out = f_out; a.u_out = u_out;
   ProfScope prof(1, 0.0, st);
   hipLaunchKernelGGL(loss_hessian_kernel, dim3(N), dim3(C <= 64 ? 64 : 256), 0, st, a);
@@ -2133,17 +2145,28 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
     lstart = L - 1;
   } else if (head_rows) {
     const int d = dims[L - 1], C = dims[L];
+    // few row blocks: split the features so that ~128 blocks share the two weight rows' stream
+    const long row_blocks = cdiv(N, HR_ROWS);
+    int hsplit = (int)std::max<long>(1, std::min<long>({128 / row_blocks, cdiv(d, 256), 16L}));
+    if ((long)hsplit * 2 * N * C > gws_sz) hsplit = 1;
+    const int d_per = (int)cdiv(cdiv(d, hsplit), 256) * 256;
+    hsplit = (int)cdiv(d, d_per);
+    const dim3 hgrid((unsigned)row_blocks, (unsigned)hsplit);
     if (vec_ok(d, {a[L - 1], da[L - 1], W[L - 1], VW[L - 1]}))
-      hipLaunchKernelGGL(head_rows_fwd_kernel<true>, dim3((unsigned)cdiv(N, HR_ROWS)),
-                         dim3(HEAD_CMAX * 64), 0, st, a[L - 1], da[L - 1], W[L - 1], VW[L - 1],
-                         b ? b[L - 1] : nullptr, Vb ? Vb[L - 1] : nullptr, a[L], da[L], N, d, C);
+      hipLaunchKernelGGL(head_rows_fwd_kernel<true>, hgrid, dim3(HEAD_CMAX * 64), 0, st, a[L - 1],
+                         da[L - 1], W[L - 1], VW[L - 1], b ? b[L - 1] : nullptr,
+                         Vb ? Vb[L - 1] : nullptr, a[L], da[L], N, d, C, d_per, gws);
     else
-      hipLaunchKernelGGL(head_rows_fwd_kernel<false>, dim3((unsigned)cdiv(N, HR_ROWS)),
-                         dim3(HEAD_CMAX * 64), 0, st, a[L - 1], da[L - 1], W[L - 1], VW[L - 1],
-                         b ? b[L - 1] : nullptr, Vb ? Vb[L - 1] : nullptr, a[L], da[L], N, d, C);
+      hipLaunchKernelGGL(head_rows_fwd_kernel<false>, hgrid, dim3(HEAD_CMAX * 64), 0, st, a[L - 1],
+                         da[L - 1], W[L - 1], VW[L - 1], b ? b[L - 1] : nullptr,
+                         Vb ? Vb[L - 1] : nullptr, a[L], da[L], N, d, C, d_per, gws);
     CLO_CHECK_LAUNCH("head_rows_fwd_kernel");
-    rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], nullptr, dl0, N, C, loss_scale * alpha,
-                     nullptr, 1, nullptr, nullptr, a[L], da[L], st);
+    if (hsplit > 1)
+      rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], nullptr, dl0, N, C, loss_scale * alpha,
+                       gws, hsplit, b ? b[L - 1] : nullptr, Vb ? Vb[L - 1] : nullptr, a[L], da[L], st, N);
+    else
+      rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], nullptr, dl0, N, C, loss_scale * alpha,
+                       nullptr, 1, nullptr, nullptr, a[L], da[L], st);
     if (rc != CLO_OK) return rc;
     rc = launch_small_outer(OW[L - 1], dl0, a[L - 1], N, d, C, beta, gws, gws_sz, st);
     if (rc != CLO_OK) return rc;
