@@ -40,6 +40,13 @@ struct GemmArgs {
   //   TRI_KGE_M: A(m, k) == 0 for k < m     TRI_KLT_M: A(m, k) == 0 for k > m
   //   TRI_KGE_N: B(k, n) == 0 for k < n     TRI_KLT_N: B(k, n) == 0 for k > n
   int tri;
+  // B-side implicit ones column only (outer index N-1 of B; A has no extra row), and a separate
+  // destination for that output column: C(:, N-1) goes to col_out[row] (same alpha / beta) while
+  // the first N-1 columns keep ldc.  With B = layer inputs [rows][d_in] and A = delta^T this is the
+  // weight gradient with the BIAS gradient (column sums of delta) as its extra column, one launch.
+  // v2 engine only (launch_gemm returns CLO_EUNSUP otherwise).
+  int ones_b;
+  float *col_out;
 };
 enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2, EPI_MUL_T = 3 };
 enum { TRI_KGE_M = 1, TRI_KLT_M = 2, TRI_KGE_N = 4, TRI_KLT_N = 8 };

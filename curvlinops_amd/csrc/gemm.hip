@@ -423,7 +423,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
   TA la;
   TB lb;
   la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
-  lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid, p.ones);
+  lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid, p.ones | p.ones_b);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
         const int row = m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < p.M && col < p.N) {
           float v = alpha * acc[mt][nt][r];
-          float *c = C + (long)row * ldc + col;
+          float *c = (!to_ws && p.col_out && col == p.N - 1) ? p.col_out + row : C + (long)row * ldc + col;
           if (!to_ws && p.epi != EPI_NONE) {
             store_final(p, c, row, col, acc[mt][nt][r], alpha, beta);
             continue;
@@ -710,7 +710,7 @@ __global__ void splitk_reduce_kernel(const GemmArgs p, int splitk) {
       s2 += w[(k + 2) * total]; s3 += w[(k + 3) * total];
     }
     for (; k < splitk; ++k) s0 += w[k * total];
-    float *c = p.C + (long)b * p.sc_b + (long)m * p.ldc + n;
+    float *c = (p.col_out && n == N - 1) ? p.col_out + m : p.C + (long)b * p.sc_b + (long)m * p.ldc + n;
     store_final(p, c, m, n, (s0 + s1) + (s2 + s3), p.alpha, p.beta);
   }
 }
@@ -752,7 +752,8 @@ bool gemm_v2_eligible(const GemmArgs &a, int batch) {
   const int Kc = a.A2 ? a.K1 : a.K;  // every segment must be float4-complete
   if (a.A2 && (!aligned16(a.A2) || !aligned16(a.B2))) return false;
   if (a.ones && (a_kc || b_kc)) return false;  // the ones column lives in the outer-contiguous loader
-  const int Mr = a.M - a.ones, Nr = a.N - a.ones;   // extents that exist in memory
+  if (a.ones_b && b_kc) return false;
+  const int Mr = a.M - a.ones, Nr = a.N - (a.ones | a.ones_b);   // extents that exist in memory
   return !v2_off && a_vec && b_vec && a.K > 0 &&
          (a_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (Mr % 4 == 0 && Mr >= 4)) &&
          (b_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (Nr % 4 == 0 && Nr >= 4));
@@ -779,6 +780,10 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   constexpr int bk2 = 32;
   if (a.A2 && !(v2 && a.K1 % bk2 == 0 && a.K1 > 0 && a.K1 < a.K)) {
     set_error("clo_gemm: a second K segment needs the aligned engine and K1 %% %d == 0", bk2);
+    return CLO_EUNSUP;
+  }
+  if ((a.ones_b || a.col_out) && (!v2 || a.sym || a.epi != EPI_NONE || batch != 1)) {
+    set_error("clo_gemm: the B-side ones column / col_out need the aligned engine (plain single product)");
     return CLO_EUNSUP;
   }
   if (v2) {

@@ -2242,11 +2242,21 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
                              N, di, dout, part, stream);
       if (rc != CLO_OK) return rc;
     } else {
-      // out_W = beta out_W + delta^T a_prev
+      // out_W = beta out_W + delta^T a_prev; with an implicit ones column appended to a_prev the
+      // extra output column is the bias gradient (column sums of delta): one launch for both
       GemmArgs go = gemm_problem(dout, di, N, dcur, 1, dout, a[l - 1], di, 1, beta, OW[l - 1], di);
+      bool bias_done = false;
+      if (obl) {
+        GemmArgs gb = go;
+        gb.N = di + 1; gb.ones_b = 1; gb.col_out = obl;
+        if (gemm_v2_eligible(gb, 1)) {
+          go = gb;
+          bias_done = true;
+        }
+      }
       rc = launch_gemm_auto(go, gws, gws_sz, st);
       if (rc != CLO_OK) return rc;
-      if (obl) {
+      if (obl && !bias_done) {
         rc = launch_small_outer(obl, nullptr, dcur, N, dout, 1, beta, nullptr, 0, st);
         if (rc != CLO_OK) return rc;
       }
