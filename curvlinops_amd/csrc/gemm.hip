@@ -448,11 +448,15 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
   }
   __syncthreads();
 
+  // Where the next tile's global loads are issued.  One 8-wave block per CU: behind the first
+  // fragment reads (right after the barrier ALL waves of the CU wait for LDS data; the global loads
+  // have the whole MFMA block to land): 2048^3 104 -> 111 TFLOP/s.  Two 4-wave blocks per CU cover
+  // each other's barriers, there the earlier issue is the better one (8192^3: 132 vs 128).
+  constexpr bool LATE_PREFETCH = NW == 8;
   for (int it = 0; it < nk; ++it) {
     const int cur = it & 1;
-    // prefetch the next tile (past the end: clamped addresses, zeroed values, never stored)
     const int k0 = kb + (it + 1) * BKT;
-    {
+    if (!LATE_PREFETCH) {
       const bool s2 = k0 >= K1;
       const int kr = s2 ? k0 - K1 : k0, kend = s2 ? ke - K1 : min(ke, K1);
       la.load(ra, kr, kend, p.sa_k, s2 ? dA2 : 0);
@@ -467,6 +471,15 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
       for (int i = 0; i < MT; ++i) af[i] = TA::frag(as, wm * WM + i * 32 + li, g, lh);
 #pragma unroll
       for (int j = 0; j < NT; ++j) bf[j] = TB::frag(bs, wn * WNC + j * 32 + li, g, lh);
+      if (LATE_PREFETCH && g == 0) {
+        // prefetch the next tile (past the end: clamped addresses, zeroed values, never stored)
+        __builtin_amdgcn_sched_barrier(0);
+        const bool s2 = k0 >= K1;
+        const int kr = s2 ? k0 - K1 : k0, kend = s2 ? ke - K1 : min(ke, K1);
+        la.load(ra, kr, kend, p.sa_k, s2 ? dA2 : 0);
+        lb.load(rb, kr, kend, p.sb_k, s2 ? dB2 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #define CLO_MM(E)                                                                               \
   _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].E, bf[j].E, acc[i][j], 0, 0, 0);
@@ -593,9 +606,11 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_fwd3_kernel(const Fwd3
     store_all(lds3);
   }
   __syncthreads();
+  // as in gemm_v2_kernel: the next tile's global loads go behind the first fragment reads
+  constexpr bool kLate = BMt < 128;  // (128-row tiles, many blocks: measured worse, 516 -> 526 us at N = 512)
   for (int it = 0; it < nk; ++it) {
     const int cur = it & 1;
-    load_all(kb + (it + 1) * BKT);
+    if (!kLate) load_all(kb + (it + 1) * BKT);
     const float *S = lds3 + cur * STAGE;
     const float *as = S, *das = S + TA::FLOATS;
     const float *wsm = S + (HAS_DA ? 2 : 1) * TA::FLOATS, *vsm = wsm + TB::FLOATS;
@@ -611,6 +626,11 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_fwd3_kernel(const Fwd3
       for (int j = 0; j < NT; ++j) {
         wf[j] = TB::frag(wsm, wn * WNC + j * 32 + li, g, lh);
         vf[j] = TB::frag(vsm, wn * WNC + j * 32 + li, g, lh);
+      }
+      if (kLate && g == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_all(kb + (it + 1) * BKT);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #define CLO_M3(E)                                                                                  \
   _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) {  \
