@@ -45,6 +45,9 @@ _SIGNATURES = {
     "clo_potrf_diag_f32": (c_int, [_PF, c_long, c_int, _PF, c_long, c_void_p, c_int, c_void_p]),
     "clo_cholesky_inverse_f32": (c_int, [_PF, c_long, _PF, c_long, c_int, c_float, _PF, c_void_p, c_void_p]),
     "clo_cholesky_inverse_ws_floats": (c_long, [c_int]),
+    "clo_cholesky_inverse_batched_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                                 _PF, c_void_p, c_void_p]),
+    "clo_cholesky_inverse_batched_ws_floats": (c_long, [c_int, c_int]),
     "clo_im2col_f32": (
         c_int,
         [_PF, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -328,6 +331,29 @@ def cholesky_inverse_into(A: Tensor, damping: float, out: Tensor, status: Tensor
     rc = lib.clo_cholesky_inverse_f32(_p(A), A.stride(0) if n > 1 else 1, _p(out), n, n, damping, _p(ws),
                                       status.data_ptr(), _stream())
     _check(rc, "clo_cholesky_inverse_f32")
+
+
+def cholesky_inverse_batched_into(As: list[Tensor], dampings: list[float], outs: list[Tensor],
+                                  status: Tensor) -> None:
+    """``outs[b] = (As[b] + dampings[b] I)^-1`` for equally sized fp32 GPU factors in ONE chain of
+    launches (``clo_cholesky_inverse_batched_f32``); ``status``: device int32 ``[len(As)]``."""
+    import ctypes
+
+    lib = load()
+    n, nb = As[0].shape[0], len(As)
+    if n == 0 or nb == 0:
+        return
+    As = [A if (A.stride(-1) == 1 or n == 1) else A.contiguous() for A in As]
+    ptr_t, long_t, float_t = ctypes.c_void_p * nb, ctypes.c_long * nb, ctypes.c_float * nb
+    a_ptrs = ptr_t(*[A.data_ptr() for A in As])
+    ldas = long_t(*[A.stride(0) if n > 1 else 1 for A in As])
+    o_ptrs = ptr_t(*[o.data_ptr() for o in outs])
+    ldos = long_t(*[o.stride(0) if n > 1 else 1 for o in outs])
+    damps = float_t(*[float(d) for d in dampings])
+    ws = torch.empty(lib.clo_cholesky_inverse_batched_ws_floats(n, nb), device=As[0].device, dtype=torch.float32)
+    rc = lib.clo_cholesky_inverse_batched_f32(a_ptrs, ldas, o_ptrs, ldos, n, nb, damps, _p(ws), status.data_ptr(),
+                                              _stream())
+    _check(rc, "clo_cholesky_inverse_batched_f32")
 
 
 def not_pd_error(pivot: int, n: int) -> RuntimeError:

@@ -53,7 +53,7 @@ enum { TRI_KGE_M = 1, TRI_KLT_M = 2, TRI_KGE_N = 4, TRI_KLT_N = 8 };
 
 bool gemm_v2_eligible(const GemmArgs &a, int batch);
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream);
-int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st);
+int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int batch = 1);
 int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float *V, const float *b,
                     const float *Vb, float *a, float *da, float *dphi, int N, int d_in, int d_out,
                     int act, float *ws, long ws_floats, hipStream_t st);

@@ -1027,13 +1027,13 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
 
 // Single problem described by `a` (operands, epilogue, optional second K segment); split-K from the
 // cost model, capped by the caller's workspace.
-int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st) {
-  long s = suggest_splitk_for(a.M, a.N, a.K, 1, gemm_v2_eligible(a, 1));
-  const long per = (long)a.M * a.N;
+int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int batch) {
+  long s = suggest_splitk_for(a.M, a.N, a.K, batch, gemm_v2_eligible(a, batch));
+  const long per = (long)a.M * a.N * batch;
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws;
-  return launch_gemm(a, 1, st);
+  return launch_gemm(a, batch, st);
 }
 
 // Fused forward + JVP of one Linear layer for a batch of N rows (see gemm_fwd3_kernel).  Needs

@@ -59,7 +59,12 @@ __device__ __forceinline__ lf32x4 mm16(const float4 a, const float4 b, lf32x4 ac
 __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long ldin, float *A,
                                                         long lda, int nb, float *__restrict__ Linv,
                                                         long ldinv, int *__restrict__ status,
-                                                        int pivot_base) {
+                                                        int pivot_base, long batch_stride) {
+  // grid.x = batch: matrix b of a batch of equally sized factors lives batch_stride floats further
+  Ain += blockIdx.x * batch_stride;
+  A += blockIdx.x * batch_stride;
+  Linv += blockIdx.x * batch_stride;
+  status += blockIdx.x;
   __shared__ __attribute__((aligned(16))) float S[PNB * PLD];   // becomes L (lower blocks)
   __shared__ __attribute__((aligned(16))) float X[PNB * PLD];   // L^-1
   __shared__ __attribute__((aligned(16))) float XT[PNB * PLD];  // (L^-1)^T
@@ -205,16 +210,52 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
   CLO_TICK(7)
 }
 
-// S = A + damping * I ; L = 0 ; Li = 0
-__global__ void chol_init_kernel(const float *__restrict__ A, long lda, float *__restrict__ S,
-                                 float *__restrict__ L, float *__restrict__ Li, int n, float damping) {
+// S = (A + damping * I) (+) I ; L = 0 ; Li = 0.  The working matrices are np x np with
+// np = n rounded up to a multiple of 4 (identity on the padding): joint weight + bias factors have
+// odd sizes (577, 1153, 2305, 4609), and only float4-complete rows run on the aligned GEMM engine
+// (n = 4609 took 14.1 ms against 7.5 ms for n = 4608 before the padding).
+struct InitBatch {
+  static constexpr int MAX = 32;
+  const float *A[MAX];
+  long lda[MAX];
+  float damping[MAX];
+};
+__global__ void chol_init_kernel(const InitBatch ib, float *__restrict__ S, float *__restrict__ L,
+                                 float *__restrict__ Li, int n, int np, long stride) {
+  const int b = blockIdx.y;
+  const float *__restrict__ A = ib.A[b];
+  const long lda = ib.lda[b];
+  const float damping = ib.damping[b];
+  S += b * stride; L += b * stride; Li += b * stride;
+  const long total = (long)np * np;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const int i = e / np, j = e % np;
+    float v = (i == j) ? 1.f : 0.f;
+    if (i < n && j < n) v = A[(long)i * lda + j] + (i == j ? damping : 0.f);
+    S[e] = v;
+    L[e] = 0.f;
+    Li[e] = 0.f;
+  }
+}
+
+// out_b[i][j] = src_b[i][j], i, j < n (padded product -> the caller's tensors)
+struct OutBatch {
+  static constexpr int MAX = 32;
+  float *out[MAX];
+  long ldo[MAX];
+};
+__global__ void chol_copy_out_kernel(const OutBatch ob, const float *__restrict__ src, int n, int np,
+                                     long stride) {
+  const int b = blockIdx.y;
+  float *__restrict__ out = ob.out[b];
+  const long ldo = ob.ldo[b];
+  src += b * stride;
   const long total = (long)n * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
     const int i = e / n, j = e % n;
-    S[e] = A[(long)i * lda + j] + (i == j ? damping : 0.f);
-    L[e] = 0.f;
-    Li[e] = 0.f;
+    out[(long)i * ldo + j] = src[(long)i * np + j];
   }
 }
 
@@ -225,7 +266,9 @@ namespace clo {
 struct CholCtx {
   float *S, *L, *Li, *T, *G;
   long gws;
-  int n;
+  int n;        // padded size = leading dimension of S, L, Li
+  int batch;    // equally sized factors processed by every launch
+  long stride;  // floats between consecutive matrices in S, L, Li (and T)
   int *status;
   hipStream_t st;
 };
@@ -233,11 +276,12 @@ struct CholCtx {
 // Recursive blocked Cholesky carrying the inverse of the triangular factor:
 //   L11, L11^-1 = rec(A11);  L21 = A21 L11^-T;  S22 -= L21 L21^T;  L22, L22^-1 = rec(S22);
 //   (L^-1)21 = -L22^-1 (L21 L11^-1)
+// Every launch covers the whole batch (leaf: one workgroup per matrix, products: batched GEMMs).
 static int chol_rec(const CholCtx &c, int o, int m) {
   const long n = c.n;
   if (m <= PNB) {
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, c.st, c.S + o * n + o, n,
-                       c.L + o * n + o, n, m, c.Li + o * n + o, n, c.status, o);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(c.batch), dim3(64), 0, c.st, c.S + o * n + o, n,
+                       c.L + o * n + o, n, m, c.Li + o * n + o, n, c.status, o, c.stride);
     CLO_CHECK_LAUNCH("potrf_diag_kernel");
     return CLO_OK;
   }
@@ -247,37 +291,108 @@ static int chol_rec(const CholCtx &c, int o, int m) {
   if (rc != CLO_OK) return rc;
   const float *L11i = c.Li + a * n + a;
   float *L21 = c.L + b * n + a;
-  // one product on the GEMM engine; `tri` names the triangular operand so that only the k range
-  // of each tile that can be nonzero is visited, `sym` computes the block-upper triangle and mirrors
-  auto gemm = [&](int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k, const float *B,
-                  long sb_k, long sb_n, float beta, float *C, long ldc, int tri, int sym) {
+  // one (batched) product on the GEMM engine; `tri` names the triangular operand so that only the
+  // k range of each tile that can be nonzero is visited, `sym` computes the block-upper triangle
+  // and mirrors
+  auto gemm = [&](int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k, long sa_b,
+                  const float *B, long sb_k, long sb_n, long sb_b, float beta, float *C, long ldc,
+                  long sc_b, int tri, int sym) {
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
-    g.A = A; g.sa_m = sa_m; g.sa_k = sa_k; g.B = B; g.sb_k = sb_k; g.sb_n = sb_n;
-    g.C = C; g.ldc = ldc; g.tri = tri; g.sym = sym;
-    return launch_gemm_auto(g, c.G, c.gws, c.st);
+    g.A = A; g.sa_m = sa_m; g.sa_k = sa_k; g.sa_b = sa_b;
+    g.B = B; g.sb_k = sb_k; g.sb_n = sb_n; g.sb_b = sb_b;
+    g.C = C; g.ldc = ldc; g.sc_b = sc_b; g.tri = tri; g.sym = sym;
+    return launch_gemm_auto(g, c.G, c.gws, c.st, c.batch);
   };
+  const long sb = c.stride;
   // L21 = S21 * L11i^T      (B(k,n) = L11i[n][k], zero for k > n)
-  rc = gemm(m2, m1, m1, 1.f, c.S + b * n + a, n, 1, L11i, 1, n, 0.f, L21, n, TRI_KLT_N, 0);
+  rc = gemm(m2, m1, m1, 1.f, c.S + b * n + a, n, 1, sb, L11i, 1, n, sb, 0.f, L21, n, sb, TRI_KLT_N, 0);
   if (rc != CLO_OK) return rc;
   // S22 -= L21 * L21^T      (symmetric: half the tiles, mirrored)
-  rc = gemm(m2, m2, m1, -1.f, L21, n, 1, L21, 1, n, 1.f, c.S + b * n + b, n, 0, 1);
+  rc = gemm(m2, m2, m1, -1.f, L21, n, 1, sb, L21, 1, n, sb, 1.f, c.S + b * n + b, n, sb, 0, 1);
   if (rc != CLO_OK) return rc;
   rc = chol_rec(c, b, m2);
   if (rc != CLO_OK) return rc;
   // T = L21 * L11i (B(k,n) = L11i[k][n], zero for k < n) ; Li21 = -L22i * T (A(m,k) zero for k > m)
-  rc = gemm(m2, m1, m1, 1.f, L21, n, 1, L11i, n, 1, 0.f, c.T, m1, TRI_KGE_N, 0);
+  rc = gemm(m2, m1, m1, 1.f, L21, n, 1, sb, L11i, n, 1, sb, 0.f, c.T, m1, sb, TRI_KGE_N, 0);
   if (rc != CLO_OK) return rc;
-  return gemm(m2, m1, m2, -1.f, c.Li + b * n + b, n, 1, c.T, m1, 1, 0.f, c.Li + b * n + a, n, TRI_KLT_M, 0);
+  return gemm(m2, m1, m2, -1.f, c.Li + b * n + b, n, 1, sb, c.T, m1, 1, sb, 0.f, c.Li + b * n + a, n, sb,
+              TRI_KLT_M, 0);
 }
+
+static inline long pad4(long n) { return (n + 3) & ~3L; }
+static const long kCholSlabFloats = 16L * 256 * 256;
 
 }  // namespace clo
 
 using namespace clo;
 
-extern "C" long clo_cholesky_inverse_ws_floats(int n) {
-  const long nn = (long)n * n;
-  return 3 * nn + nn / 2 + n + 16L * 256 * 256 + 1024;  // S, L, Li, T, split-K slabs
+// workspace of a batch of `batch` equally sized n x n factors
+extern "C" long clo_cholesky_inverse_batched_ws_floats(int n, int batch) {
+  const long np = pad4(n), nn = np * np;
+  // per matrix: S, L, Li, T (shares the stride), padded product; plus the split-K slabs
+  return (long)batch * 5 * nn + (long)batch * kCholSlabFloats + 1024;
+}
+extern "C" long clo_cholesky_inverse_ws_floats(int n) { return clo_cholesky_inverse_batched_ws_floats(n, 1); }
+
+// out_b = (A_b + damping_b I)^-1 for b < batch: symmetric positive definite n x n factors of EQUAL
+// size (row-major, lda_b), out_b row-major ldo_b.  One chain of launches serves the whole batch: the
+// leaves run one workgroup per matrix, every product is a batched GEMM -- the many small launches of
+// the recursion, which leave most of the chip idle for a single factor, are shared by all factors
+// (transformer blocks and ResNet stages repeat the same layer shapes).
+// The pointer / stride / damping arrays are HOST arrays.  ws: clo_cholesky_inverse_batched_ws_floats
+// floats; status: `batch` device ints (zeroed here) = offending pivot of each factor.
+extern "C" int clo_cholesky_inverse_batched_f32(const float *const *A, const long *lda, float *const *out,
+                                                const long *ldo, int n, int batch, const float *damping,
+                                                float *ws, int *status, void *stream) {
+  CLO_REQUIRE(n >= 0 && batch >= 0, "clo_cholesky_inverse_batched_f32: bad sizes");
+  if (n == 0 || batch == 0) return CLO_OK;
+  CLO_REQUIRE(A && lda && out && ldo && damping && ws && status, "clo_cholesky_inverse_batched_f32: null pointer");
+  for (int b = 0; b < batch; ++b)
+    CLO_REQUIRE(A[b] && out[b] && lda[b] >= n && ldo[b] >= n, "clo_cholesky_inverse_batched_f32: bad operand %d", b);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = check_hip(hipMemsetAsync(status, 0, sizeof(int) * batch, st), "hipMemsetAsync");
+  if (rc != CLO_OK) return rc;
+  const int np = (int)pad4(n);
+  const long nn = (long)np * np;
+  CholCtx c;
+  c.stride = nn;
+  c.S = ws; c.L = ws + (long)batch * nn; c.Li = ws + 2L * batch * nn; c.T = ws + 3L * batch * nn;
+  float *prod = ws + 4L * batch * nn;
+  c.G = ws + 5L * batch * nn;
+  c.gws = (long)batch * kCholSlabFloats;
+  c.n = np; c.batch = batch; c.status = status; c.st = st;
+  const unsigned iblocks = (unsigned)std::min<long>(cdiv(nn, 256), kNumCU * 8L);
+  for (int b0 = 0; b0 < batch; b0 += InitBatch::MAX) {
+    InitBatch ib{};
+    const int cnt = std::min(InitBatch::MAX, batch - b0);
+    for (int i = 0; i < cnt; ++i) { ib.A[i] = A[b0 + i]; ib.lda[i] = lda[b0 + i]; ib.damping[i] = damping[b0 + i]; }
+    hipLaunchKernelGGL(chol_init_kernel, dim3(iblocks, cnt), dim3(256), 0, st, ib, c.S + (long)b0 * nn,
+                       c.L + (long)b0 * nn, c.Li + (long)b0 * nn, n, np, nn);
+    CLO_CHECK_LAUNCH("chol_init_kernel");
+  }
+  rc = chol_rec(c, 0, np);
+  if (rc != CLO_OK) return rc;
+  // A^-1 = Li^T Li: A(m,k) = Li[k][m] and B(k,n) = Li[k][n] are zero for k < m / k < n.  A single
+  // factor with float4-complete rows goes straight to the caller's tensor.
+  const bool direct = batch == 1 && np == n;
+  GemmArgs g{};
+  g.M = np; g.N = np; g.K = np; g.alpha = 1.f; g.beta = 0.f;
+  g.A = c.Li; g.sa_m = 1; g.sa_k = np; g.sa_b = nn; g.B = c.Li; g.sb_k = np; g.sb_n = 1; g.sb_b = nn;
+  g.C = direct ? out[0] : prod; g.ldc = direct ? ldo[0] : np; g.sc_b = nn;
+  g.sym = 1; g.tri = TRI_KGE_M | TRI_KGE_N;
+  rc = launch_gemm_auto(g, c.G, c.gws, st, batch);
+  if (rc != CLO_OK || direct) return rc;
+  const unsigned oblocks = (unsigned)std::min<long>(cdiv((long)n * n, 256), kNumCU * 8L);
+  for (int b0 = 0; b0 < batch; b0 += OutBatch::MAX) {
+    OutBatch ob{};
+    const int cnt = std::min(OutBatch::MAX, batch - b0);
+    for (int i = 0; i < cnt; ++i) { ob.out[i] = out[b0 + i]; ob.ldo[i] = ldo[b0 + i]; }
+    hipLaunchKernelGGL(chol_copy_out_kernel, dim3(oblocks, cnt), dim3(256), 0, st, ob, prod + (long)b0 * nn, n,
+                       np, nn);
+    CLO_CHECK_LAUNCH("chol_copy_out_kernel");
+  }
+  return CLO_OK;
 }
 
 // out = (A + damping I)^-1, A symmetric positive definite n x n (row-major, lda), out row-major ldo.
@@ -287,26 +402,7 @@ extern "C" int clo_cholesky_inverse_f32(const float *A, long lda, float *out, lo
   CLO_REQUIRE(n >= 0 && lda >= n && ldo >= n, "clo_cholesky_inverse_f32: bad sizes");
   if (n == 0) return CLO_OK;
   CLO_REQUIRE(A && out && ws && status, "clo_cholesky_inverse_f32: null pointer");
-  hipStream_t st = (hipStream_t)stream;
-  int rc = check_hip(hipMemsetAsync(status, 0, sizeof(int), st), "hipMemsetAsync");
-  if (rc != CLO_OK) return rc;
-  const long nn = (long)n * n;
-  CholCtx c;
-  c.S = ws; c.L = ws + nn; c.Li = ws + 2 * nn; c.T = ws + 3 * nn;
-  c.G = c.T + nn / 2 + n;
-  c.gws = 16L * 256 * 256;
-  c.n = n; c.status = status; c.st = st;
-  hipLaunchKernelGGL(chol_init_kernel, dim3((unsigned)std::min<long>(cdiv(nn, 256), kNumCU * 8L)),
-                     dim3(256), 0, st, A, lda, c.S, c.L, c.Li, n, damping);
-  CLO_CHECK_LAUNCH("chol_init_kernel");
-  rc = chol_rec(c, 0, n);
-  if (rc != CLO_OK) return rc;
-  // A^-1 = Li^T Li: A(m,k) = Li[k][m] and B(k,n) = Li[k][n] are zero for k < m / k < n
-  GemmArgs g{};
-  g.M = n; g.N = n; g.K = n; g.alpha = 1.f; g.beta = 0.f;
-  g.A = c.Li; g.sa_m = 1; g.sa_k = n; g.B = c.Li; g.sb_k = n; g.sb_n = 1;
-  g.C = out; g.ldc = ldo; g.sym = 1; g.tri = TRI_KGE_M | TRI_KGE_N;
-  return launch_gemm_auto(g, c.G, c.gws, st);
+  return clo_cholesky_inverse_batched_f32(&A, &lda, &out, &ldo, n, 1, &damping, ws, status, stream);
 }
 
 extern "C" int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int *status,
@@ -314,7 +410,7 @@ extern "C" int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long 
   CLO_REQUIRE(nb >= 1 && nb <= PNB, "clo_potrf_diag_f32: nb must be in [1, %d], got %d", PNB, nb);
   CLO_REQUIRE(A && Linv && status && lda >= nb && ldinv >= nb, "clo_potrf_diag_f32: bad operand");
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, lda, A, lda,
-                     nb, Linv, ldinv, status, pivot_base);
+                     nb, Linv, ldinv, status, pivot_base, 0L);
   CLO_CHECK_LAUNCH("potrf_diag_kernel");
   return CLO_OK;
 }

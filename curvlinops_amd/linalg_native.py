@@ -30,11 +30,12 @@ def _torch_damped_cholesky_inverse(A: Tensor, damping: float) -> Tensor:
 
 
 class _InverseBatch:
-    """Factor inverses are independent dependency-bound chains of small kernels (a few hundred
-    launches for a 4608 x 4608 factor), limited as much by the host's launch rate as by the GPU.
-    The jobs are collected, then driven largest-first by a few worker threads that each own a HIP
-    stream (one foreign call per factor, GIL released), and all pivot statuses are inspected with
-    ONE device read at the end.
+    """Factor inverses are dependency-bound chains of small kernels (a few hundred launches for a
+    4608 x 4608 factor) that leave most of the chip idle.  The jobs are collected; factors of EQUAL
+    size then share one chain (``clo_cholesky_inverse_batched_f32``: one workgroup per factor in the
+    leaves, batched GEMMs), the chains of different sizes are driven largest-first by a few worker
+    threads that each own a HIP stream (one foreign call per chain, GIL released), and all pivot
+    statuses are inspected with ONE device read at the end.
 
     ``distributed=True`` (factors replicated on every rank, as after the KFAC factor all-reduce):
     the jobs are additionally sharded over the ranks, largest-first, and the inverses exchanged
@@ -67,15 +68,42 @@ class _InverseBatch:
         except RuntimeError as error:
             job[5] = error
 
+    MAX_GROUP_BYTES = 8 << 30  # workspace bound of one batched call
+
+    def _units(self, native: list) -> list[list]:
+        """Factors of equal size share ONE chain of launches (batched leaves / GEMMs); split only to
+        bound the workspace."""
+        by_n: dict[int, list] = {}
+        for job in native:
+            by_n.setdefault(job[0].shape[0], []).append(job)
+        units = []
+        for n, group in by_n.items():
+            per = 5 * 4 * ((n + 3) // 4 * 4) ** 2 + (4 << 20)
+            chunk = max(1, self.MAX_GROUP_BYTES // per)
+            units.extend(group[i : i + chunk] for i in range(0, len(group), chunk))
+        units.sort(key=lambda u: -len(u) * u[0][0].shape[0] ** 3)
+        return units
+
+    @staticmethod
+    def _run_unit(unit: list) -> None:
+        if len(unit) == 1:
+            _InverseBatch._run_job(unit[0])
+            return
+        status = torch.zeros(len(unit), device=unit[0][0].device, dtype=torch.int32)
+        _hip.cholesky_inverse_batched_into([j[0] for j in unit], [j[1] for j in unit], [j[3] for j in unit], status)
+        for i, job in enumerate(unit):
+            job[4] = status[i : i + 1]
+
     def _run(self, jobs: list) -> None:
         native = [j for j in jobs if j[4] is not None]
         for job in jobs:
             if job[4] is None:
                 self._run_job(job)
-        if (len(native) < self.MIN_THREADED or self._num < 2
-                or sum(j[0].shape[0] for j in native) < self.MIN_TOTAL_N):
-            for job in native:
-                self._run_job(job)
+        units = self._units(native)
+        if (len(units) < self.MIN_THREADED or self._num < 2
+                or sum(len(u) * u[0][0].shape[0] for u in units) < self.MIN_TOTAL_N):
+            for unit in units:
+                self._run_unit(unit)
             return
         import queue
         import threading
@@ -84,8 +112,8 @@ class _InverseBatch:
         main = torch.cuda.current_stream(device)
         ready = main.record_event()
         todo: queue.SimpleQueue = queue.SimpleQueue()
-        for job in sorted(native, key=lambda j: -j[0].shape[0]):
-            todo.put(job)
+        for unit in units:
+            todo.put(unit)
         done: list = []
         errors: list = []
 
@@ -97,17 +125,20 @@ class _InverseBatch:
                     with torch.cuda.stream(side):
                         while True:
                             try:
-                                job = todo.get_nowait()
+                                unit = todo.get_nowait()
                             except queue.Empty:
                                 break
-                            for t in (job[0], job[3], job[4]):
-                                t.record_stream(side)
-                            self._run_job(job)
+                            for job in unit:
+                                for t in (job[0], job[3], job[4]):
+                                    t.record_stream(side)
+                            self._run_unit(unit)
+                            for job in unit:
+                                job[4].record_stream(side)
                     done.append(side.record_event())
             except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
                 errors.append(e)
 
-        threads = [threading.Thread(target=worker) for _ in range(min(self._num, len(native)))]
+        threads = [threading.Thread(target=worker) for _ in range(min(self._num, len(units)))]
         for t in threads:
             t.start()
         for t in threads:

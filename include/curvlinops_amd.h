@@ -128,6 +128,15 @@ int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int 
 int clo_cholesky_inverse_f32(const float *A, long lda, float *out, long ldo, int n, float damping,
                              float *ws, int *status, void *stream);
 long clo_cholesky_inverse_ws_floats(int n);
+/* The same for `batch` factors of EQUAL size n in one chain of launches (leaves: one workgroup per
+ * factor, products: batched GEMMs): the factors of repeated layer shapes (transformer blocks,
+ * ResNet stages; reference kfac.py:224-271 builds one Kronecker block per layer) share the many
+ * small launches of the recursion.  A, lda, out, ldo, damping are HOST arrays of length batch;
+ * ws: clo_cholesky_inverse_batched_ws_floats(n, batch) floats; status: batch device ints. */
+int clo_cholesky_inverse_batched_f32(const float *const *A, const long *lda, float *const *out,
+                                     const long *ldo, int n, int batch, const float *damping,
+                                     float *ws, int *status, void *stream);
+long clo_cholesky_inverse_batched_ws_floats(int n, int batch);
 
 /* ------------------------------------------------------------------------- *
  * MLP fast path (Sequential of Linear + elementwise activation), one mini-batch,

@@ -462,3 +462,30 @@ def test_im2col(hip, geom):
     ref = torch.nn.functional.unfold(x, geom["k"], dilation=geom["d"], padding=geom["p"], stride=geom["s"]).transpose(1, 2)
     got = hip.im2col(x.cuda(), geom["k"], geom["s"], geom["p"], geom["d"])
     assert torch.equal(got.cpu(), ref.contiguous())
+
+
+@pytest.mark.parametrize("n", [3, 64, 130, 577, 1153])
+def test_cholesky_inverse_batched_equal_sizes(hip, n):
+    """Factors of equal size in ONE chain of launches (one workgroup per factor in the leaves, batched
+    GEMMs), odd sizes padded internally to float4-complete rows: every member equals the
+    single-factor result and the float64 inverse; a non-positive-definite member is reported by its
+    own status entry without disturbing the others."""
+    g = torch.Generator().manual_seed(n)
+    mats, damps = [], [1e-3, 2e-3, 5e-4, 1e-3]
+    for _ in range(4):
+        X = torch.rand(n + 5, n, generator=g, dtype=torch.float64)
+        mats.append((X.T @ X / n).float().cuda())
+    bad = mats[2].clone()
+    bad[n // 2, n // 2] = -5.0
+    members = [mats[0], mats[1], bad, mats[3]]
+    outs = [torch.empty(n, n, device="cuda") for _ in members]
+    status = torch.zeros(len(members), device="cuda", dtype=torch.int32)
+    hip.cholesky_inverse_batched_into(members, damps, outs, status)
+    st = status.cpu().tolist()
+    assert st[0] == st[1] == st[3] == 0 and 0 < st[2] <= n
+    for i in (0, 1, 3):
+        single = hip.cholesky_inverse(members[i], damps[i])
+        assert rel_err(outs[i].cpu(), single.cpu()) < 1e-3  # other split-K choices: rounding order only
+        ref = torch.linalg.inv(members[i].double().cpu() + damps[i] * torch.eye(n, dtype=torch.float64))
+        assert rel_err(outs[i].cpu(), ref) < 2e-3
+        assert torch.equal(outs[i], outs[i].T)

@@ -5,7 +5,7 @@ import torch
 from curvlinops_amd import _hip
 _hip.load()
 dev = torch.device("cuda:0")
-for n in (64, 128, 256, 512, 1152, 2304, 4608):
+for n in (64, 128, 256, 512, 577, 1152, 1153, 2304, 2305, 4608, 4609):
     X = torch.randn(2 * n, n, device=dev)
     A = X.T @ X / (2 * n)
     def ours(): return _hip.cholesky_inverse_async(A, 1e-3)[0]

@@ -16,7 +16,7 @@ int main() {
   hipMalloc(&A, n * n * 4); hipMalloc(&L, n * n * 4); hipMalloc(&Li, n * n * 4); hipMalloc(&st, 4);
   hipMemcpy(A, h.data(), n * n * 4, hipMemcpyHostToDevice);
   for (int rep = 0; rep < 5; ++rep) {
-    hipLaunchKernelGGL(clo::potrf_diag_kernel, dim3(1), dim3(64), 0, 0, A, (long)n, L, (long)n, n, Li, (long)n, st, 0);
+    hipLaunchKernelGGL(clo::potrf_diag_kernel, dim3(1), dim3(64), 0, 0, A, (long)n, L, (long)n, n, Li, (long)n, st, 0, 0L);
     hipError_t e0 = hipGetLastError();
     hipError_t e1 = hipDeviceSynchronize();
     float l00 = 0; int hst = -1;
