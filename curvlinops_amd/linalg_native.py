@@ -287,22 +287,52 @@ def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
 
 def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Tensor]]:
     """:func:`eigh` of several independent symmetric matrices.  On the GPU the solver (rocSOLVER
-    through ``torch.linalg.eigh``) is a long chain of small dependent kernels with host
-    synchronisation in between, so the factors of an EKFAC operator are spread, largest first,
-    over a few worker threads that each own a HIP stream (ResNet-18: 780 -> 337 ms)."""
-    gpu = [i for i, A in enumerate(mats) if A.is_cuda]
-    if len(gpu) < 3 or num_streams < 2:
-        return [eigh(A) for A in mats]
-    import queue
-    import threading
+    through ``torch.linalg.eigh``) is a long chain of small dependent kernels, so
 
+    * factors of EQUAL size are stacked and decomposed by ONE batched call (networks repeat layer
+      shapes; measured on MI355X: 12 x 768^2 208 -> 21 ms, 4 x 2305^2 220 -> 75 ms, 3 x 4609^2
+      409 -> 258 ms), and
+    * the groups are spread, largest first, over a few worker threads that each own a HIP stream
+      (the solver synchronises with the host in between)."""
+    gpu = [i for i, A in enumerate(mats) if A.is_cuda]
     out: list = [None] * len(mats)
     for i, A in enumerate(mats):
         if not A.is_cuda:
             out[i] = eigh(A)
+    if not gpu:
+        return out
+    groups: dict = {}
+    for i in gpu:
+        groups.setdefault((mats[i].shape[0], mats[i].dtype), []).append(i)
+    units: list[list[int]] = []
+    total = sum(float(mats[i].shape[0]) ** 3 for i in gpu)
+    share = total / max(num_streams, 1)  # a group worth more than one worker's share is split
+    for (n, dtype), idx in groups.items():
+        per = 8 * max(n, 1) ** 2 * mats[idx[0]].element_size()  # stacked input + vectors + solver workspace
+        parts = max(1, min(len(idx), round(len(idx) * float(n) ** 3 / max(share, 1.0))))
+        chunk = max(1, min((8 << 30) // per, -(-len(idx) // parts)))
+        units.extend(idx[k : k + chunk] for k in range(0, len(idx), chunk))
+    units.sort(key=lambda u: -len(u) * mats[u[0]].shape[0] ** 3)
+
+    def run(unit: list[int]) -> None:
+        if len(unit) == 1 or _hip.has("clo_eigh_f32"):
+            for i in unit:
+                out[i] = eigh(mats[i])
+            return
+        res = torch.linalg.eigh(torch.stack([mats[i] for i in unit]))
+        for k, i in enumerate(unit):
+            out[i] = (res.eigenvalues[k], res.eigenvectors[k])
+
+    if len(units) < 2 or num_streams < 2:
+        for unit in units:
+            run(unit)
+        return out
+    import queue
+    import threading
+
     jobs: queue.SimpleQueue = queue.SimpleQueue()
-    for i in sorted(gpu, key=lambda i: -mats[i].shape[0]):
-        jobs.put(i)
+    for unit in units:
+        jobs.put(unit)
     device = mats[gpu[0]].device
     main = torch.cuda.current_stream(device)
     ready = main.record_event()
@@ -317,16 +347,17 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
                 with torch.cuda.stream(side):
                     while True:
                         try:
-                            i = jobs.get_nowait()
+                            unit = jobs.get_nowait()
                         except queue.Empty:
                             break
-                        mats[i].record_stream(side)
-                        out[i] = eigh(mats[i])
+                        for i in unit:
+                            mats[i].record_stream(side)
+                        run(unit)
                 done.append(side.record_event())
         except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
             errors.append(e)
 
-    threads = [threading.Thread(target=worker, args=(i,)) for i in range(min(num_streams, len(gpu)))]
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(min(num_streams, len(units)))]
     for t in threads:
         t.start()
     for t in threads:
@@ -340,4 +371,3 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
             if t.is_cuda:
                 t.record_stream(main)
     return out
-
