@@ -934,11 +934,14 @@ namespace clo {
 // tile_scale = block tile area / (128 x 128): MFMA time per k of one block
 // waves = waves per block: with fewer than two waves per SIMD resident on a CU nothing hides a
 // wave's barrier / LDS stalls (measured ~1.5x the MFMA time)
-int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale, int waves) {
+// cap: largest split the caller's slab workspace can hold -- the search runs INSIDE the cap (clamping
+// the unconstrained optimum afterwards lands on block counts like 1.3 x the CUs: two rounds of work
+// for one round's worth of blocks)
+int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale, int waves, long cap = 64) {
   if (tiles <= 0 || K <= 0) return 1;
   double best = 1e30;
   int best_s = 1;
-  const long smax = std::min<long>(64, std::max<long>(1, K / 64));
+  const long smax = std::min<long>({64L, std::max<long>(1, K / 64), std::max<long>(1, cap)});
   for (long s = 1; s <= smax; ++s) {
     const long kps = cdiv(cdiv(K, s), 32) * 32;
     const long se = cdiv(K, kps);
@@ -955,10 +958,10 @@ int suggest_splitk_tiles(long tiles, long K, long MN, double tile_scale, int wav
 
 // `aligned`: the v2 engine will take the problem (its tile configuration applies); otherwise the
 // v1 kernel with its fixed 128 x 128 tiles runs
-static int suggest_splitk_for(int M, int N, int K, long b, bool aligned) {
+static int suggest_splitk_for(int M, int N, int K, long b, bool aligned, long cap = 64) {
   const V2Config cfg = aligned ? v2_config(M, N, K, b, 0) : V2Config{128, 128, 32};
   return clo::suggest_splitk_tiles(cdiv(M, cfg.bm) * cdiv(N, cfg.bn) * b, K, (long)M * N * b,
-                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0), cfg.bk == 64 ? 4 : 8);
+                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0), cfg.bk == 64 ? 4 : 8, cap);
 }
 
 extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
@@ -1017,8 +1020,8 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
   a.A = A; a.sa_m = sa_m; a.sa_k = sa_k; a.sa_b = 0;
   a.B = B; a.sb_k = sb_k; a.sb_n = sb_n; a.sb_b = 0;
   a.C = C; a.ldc = ldc; a.sc_b = 0;
-  long s = suggest_splitk_for(M, N, K, 1, gemm_v2_eligible(a, 1));
   const long per = (long)M * N;
+  long s = suggest_splitk_for(M, N, K, 1, gemm_v2_eligible(a, 1), per > 0 && ws ? ws_floats / per : 1);
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws; a.sym = 0;
@@ -1028,8 +1031,9 @@ int launch_gemm_simple(int M, int N, int K, float alpha, const float *A, long sa
 // Single problem described by `a` (operands, epilogue, optional second K segment); split-K from the
 // cost model, capped by the caller's workspace.
 int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int batch) {
-  long s = suggest_splitk_for(a.M, a.N, a.K, batch, gemm_v2_eligible(a, batch));
   const long per = (long)a.M * a.N * batch;
+  long s = suggest_splitk_for(a.M, a.N, a.K, batch, gemm_v2_eligible(a, batch),
+                              per > 0 && ws ? ws_floats / per : 1);
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws;
@@ -1061,7 +1065,7 @@ int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float
   const long tiles = (long)p.tiles_m * p.tiles_n, MN = (long)N * d_out;
   // two or three products per tile: the MFMA time of a plain tile of the same area times that
   long s = suggest_splitk_tiles(tiles, d_in, 2 * MN, (dA ? 3.0 : 2.0) * bm * bn / (128.0 * 128.0),
-                                tiny ? 2 : (bm == 64 ? 8 : 4));
+                                tiny ? 2 : (bm == 64 ? 8 : 4), MN > 0 && ws ? ws_floats / (2 * MN) : 1);
   if (MN > 0) s = std::min<long>(s, ws ? ws_floats / (2 * MN) : 1);
   s = std::max<long>(1, s);
   p.k_per_split = (int)cdiv(cdiv(d_in, s), bk) * bk;
@@ -1111,8 +1115,8 @@ int launch_syrk_simple(float *C, long ldc, const float *X, long rows, int d, lon
   a.B = X; a.sb_k = ldx; a.sb_n = 1; a.sb_b = 0;
   a.C = C; a.ldc = ldc; a.sc_b = 0;
   const long td = cdiv(d, BM);
-  long s = suggest_splitk_tiles(td * (td + 1) / 2, rows, (long)d * d, 1.0, 8);
   const long per = (long)d * d;
+  long s = suggest_splitk_tiles(td * (td + 1) / 2, rows, (long)d * d, 1.0, 8, per > 0 && ws ? ws_floats / per : 1);
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws; a.sym = 1;

@@ -1854,7 +1854,7 @@ constexpr int SKINNY_MAX_N = 8;  // whole-network matvec: one 8-row streaming pa
 
 static long gemm_ws_floats(int N, int dmax) {
   // split-K partial slabs for the widest product of the large-batch path
-  return 16L * (long)std::max(N, 128) * dmax;
+  return 32L * (long)std::max(N, 128) * dmax;
 }
 
 // out[c][j] = beta out + sum_n g[n][c] X[n][j] (g == nullptr: column sums, C = 1); ws >= 16 C d
