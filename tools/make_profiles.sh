@@ -41,3 +41,6 @@ python tools/probe_syrk_skinny.py > $OUT/r01_gram_tall_shapes.txt 2>/dev/null
 python tools/probe_c1.py 2>/dev/null | grep -v amdgpu > $OUT/r01_c1_matvec.txt
 python tools/probe_chol.py 2>/dev/null | grep -v amdgpu > $OUT/r01_cholesky_inverse_sizes.txt
 python tools/probe_mlp_zoo.py 2>/dev/null | grep -v amdgpu > $OUT/r01_mlp_shapes.txt
+python tools/probe_kfoc.py 2>/dev/null | grep -v amdgpu > $OUT/r01_kfoc_build.txt
+python tools/probe_eigh_batched.py 2>/dev/null | grep "n=" > $OUT/r01_eigh_batched.txt
+python benchmarks/bench_kfac.py encoder --ekfac > $OUT/r01_kfac_encoder_b8.json 2>/dev/null
