@@ -489,3 +489,18 @@ def test_cholesky_inverse_batched_equal_sizes(hip, n):
         ref = torch.linalg.inv(members[i].double().cpu() + damps[i] * torch.eye(n, dtype=torch.float64))
         assert rel_err(outs[i].cpu(), ref) < 2e-3
         assert torch.equal(outs[i], outs[i].T)
+
+
+def test_gemm_and_syrk_randomised(hip):
+    """Random shapes (tiny ... 700), transposed views, batches, alpha / beta, forced split-K, SYRK with
+    the implicit ones column: every engine of clo_gemm_f32 (aligned tiles, 64x64x64 small tiles, v1,
+    the one-launch tiny kernel) against float64 (tools/fuzz_gemm.py)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gemm
+
+    worst, failures = fuzz_gemm.run(seed=5, ncase=150)
+    assert not failures, failures
+    assert worst < 2e-5
