@@ -63,11 +63,14 @@ def main():
         res["ef_matmat_k32_ms"], _ = timed(lambda: op @ V, repeats=1)
         del V
         print(json.dumps(res), file=sys.stderr, flush=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        tr = C.hutchpp_trace(op, num_matvecs=96)
-        torch.cuda.synchronize()
-        res["hutchpp_96_ms"] = 1e3 * (time.perf_counter() - t0)
+        best = float("inf")
+        for _ in range(2):  # min of two: the first call also pays for 10 GB-sized first allocations
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr = C.hutchpp_trace(op, num_matvecs=96)
+            torch.cuda.synchronize()
+            best = min(best, 1e3 * (time.perf_counter() - t0))
+        res["hutchpp_96_ms"] = best
         res["hutchpp_trace"] = float(tr)
     print(json.dumps(res))
 
