@@ -293,6 +293,12 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         _expect_same_device(old, value)
         _expect_same_dtype(old, value)
         self._blocks[index] = value
+        self._group_cache = None
+
+    def __getstate__(self) -> dict:
+        state = self.__dict__.copy()
+        state["_group_cache"] = None  # derived data (stacked factor copies): rebuilt on first use
+        return state
 
     _POOL_STREAMS = 4
     _pool: dict = {}
@@ -300,11 +306,83 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
     def _matmat(self, X: list[Tensor]) -> list[Tensor]:
         parts = split_list(X, [len(B._in_shape) for B in self._blocks])
         if len(self._blocks) >= 4 and all(is_native_tensor(x) for x in X):
+            if X[0].shape[-1] == 1:
+                out = self._matmat_grouped(parts)
+                if out is not None:
+                    return out
             return self._matmat_concurrent(parts)
         out: list[Tensor] = []
         for B, xs in zip(self._blocks, parts):
             out.extend(B._matmat(xs))
         return out
+
+    @staticmethod
+    def _kron_pair(B) -> tuple[KroneckerProductLinearOperator, Tensor | None] | None:
+        """(two-factor native Kronecker operator, eigenvalues or None) of a groupable block."""
+        lam = None
+        if type(B) is EighDecomposedLinearOperator and is_native_tensor(B.eigenvalues):
+            B, lam = B._eigenvectors, B.eigenvalues
+        if type(B) is KroneckerProductLinearOperator and len(B) == 2 and all(is_native_tensor(f) for f in B):
+            return B, lam
+        return None
+
+    def _kron_groups(self) -> list[tuple[list[int], Tensor, Tensor, Tensor | None]]:
+        """Blocks ``S1 (x) S2`` (KFAC) or ``(Q1 (x) Q2) diag(lambda) (Q1 (x) Q2)^T`` (EKFAC) with
+        identical factor shapes (repeated layer shapes), their factors stacked ONCE:
+        ``[(block indices, S1 [n, A, a], S2 [n, B, b], lambda [n, A, B] | None), ...]``."""
+        pairs = [self._kron_pair(B) for B in self._blocks]
+        key = tuple(id(t) for p in pairs if p is not None for t in (*p[0], p[1]))
+        cached = getattr(self, "_group_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        by_shape: dict = {}
+        for i, p in enumerate(pairs):
+            if p is not None:
+                by_shape.setdefault((tuple(p[0][0].shape), tuple(p[0][1].shape), p[1] is None), []).append(i)
+        groups = []
+        for idx in by_shape.values():
+            if len(idx) < 2:
+                continue
+            S1 = torch.stack([pairs[i][0][0] for i in idx])
+            S2 = torch.stack([pairs[i][0][1] for i in idx])
+            lam = None
+            if pairs[idx[0]][1] is not None:
+                lam = torch.stack([pairs[i][1] for i in idx]).reshape(len(idx), S1.shape[1], S2.shape[1])
+            groups.append((idx, S1, S2, lam))
+        self._group_cache = (key, groups)
+        return groups
+
+    def _matmat_grouped(self, parts: list[list[Tensor]]) -> list[Tensor] | None:
+        """Single vectors: blocks of equal shape run as ONE batched product pair ``S1_i X_i S2_i^T``
+        instead of 2 GEMMs each on a handful of CUs (no split-K slabs, no reduce launches: the batch
+        fills the chip); the remaining blocks go through the stream pool."""
+        groups = self._kron_groups()
+        if not groups:
+            return None
+        results: dict[int, list[Tensor]] = {}
+        for idx, S1, S2, lam in groups:
+            if lam is None:   # Y_i = S1_i X_i S2_i^T
+                a, b = S1.shape[2], S2.shape[2]
+                Xb = torch.stack([parts[i][0].reshape(a, b) for i in idx])      # [n, a, b]
+                Y = _hip.gemm(_hip.gemm(S1, Xb), S2.transpose(1, 2))           # [n, A, B]
+            else:             # Y_i = Q1_i (lambda_i * (Q1_i^T X_i Q2_i)) Q2_i^T
+                a, b = S1.shape[1], S2.shape[1]
+                Xb = torch.stack([parts[i][0].reshape(a, b) for i in idx])
+                Z = _hip.gemm(_hip.gemm(S1.transpose(1, 2), Xb), S2)
+                Z.mul_(lam)
+                Y = _hip.gemm(_hip.gemm(S1, Z), S2.transpose(1, 2))
+            for k, i in enumerate(idx):
+                results[i] = [Y[k].reshape(-1, 1)]
+        rest = [i for i in range(len(self._blocks)) if i not in results]
+        if len(rest) >= 4:
+            sub = BlockDiagonalLinearOperator([self._blocks[i] for i in rest])
+            ys = split_list(sub._matmat_concurrent([parts[i] for i in rest]), [len(self._blocks[i]._out_shape) for i in rest])
+            for i, y in zip(rest, ys):
+                results[i] = y
+        else:
+            for i in rest:
+                results[i] = self._blocks[i]._matmat(parts[i])
+        return [t for i in range(len(self._blocks)) for t in results[i]]
 
     def _matmat_concurrent(self, parts: list[list[Tensor]]) -> list[Tensor]:
         """The blocks are independent and individually too small to fill 256 CUs (a ResNet-18 KFAC

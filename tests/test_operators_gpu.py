@@ -406,3 +406,33 @@ def test_randomised_native_vs_autograd(dev):
     worst, failures = fuzz_native.run(seed=11, ncase=40)
     assert not failures, failures
     assert worst < 1e-4
+
+
+@pytest.mark.parametrize("sep", [True, False], ids=["sep", "joint"])
+@pytest.mark.parametrize("cls_name", ["KFACLinearOperator", "EKFACLinearOperator"])
+def test_equal_shape_blocks_run_batched(dev, cls_name, sep):
+    """Repeated layer shapes: the block-diagonal product groups equal-shape Kronecker / eigenbasis
+    blocks into batched GEMMs (single vectors); the result must equal the float64 CPU operator, for
+    the operator, its damped inverse, and K-column blocks (ungrouped path)."""
+    import curvlinops_amd as C
+    from curvlinops_amd.kronecker import BlockDiagonalLinearOperator
+
+    torch.manual_seed(0)
+    layers = []
+    for _ in range(4):
+        layers += [nn.Linear(16, 16), nn.Tanh()]
+    model64 = nn.Sequential(*layers, nn.Linear(16, 4)).double()
+    X64, y64 = torch.rand(12, 16, dtype=torch.float64), torch.randint(0, 4, (12,))
+    cls = getattr(C, cls_name)
+    kw = dict(fisher_type="type-2", separate_weight_and_bias=sep, check_deterministic=False)
+    ref = cls(model64, nn.CrossEntropyLoss(), dict(model64.named_parameters()), [(X64, y64)], **kw)
+    model = nn.Sequential(*[type(m)(*((m.in_features, m.out_features) if isinstance(m, nn.Linear) else ())) for m in model64]).to(dev)
+    model.load_state_dict({k: v.float() for k, v in model64.state_dict().items()})
+    op = cls(model, nn.CrossEntropyLoss(), dict(model.named_parameters()), [(X64.float().to(dev), y64.to(dev))], **kw)
+    _, K, _ = op
+    assert isinstance(K, BlockDiagonalLinearOperator) and K._kron_groups(), "equal-shape blocks must be grouped"
+    v = torch.rand(op.shape[1], dtype=torch.float64)
+    V = torch.rand(op.shape[1], 3, dtype=torch.float64)
+    assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4
+    assert rel_err((op @ V.float().to(dev)).cpu(), (ref @ V).numpy()) < 1e-4
+    assert rel_err((op.inverse(damping=1e-1) @ v.float().to(dev)).cpu(), (ref.inverse(damping=1e-1) @ v).numpy()) < 1e-3
