@@ -6,7 +6,9 @@ D = 10 010 122, MSE(mean), fp32, synthetic data).
 
 One "step" = one ``GGNLinearOperator @ v`` over this rank's mini-batch shard (B rows, default 8:
 the HBM-bound regime the north star targets) through the public operator API, followed -- when
-N > 1 -- by the RCCL all-reduce that sums the per-shard products.  Weak scaling: every rank holds
+N > 1 -- by the RCCL all-reduce that sums the per-shard products (started asynchronously: the
+collective of step i overlaps the kernels of step i + 1; all K products are fully reduced inside the
+timed region).  Weak scaling: every rank holds
 B rows, ``num_data = N * B``.  ``value`` = (N * K) shard-matvecs / max-over-ranks time.  The probe
 vectors rotate over several buffers so that v and the result stream from / to HBM instead of
 living in the 256 MiB Infinity Cache; the weights are constant across products, as in any real
@@ -186,8 +188,25 @@ def main() -> None:
     g = torch.Generator(device="cpu").manual_seed(7)
     vs = [torch.rand(D, generator=g).to(device) for _ in range(nbuf)]
 
+    # N > 1: the 40 MB all-reduce of product i runs on RCCL's stream while the kernels of product
+    # i + 1 run on the compute stream (at most two collectives in flight; every product of the K
+    # timed steps is fully reduced before the closing synchronisation).  CLO_BENCH_OVERLAP=0: strictly
+    # sequential product -> all-reduce.
+    overlap = world > 1 and os.environ.get("CLO_BENCH_OVERLAP", "1") != "0"
+    inflight: list = []
+
     def step(i: int):
-        return op @ vs[i % nbuf]
+        if not overlap:
+            return op @ vs[i % nbuf]
+        y, work = op.matmul_async(vs[i % nbuf])
+        inflight.append((y, work))
+        if len(inflight) > 2:
+            inflight.pop(0)[1].wait()
+        return y
+
+    def drain():
+        while inflight:
+            inflight.pop(0)[1].wait()
 
     def sync():
         torch.cuda.synchronize()
@@ -197,11 +216,13 @@ def main() -> None:
 
     for i in range(args.warmup):
         step(i)
+    drain()
     sync()
     t0 = time.perf_counter()
     out = None
     for i in range(args.steps):
         out = step(i)
+    drain()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,7 +249,8 @@ def main() -> None:
             "workload": "C2: GGNLinearOperator @ v, MLP 1024-2688-2688-10 (D=10010122), MSE mean, "
                         f"{args.batch} rows per GPU, K=1",
             "rows_per_gpu": args.batch,
-            "parallelism": f"dp{world} (data shards + RCCL all-reduce of the [D] result)" if world > 1 else "single GPU",
+            "parallelism": (f"dp{world} (data shards + RCCL all-reduce of the [D] result"
+                            + (", overlapped with the next product)" if overlap else ")")) if world > 1 else "single GPU",
         },
     }
 

@@ -53,6 +53,11 @@ def _worker(rank: int, world: int, port: int, ret):
         got = torch.cat([o.flatten() for o in AR @ vl])
         ok &= _check(failed, 2, torch.allclose(got, (full @ v)[:, 1], rtol=1e-10, atol=1e-12))
 
+        # asynchronous form: product now, collective in flight, reduced after wait()
+        Ya, work = AR.matmul_async(v)
+        work.wait()
+        ok &= _check(failed, 50, torch.allclose(Ya, full @ v, rtol=1e-10, atol=1e-12))
+
         # one mini-batch split by rows
         X, y = torch.cat([x for x, _ in data]), torch.cat([t for _, t in data])
         Xr, yr = shard_rows(X, y)
