@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from collections.abc import Callable, Iterable, MutableMapping
 
+import torch
 from torch import Tensor
 from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss, Module, MSELoss
 
@@ -105,6 +106,25 @@ class KFACLinearOperator(_ChainPyTorchLinearOperator):
         retry_double_precision: bool = True,
     ) -> _ChainPyTorchLinearOperator:
         P, K, PT = self
+        if use_exact_damping and not use_heuristic_damping and all(
+                isinstance(b, KroneckerProductLinearOperator) for b in K):
+            # exact damping = eigendecompositions of all factors: decompose them together (equal sizes
+            # batched, groups on worker threads) instead of one by one inside every block
+            from curvlinops_amd.kronecker import ensure_all_square
+
+            factors = [S for block in K for S in block]
+            ensure_all_square(*factors)
+            decs = linalg_native.eigh_many(factors)
+            blocks, pos = [], 0
+            for block in K:
+                evals, evecs = zip(*decs[pos : pos + len(block)])
+                pos += len(block)
+                lam = evals[0]
+                for e in evals[1:]:
+                    lam = torch.kron(lam, e)
+                blocks.append(EighDecomposedLinearOperator(lam, KroneckerProductLinearOperator(*evecs))
+                              .inverse(damping=damping))
+            return _ChainPyTorchLinearOperator(P, BlockDiagonalLinearOperator(blocks), PT)
         # the factors of all blocks are independent: their Cholesky inverses run concurrently (and,
         # for a data-parallel operator whose factors are replicated, sharded over the ranks)
         with linalg_native.concurrent_inverses(distributed=getattr(self, "_distributed", False)):
