@@ -1633,14 +1633,18 @@ __device__ __forceinline__ float act_second_times_dz(int act, float a, float da)
 __global__ void hess_combine_kernel(const float *__restrict__ dA, const float *__restrict__ T,
                                     const float *__restrict__ a, const float *__restrict__ da,
                                     const float *__restrict__ dphi, float *__restrict__ d,
-                                    float *__restrict__ Rd, long n, int act) {
+                                    float *__restrict__ Rd, long n, int act,
+                                    const float *__restrict__ T2 = nullptr) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (long)gridDim.x * blockDim.x) {
     const float g = dA[e], ph = dphi[e];
-    const float t = T ? T[e] : Rd[e];
+    const float t = (T ? T[e] : Rd[e]) + (T2 ? T2[e] : 0.f);
     Rd[e] = act_second_times_dz(act, a[e], da[e]) * g + ph * t;
     d[e] = ph * g;
   }
+}
+__global__ void fill_kernel(float *__restrict__ y, long n, float v) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) y[e] = v;
 }
 __global__ void mask_scale_kernel(float *__restrict__ y, const float *__restrict__ x,
                                   const float *__restrict__ m, long n, float s) {
@@ -2481,11 +2485,30 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
   float *gws = p;
   const long gws_sz = gemm_ws_floats(N, dmax);
   int rc;
+  // ---- up to 8 rows: the weight-streaming kernels of the GGN chain instead of GEMM tiles (each
+  // weight matrix is the traffic; the GEMM engine spends ~10 us per launch on 8-row products).
+  // Slabs, an all-ones mask and the d V product live in the (otherwise unused) GEMM slab region.
+  long part_sz = 0;
+  for (int l = 1; l <= L; ++l)
+    part_sz = std::max({part_sz, clo_mlp_bwd_ws_floats(N, dims[l - 1], dims[l]),
+                        clo_mlp_fwd_ws_floats(N, dims[l - 1], dims[l])});
+  part_sz = (part_sz + 3) & ~3L;
+  static const int no_skinny = getenv("CLO_HESSIAN_GEMM") ? atoi(getenv("CLO_HESSIAN_GEMM")) : 0;
+  const bool skinny = N <= SKINNY_MAX_N && !no_skinny && part_sz + 2 * nd <= gws_sz;
+  float *part = gws, *ones = gws + part_sz, *T2b = ones + nd;
+  if (skinny) {
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(nd)), dim3(256), 0, st, ones, nd, 1.f);
+    CLO_CHECK_LAUNCH("fill_kernel");
+  }
   // ---- tangent forward pass, one fused launch per layer
   for (int l = 1; l <= L; ++l) {
-    rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
-                         Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l],
-                         acts[l - 1], gws, gws_sz, st);
+    if (skinny)
+      rc = fwd_pass(W[l - 1], b ? b[l - 1] : nullptr, VW[l - 1], Vb ? Vb[l - 1] : nullptr, a[l - 1], da[l - 1],
+                    a[l], da[l], dphi[l], N, dims[l - 1], dims[l], acts[l - 1], part, false, nullptr, st);
+    else
+      rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
+                           Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l],
+                           acts[l - 1], gws, gws_sz, st);
     if (rc != CLO_OK) return rc;
   }
   // ---- output layer: dA = alpha G, T = alpha s H(f) Jv  ->  d_L, Rd_L
@@ -2498,11 +2521,31 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
   if (rc != CLO_OK) return rc;
   float *dcur = d0, *dnext = d1, *Rcur = R0, *Rnext = R1;
   hipLaunchKernelGGL(hess_combine_kernel, dim3(ew_grid(nc)), dim3(256), 0, st, dAb, Tb, a[L], da[L], dphi[L],
-                     dcur, Rcur, nc, acts[L - 1]);
+                     dcur, Rcur, nc, acts[L - 1], nullptr);
   CLO_CHECK_LAUNCH("hess_combine_kernel");
   // ---- backward
   for (int l = L; l >= 1; --l) {
     const int di = dims[l - 1], dout = dims[l];
+    if (skinny) {
+      // three weight-streaming passes: (Rd^T a_prev -> out_W, col sums -> out_b, Rd W -> T),
+      // (d^T da_prev -> out_W +=, d W -> dA), (d V -> T2); the mask of the fused kernel is all ones
+      const bool more = l > 1;
+      rc = bwd_pass(W[l - 1], Rcur, a[l - 1], ones, OW[l - 1], Ob ? Ob[l - 1] : nullptr, more ? Tb : nullptr,
+                    1.f, beta, N, di, dout, part, st);
+      if (rc != CLO_OK) return rc;
+      if (!more) break;
+      rc = bwd_pass(W[l - 1], dcur, da[l - 1], ones, OW[l - 1], nullptr, dAb, 1.f, 1.f, N, di, dout, part, st);
+      if (rc != CLO_OK) return rc;
+      rc = bwd_pass(VW[l - 1], dcur, nullptr, ones, nullptr, nullptr, T2b, 1.f, 0.f, N, di, dout, part, st);
+      if (rc != CLO_OK) return rc;
+      const long ne = (long)N * di;
+      hipLaunchKernelGGL(hess_combine_kernel, dim3(ew_grid(ne)), dim3(256), 0, st, dAb, Tb, a[l - 1],
+                         da[l - 1], dphi[l - 1], dnext, Rnext, ne, acts[l - 2], T2b);
+      CLO_CHECK_LAUNCH("hess_combine_kernel");
+      std::swap(dcur, dnext);
+      std::swap(Rcur, Rnext);
+      continue;
+    }
     // out_W = beta out_W + Rd^T a_prev (+ d^T da_prev)
     GemmArgs go = gemm_problem(dout, di, N, Rcur, 1, dout, a[l - 1], di, 1, beta, OW[l - 1], di);
     rc = launch_gemm_auto(go, gws, gws_sz, st);
@@ -2535,7 +2578,7 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
     if (rc != CLO_OK) return rc;
     const long ne = (long)N * di;
     hipLaunchKernelGGL(hess_combine_kernel, dim3(ew_grid(ne)), dim3(256), 0, st, dAb, Tb, a[l - 1],
-                       da[l - 1], dphi[l - 1], dnext, Rnext, ne, acts[l - 2]);
+                       da[l - 1], dphi[l - 1], dnext, Rnext, ne, acts[l - 2], nullptr);
     CLO_CHECK_LAUNCH("hess_combine_kernel");
     std::swap(dcur, dnext);
     std::swap(Rcur, Rnext);
