@@ -1643,6 +1643,37 @@ __global__ void hess_combine_kernel(const float *__restrict__ dA, const float *_
     d[e] = ph * g;
   }
 }
+// The same with the three products (d W, Rd W, d V) still spread over the row-range slabs of
+// bwd_fused_kernel (P[jb][NB][d_in]; njb == 0: a final [N][d_in] array): the slab sums are folded
+// into the combine instead of three bwd_finish launches.
+struct HessSlabs {
+  const float *dA, *T1, *T2;
+  int n_dA, n_T1, n_T2;
+};
+__device__ __forceinline__ float slab_sum(const float *P, int njb, int n, int i, int d_in) {
+  const float *p = P + (long)n * d_in + i;
+  if (njb == 0) return p[0];
+  const long stride = (long)NB * d_in;
+  float s0 = 0.f, s1 = 0.f;
+  int jb = 0;
+  for (; jb + 1 < njb; jb += 2) { s0 += p[jb * stride]; s1 += p[(jb + 1) * stride]; }
+  if (jb < njb) s0 += p[jb * stride];
+  return s0 + s1;
+}
+__global__ void hess_combine_slabs_kernel(const HessSlabs hs, const float *__restrict__ a,
+                                          const float *__restrict__ da, const float *__restrict__ dphi,
+                                          float *__restrict__ d, float *__restrict__ Rd, int N, int d_in,
+                                          int act) {
+  const int total = N * d_in;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int n = e / d_in, i = e % d_in;
+    const float g = slab_sum(hs.dA, hs.n_dA, n, i, d_in);
+    const float t = slab_sum(hs.T1, hs.n_T1, n, i, d_in) + slab_sum(hs.T2, hs.n_T2, n, i, d_in);
+    const float ph = dphi[e];
+    Rd[e] = act_second_times_dz(act, a[e], da[e]) * g + ph * t;
+    d[e] = ph * g;
+  }
+}
 __global__ void fill_kernel(float *__restrict__ y, long n, float v) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) y[e] = v;
 }
@@ -2494,8 +2525,8 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
                         clo_mlp_fwd_ws_floats(N, dims[l - 1], dims[l])});
   part_sz = (part_sz + 3) & ~3L;
   static const int no_skinny = getenv("CLO_HESSIAN_GEMM") ? atoi(getenv("CLO_HESSIAN_GEMM")) : 0;
-  const bool skinny = N <= SKINNY_MAX_N && !no_skinny && part_sz + 2 * nd <= gws_sz;
-  float *part = gws, *ones = gws + part_sz, *T2b = ones + nd;
+  const bool skinny = N <= SKINNY_MAX_N && !no_skinny && 3 * part_sz + 2 * nd <= gws_sz;
+  float *part = gws, *part2 = gws + part_sz, *part3 = gws + 2 * part_sz, *ones = gws + 3 * part_sz, *T2b = ones + nd;
   if (skinny) {
     hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(nd)), dim3(256), 0, st, ones, nd, 1.f);
     CLO_CHECK_LAUNCH("fill_kernel");
@@ -2530,18 +2561,20 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
       // three weight-streaming passes: (Rd^T a_prev -> out_W, col sums -> out_b, Rd W -> T),
       // (d^T da_prev -> out_W +=, d W -> dA), (d V -> T2); the mask of the fused kernel is all ones
       const bool more = l > 1;
+      int n1 = 0, n2 = 0, n3 = 0;  // > 0: the product is still spread over that many slabs
       rc = bwd_pass(W[l - 1], Rcur, a[l - 1], ones, OW[l - 1], Ob ? Ob[l - 1] : nullptr, more ? Tb : nullptr,
-                    1.f, beta, N, di, dout, part, st);
+                    1.f, beta, N, di, dout, part, st, &n1);
       if (rc != CLO_OK) return rc;
       if (!more) break;
-      rc = bwd_pass(W[l - 1], dcur, da[l - 1], ones, OW[l - 1], nullptr, dAb, 1.f, 1.f, N, di, dout, part, st);
+      rc = bwd_pass(W[l - 1], dcur, da[l - 1], ones, OW[l - 1], nullptr, dAb, 1.f, 1.f, N, di, dout, part2, st, &n2);
       if (rc != CLO_OK) return rc;
-      rc = bwd_pass(VW[l - 1], dcur, nullptr, ones, nullptr, nullptr, T2b, 1.f, 0.f, N, di, dout, part, st);
+      rc = bwd_pass(VW[l - 1], dcur, nullptr, ones, nullptr, nullptr, T2b, 1.f, 0.f, N, di, dout, part3, st, &n3);
       if (rc != CLO_OK) return rc;
       const long ne = (long)N * di;
-      hipLaunchKernelGGL(hess_combine_kernel, dim3(ew_grid(ne)), dim3(256), 0, st, dAb, Tb, a[l - 1],
-                         da[l - 1], dphi[l - 1], dnext, Rnext, ne, acts[l - 2], T2b);
-      CLO_CHECK_LAUNCH("hess_combine_kernel");
+      HessSlabs hs{n2 ? part2 : dAb, n1 ? part : Tb, n3 ? part3 : T2b, n2, n1, n3};
+      hipLaunchKernelGGL(hess_combine_slabs_kernel, dim3(ew_grid(ne)), dim3(256), 0, st, hs, a[l - 1], da[l - 1],
+                         dphi[l - 1], dnext, Rnext, N, di, acts[l - 2]);
+      CLO_CHECK_LAUNCH("hess_combine_slabs_kernel");
       std::swap(dcur, dnext);
       std::swap(Rcur, Rnext);
       continue;
