@@ -152,6 +152,57 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         c = 1.0 if red == "sum" else float(N if isinstance(self._loss_func, CrossEntropyLoss) else N * C)
         return _hip.LOSS_RANK1, 1.0 / c, aux
 
+    _MERGE_MAX_ROWS = 1024
+
+    @staticmethod
+    def _native_cost(n: int) -> float:
+        """Relative time of one native product over ``n`` rows (measured on C2: 8 rows 55 us on the
+        streaming kernels; beyond that the GEMM path, ~100 us of launches plus ~0.85 us per row)."""
+        return 1.0 if n <= 8 else 1.8 + n / 65.0
+
+    def _merge_native_batches(self, entries: list[tuple]) -> list[tuple]:
+        """``entries``: ``(X, kind, scale, aux, norm)`` per mini-batch.  The curvature is a sum over
+        data in which every row carries the same weight ``scale * norm`` (the batch mean times
+        ``B / N_data``, or the plain sum), so consecutive mini-batches can be processed as ONE larger
+        batch -- same result up to the order of the floating-point sums, a fraction of the launches
+        (two batches of 64 rows: 2 x 150 us vs 192 us for 128 rows).  Groups are formed greedily up to
+        ``_MERGE_MAX_ROWS`` rows and kept only where the cost model says they pay off."""
+        if len(entries) < 2:
+            return entries
+        out: list[tuple] = []
+        group: list[tuple] = []
+
+        def flush() -> None:
+            if len(group) >= 2 and self._native_cost(sum(e[0].shape[0] for e in group)) < sum(
+                    self._native_cost(e[0].shape[0]) for e in group):
+                X = torch.cat([e[0] for e in group])
+                kind, weight = group[0][1], group[0][2] * group[0][4]
+                if group[0][3] is None:
+                    aux = None
+                elif self._NATIVE_KIND == "hessian":  # gradients of the REDUCED batch losses: weight them here
+                    aux = torch.cat([e[3] * e[4] for e in group])
+                else:
+                    aux = torch.cat([e[3] for e in group])
+                out.append((X, kind, weight, aux, 1.0))
+            else:
+                out.extend(group)
+            group.clear()
+
+        for e in entries:
+            X, kind, scale, aux, norm = e
+            compatible = bool(group) and (
+                kind == group[0][1]
+                and abs(scale * norm - group[0][2] * group[0][4]) <= 1e-6 * abs(group[0][2] * group[0][4])
+                and (aux is None) == (group[0][3] is None)
+                and (aux is None or aux.shape[1:] == group[0][3].shape[1:])
+                and sum(g[0].shape[0] for g in group) + X.shape[0] <= self._MERGE_MAX_ROWS
+            )
+            if group and not compatible:
+                flush()
+            group.append(e)
+        flush()
+        return out
+
     def _matmat_native(self, M: list[Tensor]) -> list[Tensor] | None:
         """All columns of ``M`` through the HIP kernels; None if some batch does not qualify
         (then nothing has been written and the caller uses the autograd path)."""
@@ -174,11 +225,11 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if not batches:
             for o in Ok:
                 o.zero_()
+        merged = self._merge_native_batches([(Xn, *bargs[bi], norm) for bi, (Xn, _, norm) in enumerate(batches)])
         for k in range(K):
             V = [v[k] for v in Vk]
             O = [o[k] for o in Ok]
-            for bi, (Xn, y, norm) in enumerate(batches):
-                kind, scale, aux = bargs[bi]
+            for bi, (Xn, kind, scale, aux, norm) in enumerate(merged):
                 if self._NATIVE_KIND == "hessian":
                     nat.hessian_matvec(V, O, Xn, aux, kind, scale, alpha=norm, beta=0.0 if bi == 0 else 1.0)
                 else:
@@ -241,19 +292,20 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if (self._native is None or self._NATIVE_KIND not in ("ggn", "ef")
                 or not isinstance(self._data, (list, tuple))):
             return None  # the flat path is the whole-network GGN-type kernel only
-        batches = []
+        entries = []
         for bi, (X, y) in enumerate(self._data):
             if not (isinstance(X, Tensor) and X.device == self.device and y.device == self.device):
                 return None
             Xn = self._native.prepare_input(X)
             if Xn is None or y.shape[0] != Xn.shape[0] or Xn.shape[0] == 0:
                 return None
-            kind, scale, aux = self._native_batch_args(bi, Xn, y)
-            batches.append((Xn, Xn.data_ptr(), Xn.shape[0], kind, scale,
-                            None if aux is None else aux.data_ptr(), 1, aux,
-                            self._get_normalization_factor(X, y)))
-        if not batches:
+            entries.append((Xn, *self._native_batch_args(bi, Xn, y), self._get_normalization_factor(X, y)))
+        if not entries:
             return None
+        # consecutive mini-batches as one larger batch where that pays off (concatenated copies, kept)
+        batches = [(Xn, Xn.data_ptr(), Xn.shape[0], kind, scale, None if aux is None else aux.data_ptr(),
+                    1 if aux is None else aux.shape[1], aux, norm)
+                   for Xn, kind, scale, aux, norm in self._merge_native_batches(entries)]
         nmax = max(b[2] for b in batches)
         ws = self._native.plan.workspace(nmax, self.device)
         self._native_flat = (batches, ws, ws.data_ptr())

@@ -436,3 +436,44 @@ def test_equal_shape_blocks_run_batched(dev, cls_name, sep):
     assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4
     assert rel_err((op @ V.float().to(dev)).cpu(), (ref @ V).numpy()) < 1e-4
     assert rel_err((op.inverse(damping=1e-1) @ v.float().to(dev)).cpu(), (ref.inverse(damping=1e-1) @ v).numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("cls_name,loss,red", [
+    ("GGNLinearOperator", "mse", "mean"), ("GGNLinearOperator", "ce", "sum"),
+    ("EFLinearOperator", "ce", "mean"), ("HessianLinearOperator", "mse", "mean"),
+    ("HessianLinearOperator", "ce", "mean"),
+])
+def test_consecutive_mini_batches_are_merged(dev, cls_name, loss, red):
+    """The native path processes consecutive mini-batches as one larger batch where that is cheaper
+    (every row carries the same weight scale * B / N_data): same product as batch by batch, and as
+    the float64 CPU operator; unequal batch sizes, vectors through `@` (flat path) and matrices."""
+    import curvlinops_amd as C
+
+    torch.manual_seed(1)
+    model64 = nn.Sequential(nn.Linear(20, 32), nn.Tanh(), nn.Linear(32, 24), nn.ReLU(), nn.Linear(24, 4)).double()
+    sizes = (12, 12, 40, 7, 64)
+    data64 = []
+    for b in sizes:
+        X = torch.rand(b, 20, dtype=torch.float64)
+        y = torch.randint(0, 4, (b,)) if loss == "ce" else torch.rand(b, 4, dtype=torch.float64)
+        data64.append((X, y))
+    lf = LOSS[loss](reduction=red)
+    cls = getattr(C, cls_name)
+    ref = cls(model64, lf, dict(model64.named_parameters()), data64)
+    model = nn.Sequential(nn.Linear(20, 32), nn.Tanh(), nn.Linear(32, 24), nn.ReLU(), nn.Linear(24, 4)).to(dev)
+    model.load_state_dict({k: v.float() for k, v in model64.state_dict().items()})
+    data = [(X.float().to(dev), (y if loss == "ce" else y.float()).to(dev)) for X, y in data64]
+    params = dict(model.named_parameters())
+    merged = cls(model, lf, params, data, check_deterministic=False)
+    single = cls(model, lf, params, data, check_deterministic=False)
+    single._MERGE_MAX_ROWS = 0  # batch by batch
+    assert merged.uses_native_kernels
+    entries = [(X, 0, 1.0, None, 1.0) for X, _ in data]
+    assert len(merged._merge_native_batches(entries)) < len(entries)
+    assert len(single._merge_native_batches(entries)) == len(entries)
+    v64 = torch.rand(ref.shape[1], dtype=torch.float64)
+    V64 = torch.rand(ref.shape[1], 3, dtype=torch.float64)
+    v, V = v64.float().to(dev), V64.float().to(dev)
+    assert rel_err((merged @ v).cpu(), (single @ v).cpu().numpy()) < 1e-5
+    assert rel_err((merged @ v).cpu(), (ref @ v64).numpy()) < 1e-4
+    assert rel_err((merged @ V).cpu(), (ref @ V64).numpy()) < 1e-4
