@@ -44,3 +44,4 @@ python tools/probe_mlp_zoo.py 2>/dev/null | grep -v amdgpu > $OUT/r01_mlp_shapes
 python tools/probe_kfoc.py 2>/dev/null | grep -v amdgpu > $OUT/r01_kfoc_build.txt
 python tools/probe_eigh_batched.py 2>/dev/null | grep "n=" > $OUT/r01_eigh_batched.txt
 python benchmarks/bench_kfac.py encoder --ekfac > $OUT/r01_kfac_encoder_b8.json 2>/dev/null
+python tools/probe_chol_batched.py 2>/dev/null | grep "n=" > $OUT/r01_cholesky_inverse_batched.txt
