@@ -145,15 +145,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   // contiguous run of logical tiles so neighbours share operand panels in one L2), then a
   // grouped raster (8 tile-rows per group) over the tile grid.
   const int ntiles = p.tiles_m * p.tiles_n;
-  int lid;
-  {
-    const int b = blockIdx.x;
-    const int q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
-    const int xcd = b % kNumXCD, idx = b / kNumXCD;
-    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-  }
   int bm, bn;
-  {
+  if (p.sym) {
+    // symmetric output: the grid holds ONLY the upper-triangular tiles, column by column
+    // (t = bn (bn + 1) / 2 + bm).  Consecutive blocks land on different XCDs, so every XCD gets the
+    // same share of every column -- with the rectangular raster below (and an early exit for the
+    // lower tiles) the XCDs that own the last tile rows had almost nothing to do and the symmetry
+    // bought no time at all (24 x 3072^2, L^-T L^-1: 11.0 ms with and without it).
+    const int t = blockIdx.x;
+    bn = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((bn + 1) * (bn + 2) / 2 <= t) ++bn;
+    while (bn * (bn + 1) / 2 > t) --bn;
+    bm = t - bn * (bn + 1) / 2;
+  } else {
+    int lid;
+    {
+      const int b = blockIdx.x;
+      const int q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
+      const int xcd = b % kNumXCD, idx = b / kNumXCD;
+      lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
     constexpr int GROUP = 8;
     const int per_group = GROUP * p.tiles_n;
     const int g = lid / per_group;
@@ -163,7 +174,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     bm = first_m + in_g % gsz;
     bn = in_g / gsz;
   }
-  if (p.sym && bn < bm) return;
 
   // plain GEMM: grid.y = batch * splitk, each block one (batch, k-range).
   // SQSUM:     grid.y = splitk, each block sums (A_b B_b)^2 over its range of batches.
@@ -381,15 +391,26 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
   float *Bs = lds2 + 2 * TA::FLOATS;   // [2][TB::FLOATS]
 
   const int ntiles = p.tiles_m * p.tiles_n;
-  int lid;
-  {
-    const int b = blockIdx.x;
-    const int q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
-    const int xcd = b % kNumXCD, idx = b / kNumXCD;
-    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-  }
   int bm, bn;
-  {
+  if (p.sym) {
+    // symmetric output: the grid holds ONLY the upper-triangular tiles, column by column
+    // (t = bn (bn + 1) / 2 + bm).  Consecutive blocks land on different XCDs, so every XCD gets the
+    // same share of every column -- with the rectangular raster below (and an early exit for the
+    // lower tiles) the XCDs that own the last tile rows had almost nothing to do and the symmetry
+    // bought no time at all (24 x 3072^2, L^-T L^-1: 11.0 ms with and without it).
+    const int t = blockIdx.x;
+    bn = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((bn + 1) * (bn + 2) / 2 <= t) ++bn;
+    while (bn * (bn + 1) / 2 > t) --bn;
+    bm = t - bn * (bn + 1) / 2;
+  } else {
+    int lid;
+    {
+      const int b = blockIdx.x;
+      const int q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
+      const int xcd = b % kNumXCD, idx = b / kNumXCD;
+      lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
     constexpr int GROUP = 8;
     const int per_group = GROUP * p.tiles_n;
     const int g = lid / per_group;
@@ -399,7 +420,6 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
     bm = first_m + in_g % gsz;
     bn = in_g / gsz;
   }
-  if (p.sym && bn < bm) return;
 
   const int z = blockIdx.y;
   const int batch = z / p.splitk, split = z % p.splitk;
@@ -794,7 +814,10 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   }
   a.mode_a = pick_mode(a.A, a.sa_m, a.sa_k, a.sa_b, batch);
   a.mode_b = pick_mode(a.B, a.sb_n, a.sb_k, a.sb_b, batch);
-  dim3 grid(a.tiles_m * a.tiles_n, batch * a.splitk);
+  auto tile_blocks = [&]() {  // symmetric output: upper-triangular tiles only
+    return a.sym ? (unsigned)((long)a.tiles_m * (a.tiles_m + 1) / 2) : (unsigned)(a.tiles_m * a.tiles_n);
+  };
+  dim3 grid(tile_blocks(), batch * a.splitk);
   const bool a_kc = a.mode_a == MODE_KC_VEC, b_kc = a.mode_b == MODE_KC_VEC;
   const bool v2 = gemm_v2_eligible(a, batch);
   constexpr int bk2 = 32;
@@ -813,7 +836,7 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
     a.tbm = cfg.bm; a.tbn = cfg.bn;
     a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), cfg.bk) * cfg.bk;
     a.splitk = (int)cdiv(a.K, a.k_per_split);
-    grid = dim3(a.tiles_m * a.tiles_n, batch * a.splitk);
+    grid = dim3(tile_blocks(), batch * a.splitk);
 #define CLO_V2(AK, BKC_, BKV, BMV, BNV, WM_, WN_)                                                 \
   {                                                                                               \
     constexpr int nthr = WM_ * WN_ * 64;                                                          \
