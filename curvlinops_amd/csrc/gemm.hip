@@ -159,7 +159,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     bm = t - bn * (bn + 1) / 2;
   } else {
     int lid;
-    {
+    if (p.tri) {
+      // triangular operand: the work of a tile depends on its row / column; contiguous tile ranges
+      // per XCD would give some XCDs only the short tiles, so neighbours go to different XCDs
+      lid = blockIdx.x;
+    } else {
       const int b = blockIdx.x;
       const int q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
       const int xcd = b % kNumXCD, idx = b / kNumXCD;
@@ -405,7 +409,11 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
     bm = t - bn * (bn + 1) / 2;
   } else {
     int lid;
-    {
+    if (p.tri) {
+      // triangular operand: the work of a tile depends on its row / column; contiguous tile ranges
+      // per XCD would give some XCDs only the short tiles, so neighbours go to different XCDs
+      lid = blockIdx.x;
+    } else {
       const int b = blockIdx.x;
       const int q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
       const int xcd = b % kNumXCD, idx = b / kNumXCD;
