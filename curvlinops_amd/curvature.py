@@ -212,6 +212,8 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             Xn = nat.prepare_input(X)
             if Xn is None or y.shape[0] != Xn.shape[0]:
                 return None
+            if Xn.shape[0] == 0:
+                continue  # an empty mini-batch contributes nothing to the sum over data
             batches.append((Xn, y, self._get_normalization_factor(X, y)))
         K = M[0].shape[-1]
         # per-batch curvature arguments ONCE per product and in data order (MC draws its samples here)

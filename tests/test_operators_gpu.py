@@ -477,3 +477,23 @@ def test_consecutive_mini_batches_are_merged(dev, cls_name, loss, red):
     assert rel_err((merged @ v).cpu(), (single @ v).cpu().numpy()) < 1e-5
     assert rel_err((merged @ v).cpu(), (ref @ v64).numpy()) < 1e-4
     assert rel_err((merged @ V).cpu(), (ref @ V64).numpy()) < 1e-4
+
+
+def test_empty_and_ragged_mini_batches(dev):
+    """An empty mini-batch contributes nothing to the sum over data (and must not break the native
+    path); ragged batch sizes incl. a single row."""
+    import curvlinops_amd as C
+
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(8, 12), nn.ReLU(), nn.Linear(12, 4)).to(dev)
+    params = dict(model.named_parameters())
+    mk = lambda n: (torch.rand(n, 8, device=dev), torch.rand(n, 4, device=dev))  # noqa: E731
+    b5, b0, b3, b1 = mk(5), mk(0), mk(3), mk(1)
+    for cls in (C.GGNLinearOperator, C.EFLinearOperator, C.HessianLinearOperator):
+        for red in ("mean", "sum"):
+            with_empty = cls(model, nn.MSELoss(reduction=red), params, [b5, b0, b3, b1], check_deterministic=False, num_data=9)
+            without = cls(model, nn.MSELoss(reduction=red), params, [b5, b3, b1], check_deterministic=False, num_data=9)
+            assert with_empty.uses_native_kernels
+            v, V = torch.rand(with_empty.shape[1], device=dev), torch.rand(with_empty.shape[1], 2, device=dev)
+            assert rel_err((with_empty @ v).cpu(), (without @ v).cpu().numpy()) < 1e-6
+            assert rel_err((with_empty @ V).cpu(), (without @ V).cpu().numpy()) < 1e-6
