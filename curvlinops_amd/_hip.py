@@ -8,6 +8,7 @@ the shared object is missing or a call fails, a ``RuntimeError`` is raised.
 from __future__ import annotations
 
 import ctypes
+import threading
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
 from pathlib import Path
 
@@ -164,7 +165,14 @@ def prof_collect() -> dict[str, dict[str, float]]:
     return {n: {"ms": ms[i], "launches": int(cnt[i]), "alg_bytes": by[i]} for i, n in enumerate(names) if cnt[i]}
 
 
+_tls = threading.local()
+
+
 def _check(rc: int, what: str) -> None:
+    prev = getattr(_tls, "restore", None)
+    if prev is not None:  # `_stream()` switched the current device for this call: switch back
+        _tls.restore = None
+        torch.cuda.set_device(prev)
     if rc != 0:
         msg = load().clo_last_error().decode(errors="replace")
         kind = {-1: ValueError, -3: RuntimeError}.get(rc, RuntimeError)
@@ -172,7 +180,20 @@ def _check(rc: int, what: str) -> None:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The current HIP stream of the device the call's operands live on (the device of the last
+    tensor `_p` converted in this thread; argument lists convert their tensors before the stream).
+    If that is not the current device -- an operator on ``cuda:1`` used while ``cuda:0`` is current --
+    the device is made current for the duration of the foreign call (`_check` switches back): kernels
+    must be launched with their stream's device current."""
+    dev = getattr(_tls, "dev", None)
+    _tls.dev = None
+    if dev is None:
+        return torch.cuda.current_stream().cuda_stream
+    cur = torch.cuda.current_device()
+    if dev.index is not None and dev.index != cur:
+        _tls.restore = cur
+        torch.cuda.set_device(dev)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _p(t: Tensor | None) -> int | None:
@@ -181,6 +202,7 @@ def _p(t: Tensor | None) -> int | None:
         return None
     if not t.is_cuda or t.dtype != torch.float32:
         raise ValueError(f"expected a float32 GPU tensor, got {t.dtype} on {t.device}")
+    _tls.dev = t.device
     return t.data_ptr()
 
 

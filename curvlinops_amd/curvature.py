@@ -25,7 +25,7 @@ from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss, Module, MSELoss
 
 from curvlinops_amd import _hip
 from curvlinops_amd.enums import FisherType
-from curvlinops_amd.linop import PyTorchLinearOperator
+from curvlinops_amd.linop import PyTorchLinearOperator, fresh_result_buffer
 from curvlinops_amd.loss_sampling import make_grad_output_fn
 from curvlinops_amd.mlp_native import NativeMLP, detect_mlp, loss_kind_and_scale
 from curvlinops_amd.risk import EmpiricalRiskMixin
@@ -107,9 +107,43 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
     def uses_native_kernels(self) -> bool:
         return self._native is not None
 
-    def _native_batch_args(self, idx: int, X: Tensor, y: Tensor):
-        """(loss_kind, scale, aux) of batch ``idx`` for the native kernel."""
+    # The reference recomputes everything per product and holds params / data by reference
+    # (`_torch_base.py:832-905`, `gradient_moments.py:48-87`, `hessian.py:66`).  The native path keeps
+    # two derived quantities between products -- the per-batch output gradients of the EF / Hessian
+    # kernels and the merged input batches of the flat fast path -- and validates them on every
+    # product: same parameter tensors at the same autograd version, same batch tensor OBJECTS (held
+    # by the cache entry, so an address cannot be recycled) at the same version.  A `DataLoader`
+    # yields new tensors every sweep, so nothing is ever reused for it.
+    def _params_state(self) -> tuple:
+        return tuple((id(p), p._version) for p in self._params.values())
+
+    def _aux_lookup(self, idx: int, X: Tensor, y: Tensor) -> Tensor | None:
+        hit = self._native_aux.get(idx)
+        if hit is None:
+            return None
+        Xr, yr, xv, yv, pstate, value = hit
+        if Xr is X and yr is y and xv == X._version and yv == y._version and pstate == self._params_state():
+            return value
+        return None
+
+    def _aux_store(self, idx: int, X: Tensor, y: Tensor, value: Tensor) -> Tensor:
+        self._native_aux[idx] = (X, y, X._version, y._version, self._params_state(), value)
+        return value
+
+    def _native_rebind_if_replaced(self) -> None:
+        """Entries of the ``params`` dict replaced by other tensors: bind the kernels to the new ones."""
+        nat = self._native
+        if nat is not None and any(p is not q for p, q in zip(self._params.values(), nat.bound)):
+            self._native = None
+            self._native_aux.clear()
+            self._native_flat = False
+            self._init_native()
+
+    def _native_batch_args(self, idx: int, X: Tensor, y: Tensor, X_user: Tensor | None = None):
+        """(loss_kind, scale, aux) of batch ``idx`` for the native kernel; ``X`` is the prepared
+        (flattened, contiguous) input, ``X_user`` the tensor object the data iterable yielded."""
         N, C = X.shape[0], self._native.s.dims[-1]
+        X_user = X if X_user is None else X_user
         if self._NATIVE_KIND == "ggn":
             kind, scale = loss_kind_and_scale(self._loss_func, N, C)
             return kind, scale, None
@@ -117,12 +151,12 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             # exact Hessian: besides the loss Hessian (as for the GGN) the R-operator backward needs
             # the gradient of the reduced mini-batch loss w.r.t. the prediction, G [N, C]
             kind, scale = loss_kind_and_scale(self._loss_func, N, C)
-            G = self._native_aux.get(idx)
+            G = self._aux_lookup(idx, X_user, y)
             if G is None:
                 with torch.enable_grad():
                     f = self._model_func(self._params, X).detach().requires_grad_(True)
                     (G,) = torch.autograd.grad(self._loss_func(f, y), f)
-                G = self._native_aux[idx] = G.contiguous()
+                G = self._aux_store(idx, X_user, y, G.contiguous())
             return kind, scale, G
         if self._NATIVE_KIND == "mc":
             # MC-GGN: H_n = (1/c) sum_m g'_nm g'_nm^T with would-be gradients drawn from the model's
@@ -133,9 +167,9 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             c = {"mean": float(N), "sum": 1.0}[self._loss_func.reduction]
             return _hip.LOSS_RANK1, 1.0 / c, g.reshape(N, g.shape[1], C).contiguous()
         # empirical Fisher: H_n = (1/c) g_n g_n^T with g_n the UNREDUCED per-sample gradient
-        # of the loss w.r.t. the prediction (gradient_moments.py:48-87); params are fixed, so
-        # g_n is cached per batch.
-        aux = self._native_aux.get(idx)
+        # of the loss w.r.t. the prediction (gradient_moments.py:48-87); kept per batch for as long
+        # as neither the parameters nor the batch tensors change (`_aux_lookup`).
+        aux = self._aux_lookup(idx, X_user, y)
         if aux is None:
             with torch.no_grad():
                 f = self._model_func(self._params, X)
@@ -146,8 +180,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                     g[torch.arange(N, device=f.device), y] -= 1.0
                 else:
                     g = f.sigmoid() - y
-            aux = g.contiguous().unsqueeze(1)  # [N, 1, C]
-            self._native_aux[idx] = aux
+            aux = self._aux_store(idx, X_user, y, g.contiguous().unsqueeze(1))  # [N, 1, C]
         red = self._loss_func.reduction
         c = 1.0 if red == "sum" else float(N if isinstance(self._loss_func, CrossEntropyLoss) else N * C)
         return _hip.LOSS_RANK1, 1.0 / c, aux
@@ -206,8 +239,11 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
     def _matmat_native(self, M: list[Tensor]) -> list[Tensor] | None:
         """All columns of ``M`` through the HIP kernels; None if some batch does not qualify
         (then nothing has been written and the caller uses the autograd path)."""
+        self._native_rebind_if_replaced()
         nat = self._native
-        batches = []
+        if nat is None:
+            return None
+        batches, origs = [], []
         for X, y in self._loop_over_data(desc="_matmat"):
             Xn = nat.prepare_input(X)
             if Xn is None or y.shape[0] != Xn.shape[0]:
@@ -215,9 +251,10 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             if Xn.shape[0] == 0:
                 continue  # an empty mini-batch contributes nothing to the sum over data
             batches.append((Xn, y, self._get_normalization_factor(X, y)))
+            origs.append(X)
         K = M[0].shape[-1]
         # per-batch curvature arguments ONCE per product and in data order (MC draws its samples here)
-        bargs = [self._native_batch_args(bi, Xn, y) for bi, (Xn, y, _) in enumerate(batches)]
+        bargs = [self._native_batch_args(bi, Xn, y, origs[bi]) for bi, (Xn, y, _) in enumerate(batches)]
         out = self._matmat_native_cols(M, batches, bargs, K)
         if out is not None:
             return out
@@ -254,7 +291,13 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if not all(m.is_contiguous() and m.data_ptr() % 16 == 0 for m in M) or not plan.matmat_supported(4, K, rank):
             return None
         out = self._alloc_cols_like(M)
-        stream = torch.cuda.current_stream().cuda_stream
+        with torch.cuda.device(self.device):  # kernels launch on the operands' device, whatever is current
+            return self._matmat_native_cols_run(M, out, batches, bargs, K)
+
+    def _matmat_native_cols_run(self, M, out, batches, bargs, K: int) -> list[Tensor]:
+        nat = self._native
+        plan = nat.plan
+        stream = torch.cuda.current_stream(self.device).cuda_stream
         for k0 in range(0, K, plan.MATMAT_MAX_K):
             kc = min(plan.MATMAT_MAX_K, K - k0)
             ws = plan.matmat_workspace(kc, self.device)
@@ -276,7 +319,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         result the base class builds with ``cat`` is already laid out."""
         K = M[0].shape[-1]
         rows = [m.numel() // K for m in M]
-        buf = torch.empty(sum(rows), K, device=M[0].device, dtype=M[0].dtype)
+        buf = fresh_result_buffer(sum(rows), K, M[0].device, M[0].dtype)
         out, pos = [], 0
         for m, r in zip(M, rows):
             out.append(buf[pos:pos + r].view(m.shape))
@@ -284,16 +327,39 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         return out
 
     # ------------------------------------------------------------------ flat fast path
+    def _native_flat_state(self) -> tuple | None:
+        """What the kept flat-path constants were derived from: the batch tensor objects and their
+        versions, plus the parameter versions where per-batch output gradients are cached (EF)."""
+        if not isinstance(self._data, (list, tuple)):
+            return None
+        try:
+            data = tuple((X, X._version, y, y._version) for X, y in self._data)
+        except (AttributeError, TypeError, ValueError):
+            return None
+        return data, (self._params_state() if self._NATIVE_KIND == "ef" else None)
+
+    @staticmethod
+    def _same_flat_state(a: tuple | None, b: tuple | None) -> bool:
+        if a is None or b is None or len(a[0]) != len(b[0]) or a[1] != b[1]:
+            return False
+        return all(p[0] is q[0] and p[1] == q[1] and p[2] is q[2] and p[3] == q[3] for p, q in zip(a[0], b[0]))
+
     def _native_flat_setup(self):
         """Per-batch constants of the native path when ``data`` is a list of device-resident
-        fp32 batches (references only, nothing is copied); None otherwise."""
-        cached = getattr(self, "_native_flat", False)
-        if cached is not False:
-            return cached
-        self._native_flat = None
+        fp32 batches (references only, nothing is copied unless mini-batches are merged); None
+        otherwise.  Re-derived whenever a batch tensor or (for the EF) a parameter was replaced or
+        modified in place since they were computed."""
+        self._native_rebind_if_replaced()
         if (self._native is None or self._NATIVE_KIND not in ("ggn", "ef")
                 or not isinstance(self._data, (list, tuple))):
             return None  # the flat path is the whole-network GGN-type kernel only
+        state = self._native_flat_state()
+        cached = getattr(self, "_native_flat", False)
+        if cached is not False and cached is not None and self._same_flat_state(cached[0], state):
+            return cached[1]
+        self._native_flat = None
+        if state is None:
+            return None
         entries = []
         for bi, (X, y) in enumerate(self._data):
             if not (isinstance(X, Tensor) and X.device == self.device and y.device == self.device):
@@ -301,7 +367,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             Xn = self._native.prepare_input(X)
             if Xn is None or y.shape[0] != Xn.shape[0] or Xn.shape[0] == 0:
                 return None
-            entries.append((Xn, *self._native_batch_args(bi, Xn, y), self._get_normalization_factor(X, y)))
+            entries.append((Xn, *self._native_batch_args(bi, Xn, y, X), self._get_normalization_factor(X, y)))
         if not entries:
             return None
         # consecutive mini-batches as one larger batch where that pays off (concatenated copies, kept)
@@ -310,8 +376,8 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                    for Xn, kind, scale, aux, norm in self._merge_native_batches(entries)]
         nmax = max(b[2] for b in batches)
         ws = self._native.plan.workspace(nmax, self.device)
-        self._native_flat = (batches, ws, ws.data_ptr())
-        return self._native_flat
+        self._native_flat = (state, (batches, ws, ws.data_ptr()))
+        return self._native_flat[1]
 
     def __matmul__(self, X):
         """Fast path for a flat fp32 GPU vector on the native kernels: one output allocation and
@@ -333,12 +399,21 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                 nat = self._native
                 out = torch.empty_like(X)
                 vp, op = X.data_ptr(), out.data_ptr()
-                stream = torch.cuda.current_stream().cuda_stream
-                beta = 0.0
-                for (_Xn, xptr, N, kind, scale, auxp, auxr, _aux, norm) in batches:
-                    nat.plan.ggn_matvec_flat(vp, op, nat.w_off, nat.b_off, xptr, N, kind, scale, norm, beta,
-                                             auxp, auxr, ws_ptr, stream)
-                    beta = 1.0
+                dev = X.device
+                foreign = dev.index != torch.cuda.current_device()
+                if foreign:  # operator on another GPU than the current one: launch with ITS device current
+                    prev = torch.cuda.current_device()
+                    torch.cuda.set_device(dev)
+                try:
+                    stream = torch.cuda.current_stream(dev).cuda_stream
+                    beta = 0.0
+                    for (_Xn, xptr, N, kind, scale, auxp, auxr, _aux, norm) in batches:
+                        nat.plan.ggn_matvec_flat(vp, op, nat.w_off, nat.b_off, xptr, N, kind, scale, norm, beta,
+                                                 auxp, auxr, ws_ptr, stream)
+                        beta = 1.0
+                finally:
+                    if foreign:
+                        torch.cuda.set_device(prev)
                 return out
         return super().__matmul__(X)
 

@@ -331,7 +331,8 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         identical factor shapes (repeated layer shapes), their factors stacked ONCE:
         ``[(block indices, S1 [n, A, a], S2 [n, B, b], lambda [n, A, B] | None), ...]``."""
         pairs = [self._kron_pair(B) for B in self._blocks]
-        key = tuple(id(t) for p in pairs if p is not None for t in (*p[0], p[1]))
+        # identity AND autograd version: an in-place update of a factor (e.g. an EMA) must refresh the stacks
+        key = tuple((id(t), getattr(t, "_version", 0)) for p in pairs if p is not None for t in (*p[0], p[1]))
         cached = getattr(self, "_group_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]

@@ -60,12 +60,28 @@ def _adjacent_rows(Y: list[Tensor], sizes: list[int], K: int) -> Tensor | None:
     base = Y[0]._base
     if base is None or base.dim() != 2 or base.shape != (sum(sizes), K) or not base.is_contiguous():
         return None
+    # only buffers a producer allocated for this very result (tagged by ``fresh_result_buffer``):
+    # a pass-through operator may hand back views of the CALLER's matrix, which must never be
+    # returned as "our" result (composites scale / accumulate results in place)
+    if not getattr(base, "_clo_fresh_result", False):
+        return None
     off = base.storage_offset()
     for y, n in zip(Y, sizes):
         if y._base is not base or not y.is_contiguous() or y.storage_offset() != off:
             return None
         off += n * K
     return base
+
+
+def fresh_result_buffer(rows: int, K: int, device, dtype) -> Tensor:
+    """A ``[rows, K]`` result buffer whose row-range views ``_from_list`` may return without a copy."""
+    buf = torch.empty(rows, K, device=device, dtype=dtype)
+    buf._clo_fresh_result = True
+    return buf
+
+
+def _shares_storage(a: Tensor, b) -> bool:
+    return isinstance(b, Tensor) and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
 
 
 class PyTorchLinearOperator:
@@ -255,7 +271,10 @@ class _SumPyTorchLinearOperator(PyTorchLinearOperator):
         # flat operands go through the summands' own `@` (and thus their fast paths), not through
         # the tensor-list detour
         if isinstance(X, Tensor) and X.dim() in (1, 2):
-            return (self._A @ X).add_(self._B @ X)
+            a, b = self._A @ X, self._B @ X
+            # in place only on memory that is provably not the caller's (inputs are never mutated,
+            # reference `_torch_base.py:937`)
+            return a + b if _shares_storage(a, X) else a.add_(b)
         return super().__matmul__(X)
 
     def _adjoint(self) -> "_SumPyTorchLinearOperator":
@@ -283,7 +302,8 @@ class _ScalePyTorchLinearOperator(PyTorchLinearOperator):
 
     def __matmul__(self, X):
         if isinstance(X, Tensor) and X.dim() in (1, 2):
-            return (self._A @ X).mul_(self._scalar)
+            y = self._A @ X
+            return self._scalar * y if _shares_storage(y, X) else y.mul_(self._scalar)
         return super().__matmul__(X)
 
     def _adjoint(self) -> "_ScalePyTorchLinearOperator":

@@ -36,7 +36,11 @@ def detect_mlp(model: nn.Module | None, params: dict[str, Tensor]) -> MLPStructu
     parameters are exactly ``params``; else None."""
     if not isinstance(model, nn.Sequential) or len(model) == 0:
         return None
-    mods = list(model.named_children())
+    # every POSITION of the container (``named_children`` de-duplicates repeated instances, which would
+    # silently drop a shared activation / layer); a module that appears twice is not supported natively
+    mods = list(model._modules.items())
+    if any(m is None for _, m in mods) or len({id(m) for _, m in mods}) != len(mods):
+        return None
     leading_flatten = False
     if isinstance(mods[0][1], nn.Flatten):
         if mods[0][1].start_dim != 1 or mods[0][1].end_dim != -1:
@@ -117,6 +121,7 @@ class NativeMLP:
         self.D = pos
         self.w_off = [offs[n] for n in structure.weight_names]
         self.b_off = [None if n is None else offs[n] for n in structure.bias_names]
+        self.bound = [params[n] for n in self.names]  # the tensor objects the plan's pointers refer to
         self.plan.bind_params(self.W, self.b)
 
     def prepare_input(self, X: Tensor) -> Tensor | None:

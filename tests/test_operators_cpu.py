@@ -324,3 +324,35 @@ def test_tsqr_orthonormal_basis_matches_direct_qr(monkeypatch):
     monkeypatch.setattr(T, "_QR_MAX_ELEMS", 2**30)
     assert torch.allclose(chunked, T.hutchpp_trace(A, 18, probes=(S, G)), rtol=1e-10)
 
+
+
+# ----------------------------------------------------------------------------- ownership of inputs
+class _PassThrough(C.PyTorchLinearOperator):
+    """Identity whose ``_matmat`` hands back its INPUT tensors (like the reference's
+    ``curvlinops.examples.IdentityLinearOperator``)."""
+
+    SELF_ADJOINT = True
+
+    def __init__(self, shapes):
+        super().__init__(shapes, shapes)
+
+    def _matmat(self, X):
+        return X
+
+    device = torch.device("cpu")
+    dtype = torch.float64
+
+
+@pytest.mark.parametrize("K", [None, 1, 3])
+def test_composites_never_mutate_the_operand(K):
+    """`(c*I) @ X`, `(I+I) @ X`, `(A + d*I) @ X` must leave X untouched (reference `_torch_base.py:937`:
+    results are fresh tensors): a pass-through block returns views of the caller's matrix."""
+    I = _PassThrough([(3, 2), (4,)])
+    X = torch.rand(10, dtype=torch.float64) if K is None else torch.rand(10, K, dtype=torch.float64)
+    X0 = X.clone()
+    assert torch.equal((0.5 * I) @ X, 0.5 * X0) and torch.equal(X, X0)
+    assert torch.equal((I + I) @ X, 2 * X0) and torch.equal(X, X0)
+    assert torch.equal((I - 0.25 * I) @ X, 0.75 * X0) and torch.equal(X, X0)
+    Y = I @ X
+    Y.mul_(2.0)  # even the plain product is the caller's to modify
+    assert torch.equal(X, X0)

@@ -497,3 +497,79 @@ def test_empty_and_ragged_mini_batches(dev):
             v, V = torch.rand(with_empty.shape[1], device=dev), torch.rand(with_empty.shape[1], 2, device=dev)
             assert rel_err((with_empty @ v).cpu(), (without @ v).cpu().numpy()) < 1e-6
             assert rel_err((with_empty @ V).cpu(), (without @ V).cpu().numpy()) < 1e-6
+
+
+# ----------------------------------------------------------------------------- round-2 regressions
+def test_shared_module_instance_is_not_run_natively(dev):
+    """`act = ReLU(); Sequential(Linear, act, Linear, act, Linear)`: `named_children` would drop the
+    second activation.  Such a model must take the autograd path and agree with a model that
+    uses two activation instances (which runs natively)."""
+    torch.manual_seed(0)
+    act = nn.ReLU()
+    shared = nn.Sequential(nn.Linear(12, 16), act, nn.Linear(16, 8), act, nn.Linear(8, 3)).to(dev)
+    twin = nn.Sequential(nn.Linear(12, 16), nn.ReLU(), nn.Linear(16, 8), nn.ReLU(), nn.Linear(8, 3)).to(dev)
+    twin.load_state_dict(shared.state_dict())
+    X, y = torch.rand(6, 12, device=dev), torch.rand(6, 3, device=dev)
+    ops = [C.GGNLinearOperator(m, nn.MSELoss(), dict(m.named_parameters()), [(X, y)]) for m in (shared, twin)]
+    assert not ops[0].uses_native_kernels and ops[1].uses_native_kernels
+    v = torch.rand(ops[0].shape[1], device=dev)
+    assert rel_err(ops[0] @ v, (ops[1] @ v).cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("cls", [C.GGNLinearOperator, C.EFLinearOperator, C.HessianLinearOperator])
+@pytest.mark.parametrize("loss", ["mse", "ce"])
+def test_inplace_updates_of_params_and_data_are_seen(dev, cls, loss):
+    """The reference recomputes per product and holds params / data by reference
+    (`_torch_base.py:832-905`): after `p.add_()` / `X.mul_()` an existing operator must equal a freshly
+    built one (the native path keeps per-batch output gradients, validated by version counters)."""
+    torch.manual_seed(1)
+    model = build_mlp([16, 24, 12, 4], ["tanh", "relu", "identity"], [True, True, True]).to(dev)
+    params = dict(model.named_parameters())
+    mk = lambda: (torch.rand(5, 16, device=dev),  # noqa: E731
+                  torch.randint(0, 4, (5,), device=dev) if loss == "ce" else torch.rand(5, 4, device=dev))
+    data = [mk(), mk()]
+    lf = LOSS[loss]()
+    op = cls(model, lf, params, data)
+    assert op.uses_native_kernels
+    v = torch.rand(op.shape[1], device=dev)
+    V = torch.rand(op.shape[1], 8, device=dev)
+    first = op @ v
+
+    def fresh():
+        return cls(model, lf, params, data)
+
+    with torch.no_grad():
+        for p in params.values():
+            p.add_(0.05 * torch.randn_like(p))
+    assert rel_err(first, (fresh() @ v).cpu().numpy()) > 1e-3  # the update matters ...
+    assert rel_err(op @ v, (fresh() @ v).cpu().numpy()) < 1e-6  # ... and is seen (flat fast path)
+    assert rel_err(op @ V, (fresh() @ V).cpu().numpy()) < 1e-6  # (matrix path)
+    with torch.no_grad():
+        data[0][0].mul_(1.5)
+    assert rel_err(op @ v, (fresh() @ v).cpu().numpy()) < 1e-6
+    data[1] = mk()  # a batch replaced by other tensors
+    assert rel_err(op @ v, (fresh() @ v).cpu().numpy()) < 1e-6
+    assert rel_err(op @ V, (fresh() @ V).cpu().numpy()) < 1e-6
+    # a parameter tensor replaced in the dict the operator holds by reference
+    name = next(iter(params))
+    new = torch.nn.Parameter(params[name].detach() * 0.5)
+    setattr(model[0], name.split(".")[1], new)
+    params[name] = new
+    assert rel_err(op @ v, (fresh() @ v).cpu().numpy()) < 1e-6
+
+
+def test_grouped_kronecker_blocks_see_inplace_factor_updates(dev):
+    """Equal-shape blocks run as one batched product on stacked factor copies; an in-place update of
+    a factor (EMA) must refresh them (K = 1 grouped path == K > 1 path)."""
+    torch.manual_seed(0)
+    blocks = []
+    for _ in range(4):
+        A, B = torch.rand(6, 6, device=dev), torch.rand(5, 5, device=dev)
+        blocks.append(C.KroneckerProductLinearOperator(A + A.T, B + B.T))
+    bd = C.BlockDiagonalLinearOperator(blocks)
+    x = torch.rand(bd.shape[1], device=dev)
+    _ = bd @ x
+    with torch.no_grad():
+        blocks[2][0].mul_(0.5).add_(torch.eye(6, device=dev))
+    dense = torch.block_diag(*[torch.kron(b[0], b[1]) for b in blocks])
+    assert rel_err(bd @ x, (dense @ x).cpu().numpy()) < TOL
