@@ -505,6 +505,7 @@ __global__ __launch_bounds__(WAVES * 64) void fwd_mfma_first_kernel(
       for (int g = 0; g < RG; ++g) av[u][g] = CLO_LDW(pA[g] + (step + u) * 16);
       bv[u] = ld4(pB + (step + u) * 16);
     }
+    __builtin_amdgcn_sched_barrier(0);  // every load of the group is issued before the first MFMA waits
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float bx = __uint_as_float(__float_as_uint(bv[u].x) & bmask);
@@ -1754,9 +1755,15 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
     // features per block: fill the CUs evenly (11 for d_out = 2688), at most one RG x 8 tile group
     const int fpb = (int)std::min<long>(MF1_RG * 8, std::max<long>(4, cdiv(d_out, kNumCU)));
     ProfScope prof(0, 4.0 * d_in * d_out * 2, st);
-    hipLaunchKernelGGL((fwd_mfma_first_kernel<MF1_WAVES, MF1_RG, MF1_U>), dim3((unsigned)cdiv(d_out, fpb)),
-                       dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in,
-                       d_out, act, kpw, fpb);
+    // all of a wave's weight loads in ONE round trip where its K range is 8 steps (d_in = 1024)
+    if (kpw == 128 && d_in % 128 == 0)
+      hipLaunchKernelGGL((fwd_mfma_first_kernel<MF1_WAVES, MF1_RG, 8>), dim3((unsigned)cdiv(d_out, fpb)),
+                         dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in,
+                         d_out, act, kpw, fpb);
+    else
+      hipLaunchKernelGGL((fwd_mfma_first_kernel<MF1_WAVES, MF1_RG, MF1_U>), dim3((unsigned)cdiv(d_out, fpb)),
+                         dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in,
+                         d_out, act, kpw, fpb);
     CLO_CHECK_LAUNCH("fwd_mfma_first_kernel");
     return CLO_OK;
   }

@@ -1,0 +1,11 @@
+# usage: buildvar.sh name "-DFLAGS"
+set -e
+cd /root/repo/curvlinops_amd/csrc
+name=$1; shift
+mkdir -p /tmp/obj_$name
+for f in gemm mlp stream_ops linalg conv gram; do
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $f.hip -o /tmp/obj_$name/$f.o ) &
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libclo_$name.so /tmp/obj_$name/*.o
+echo built $name
