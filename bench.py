@@ -14,14 +14,22 @@ vectors rotate over several buffers so that v and the result stream from / to HB
 living in the 256 MiB Infinity Cache; the weights are constant across products, as in any real
 use of the operator.
 
-Extra legs on rank 0 at N = 1 (outside the timed region):
-* ``roofline``: the same steps with the library's HIP-event instrumentation on (events on the
-  launch stream); the dominant kernel family is the forward+JVP weight stream
-  (``fwd_mfma_first_kernel`` + ``fwd_mfma_kernel``: W and V of every layer read once = 8 B per
-  parameter of the 12 B/parameter a matvec moves algorithmically); achieved = its algorithmic
-  bytes / its summed launch durations, against the 8 TB/s HBM3E peak.
-* ``cpu_baseline``: the NumPy oracle (``oracle/mlp_numpy.py``, "port") in float32 on the host
-  cores for a bounded number of matvecs of the same workload.
+Extra legs (outside the timed region of the headline metric, same JSON line):
+* ``roofline`` (rank 0, N = 1): ``frac`` is the WHOLE matvec against the HBM roofline --
+  ``12 D`` algorithmic bytes (theta, v and the result once each) / the step time of the
+  timed region / 8 TB/s -- the quantity the north star's ">= 50 %" refers to.  The per-kernel
+  picture (HIP events on the launch stream, live) sits under ``kernels``; ``traffic`` is the HBM
+  bytes of one matvec from the committed PMC passes.
+* ``kfac`` (every N): the second half of BASELINE.json's metric -- KFAC factor build ms per batch
+  on config C4 (ResNet-18, 512 rows per GPU, joint W+b, one MC sample; reference phases
+  ``benchmark_utils.py:139-143``, protocol ``benchmark_execute.py:288-301``: min of 5 after one
+  warm-up).  N > 1: every rank builds on its shard and the factors are summed by ONE in-place
+  all-reduce of the flat factor buffer (weak scaling, 512 rows per rank).
+* ``scalable_points`` (N > 1): the same operator at 512 rows per rank (MFMA-bound; the regime in
+  which a 40 MB all-reduce per product can hide behind the kernels).
+* ``cpu_baseline`` (rank 0, N = 1): this package's own operators on CPU tensors (torch ops, fp32,
+  all physical cores, min of 10 after one warm-up -- the reference's protocol), GGN matvec of the
+  same workload and a bounded KFAC factor build.
 """
 
 from __future__ import annotations
@@ -59,7 +67,7 @@ def build_problem(device, batch: int, seed: int):
 def pmc_traffic_per_launch(kernel: str):
     """Mean HBM bytes per launch of `kernel` from the committed PMC summary (collected by separate
     rocprofv3 --pmc passes of this same command; see tools/pmc_summary.py); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_n8_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_c2_n8_pmc_traffic.json")
     try:
         rows = [k for k in json.load(open(path))["kernels"] if kernel in k["kernel"]]
     except (OSError, ValueError, KeyError):
@@ -71,7 +79,7 @@ def pmc_traffic_per_launch(kernel: str):
 
 def rocprof_avg_us(kernels):
     """Launch-weighted mean duration of `kernels` in the committed rocprofv3 --stats summary."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_n8_bench_kernel_stats.txt")
+    path = os.path.join(ROOT, "profiles", "r02_c2_n8_bench_kernel_stats.txt")
     tot = cnt = 0.0
     try:
         for line in open(path):
@@ -114,34 +122,172 @@ def other_points(model, params, device, D: int) -> dict:
     return out
 
 
-def cpu_baseline(batch: int, budget_s: float = 12.0) -> dict:
-    """Time the float32 NumPy oracle on the host cores for a bounded number of matvecs."""
-    from oracle import mlp_numpy as O
-
-    rng = np.random.default_rng(0)
-    Ws = [(rng.random((DIMS[i + 1], DIMS[i]), dtype=np.float32) - 0.5) / np.sqrt(DIMS[i]) for i in range(3)]
-    bs = [rng.random(DIMS[i + 1], dtype=np.float32) - 0.5 for i in range(3)]
-    vWs = [rng.random(W.shape, dtype=np.float32) for W in Ws]
-    vbs = [rng.random(b.shape, dtype=np.float32) for b in bs]
-    X = rng.random((batch, DIMS[0]), dtype=np.float32)
-    y = rng.random((batch, DIMS[3]), dtype=np.float32)
-    acts = ["relu", "relu", "identity"]
-    O.ggn_matvec_batch(Ws, bs, acts, X, y, "mse", "mean", vWs, vbs)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.ggn_matvec_batch(Ws, bs, acts, X, y, "mse", "mean", vWs, vbs)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 2000:
-            break
+def physical_cores() -> int:
     try:
-        from threadpoolctl import threadpool_info
+        import psutil
 
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
     except Exception:  # noqa: BLE001
-        cores = os.cpu_count() or 1
-    return {"value": n / el, "unit": "matvecs/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} float32 GGN matvecs of the same C2 workload (B={batch}) with oracle/mlp_numpy.py in {el:.1f} s"}
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(batch: int) -> dict:
+    """This package's operators on CPU tensors (the torch.func path of `curvlinops_amd.curvature`,
+    validated against the reference goldens by the CPU test-suite), fp32, all physical cores, the
+    reference's protocol: `perf_counter`, min of 10 repeats after one warm-up
+    (`docs/examples/basic_usage/benchmark_execute.py:288-301`)."""
+    import curvlinops_amd as C
+
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    cpu = torch.device("cpu")
+    model, X, y = build_problem(cpu, batch, seed=0)
+    params = dict(model.named_parameters())
+    D = sum(p.numel() for p in params.values())
+    G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X, y)], check_deterministic=False)
+    v = torch.rand(D)
+    G @ v  # warm-up
+    best, t_all = float("inf"), time.perf_counter()
+    for _ in range(10):
+        t0 = time.perf_counter()
+        G @ v
+        best = min(best, time.perf_counter() - t0)
+    out = {"value": 1.0 / best, "unit": "matvecs/s", "cores": cores, "kind": "port",
+           "sample": f"min of 10 float32 GGN matvecs (1 warm-up) of the same C2 workload (B={batch}) with "
+                     f"curvlinops_amd.GGNLinearOperator on CPU tensors, {cores} threads, "
+                     f"{time.perf_counter() - t_all:.1f} s of CPU work"}
+    # bounded KFAC sample: ResNet-18 factor build on 32 rows (the GPU leg uses 512 per GPU)
+    try:
+        from benchmarks.models import ResNet18, kfac_params
+
+        torch.manual_seed(0)
+        net = ResNet18().eval()
+        kp = kfac_params(net)
+        rows = 32
+        Xc, yc = torch.rand(rows, 3, 32, 32), torch.randint(0, 10, (rows,))
+        kw = dict(fisher_type="mc", separate_weight_and_bias=False, check_deterministic=False, num_data=rows)
+        t0 = time.perf_counter()
+        C.KFACLinearOperator(net, nn.CrossEntropyLoss(), kp, [(Xc, yc)], **kw)
+        first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        C.KFACLinearOperator(net, nn.CrossEntropyLoss(), kp, [(Xc, yc)], **kw)
+        second = time.perf_counter() - t0
+        out["kfac_factor_build"] = {"ms_per_batch": 1e3 * min(first, second), "rows": rows, "cores": cores,
+                                    "sample": f"ResNet-18 KFAC factor build, {rows} rows, min of 2, CPU tensors"}
+    except Exception as e:  # noqa: BLE001
+        out["kfac_factor_build"] = {"error": repr(e)}
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# KFAC factor build (BASELINE config C4): the second half of the metric
+# --------------------------------------------------------------------------------------------
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -> dict:
+    import curvlinops_amd as C
+    from benchmarks.models import ResNet18, kfac_params
+
+    torch.manual_seed(0)
+    model = ResNet18().to(device).eval()
+    params = kfac_params(model)
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    X = torch.rand(rows, 3, 32, 32, generator=g).to(device)
+    y = torch.randint(0, 10, (rows,), generator=g).to(device)
+    kw = dict(fisher_type="mc", mc_samples=1, separate_weight_and_bias=False, check_deterministic=False,
+              num_data=rows * world, distributed=world > 1)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def build():
+        return C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw)
+
+    K = build()  # warm-up
+    best = float("inf")
+    for _ in range(repeats):
+        sync()
+        t0 = time.perf_counter()
+        K = build()
+        sync()
+        best = min(best, time.perf_counter() - t0)
+    if world > 1:
+        t = torch.tensor([best], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        best = float(t.item())
+    # algorithmic work (SURVEY 8d): sum_l 2 B S_l (d_in'^2 + V d_out^2) flop with V = 1 MC sample
+    pos = {}
+
+    def shared_positions(mod, o):
+        feat = o.shape[1] if isinstance(mod, nn.Conv2d) else o.shape[-1]
+        return o.numel() // (o.shape[0] * feat)
+
+    hooks = [m.register_forward_hook(lambda mod, i, o: pos.__setitem__(mod, shared_positions(mod, o)))
+             for m in model.modules() if isinstance(m, (nn.Conv2d, nn.Linear))]
+    with torch.no_grad():
+        model(X[:2])
+    for h in hooks:
+        h.remove()
+    flops = 0.0
+    factor_floats = 0
+    for m, S in pos.items():
+        d_out = m.weight.shape[0]
+        d_in = m.weight[0].numel() + (1 if m.bias is not None else 0)
+        flops += 2.0 * rows * S * (d_in**2 + d_out**2)
+        factor_floats += d_in**2 + d_out**2
+    out = {
+        "metric": "KFAC factor build ms/batch (ResNet-18, C4)",
+        "ms_per_batch": 1e3 * best,
+        "rows_per_gpu": rows,
+        "global_batch": rows * world,
+        "n_gpus": world,
+        "rows_per_s": rows * world / best,
+        "config": "ResNet-18 (torchvision topology, 10 classes, eval), 3x32x32, CE mean, fisher mc x1, joint W+b, "
+                  "Linear/Conv2d parameters only" + (", sharded build + ONE all-reduce of the flat factor buffer"
+                                                     if world > 1 else ""),
+        "protocol": f"min of {repeats} after 1 warm-up, device (and ranks) synchronised around each build",
+        "factor_gflop_per_gpu": flops / 1e9,
+        "factor_buffer_MB": 4.0 * factor_floats / 1e6,
+        "roofline": {"bound": "mfma", "achieved": flops / best / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / best / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     "note": "factor SYRK flops (full figure, symmetry not discounted) over the WHOLE build time, "
+                             "which also contains the autograd forward/backward pass (host framework)"},
+    }
+    if world == 1:
+        def fwdbwd():
+            o = model(X)
+            return torch.autograd.grad(nn.functional.cross_entropy(o, y), list(params.values()))
+
+        fwdbwd()
+        t_ag = float("inf")
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fwdbwd()
+            torch.cuda.synchronize()
+            t_ag = min(t_ag, time.perf_counter() - t0)
+        out["gradient_and_loss_ms"] = 1e3 * t_ag
+        out["roofline"]["achieved_excl_autograd"] = flops / max(best - t_ag, 1e-9) / 1e12
+        v = torch.rand(K.shape[1], device=device)
+        K @ v
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            K @ v
+        torch.cuda.synchronize()
+        out["kfac_matvec_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        Kinv = K.inverse(damping=1e-3)
+        torch.cuda.synchronize()
+        Kinv = K.inverse(damping=1e-3)
+        torch.cuda.synchronize()
+        out["cholesky_inverse_ms_second_call"] = 1e3 * (time.perf_counter() - t0) / 2  # incl. the first call's allocations
+        del Kinv
+    return out
 
 
 def main() -> None:
@@ -263,42 +409,94 @@ def main() -> None:
         torch.cuda.synchronize()
         prof = _hip.prof_collect()
         _hip.prof_enable(False)
-        # dominant kernel family: the forward+JVP weight stream (fwd_mfma_first_kernel for layer 1,
-        # fwd_mfma_kernel for the others): reads W and V of every layer exactly once = 8 B/parameter
-        fam = max(prof, key=lambda k: prof[k]["ms"])
-        r = prof[fam]
-        kernel_names = {"fwd_mfma": ["fwd_mfma_first_kernel", "fwd_mfma_kernel"], "bwd_dprev": ["bwd_fused_kernel"],
-                        "outer_all": ["outer_all_kernel"]}.get(fam, [fam])
-        tr = [pmc_traffic_per_launch(k) for k in kernel_names]
-        traffic = (sum(t for t in tr if t) / max(sum(1 for t in tr if t), 1)) if any(tr) else None
-        achieved = r["alg_bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
-        kernels_ms = sum(v["ms"] for v in prof.values()) / nprof
+        fam_kernels = {"fwd_mfma": ["fwd_mfma_first_kernel", "fwd_mfma_kernel"], "bwd_dprev": ["bwd_fused_kernel"],
+                       "outer_all": ["outer_all_kernel"], "finish_head_fwd": ["head_fwd_kernel"],
+                       "loss_head_bwd": ["head_bwd_kernel"]}
+        kernels = {}
+        for fam, r in prof.items():
+            names = fam_kernels.get(fam, [fam])
+            kernels[fam] = {
+                "kernels": names, "launches_per_matvec": r["launches"] / nprof,
+                "alg_bytes_per_launch": r["alg_bytes"] / max(r["launches"], 1),
+                "avg_launch_us_hip_events": 1e3 * r["ms"] / max(r["launches"], 1),
+                "rocprof_avg_kernel_us": rocprof_avg_us(names),
+                "achieved_GBps": (r["alg_bytes"] / (r["ms"] * 1e-3) / 1e9) if r["ms"] > 0 else 0.0,
+                "us_per_matvec": 1e3 * r["ms"] / nprof,
+            }
+        dom = max(kernels, key=lambda k: kernels[k]["us_per_matvec"])
+        tr = [pmc_traffic_per_launch(k) for names in fam_kernels.values() for k in names]
+        traffic = sum(t for t in tr if t) if any(tr) else None  # every kernel of the chain runs once per matvec
+        achieved = 12 * D / (ms_per_step * 1e-3) / 1e9
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": " + ".join(kernel_names),
+            "kernel": "whole GGN matvec = the chain of " + str(int(round(sum(k["launches_per_matvec"] for k in kernels.values()))))
+                      + " launches (" + ", ".join(n for k in kernels.values() for n in k["kernels"]) + ")",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
+            "alg_bytes_per_matvec": 12 * D,
+            "definition": "12 D algorithmic bytes (theta, v, result once; SURVEY 8d) / step time of the timed region",
             "traffic": traffic,
-            "traffic_source": "profiles/r01_c2_n8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                              "separate passes, FETCH doubled per the gfx950 note; mean over the family's launches)" if traffic else None,
-            "launches": r["launches"],
-            "avg_launch_us": 1e3 * r["ms"] / max(r["launches"], 1),
-            "avg_launch_us_note": "HIP-event interval around each launch on the launch stream: includes the "
-                                  "dispatch latency (~2.5 us) that rocprofv3's kernel durations exclude",
-            "rocprof_avg_kernel_us": rocprof_avg_us(kernel_names),
-            "alg_bytes_per_launch": r["alg_bytes"] / max(r["launches"], 1),
-            "whole_matvec": {
-                "alg_bytes": 12 * D,
-                "achieved_GBps": 12 * D / (ms_per_step * 1e-3) / 1e9,
-                "frac": 12 * D / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "kernel_ms_per_matvec": kernels_ms,
-            },
-            "per_family_ms_per_matvec": {k: v["ms"] / nprof for k, v in prof.items()},
+            "traffic_source": "profiles/r02_c2_n8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                              "passes, FETCH doubled per the gfx950 note), summed over the kernels of one matvec" if traffic else None,
+            "dominant_kernel": dom,
+            "dominant_kernel_frac": kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS,
+            "kernels": kernels,
+            "kernels_note": "avg_launch_us_hip_events = HIP-event interval around each launch on the launch stream "
+                            "(includes ~2.5 us dispatch latency that rocprofv3 durations exclude); "
+                            "rocprof_avg_kernel_us from profiles/r02_c2_n8_bench_kernel_stats.txt (same command)",
+            "kernel_us_per_matvec_hip_events": sum(k["us_per_matvec"] for k in kernels.values()),
         }
         result["cpu_baseline"] = cpu_baseline(args.batch)
         result["other_points"] = other_points(model, params, device, D)
+
+    if not args.no_extras:
+        # ---- second half of the metric: KFAC factor build ms/batch (every rank takes part)
+        try:
+            result["kfac"] = kfac_leg(device, world, rank)
+        except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+            result["kfac"] = {"error": repr(e)}
+        if world > 1:
+            # ---- the same operator where data-parallel matvecs can scale: 512 rows per rank
+            try:
+                rows = 512
+                m2, X2, y2 = build_problem(device, rows, seed=100 + rank)
+                p2 = dict(m2.named_parameters())
+                G2 = AllReducedLinearOperator(C.GGNLinearOperator(m2, nn.MSELoss(), p2, [(X2, y2)],
+                                                                  check_deterministic=False, num_data=rows * world))
+                vv = [torch.rand(D, device=device) for _ in range(4)]
+                pend: list = []
+
+                def step2(i):
+                    yv, work = G2.matmul_async(vv[i % 4])
+                    pend.append(work)
+                    if len(pend) > 2:
+                        pend.pop(0).wait()
+
+                for i in range(5):
+                    step2(i)
+                while pend:
+                    pend.pop(0).wait()
+                sync()
+                t0 = time.perf_counter()
+                nst = 40
+                for i in range(nst):
+                    step2(i)
+                while pend:
+                    pend.pop(0).wait()
+                sync()
+                el = time.perf_counter() - t0
+                t = torch.tensor([el], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+                result["scalable_points"] = {"rows512": {
+                    "shard_matvecs_per_s": world * nst / el, "ms_per_step": 1e3 * el / nst, "rows_per_gpu": rows,
+                    "alg_tflops_total": world * 10.0 * rows * D * nst / el / 1e12,
+                    "note": "same operator, 512 rows per rank (MFMA-bound), all-reduce of the [D] result overlapped "
+                            "with the next product"}}
+            except Exception as e:  # noqa: BLE001
+                result["scalable_points"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result))

@@ -193,22 +193,48 @@ def _join_factor_stream(device) -> None:
         torch.cuda.current_stream(device).wait_stream(side)
 
 
+class _FactorStore(dict):
+    """``{group key: factor}``.  With ``preallocate`` every factor is a view into ONE flat buffer
+    (``.flat``) that the data-parallel build all-reduces in place -- no pack / unpack copies around
+    the collective; ``fresh`` holds the keys whose view has not been written yet."""
+
+    def __init__(self):
+        super().__init__()
+        self.flat: Tensor | None = None
+        self.fresh: set = set()
+
+    def preallocate(self, sizes: dict, device, dtype) -> None:
+        """``sizes``: ``{key: d}`` for ``d x d`` factors, laid out in dict order."""
+        self.flat = torch.empty(sum(d * d for d in sizes.values()), device=device, dtype=dtype)
+        off = 0
+        for key, d in sizes.items():
+            self[key] = self.flat[off:off + d * d].view(d, d)
+            off += d * d
+        self.fresh = set(sizes)
+
+
 def _gram_accumulate(store: dict, key, X2d: Tensor, alpha: float, ones_col: bool) -> None:
     """``store[key] += alpha * [X|1]^T [X|1]`` -- HIP SYRK for fp32 GPU tensors."""
     d = X2d.shape[1] + (1 if ones_col else 0)
+    fresh = getattr(store, "fresh", None)
     if is_native_tensor(X2d):
         X2d = X2d if X2d.stride(-1) == 1 else X2d.contiguous()
         C = store.get(key)
-        first = C is None
-        if first:
+        first = C is None or (fresh is not None and key in fresh)
+        if C is None:
             C = torch.empty(d, d, device=X2d.device, dtype=torch.float32)
             store[key] = C
+        if fresh:
+            fresh.discard(key)
         _hip.syrk_accum(C, X2d, alpha=alpha, beta=0.0 if first else 1.0, ones_col=ones_col)
         return
     if ones_col:
         X2d = torch.cat([X2d, X2d.new_ones(X2d.shape[0], 1)], dim=1)
     upd = (X2d.T @ X2d).mul_(alpha)
-    if key in store:
+    if fresh is not None and key in fresh:
+        fresh.discard(key)
+        store[key].copy_(upd)
+    elif key in store:
         store[key].add_(upd)
     else:
         store[key] = upd
@@ -320,8 +346,25 @@ class HipKFACComputer(EmpiricalRiskMixin):
 
     def _compute_kronecker_factors(self):
         mapping = self.compute_parameter_groups(self._params, self._model_module, self._separate_weight_and_bias)
-        A: dict[ParamGroupKey, Tensor] = {}
-        G: dict[ParamGroupKey, Tensor] = {}
+        A: dict[ParamGroupKey, Tensor] = _FactorStore()
+        G: dict[ParamGroupKey, Tensor] = _FactorStore()
+        if self._distributed:
+            # all factors of this rank in ONE flat buffer, accumulated in place and all-reduced in
+            # place (A_l first, then G_l): sizes follow from the layer shapes
+            sizes_a, sizes_g = {}, {}
+            for group in mapping:
+                mod, key = self._module_of(group), tuple(group.values())
+                if "W" in group:
+                    sizes_a[key] = mod.weight[0].numel() + (1 if "b" in group else 0)
+                if self._fisher_type != FisherType.FORWARD_ONLY:
+                    sizes_g[key] = self._params[next(iter(group.values()))].shape[0]
+            both = _FactorStore()
+            both.preallocate({("a", k): d for k, d in sizes_a.items()} | {("g", k): d for k, d in sizes_g.items()},
+                             self.device, self.dtype)
+            for (which, k), view in both.items():
+                (A if which == "a" else G)[k] = view
+            A.fresh, G.fresh = set(sizes_a), set(sizes_g)
+            flat = both.flat
         handles = []
         for group in mapping:
             mod = self._module_of(group)
@@ -341,14 +384,18 @@ class HipKFACComputer(EmpiricalRiskMixin):
                 h.remove()
             _join_factor_stream(self.device)
         if self._distributed:
-            from curvlinops_amd.dist import allreduce_tensors_
+            from curvlinops_amd.dist import allreduce_flat_
 
-            allreduce_tensors_([*A.values(), *G.values()])
+            for store in (A, G):  # a factor no batch contributed to (empty shard) is zero
+                for k in store.fresh:
+                    store[k].zero_()
+                store.fresh = set()
+            allreduce_flat_(flat)
         if self._fisher_type == FisherType.FORWARD_ONLY:
             for group in mapping:
                 p = self._params[next(iter(group.values()))]
                 G[tuple(group.values())] = torch.eye(p.shape[0], dtype=p.dtype, device=self.device)
-        return A, G, mapping
+        return dict(A), dict(G), mapping
 
     def _backpropagate(self, output: Tensor, y: Tensor) -> None:
         """Backpropagate V vectors per datum (0 forward-only, 1 empirical, M for MC, C for

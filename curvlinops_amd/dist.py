@@ -8,7 +8,8 @@ its operator / computer on its own shard of the mini-batches with ``num_data=<gl
 per-rank results are combined by ONE all-reduce(sum) of a packed buffer:
 
 * matvec:  ``AllReducedLinearOperator(op)`` -- packed ``[D, K]`` result, ``4 D K`` bytes;
-* KFAC:    ``allreduce_tensors_(factors)``  -- all ``A_l, G_l`` in one flat buffer;
+* KFAC:    ``allreduce_flat_(buffer)``  -- all ``A_l, G_l`` are views into one pre-allocated flat
+  buffer that the SYRKs accumulate into and the collective reduces in place;
 * EKFAC:   the same for the corrected eigenvalues.
 
 After the factor all-reduce every rank holds IDENTICAL factors, so the O(n^3) post-processing
@@ -73,6 +74,14 @@ def allreduce_tensors_(tensors: Iterable[Tensor], group=None) -> None:
         n = t.numel()
         t.copy_(flat[off : off + n].view_as(t))
         off += n
+
+
+def allreduce_flat_(flat: Tensor, group=None):
+    """In-place sum over ranks of ONE pre-packed contiguous buffer (the factor buffer of a
+    data-parallel KFAC build: every factor is a view into it, so nothing is packed or copied back).
+    """
+    if is_distributed() and flat.numel():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
 
 
 def partition_by_cost(costs: Sequence[float], world_size: int) -> list[int]:
