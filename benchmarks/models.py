@@ -48,6 +48,25 @@ class ResNet18(nn.Module):
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
+class ResNetToy(nn.Module):
+    """The ResNet-18 building blocks at toy size (golden-vector fixture `tests/golden/nets.npz`): stem
+    conv + BatchNorm, a plain BasicBlock, a strided BasicBlock with a 1x1 down-sampling branch, global
+    average pool, Linear head."""
+
+    def __init__(self, classes: int = 5):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 4, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(4)
+        self.relu = nn.ReLU()
+        self.layers = nn.Sequential(BasicBlock(4, 4, 1), BasicBlock(4, 6, 2))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(6, classes)
+
+    def forward(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        return self.fc(torch.flatten(self.avgpool(self.layers(x)), 1))
+
+
 def lenet5() -> nn.Sequential:
     return nn.Sequential(
         nn.Conv2d(1, 6, 5), nn.ReLU(), nn.MaxPool2d(2), nn.Conv2d(6, 16, 5), nn.ReLU(), nn.MaxPool2d(2),
@@ -96,3 +115,8 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         return self.head(self.ln(self.blocks(x)).mean(dim=1))
+
+
+def encoder_toy() -> Encoder:
+    """The C5 encoder at toy size (golden-vector fixture `tests/golden/nets.npz`)."""
+    return Encoder(d=32, layers=2, heads=4, ffn=64, classes=5)

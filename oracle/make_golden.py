@@ -250,7 +250,7 @@ def main():
     import curvlinops
 
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["mlp", "jacobian", "ggn_diagonal", "linops", "kfac", "trace", "kfoc"]
+    which = sys.argv[1:] or ["mlp", "jacobian", "ggn_diagonal", "linops", "kfac", "trace", "kfoc", "nets"]
     if "mlp" in which:
         gen_mlp(curvlinops)
     if "jacobian" in which:
@@ -271,6 +271,10 @@ def main():
         from make_golden_kfac import gen_kfoc
 
         gen_kfoc(curvlinops, OUT)
+    if "nets" in which:
+        from make_golden_nets import gen_nets
+
+        gen_nets(curvlinops, OUT)
 
 
 if __name__ == "__main__":

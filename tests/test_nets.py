@@ -1,0 +1,264 @@
+"""Parity on the network FAMILIES of BASELINE configs C4 (ResNet-18: BatchNorm in eval mode, residual
+blocks, strided 1x1 down-sampling) and C5 (pre-LN transformer encoder) against golden vectors the
+reference produced on toy instances of the very same module classes (`oracle/make_golden_nets.py` ->
+`tests/golden/nets.npz`), on CPU in float64 and -- marked `gpu` -- on the MI355X in float32 through the
+HIP kernels; plus size-independent properties at the FULL BASELINE sizes on the GPU.
+
+Tolerances: products / factors 1e-4, damped inverses 1e-3 in fp32; 1e-7 in float64.
+"""
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import curvlinops_amd as C
+from benchmarks.models import Encoder, ResNet18, ResNetToy, encoder_toy, kfac_params, lenet5
+from conftest import load_golden
+from helpers import rel_err
+
+F32, F64 = torch.float32, torch.float64
+
+
+def _load(model: nn.Module, rec: dict, dtype, device) -> nn.Module:
+    sd = {k[len("state:"):]: torch.as_tensor(v) for k, v in rec.items() if k.startswith("state:")}
+    model = model.to(torch.float64)  # load at full precision, then cast
+    model.load_state_dict(sd)
+    return model.to(device=device, dtype=dtype).eval()
+
+
+def _data(rec: dict, dtype, device):
+    return [(torch.as_tensor(rec[f"X{i}"], dtype=dtype, device=device), torch.as_tensor(rec[f"y{i}"], device=device))
+            for i in range(int(rec["num_batches"]))]
+
+
+def _t(x, dtype, device):
+    return torch.as_tensor(np.asarray(x), dtype=dtype).to(device)
+
+
+# ------------------------------------------------------------------------------------------ bodies
+def check_resnet_toy(dtype, device, tol, tol_inv, tol_ekfac_inv):
+    rec = load_golden("nets")["resnet_toy"]
+    model = _load(ResNetToy(), rec, dtype, device)
+    params = kfac_params(model)
+    data = _data(rec, dtype, device)
+    V = _t(rec["V"], dtype, device)
+    lf = nn.CrossEntropyLoss()
+    for fisher in ("empirical", "type-2"):
+        for sep in (True, False):
+            tag = f"{fisher}|{'sep' if sep else 'joint'}"
+            K = C.KFACLinearOperator(model, lf, params, data, fisher_type=fisher, separate_weight_and_bias=sep,
+                                     check_deterministic=False)
+            for b, block in enumerate(K[1]):
+                for f, fac in enumerate(block):
+                    assert rel_err(fac, rec[f"kfac|{tag}/block{b}_factor{f}"]) < tol, (tag, b, f)
+            assert rel_err(K @ V, rec[f"kfac|{tag}/KV"]) < tol, tag
+            assert rel_err(K.trace(), rec[f"kfac|{tag}/trace"]) < tol, tag
+            assert rel_err(K.inverse(damping=1e-2) @ V, rec[f"kfac|{tag}/inv_plain"]) < tol_inv, tag
+            got = K.inverse(damping=1e-2, use_heuristic_damping=True, min_damping=1e-4) @ V
+            assert rel_err(got, rec[f"kfac|{tag}/inv_heur"]) < tol_inv, tag
+            got = K.inverse(damping=1e-2, use_exact_damping=True) @ V
+            assert rel_err(got, rec[f"kfac|{tag}/inv_exact"]) < tol_inv, tag
+            E = C.EKFACLinearOperator(model, lf, params, data, fisher_type=fisher, separate_weight_and_bias=sep,
+                                      check_deterministic=False)
+            assert rel_err(E.trace(), rec[f"ekfac|{tag}/trace"]) < tol_inv, tag
+            assert rel_err(E @ V, rec[f"ekfac|{tag}/EV"]) < tol_inv, tag
+            assert rel_err(E.inverse(damping=1e-2) @ V, rec[f"ekfac|{tag}/invEV"]) < tol_ekfac_inv, tag
+    G = C.GGNLinearOperator(model, lf, params, data, check_deterministic=False)
+    assert rel_err(G @ V, rec["ggn/GV"]) < tol
+    Fm = C.EFLinearOperator(model, lf, params, data, check_deterministic=False)
+    assert rel_err(Fm @ V, rec["ef/FV"]) < tol
+    assert all(p.grad is None for p in model.parameters())
+
+
+def check_encoder_toy(dtype, device, tol, tol_inv, tol_ekfac_inv):
+    rec = load_golden("nets")["encoder_toy"]
+    model = _load(encoder_toy(), rec, dtype, device)
+    params = dict(model.named_parameters())
+    data = _data(rec, dtype, device)
+    V = _t(rec["V"], dtype, device)
+    lf = nn.CrossEntropyLoss()
+    EF = C.EFLinearOperator(model, lf, params, data, check_deterministic=False)
+    assert rel_err(EF @ V, rec["ef/FV"]) < tol
+    assert rel_err(EF @ V[:, 0].contiguous(), rec["ef/Fv"]) < tol
+    GG = C.GGNLinearOperator(model, lf, params, data, check_deterministic=False)
+    assert rel_err(GG @ V, rec["ggn/GV"]) < tol
+    pool = _t(rec["ef/pool"], dtype, device)
+    got = C.hutchpp_trace(EF, 12, "rademacher", probes=(pool[:, :4].contiguous(), pool[:, 4:8].contiguous()))
+    assert rel_err(got, rec["ef/hutchpp"]) < tol_inv
+    lin = kfac_params(model)
+    Vl = _t(rec["Vlin"], dtype, device)
+    for fisher in ("empirical", "type-2"):
+        tag = f"{fisher}|joint"
+        K = C.KFACLinearOperator(model, lf, lin, data, fisher_type=fisher, separate_weight_and_bias=False,
+                                 check_deterministic=False)
+        for b, block in enumerate(K[1]):
+            for f, fac in enumerate(block):
+                assert rel_err(fac, rec[f"kfac|{tag}/block{b}_factor{f}"]) < tol, (tag, b, f)
+        assert rel_err(K @ Vl, rec[f"kfac|{tag}/KV"]) < tol, tag
+        assert rel_err(K.inverse(damping=1e-2) @ Vl, rec[f"kfac|{tag}/inv_plain"]) < tol_inv, tag
+        E = C.EKFACLinearOperator(model, lf, lin, data, fisher_type=fisher, separate_weight_and_bias=False,
+                                  check_deterministic=False)
+        assert rel_err(E @ Vl, rec[f"ekfac|{tag}/EV"]) < tol_inv, tag
+        assert rel_err(E.inverse(damping=1e-2) @ Vl, rec[f"ekfac|{tag}/invEV"]) < tol_ekfac_inv, tag
+
+
+# ------------------------------------------------------------------------------------------ CPU, float64
+def test_resnet_toy_cpu():
+    check_resnet_toy(F64, torch.device("cpu"), 1e-7, 1e-7, 1e-6)
+
+
+def test_encoder_toy_cpu():
+    check_encoder_toy(F64, torch.device("cpu"), 1e-7, 1e-7, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ GPU, float32
+@pytest.fixture(scope="module")
+def dev():
+    from curvlinops_amd import _hip
+
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_resnet_toy_gpu(dev):
+    check_resnet_toy(F32, dev, 1e-4, 1e-3, 1e-3)
+
+
+@pytest.mark.gpu
+def test_encoder_toy_gpu(dev):
+    check_encoder_toy(F32, dev, 1e-4, 1e-3, 1e-3)
+
+
+@pytest.mark.gpu
+def test_resnet18_full_size_properties(dev):
+    """BASELINE C4: ResNet-18, 512 rows per GPU, joint W+b.  Size-independent properties: factors are
+    symmetric PSD; the factors of two half shards (global `num_data`) sum to the full-batch factors --
+    the identity the multi-GPU all-reduce relies on; the inverse of the damped operator inverts it; the
+    EKFAC trace is the sum of the corrected eigenvalues and equals the trace of the exact EF blocks."""
+    torch.manual_seed(0)
+    model = ResNet18().to(dev).eval()
+    params = kfac_params(model)
+    B = 512
+    X, y = torch.rand(B, 3, 32, 32, device=dev), torch.randint(0, 10, (B,), device=dev)
+    kw = dict(fisher_type="empirical", separate_weight_and_bias=False, check_deterministic=False)
+    lf = nn.CrossEntropyLoss()
+    K = C.KFACLinearOperator(model, lf, params, [(X, y)], **kw)
+    facs = [S for blk in K[1] for S in blk]
+    assert len(facs) == 42 and max(S.shape[0] for S in facs) == 4608
+    for S in facs:
+        assert torch.equal(S, S.T)
+        assert torch.isfinite(S).all() and float(S.diagonal().min()) >= 0.0
+    small = [S for S in facs if S.shape[0] <= 600]
+    for S in small:
+        assert float(torch.linalg.eigvalsh(S.double()).min()) > -1e-5 * float(S.diagonal().max())
+    halves = [C.KFACLinearOperator(model, lf, params, [(X[i:i + B // 2], y[i:i + B // 2])], num_data=B, **kw)
+              for i in (0, B // 2)]
+    for S, S0, S1 in zip(facs, *[[T for blk in H[1] for T in blk] for H in halves]):
+        # A-type factors are plain sums over rows; G-type factors carry the (B T)^2 / (T N) correction,
+        # which also makes the shard factors add up (kfac_math.py:172-203)
+        assert rel_err(S0 + S1, S.double().cpu().numpy()) < 2e-4
+    v = torch.rand(K.shape[1], device=dev)
+    Kd = K.inverse(damping=1e-2)
+    w = Kd @ v
+    from curvlinops_amd.diag import DiagonalLinearOperator  # noqa: F401  (damped product by hand below)
+    P, Kc, PT = K
+    # (K + damping) applied block-wise to the canonical vector: A (x) G + 1e-2 I on every factor pair is
+    # NOT what `inverse` damps (it damps each factor), so check the factor-wise identity instead
+    for blk, blk_inv in zip(Kc, Kd[1]):
+        for S, Sinv in zip(blk, blk_inv):
+            n = S.shape[0]
+            if n > 1200:
+                continue
+            I = torch.eye(n, device=dev)
+            assert rel_err((S + 1e-2 * I) @ Sinv, I.cpu().numpy()) < 2e-3
+    assert torch.isfinite(w).all()
+    E = C.EKFACLinearOperator(model, lf, params, [(X[:64], y[:64])], **kw)
+    lam_sum = sum(float(blk.eigenvalues.double().sum()) for blk in E[1])
+    assert abs(float(E.trace()) - lam_sum) <= 1e-4 * abs(lam_sum)
+    # corrected eigenvalues are second moments in the eigenbasis: non-negative, and their sum is the trace
+    # of the exact per-layer EF blocks = sum_n ||grad_n of the layer||^2 / N
+    grads_sq = 0.0
+    for n in range(0, 64, 16):
+        for i in range(n, n + 16):
+            out = model(X[i:i + 1])
+            g = torch.autograd.grad(nn.functional.cross_entropy(out, y[i:i + 1]), list(params.values()))
+            grads_sq += sum(float(t.double().square().sum()) for t in g)
+    assert abs(lam_sum - grads_sq / 64) <= 2e-3 * abs(grads_sq / 64)
+
+
+@pytest.mark.gpu
+def test_encoder_full_size_properties(dev):
+    """BASELINE C5: 12-layer d = 768 encoder (D = 85 M), 8 sequences of 128, `EFLinearOperator`:
+    symmetry `<u, F v> = <v, F u>`, PSD, linearity over a K = 4 block, `F @ v` = `sum_n g_n <g_n, v> / N`
+    from per-sample gradients, and the shard-sum identity behind the data-parallel all-reduce."""
+    torch.manual_seed(0)
+    model = Encoder().to(dev).eval()
+    params = dict(model.named_parameters())
+    N = 8
+    X, y = torch.rand(N, 128, 768, device=dev), torch.randint(0, 10, (N,), device=dev)
+    lf = nn.CrossEntropyLoss()
+    EF = C.EFLinearOperator(model, lf, params, [(X, y)], check_deterministic=False)
+    D = EF.shape[1]
+    assert D == 85_063_690
+    u, v = torch.rand(D, device=dev), torch.rand(D, device=dev)
+    Fu, Fv = EF @ u, EF @ v
+    a, b = float(torch.dot(u.double(), Fv.double())), float(torch.dot(v.double(), Fu.double()))
+    assert abs(a - b) <= 1e-4 * abs(a) and a >= 0.0
+    M = torch.stack([u, v, u - v, 2 * u + v], dim=1)
+    FM = EF @ M
+    assert rel_err(FM[:, 2], (Fu - Fv).double().cpu().numpy()) < 2e-4
+    assert rel_err(FM[:, 3], (2 * Fu + Fv).double().cpu().numpy()) < 2e-4
+    # per-sample gradients: F v = (1/N) sum_n g_n <g_n, v> with g_n the gradient of the n-th loss term
+    plist = list(params.values())
+    ref = torch.zeros(D, device=dev, dtype=torch.float64)
+    for n in range(N):
+        out = model(X[n:n + 1])
+        g = torch.cat([t.reshape(-1) for t in torch.autograd.grad(nn.functional.cross_entropy(out, y[n:n + 1]), plist)])
+        ref += g.double() * torch.dot(g.double(), v.double()) / N
+    assert rel_err(Fv, ref.cpu().numpy()) < 2e-4
+    halves = [C.EFLinearOperator(model, lf, params, [(X[i:i + 4], y[i:i + 4])], num_data=N, check_deterministic=False)
+              for i in (0, 4)]
+    assert rel_err(halves[0] @ v + halves[1] @ v, Fv.double().cpu().numpy()) < 2e-4
+    # Hutch++ with 96 products (3 x K = 32 packed probes): against the exact trace sum_n ||g_n||^2 / N
+    tr_exact = 0.0
+    for n in range(N):
+        out = model(X[n:n + 1])
+        g = torch.autograd.grad(nn.functional.cross_entropy(out, y[n:n + 1]), plist)
+        tr_exact += sum(float(t.double().square().sum()) for t in g) / N
+    est = float(C.hutchpp_trace(EF, 96))
+    assert abs(est - tr_exact) <= 0.05 * tr_exact  # rank(F) <= 8 << 32: the range part is (almost) exact
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fisher", ["type-2", "mc"])
+def test_lenet_c3_full_batch(dev, fisher):
+    """BASELINE C3 at its full size: LeNet-5, B = 1024, type-2 (V = 10) and mc: factors vs float64 torch
+    on the same draws (type-2 is deterministic; mc compared in expectation through the type-2 factors)."""
+    torch.manual_seed(0)
+    model = lenet5().to(dev).eval()
+    params = dict(model.named_parameters())
+    B = 1024
+    X, y = torch.rand(B, 1, 32, 32, device=dev), torch.randint(0, 10, (B,), device=dev)
+    lf = nn.CrossEntropyLoss()
+    kw = dict(separate_weight_and_bias=False, check_deterministic=False)
+    K = C.KFACLinearOperator(model, lf, params, [(X, y)], fisher_type=fisher, **kw)
+    model64 = lenet5().to(dev).double().eval()
+    model64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+    K64 = C.KFACLinearOperator(model64, lf, dict(model64.named_parameters()), [(X.double(), y)], fisher_type="type-2", **kw)
+    for blk, blk64 in zip(K[1], K64[1]):
+        for f, (S, S64) in enumerate(zip(blk, blk64)):
+            assert torch.equal(S, S.T)
+            if fisher == "type-2" or f == 1:  # input covariances do not depend on the Fisher type
+                assert rel_err(S, S64.cpu().numpy()) < 1e-4
+            else:  # one MC sample per datum, 1024 data: the gradient covariance in expectation
+                assert rel_err(S, S64.cpu().numpy()) < 0.35
+    v = torch.rand(K.shape[1], device=dev)
+    for kwargs in (dict(), dict(use_heuristic_damping=True), dict(use_exact_damping=True)):
+        Kinv = K.inverse(damping=1e-3, **kwargs)
+        w = Kinv @ v
+        assert torch.isfinite(w).all()
+    if fisher == "type-2":
+        ref = (K64.inverse(damping=1e-3) @ v.double()).cpu().numpy()
+        assert rel_err(K.inverse(damping=1e-3) @ v, ref) < 1e-3

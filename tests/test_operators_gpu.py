@@ -292,9 +292,10 @@ def test_ekfac_gpu(dev, case):
         E = C.EKFACLinearOperator(model, LOSS[loss](reduction=red), params, data, fisher_type=fisher,
                                   separate_weight_and_bias=sep == "sep")
         assert rel_err(E.trace(), rec[f"{tag}/trace"]) < TOL_INV
-        # eigenvectors of nearly degenerate fp32 factors rotate freely; the regularised inverse
-        # is the stable quantity to compare
-        assert rel_err(E.inverse(damping=1e-2) @ V, rec[f"{tag}/invEV"]) < 5e-3, (case, tag)
+        # the product and the damped inverse product are basis-independent quantities (the eigenbases
+        # themselves are not unique): both against the reference's float64 values
+        assert rel_err(E @ V, rec[f"{tag}/EV"]) < TOL_INV, (case, tag)
+        assert rel_err(E.inverse(damping=1e-2) @ V, rec[f"{tag}/invEV"]) < TOL_INV, (case, tag)
 
 
 def test_kfac_factor_properties_lenet_size(dev):
