@@ -49,6 +49,11 @@ _SIGNATURES = {
     "clo_cholesky_inverse_batched_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                                  _PF, c_void_p, c_void_p]),
     "clo_cholesky_inverse_batched_ws_floats": (c_long, [c_int, c_int]),
+    "clo_im2col_syrk_accum_f32": (
+        c_int,
+        [_PF, c_long, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_int, c_int, c_float, c_float, c_int, _PF, c_void_p],
+    ),
     "clo_im2col_f32": (
         c_int,
         [_PF, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -321,6 +326,28 @@ def im2col(x: Tensor, kernel_size, stride, padding, dilation) -> Tensor:
                                OH, OW, _stream())
     _check(rc, "clo_im2col_f32")
     return out
+
+
+def im2col_syrk_accum(C: Tensor, x: Tensor, kernel_size, stride, padding, dilation, alpha: float = 1.0,
+                      beta: float = 1.0, ones_col: bool = False) -> Tensor:
+    """``C = beta C + alpha [P | 1]^T [P | 1]`` with ``P = unfold(x)^T`` (``[B*OH*OW, C*KH*KW]``) generated
+    inside the GEMM's tile loader: the patch matrix is never materialised."""
+    lib = load()
+    B, C_, H, W = x.shape
+    (KH, KW), (SH, SW), (PH, PW), (DH, DW) = kernel_size, stride, padding, dilation
+    OH = (H + 2 * PH - DH * (KH - 1) - 1) // SH + 1
+    OW = (W + 2 * PW - DW * (KW - 1) - 1) // SW + 1
+    dd = C_ * KH * KW + (1 if ones_col else 0)
+    if C.shape != (dd, dd) or C.stride(1) != 1:
+        raise ValueError(f"C must be a row-major [{dd}, {dd}] matrix, got {tuple(C.shape)}")
+    rows = B * OH * OW
+    splitk = lib.clo_gemm_suggest_splitk(dd, dd, rows, 1) if rows > 0 else 1
+    ws = torch.empty(splitk * dd * dd, device=x.device, dtype=torch.float32) if splitk > 1 else None
+    rc = lib.clo_im2col_syrk_accum_f32(_p(C), C.stride(0), _pc(x.contiguous()), B, C_, H, W, KH, KW, SH, SW,
+                                       PH, PW, DH, DW, OH, OW, int(ones_col), alpha, beta, splitk, _p(ws),
+                                       _stream())
+    _check(rc, "clo_im2col_syrk_accum_f32")
+    return C
 
 
 def cholesky_inverse_async(A: Tensor, damping: float = 0.0) -> tuple[Tensor, Tensor]:

@@ -240,6 +240,74 @@ def _gram_accumulate(store: dict, key, X2d: Tensor, alpha: float, ones_col: bool
         store[key] = upd
 
 
+# Conv2d input covariances: "1" = patches generated inside the SYRK's tile loader wherever that is the
+# faster or the only memory-friendly way (default), "0" = always materialise them, "all" = always fused.
+_FUSED_IM2COL = os.environ.get("CLO_KFAC_FUSED_IM2COL", "1")
+_PATCH_LIMIT_BYTES = int(float(os.environ.get("CLO_KFAC_PATCH_LIMIT_MB", "1024")) * 2**20)
+
+
+def _conv_patches_fusable(hyper: dict) -> bool:
+    pad = hyper["padding"]
+    if isinstance(pad, str):
+        try:
+            pads = [_string_padding(k, pad, d) for k, d in zip(_pair(hyper["kernel_size"]), _pair(hyper["dilation"]))]
+        except Exception:  # noqa: BLE001
+            return False
+        return all(l == r for l, r in pads)
+    return True
+
+
+def _use_fused_patches(hyper: dict, x: Tensor, ones_col: bool) -> bool:
+    """Measured on MI355X (`tools/probe_im2col_syrk.py`, profiles/r02_im2col_syrk_fused.txt): the gather
+    loader costs the symmetric GEMM 20-40 % of its MFMA rate, the materialised patches only their write +
+    read (75 MB: 30 us of a 360 us SYRK).  So the fused kernel runs where the materialised path is worse
+    off: patch lengths that are not float4-complete (ResNet stem 3x7x7 = 147: 231 vs 440 us; LeNet conv2
+    6x5x5 = 150: 112 vs 198 us), which would fall off the aligned engine, and patch matrices beyond
+    `CLO_KFAC_PATCH_LIMIT_MB` (default 1 GiB), where the copy is a memory problem before it is a time one."""
+    if _FUSED_IM2COL == "0" or not _conv_patches_fusable(hyper):
+        return False
+    if _FUSED_IM2COL == "all":
+        return True
+    ks, st, dl = _pair(hyper["kernel_size"]), _pair(hyper["stride"]), _pair(hyper["dilation"])
+    pad = hyper["padding"]
+    if isinstance(pad, str):
+        pad = tuple(_string_padding(k, pad, d)[0] for k, d in zip(ks, dl))
+    pad = _pair(pad)
+    B, C_, H, W = x.shape
+    C_ //= hyper["groups"]
+    OH = (H + 2 * pad[0] - dl[0] * (ks[0] - 1) - 1) // st[0] + 1
+    OW = (W + 2 * pad[1] - dl[1] * (ks[1] - 1) - 1) // st[1] + 1
+    Q, rows = C_ * ks[0] * ks[1], B * OH * OW
+    if 4 * rows * Q > _PATCH_LIMIT_BYTES:
+        return True
+    if Q % 4 == 0:
+        return False
+    return not _hip.load().clo_gram_tall_supported(rows, Q, int(ones_col))  # tall-skinny: the streaming Gram kernel wins
+
+
+def _patch_gram_accumulate(store: dict, key, x: Tensor, hyper: dict, n_data: int, ones_col: bool) -> None:
+    """``store[key] += [P | 1]^T [P | 1] / (N_data * O1 O2)`` for the patches ``P`` of ``x`` ([B, C, H, W])."""
+    ks, st, dl = _pair(hyper["kernel_size"]), _pair(hyper["stride"]), _pair(hyper["dilation"])
+    pad = hyper["padding"]
+    if isinstance(pad, str):
+        pad = tuple(_string_padding(k, pad, d)[0] for k, d in zip(ks, dl))
+    pad = _pair(pad)
+    B, C_, H, W = x.shape
+    OH = (H + 2 * pad[0] - dl[0] * (ks[0] - 1) - 1) // st[0] + 1
+    OW = (W + 2 * pad[1] - dl[1] * (ks[1] - 1) - 1) // st[1] + 1
+    d = C_ * ks[0] * ks[1] + (1 if ones_col else 0)
+    fresh = getattr(store, "fresh", None)
+    Cm = store.get(key)
+    first = Cm is None or (fresh is not None and key in fresh)
+    if Cm is None:
+        Cm = torch.empty(d, d, device=x.device, dtype=torch.float32)
+        store[key] = Cm
+    if fresh:
+        fresh.discard(key)
+    _hip.im2col_syrk_accum(Cm, x, ks, st, pad, dl, alpha=1.0 / (n_data * OH * OW), beta=0.0 if first else 1.0,
+                           ones_col=ones_col)
+
+
 class HipKFACComputer(EmpiricalRiskMixin):
     """Computes KFAC's Kronecker factors ``A_l`` (input covariance) and ``G_l`` (output-gradient
     covariance) for every Linear / Conv2d parameter group."""
@@ -457,9 +525,17 @@ class HipKFACComputer(EmpiricalRiskMixin):
         if len(inputs) != 1:
             raise ValueError("Modules with multiple inputs are not supported.")
         with _factor_stream(inputs[0]):
-            x = input_to_weight_sharing_format(inputs[0].data.detach(), self._kfac_approx, hyper)
-            shared = x.shape[1]
             joint = "W" in group and "b" in group
+            x_in = inputs[0].data.detach()
+            if (hyper and self._kfac_approx == KFACType.EXPAND and is_native_tensor(x_in) and x_in.dim() == 4
+                    and _use_fused_patches(hyper, x_in, joint)):
+                # Conv2d, KFAC-expand: the patch matrix [B O1 O2, C K1 K2] is generated inside the SYRK's
+                # tile loader and never written (reference materialises it, kfac_utils.py:78-121)
+                _patch_gram_accumulate(store, tuple(group.values()), _group_mean(x_in, hyper["groups"]), hyper,
+                                       self._N_data, ones_col=joint)
+                return
+            x = input_to_weight_sharing_format(x_in, self._kfac_approx, hyper)
+            shared = x.shape[1]
             _gram_accumulate(store, tuple(group.values()), x.reshape(-1, x.shape[-1]),
                              1.0 / (self._N_data * shared), ones_col=joint)
 

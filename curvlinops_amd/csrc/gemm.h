@@ -47,6 +47,11 @@ struct GemmArgs {
   // v2 engine only (launch_gemm returns CLO_EUNSUP otherwise).
   int ones_b;
   float *col_out;
+  // patch mode (clo_im2col_syrk_accum_f32; v2 engine, both operands outer-contiguous): A and B are the
+  // im2col matrix of a [B][C][H][W] tensor, X[(b, oh, ow)][(c, kh, kw)], generated in the tile loader
+  // -- it is never written to memory.  A == B == the input tensor; M == N == C*KH*KW (+ ones).
+  int patch;
+  int cvC, cvH, cvW, cvKH, cvKW, cvSH, cvSW, cvPH, cvPW, cvDH, cvDW, cvOH, cvOW;
 };
 enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2, EPI_MUL_T = 3 };
 enum { TRI_KGE_M = 1, TRI_KLT_M = 2, TRI_KGE_N = 4, TRI_KLT_N = 8 };

@@ -15,6 +15,8 @@
 // Reference call sites this replaces: kronecker.py:141-171 (einsum 'abZ,Aa,Bb->ABZ'),
 // eigh.py:84-105, computers/kfac_hooks.py:350,390 (einsum "b s i, b s j -> i j"),
 // computers/ekfac_hooks.py:206-236.
+#include <type_traits>
+
 #include "clo_common.h"
 #include "gemm.h"
 
@@ -377,19 +379,121 @@ struct TileIO {
   }
 };
 
+// Outer-contiguous operand whose elements are im2col patches generated on the fly (KFAC input
+// covariance of a Conv2d layer, reference kfac_utils.py:78-121: unfold(x).transpose(1, 2)):
+//   X[r][m],  r = (b, oh, ow),  m = (c, kh, kw)  ->  x[b][c][oh SH - PH + kh DH][ow SW - PW + kw DW]
+// (zero outside the image; m == C KH KW is the implicit ones column of a joint weight + bias factor).
+// Same LDS layout and fragment reads as TileIO<false, ...>; the four features of a float4 are four
+// scalar loads (the input tensor is 1/(KH KW) of the patch matrix and lives in L2 / MALL).
+template <int BKT, int NTHR, int T>
+struct PatchIO {
+  static constexpr int LD = T + 4;
+  static constexpr int FLOATS = BKT * LD;
+  static constexpr int F4 = T * BKT / 4;
+  static constexpr int NF4 = (F4 + NTHR - 1) / NTHR;
+  static constexpr int RSTEP = NTHR / (T / 4);  // rows between consecutive float4 of one thread
+  static_assert(NTHR % (T / 4) == 0 && F4 % NTHR == 0, "a thread keeps its four features for the whole tile");
+  const float *x;
+  // the thread's four features (the same for all of its float4): offset inside the receptive field
+  // ((c H + kh DH) W + kw DW, or -1: no such feature), (kh DH) << 16 | (kw DW), ones-column bits
+  int off[4], dhw[4];
+  unsigned one_bits;
+  int krow, soff0;
+  int H, W, OH, OW, SH, SW, PH, PW, CHW;
+  // (b, oh, ow) of the thread's first row of the CURRENT tile, advanced tile by tile (no divisions in
+  // the k loop); next_k0 = the tile start those coordinates belong to
+  int cb, coh, cow, cur_k0;
+  int d_ow, d_oh, d_b;  // RSTEP rows further in (b, oh, ow) coordinates (mixed radix, with carries)
+
+  __device__ __forceinline__ void init_patch(const GemmArgs &p, int o0, int O, int tid) {
+    x = p.A;
+    H = p.cvH; W = p.cvW; OH = p.cvOH; OW = p.cvOW; SH = p.cvSH; SW = p.cvSW; PH = p.cvPH; PW = p.cvPW;
+    CHW = p.cvC * p.cvH * p.cvW;
+    const int Q = O - p.ones, KK = p.cvKH * p.cvKW;
+    const int oq = (tid % (T / 4)) * 4;
+    krow = tid / (T / 4);
+    soff0 = krow * LD + oq;
+    one_bits = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = o0 + oq + e;
+      off[e] = -1;
+      dhw[e] = 0;
+      if (m < Q) {
+        const int c = m / KK, r = m - c * KK, kh = r / p.cvKW, kw = r - kh * p.cvKW;
+        off[e] = (c * H + kh * p.cvDH) * W + kw * p.cvDW;
+        dhw[e] = ((kh * p.cvDH) << 16) | (kw * p.cvDW);
+      } else if (p.ones && m == Q) {
+        one_bits |= 1u << e;
+      }
+    }
+    cur_k0 = -1;
+    d_ow = RSTEP % OW;
+    d_oh = (RSTEP / OW) % OH;
+    d_b = (RSTEP / OW) / OH;
+  }
+  __device__ __forceinline__ void seek(int k0) {
+    const int row = k0 + krow;
+    cow = row % OW;
+    const int t = row / OW;
+    coh = t % OH;
+    cb = t / OH;
+    cur_k0 = k0;
+  }
+  __device__ __forceinline__ void load(float4 (&r)[NF4], int k0, int Kend, long, long) {
+    if (k0 != cur_k0) seek(k0);  // first tile of this block (or a jump): the only divisions
+    int b = cb, oh = coh, ow = cow;
+#pragma unroll
+    for (int q = 0; q < NF4; ++q) {
+      const bool ok = k0 + krow + q * RSTEP < Kend;
+      const int ih0 = oh * SH - PH, iw0 = ow * SW - PW;
+      const long base = (long)b * CHW + (long)ih0 * W + iw0;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ih = ih0 + (dhw[e] >> 16), iw = iw0 + (dhw[e] & 0xffff);
+        const bool in = ok && off[e] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        const float val = x[in ? base + off[e] : 0];
+        v[e] = in ? val : (((one_bits >> e) & 1u) && ok ? 1.f : 0.f);
+      }
+      r[q] = make_float4(v[0], v[1], v[2], v[3]);
+      // next float4 of this thread: RSTEP rows further
+      ow += d_ow;
+      const int c1 = ow >= OW ? 1 : 0;
+      ow -= c1 ? OW : 0;
+      oh += d_oh + c1;
+      const int c2 = oh >= OH ? 1 : 0;
+      oh -= c2 ? OH : 0;
+      b += d_b + c2;
+    }
+    // after NF4 steps the coordinates are those of row k0 + BKT + krow = this thread's first row of the
+    // next tile (NF4 * RSTEP == BKT)
+    cb = b; coh = oh; cow = ow;
+    cur_k0 = k0 + BKT;
+  }
+  __device__ __forceinline__ void store(float *S, const float4 (&r)[NF4]) const {
+#pragma unroll
+    for (int q = 0; q < NF4; ++q) *reinterpret_cast<float4 *>(S + soff0 + q * RSTEP * LD) = r[q];
+  }
+  static __device__ __forceinline__ float4 frag(const float *S, int outer, int g, int lh) {
+    const float *p = S + (g * 8 + 4 * lh) * LD + outer;
+    return make_float4(p[0], p[LD], p[2 * LD], p[3 * LD]);
+  }
+};
+
 // Block tile BMt x BNt, WVM x WVN waves, each wave (BMt / WVM) x (BNt / WVN) in 32x32 MFMA tiles:
 //   128 x 128, 2 x 2 waves of 64x64 : large grids
 //   128 x 128, 2 x 4 waves of 64x32 : two waves per SIMD inside ONE block, for grids that cannot put
 //                                     two blocks on every CU
 //    64 x 256, 1 x 8 waves of 64x32 ; 32 x 256, 1 x 8 waves of 32x32 : few rows (M <= 64 / 32): no
 //                                     MFMA work on padding rows, the B operand streams once
-template <bool AKC, bool BKC, int BKT, int BMt, int BNt, int WVM, int WVN>
+template <bool AKC, bool BKC, int BKT, int BMt, int BNt, int WVM, int WVN, bool PATCH = false>
 __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
   constexpr int NW = WVM * WVN;
   constexpr int WM = BMt / WVM, WNC = BNt / WVN;  // rows / columns per wave
   constexpr int MT = WM / 32, NT = WNC / 32;      // MFMA tiles per wave
-  using TA = TileIO<AKC, BKT, NW * 64, BMt>;
-  using TB = TileIO<BKC, BKT, NW * 64, BNt>;
+  using TA = std::conditional_t<PATCH, PatchIO<BKT, NW * 64, BMt>, TileIO<AKC, BKT, NW * 64, BMt>>;
+  using TB = std::conditional_t<PATCH, PatchIO<BKT, NW * 64, BNt>, TileIO<BKC, BKT, NW * 64, BNt>>;
   extern __shared__ __attribute__((aligned(16))) float lds2[];
   float *As = lds2;                    // [2][TA::FLOATS]
   float *Bs = lds2 + 2 * TA::FLOATS;   // [2][TB::FLOATS]
@@ -450,8 +554,13 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
 
   TA la;
   TB lb;
-  la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
-  lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid, p.ones | p.ones_b);
+  if constexpr (PATCH) {
+    la.init_patch(p, m0, p.M, tid);
+    lb.init_patch(p, n0, p.N, tid);
+  } else {
+    la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
+    lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid, p.ones | p.ones_b);
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -826,8 +935,8 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
     return a.sym ? (unsigned)((long)a.tiles_m * (a.tiles_m + 1) / 2) : (unsigned)(a.tiles_m * a.tiles_n);
   };
   dim3 grid(tile_blocks(), batch * a.splitk);
-  const bool a_kc = a.mode_a == MODE_KC_VEC, b_kc = a.mode_b == MODE_KC_VEC;
-  const bool v2 = gemm_v2_eligible(a, batch);
+  const bool a_kc = !a.patch && a.mode_a == MODE_KC_VEC, b_kc = !a.patch && a.mode_b == MODE_KC_VEC;
+  const bool v2 = a.patch ? true : gemm_v2_eligible(a, batch);  // patch operands are generated, not loaded
   constexpr int bk2 = 32;
   if (a.A2 && !(v2 && a.K1 % bk2 == 0 && a.K1 > 0 && a.K1 < a.K)) {
     set_error("clo_gemm: a second K segment needs the aligned engine and K1 %% %d == 0", bk2);
@@ -845,12 +954,13 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
     a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), cfg.bk) * cfg.bk;
     a.splitk = (int)cdiv(a.K, a.k_per_split);
     grid = dim3(tile_blocks(), batch * a.splitk);
-#define CLO_V2(AK, BKC_, BKV, BMV, BNV, WM_, WN_)                                                 \
+#define CLO_V2(AK, BKC_, BKV, BMV, BNV, WM_, WN_) CLO_V2X(AK, BKC_, BKV, BMV, BNV, WM_, WN_, false)
+#define CLO_V2X(AK, BKC_, BKV, BMV, BNV, WM_, WN_, PT)                                            \
   {                                                                                               \
     constexpr int nthr = WM_ * WN_ * 64;                                                          \
     const size_t smem =                                                                           \
         2 * (TileIO<AK, BKV, nthr, BMV>::FLOATS + TileIO<BKC_, BKV, nthr, BNV>::FLOATS) * sizeof(float); \
-    auto kern = gemm_v2_kernel<AK, BKC_, BKV, BMV, BNV, WM_, WN_>;                                \
+    auto kern = gemm_v2_kernel<AK, BKC_, BKV, BMV, BNV, WM_, WN_, PT>;                            \
     if (smem > 64 * 1024) {                                                                       \
       static bool attr_set = false;                                                               \
       if (!attr_set) {                                                                            \
@@ -869,7 +979,12 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   else if (b_kc) CLO_V2(false, true, BKV, BMV, BNV, WM_, WN_)           \
   else CLO_V2(false, false, BKV, BMV, BNV, WM_, WN_)
     const long nblocks = (long)grid.x * grid.y;
-    if (cfg.bk == 64) { CLO_V2L(64, 64, 64, 2, 2) }
+    if (a.patch) {
+      if (cfg.bk == 64) CLO_V2X(false, false, 64, 64, 64, 2, 2, true)
+      else if (nblocks < 2L * kNumCU) CLO_V2X(false, false, 32, 128, 128, 2, 4, true)
+      else CLO_V2X(false, false, 32, 128, 128, 2, 2, true)
+    }
+    else if (cfg.bk == 64) { CLO_V2L(64, 64, 64, 2, 2) }
     else if (cfg.bm == 32) { CLO_V2L(16, 32, 256, 1, 8) }
     else if (cfg.bm == 64) { CLO_V2L(16, 64, 256, 1, 8) }
     // 8 waves (two per SIMD inside one block) when the grid cannot put two blocks on every CU
@@ -877,6 +992,7 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
     else { CLO_V2L(32, 128, 128, 2, 2) }
 #undef CLO_V2L
 #undef CLO_V2
+#undef CLO_V2X
     CLO_CHECK_LAUNCH("gemm_v2_kernel");
   } else if (!a.A2 && (long)a.M * a.N * batch <= 128L * 128L && (long)a.M * a.N * a.K * batch <= (1L << 19)) {
     a.splitk = 1;
@@ -1038,6 +1154,38 @@ extern "C" int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows,
   int rc = launch_gemm(a, 1, st);
   if (rc != CLO_OK) return rc;
   return CLO_OK;
+}
+
+// KFAC input covariance of a Conv2d layer without the patch matrix (reference kfac_utils.py:78-121 +
+// kfac_hooks.py:355-393): C = beta C + alpha [P | 1]^T [P | 1] with P = unfold(x)^T generated inside the
+// tile loader of the symmetric MFMA GEMM.
+extern "C" int clo_im2col_syrk_accum_f32(float *C, long ldc, const float *x, int B, int Cc, int H, int W,
+                                         int KH, int KW, int SH, int SW, int PH, int PW, int DH, int DW,
+                                         int OH, int OW, int ones_col, float alpha, float beta, int splitk,
+                                         float *ws, void *stream) {
+  CLO_REQUIRE(B >= 0 && Cc > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && SH > 0 && SW > 0 && DH > 0 &&
+                  DW > 0 && PH >= 0 && PW >= 0,
+              "clo_im2col_syrk_accum_f32: bad geometry");
+  CLO_REQUIRE(OH == (H + 2 * PH - DH * (KH - 1) - 1) / SH + 1 &&
+                  OW == (W + 2 * PW - DW * (KW - 1) - 1) / SW + 1 && OH > 0 && OW > 0,
+              "clo_im2col_syrk_accum_f32: output size (%d, %d) inconsistent with the geometry", OH, OW);
+  CLO_REQUIRE(KH * DH < 32768 && KW * DW < 32768, "clo_im2col_syrk_accum_f32: kernel extent too large");
+  const long rows = (long)B * OH * OW;
+  CLO_REQUIRE(rows < (1L << 31) && (long)B * Cc * H * W < (1L << 31),
+              "clo_im2col_syrk_accum_f32: sizes must fit int32");
+  const int dd = Cc * KH * KW + (ones_col ? 1 : 0);
+  CLO_REQUIRE(ldc >= dd, "clo_im2col_syrk_accum_f32: ldc (%ld) < d (%d)", ldc, dd);
+  CLO_REQUIRE(C && (x || rows == 0), "clo_im2col_syrk_accum_f32: null operand");
+  GemmArgs a{};
+  a.M = dd; a.N = dd; a.K = (int)rows; a.alpha = alpha; a.beta = beta;
+  a.A = x; a.B = x; a.sa_m = 1; a.sa_k = dd; a.sb_n = 1; a.sb_k = dd;
+  a.C = C; a.ldc = ldc;
+  a.splitk = splitk; a.ws = ws; a.sym = 1;
+  a.ones = ones_col ? 1 : 0;
+  a.patch = 1;
+  a.cvC = Cc; a.cvH = H; a.cvW = W; a.cvKH = KH; a.cvKW = KW; a.cvSH = SH; a.cvSW = SW;
+  a.cvPH = PH; a.cvPW = PW; a.cvDH = DH; a.cvDW = DW; a.cvOH = OH; a.cvOW = OW;
+  return launch_gemm(a, 1, (hipStream_t)stream);
 }
 
 namespace clo {

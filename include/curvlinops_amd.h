@@ -101,6 +101,15 @@ int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, lon
 int clo_im2col_f32(const float *x, float *out, int B, int C, int H, int W, int KH, int KW,
                    int SH, int SW, int PH, int PW, int DH, int DW, int OH, int OW, void *stream);
 
+/* The two steps above in one: C = beta C + alpha [P | 1]^T [P | 1] with P = im2col(x) generated inside
+ * the tile loader of the symmetric MFMA GEMM -- the [B*OH*OW][C*KH*KW] patch matrix is never written
+ * (kfac_utils.py:78-121 + kfac_hooks.py:355-393; 604 MB for ResNet-18 layer1 at B = 4096).  Any patch
+ * length (no alignment requirement).  ws: splitk * d * d floats if splitk > 1 (d = C*KH*KW + ones_col). */
+int clo_im2col_syrk_accum_f32(float *C, long ldc, const float *x, int B, int Cc, int H, int W,
+                              int KH, int KW, int SH, int SW, int PH, int PW, int DH, int DW,
+                              int OH, int OW, int ones_col, float alpha, float beta,
+                              int splitk, float *ws, void *stream);
+
 /* Tall-skinny Gram matrix C = beta C + alpha [X | 1]^T [X | 1] for rows >> d, d + ones_col <= 128 (KFAC
  * factors of convolution layers: G_l with few output channels against B*H*W rows, A_1 with C_in k^2 + 1
  * columns; the Gram passes of the Hutch++ range basis).  X is streamed once, linearly; per-block

@@ -504,3 +504,39 @@ def test_gemm_and_syrk_randomised(hip):
     worst, failures = fuzz_gemm.run(seed=5, ncase=150)
     assert not failures, failures
     assert worst < 2e-5
+
+
+# ----------------------------------------------------------------------------- fused im2col -> SYRK
+@pytest.mark.parametrize("B,C_,H,W,k,s,p,d,ones", [
+    (3, 2, 8, 8, (3, 3), (1, 1), (1, 1), (1, 1), False),     # 18 features
+    (5, 3, 9, 7, (3, 2), (2, 1), (0, 1), (1, 2), True),      # odd patch length + bias column, dilation
+    (4, 1, 32, 32, (5, 5), (1, 1), (0, 0), (1, 1), True),    # LeNet conv1: 25 + 1
+    (2, 3, 32, 32, (7, 7), (2, 2), (3, 3), (1, 1), False),   # ResNet stem: 147 (not a multiple of 4)
+    (64, 64, 8, 8, (3, 3), (1, 1), (1, 1), (1, 1), False),   # ResNet layer1: 576, 4096 rows (split-K)
+    (16, 128, 4, 4, (3, 3), (1, 1), (1, 1), (1, 1), False),  # 1152
+    (8, 64, 8, 8, (1, 1), (2, 2), (0, 0), (1, 1), False),    # 1x1 down-sampling
+])
+def test_im2col_syrk_fused_matches_materialised(B, C_, H, W, k, s, p, d, ones):
+    """`clo_im2col_syrk_accum_f32` (patches generated in the GEMM's tile loader) == SYRK of the
+    materialised `clo_im2col_f32` patches == float64 unfold; symmetric bitwise; accumulates with beta."""
+    from curvlinops_amd import _hip
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B + C_)
+    x = torch.randn(B, C_, H, W, device=dev)
+    P = torch.nn.functional.unfold(x.double(), k, dilation=d, padding=p, stride=s).transpose(1, 2)
+    P = P.reshape(-1, P.shape[-1])
+    if ones:
+        P = torch.cat([P, P.new_ones(P.shape[0], 1)], dim=1)
+    ref = P.T @ P
+    dd = P.shape[1]
+    Cf = torch.full((dd, dd), float("nan"), device=dev)
+    _hip.im2col_syrk_accum(Cf, x, k, s, p, d, alpha=0.5, beta=0.0, ones_col=ones)
+    assert torch.equal(Cf, Cf.T)
+    assert rel_err(Cf.cpu(), (0.5 * ref).cpu().numpy()) < 2e-5
+    pm = _hip.im2col(x, k, s, p, d)
+    Cm = torch.empty(dd, dd, device=dev)
+    _hip.syrk_accum(Cm, pm.reshape(-1, pm.shape[-1]), alpha=0.5, beta=0.0, ones_col=ones)
+    assert rel_err(Cf.cpu(), Cm.double().cpu().numpy()) < 2e-5
+    _hip.im2col_syrk_accum(Cf, x, k, s, p, d, alpha=0.25, beta=1.0, ones_col=ones)
+    assert rel_err(Cf.cpu(), (0.75 * ref).cpu().numpy()) < 2e-5

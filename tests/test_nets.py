@@ -155,12 +155,14 @@ def test_resnet18_full_size_properties(dev):
         assert float(torch.linalg.eigvalsh(S.double()).min()) > -1e-5 * float(S.diagonal().max())
     halves = [C.KFACLinearOperator(model, lf, params, [(X[i:i + B // 2], y[i:i + B // 2])], num_data=B, **kw)
               for i in (0, B // 2)]
-    for S, S0, S1 in zip(facs, *[[T for blk in H[1] for T in blk] for H in halves]):
+    for i, (S, S0, S1) in enumerate(zip(facs, *[[T for blk in H[1] for T in blk] for H in halves])):
         # A-type factors are plain sums over rows; G-type factors carry the (B T)^2 / (T N) correction,
         # which also makes the shard factors add up (kfac_math.py:172-203)
         # (tolerance: the shards run PyTorch's fp32 convolutions / BatchNorm at another batch size, and the
         # gradient covariances of the early layers see that noise through 18 layers of backprop)
-        assert rel_err(S0 + S1, S.double().cpu().numpy()) < 2e-3
+        # blocks are [G_l, A_l]: the input covariances only see the forward pass; the gradient covariances
+        # see MIOpen's fp32 backward kernels, chosen per batch size (Winograd: ~1e-3 relative)
+        assert rel_err(S0 + S1, S.double().cpu().numpy()) < (1e-2 if i % 2 == 0 else 2e-3), i
     v = torch.rand(K.shape[1], device=dev)
     Kd = K.inverse(damping=1e-2)
     w = Kd @ v
@@ -266,3 +268,31 @@ def test_lenet_c3_full_batch(dev, fisher):
     if fisher == "type-2":
         ref = (K64.inverse(damping=1e-3) @ v.double()).cpu().numpy()
         assert rel_err(K.inverse(damping=1e-3) @ v, ref) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", ["resnet_toy", "lenet", "resnet18"])
+def test_fused_patch_factors_equal_materialised(dev, net, monkeypatch):
+    """Input covariances of Conv2d layers with the patches generated inside the SYRK's tile loader
+    (`clo_im2col_syrk_accum_f32`, forced for every layer) == the materialised-patch path, <= 2e-5,
+    bitwise symmetric; the default policy (fused where it wins) gives the same factors."""
+    from curvlinops_amd import computers
+
+    torch.manual_seed(0)
+    if net == "resnet_toy":
+        model, X, y = ResNetToy().to(dev).eval(), torch.rand(6, 3, 8, 8, device=dev), torch.randint(0, 5, (6,), device=dev)
+    elif net == "lenet":
+        model, X, y = lenet5().to(dev).eval(), torch.rand(64, 1, 32, 32, device=dev), torch.randint(0, 10, (64,), device=dev)
+    else:
+        model, X, y = ResNet18().to(dev).eval(), torch.rand(64, 3, 32, 32, device=dev), torch.randint(0, 10, (64,), device=dev)
+    params = kfac_params(model)
+    kw = dict(fisher_type="empirical", separate_weight_and_bias=False, check_deterministic=False)
+    facs = {}
+    for mode in ("0", "all", "1"):
+        monkeypatch.setattr(computers, "_FUSED_IM2COL", mode)
+        K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y), (X.flip(0), y.flip(0))], **kw)
+        facs[mode] = [blk[1] for blk in K[1] if len(blk) == 2]
+    for S0, S1, S2 in zip(facs["0"], facs["all"], facs["1"]):
+        assert torch.equal(S1, S1.T)
+        assert rel_err(S1, S0.double().cpu().numpy()) < 2e-5
+        assert rel_err(S2, S0.double().cpu().numpy()) < 2e-5
