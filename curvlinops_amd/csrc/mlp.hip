@@ -907,7 +907,12 @@ __global__ __launch_bounds__(512, 4) void bwd_fused_kernel(
 // that both reads W and writes out_W runs ~1.5x slower than the read-only and the write-only
 // sweep back to back, so the data part (delta_prev) and this part are separate kernels.
 constexpr int OUTER_MAXL = 16;
-constexpr int OUTER_ROWS = 128;  // rows per block (16 per wave)
+// rows per block: 32 (4 per wave) measured best on C2 (whole matvec: 128 rows 55.0 us, 64: 53.2, 32: 52.5,
+// 256: 60.3) -- short blocks hide each other's staging prologue
+#ifndef CLO_OUTER_ROWS
+#define CLO_OUTER_ROWS 32
+#endif
+constexpr int OUTER_ROWS = CLO_OUTER_ROWS;
 struct OuterAllArgs {
   int nlayers;
   int first_block[OUTER_MAXL + 1];
@@ -1707,7 +1712,10 @@ constexpr int MF_RG = 2;
 constexpr int MF1_WAVES = 8, MF1_RG = 2, MF1_U = 4;  // fwd_mfma_first_kernel
 static int mfma_kpb(int d_in, int d_out) {
   const long row_blocks = cdiv(d_out, MF_WAVES * MF_RG * 8);
-  long ksplit = std::max<long>(1, cdiv(2 * kNumCU, row_blocks));
+#ifndef CLO_MF_BPC
+#define CLO_MF_BPC 2
+#endif
+  long ksplit = std::max<long>(1, cdiv(CLO_MF_BPC * kNumCU, row_blocks));
   ksplit = std::min<long>(ksplit, std::max<long>(1, d_in / 64));
   ksplit = std::min<long>(ksplit, 16);  // slab merges stay short (narrow layers are tiny anyway)
   long kpb = cdiv(cdiv(d_in, ksplit), 32) * 32;
@@ -1719,7 +1727,10 @@ static int bwd_jb(int d_in, int d_out, bool dprev) {
   const long cchunks = cdiv(d_in, CW);
   long jb = cdiv(kNumCU, cchunks);                    // ~1 block per CU
   jb = std::min<long>(jb, cdiv(d_out, 64));           // >= 64 rows (8 per wave) per block
-  if (dprev) jb = std::min<long>(jb, 32);             // bound the slab traffic
+#ifndef CLO_DPREV_JB
+#define CLO_DPREV_JB 24
+#endif
+  if (dprev) jb = std::min<long>(jb, CLO_DPREV_JB);   // bound the slab traffic (32 -> 24: -1 us on C2)
   jb = std::max<long>(jb, cdiv(d_out, 1024));         // <= 1024 rows of delta in LDS
   return (int)std::max<long>(1, jb);
 }
