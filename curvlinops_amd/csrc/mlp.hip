@@ -572,13 +572,14 @@ __global__ __launch_bounds__(WAVES * 64) void fwd_mfma_first_kernel(
 __global__ void fwd_finish_kernel(const float *__restrict__ part, int ksplit,
                                   const float *__restrict__ b, const float *__restrict__ Vb,
                                   float *__restrict__ a_out, float *__restrict__ da_out,
-                                  float *__restrict__ dphi_out, int N, int d_out, int act) {
+                                  float *__restrict__ dphi_out, int N, int d_out, int act,
+                                  int part_rows = NB) {
   const int total = N * d_out;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int n = e / d_out, j = e % d_out;
     float zz = b ? b[j] : 0.f, dzz = Vb ? Vb[j] : 0.f;
     const float *p0 = part + (long)n * d_out + j;
-    const long sstride = 2L * NB * d_out, dzoff = (long)NB * d_out;
+    const long sstride = 2L * part_rows * d_out, dzoff = (long)part_rows * d_out;
     int s = 0;
     for (; s + 3 < ksplit; s += 4) {  // four independent slabs per trip
       const float z0 = p0[(s + 0) * sstride], z1 = p0[(s + 1) * sstride];
@@ -985,6 +986,7 @@ struct HeadFwdArgs {
   const float *WL, *VL;         // [C][d] last-layer weight and its tangent
   int C;
   float *hp;                    // [N][nblk][2][HEAD_CMAX] partial z_L / dz_L
+  int part_rows;                // rows per slab of `part` (0: NB)
 };
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs p) {
@@ -1010,7 +1012,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs p) {
     if (p.part) {
       float zz = p.b ? p.b[j] : 0.f, dzz = p.Vb ? p.Vb[j] : 0.f;
       const float *p0 = p.part + e;
-      const long sstride = 2L * NB * p.d, dzoff = (long)NB * p.d;
+      const int prow = p.part_rows ? p.part_rows : NB;
+      const long sstride = 2L * prow * p.d, dzoff = (long)prow * p.d;
       // all slabs in flight at once (ksplit <= 16): clamped index + zero weight, no branches
       float zs[16], ds[16];
 #pragma unroll
@@ -1184,6 +1187,440 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
 #pragma unroll
       for (int n = 0; n < NB; ++n)
         if (n < N) p.delta_prev[(long)n * p.d + i] = acc[n] * dpp[n];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 9 ... 32 batch rows: the weight-streaming chain with MFMA tiles in EVERY kernel (the VALU backward
+// kernels above keep 8 rows of accumulators per lane and stop there; the GEMM engine needs a dozen
+// launches on 128-wide tiles that are mostly padding at these sizes).  Npad = 16 NT rows, NT = 1, 2.
+//   mid_fwd_kernel        forward + JVP: A = [8 rows of W ; 8 rows of V] straight from global memory,
+//                         B = 16 batch rows of a (and of da) from LDS: acc1 = [W a ; V a], acc2 = [W da ; -]
+//   head_fwd_kernel       slab sum + bias / activation (+ partial products of a narrow head)
+//   head_bwd_rows_kernel  loss Hessian + backward through the head, NB rows at a time
+//   mid_dprev_kernel      delta_{l-1} slabs: A = delta^T from LDS, B = 4 rows x 64 columns of W per load
+//   mid_outer_kernel      out_W_l = beta out_W_l + delta_l^T a_{l-1} for all layers, 16 x 64 MFMA tiles
+// ------------------------------------------------------------------------------------------
+constexpr int MID_LDD = 48;  // row stride of [row][Npad] delta tiles in LDS (conflict-free ds_read_b32)
+
+template <int NT, bool HAS_DA, int WV>
+__global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
+    const float *__restrict__ W, const float *__restrict__ VW, const float *__restrict__ a_in,
+    const float *__restrict__ da_in, float *__restrict__ part, int N, int d_in, int d_out,
+    int k_per_block) {
+  constexpr int RG = 2, NP = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) float s_b[];  // [(HAS_DA ? 2 : 1) * NP][k_per_block + 4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = lane & 15, s4 = (lane >> 4) * 4;
+  const int kb0 = blockIdx.y * k_per_block;
+  const int klen = min(d_in, kb0 + k_per_block) - kb0;  // multiple of 4
+  const int ldb = k_per_block + 4;
+
+  const int j0 = (blockIdx.x * WV + wave) * RG * 8;
+  const float *pA[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int row = min(j0 + g * 8 + (idx & 7), d_out - 1);
+    pA[g] = ((idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
+  }
+  constexpr int U = 2;
+  struct Group { float4 av[U][RG]; };
+  auto load = [&](Group &gr, int st0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int g = 0; g < RG; ++g) gr.av[u][g] = CLO_LDW(pA[g] + (st0 + u) * 16);
+  };
+  const int nfull = klen >> 4, ngroups = nfull / U;
+  Group ga, gb;
+  if (ngroups > 0) load(ga, 0);
+
+  {  // stage B: columns [0, NP) = rows of a, [NP, 2 NP) = rows of da; zero beyond N rows / klen
+    constexpr int NC = (HAS_DA ? 2 : 1) * NP;
+    const int q4 = (k_per_block + 3) >> 2;
+    for (int e = tid; e < NC * q4; e += WV * 64) {
+      const int c = e / q4, kq = (e - c * q4) * 4;
+      const int n = c < NP ? c : c - NP;
+      float4 v = zero4();
+      if (n < N && kq < klen) v = ld4((c < NP ? a_in : da_in) + (long)n * d_in + kb0 + kq);
+      *reinterpret_cast<float4 *>(&s_b[c * ldb + kq]) = v;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc1[RG][NT], acc2[RG][NT];
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc1[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const float *pBa = s_b + idx * ldb + s4;
+  const float *pBd = s_b + (NP + idx) * ldb + s4;
+  auto mma_step = [&](const float4 (&av)[RG], int st) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 ba = ld4(pBa + t * 16 * ldb + st * 16);
+      float4 bd = zero4();
+      if (HAS_DA) bd = ld4(pBd + t * 16 * ldb + st * 16);
+      // component by component over the 2 RG (4 RG with da) independent accumulators: a dependent
+      // v_mfma_f32_16x16x4_f32 can issue after 40 cycles, an independent one after 32
+#define CLO_MID_MM(E)                                                                                  \
+  _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                     \
+    acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].E, ba.E, acc1[g][t], 0, 0, 0);              \
+    if (HAS_DA) acc2[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].E, bd.E, acc2[g][t], 0, 0, 0);  \
+  }
+      CLO_MID_MM(x) CLO_MID_MM(y) CLO_MID_MM(z) CLO_MID_MM(w)
+#undef CLO_MID_MM
+    }
+  };
+  auto mma = [&](const Group &gr, int st0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) mma_step(gr.av[u], st0 + u);
+  };
+  int step = 0;
+  {
+    int gi = 0;
+    for (; gi + 1 < ngroups; gi += 2) {
+      load(gb, (gi + 1) * U);
+      mma(ga, gi * U);
+      if (gi + 2 < ngroups) load(ga, (gi + 2) * U);
+      mma(gb, (gi + 1) * U);
+    }
+    if (gi < ngroups) mma(ga, gi * U);
+    step = ngroups * U;
+  }
+  for (; step * 16 < klen; ++step) {  // leftover full steps and the partial one (B is zero beyond klen)
+    const bool ok = step * 16 + s4 < klen;
+    float4 av[RG];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) av[g] = ld4(pA[g] + (ok ? step * 16 : 0));
+    mma_step(av, step);
+  }
+
+  // D layout: row = (lane>>4)*4 + r (0..7: W rows, 8..15: V rows), col = lane&15 = batch row in the tile.
+  // z = acc1[rows 0..7], dz = acc1[rows 8..15] + acc2[rows 0..7]; lanes 0..31 hold four consecutive
+  // features each -> one float4 per (tile, quantity) into part[split][2][NP][d_out].
+  const int q = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float4 z4, d4;
+      float *pz = reinterpret_cast<float *>(&z4), *pd = reinterpret_cast<float *>(&d4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc1[g][t][r];
+        const float up = __shfl(v, (lane + 32) & 63, 64);
+        pz[r] = v;
+        pd[r] = up + (HAS_DA ? acc2[g][t][r] : 0.f);
+      }
+      const int j = j0 + g * 8 + q * 4;
+      if (q < 2 && j < d_out) {
+        float *dst = part + (((long)blockIdx.y * 2) * NP + t * 16 + col) * d_out + j;
+        st4(dst, z4);
+        st4(dst + (long)NP * d_out, d4);
+      }
+    }
+}
+
+// delta_{l-1} slabs for up to 32 rows: P[by][n][i] = sum_{j in rows(by)} delta[n][j] W[j][i].
+// grid = (column chunks of 256, JB row ranges); 8 waves = 4 column quarters x 2 row halves (merged in LDS).
+struct MidDelta {            // where delta_l comes from
+  const float *delta;        // [N][ld] final (ld = d_out unless ld_delta is set), or null
+  const float *dslabs;       // [njb][NP][d_out] row-range slabs of the previous launch (x dphi), or null
+  const float *dphi;         // [N][d_out] (with dslabs)
+  int njb;
+  int ld_delta;              // row stride of `delta` (0: d_out)
+};
+template <int NT>
+__device__ __forceinline__ float mid_delta_at(const MidDelta &md, int n, int j, int N, int d_out) {
+  constexpr int NP = 16 * NT;
+  if (n >= N || j >= d_out) return 0.f;
+  if (md.dslabs) {
+    const float *ps = md.dslabs + (long)n * d_out + j;
+    const long stride = (long)NP * d_out;
+    const float dp = md.dphi[(long)n * d_out + j];
+    float acc = 0.f;
+    for (int jb = 0; jb < md.njb; jb += 8) {  // 8 slabs in flight: clamped index + zero weight, no branches
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = ps[(long)min(jb + k, md.njb - 1) * stride];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += (jb + k < md.njb) ? t[k] : 0.f;
+    }
+    return acc * dp;
+  }
+  return md.delta[(long)n * (md.ld_delta ? md.ld_delta : d_out) + j];
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void mid_dprev_kernel(
+    const float *__restrict__ W, const MidDelta md, const float *__restrict__ dphi_prev,
+    float *__restrict__ dst, int N, int d_in, int d_out, int rows_per_block, int final_write) {
+  constexpr int NP = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_d = smem;                                  // [rows_per_block (padded to 8)][MID_LDD]
+  const int rpad = (rows_per_block + 7) & ~7;
+  float *s_red = smem + rpad * MID_LDD;               // [4 quarters][NT][4][4][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cq = wave & 3, rh = wave >> 2;
+  const int c16 = lane & 15, kg = lane >> 4;
+  const int jbase = blockIdx.y * rows_per_block;
+  const int i0 = blockIdx.x * 256 + cq * 64 + c16 * 4;
+  const bool col_ok = i0 < d_in;   // d_in % 4 == 0: the lane's four columns are all in or all out
+  // rows of this wave: half of the block's range, in steps of 4
+  const int half = ((rows_per_block + 1) / 2 + 3) & ~3;
+  const int r0 = rh * half, r1 = min(rows_per_block, r0 + half);
+  const float *pW = W + (long)(col_ok ? i0 : 0);
+  auto wrow = [&](int jj) { return pW + (long)min(jbase + jj + kg, d_out - 1) * d_in; };
+  constexpr int U = 8;
+  float4 wv[U];
+  // first loads in flight while delta is staged
+#pragma unroll
+  for (int u = 0; u < U; ++u) wv[u] = ld4(wrow(min(r0 + 4 * u, max(r1 - 1, r0))));
+
+  for (int e = tid; e < rpad * NP; e += 512) {
+    const int jj = e / NP, n = e - jj * NP;
+    s_d[jj * MID_LDD + n] = jj < rows_per_block ? mid_delta_at<NT>(md, n, jbase + jj, N, d_out) : 0.f;
+  }
+  __syncthreads();
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int jr = r0; jr < r1; jr += 4 * U) {
+    float4 cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = wv[u];
+    if (jr + 4 * U < r1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) wv[u] = ld4(wrow(min(jr + 4 * U + 4 * u, r1 - 1)));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int jj = jr + 4 * u;           // rows jj .. jj + 3 (kg selects the row of this lane)
+      if (jj < r1) {                        // wave-uniform
+        const bool rok = jj + kg < r1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float av = s_d[min(jj + kg, rpad - 1) * MID_LDD + t * 16 + c16];
+          av = rok ? av : 0.f;
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cur[u].x, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cur[u].y, acc[t][1], 0, 0, 0);
+          acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cur[u].z, acc[t][2], 0, 0, 0);
+          acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cur[u].w, acc[t][3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // merge the two row halves, then D[n = 4 q + r][column c16 of component e] -> P[n][i0 + e]
+  if (rh == 1) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[(((cq * NT + t) * 4 + e) * 4 + r) * 64 + lane] = acc[t][e][r];
+  }
+  __syncthreads();
+  if (rh == 1 || !col_ok) return;
+  const int q = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = t * 16 + q * 4 + r;
+      float4 v;
+      v.x = acc[t][0][r] + s_red[(((cq * NT + t) * 4 + 0) * 4 + r) * 64 + lane];
+      v.y = acc[t][1][r] + s_red[(((cq * NT + t) * 4 + 1) * 4 + r) * 64 + lane];
+      v.z = acc[t][2][r] + s_red[(((cq * NT + t) * 4 + 2) * 4 + r) * 64 + lane];
+      v.w = acc[t][3][r] + s_red[(((cq * NT + t) * 4 + 3) * 4 + r) * 64 + lane];
+      if (final_write) {
+        if (n < N) {
+          const float4 dp = ld4(dphi_prev + (long)n * d_in + i0);
+          st4(dst + (long)n * d_in + i0, make_float4(v.x * dp.x, v.y * dp.y, v.z * dp.z, v.w * dp.w));
+        }
+      } else {
+        st4(dst + ((long)blockIdx.y * NP + n) * d_in + i0, v);
+      }
+    }
+}
+
+// All outer products of a matvec for up to 32 rows: out_W_l = beta out_W_l + alpha delta_l^T a_{l-1}, bias
+// gradients = column sums of delta_l.  Block = 64 rows x 256 columns, 8 waves = 4 column quarters x 2
+// row halves, each wave 2 x (16 x 64) MFMA tiles with K = the batch rows.
+constexpr int MIDO_ROWS = 64;
+struct MidOuterArgs {
+  int nlayers;
+  int first_block[OUTER_MAXL + 1];
+  MidDelta md[OUTER_MAXL];
+  const float *a_prev[OUTER_MAXL];
+  float *out_W[OUTER_MAXL];
+  float *out_b[OUTER_MAXL];
+  int d_in[OUTER_MAXL], d_out[OUTER_MAXL];
+  float alpha, beta;
+  int N;
+};
+template <int NT, bool ACCUM>
+__global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
+  constexpr int NP = 16 * NT;
+  constexpr int LDR = MIDO_ROWS + 16;  // [NP][rows + 16]: conflict-free A-operand reads
+  __shared__ __attribute__((aligned(16))) float s_dT[NP * LDR];
+  __shared__ __attribute__((aligned(16))) float s_a[NP * 256];
+  int l = 0;
+  while (l + 1 < p.nlayers && (int)blockIdx.x >= p.first_block[l + 1]) ++l;
+  const int local = blockIdx.x - p.first_block[l];
+  const int d_in = p.d_in[l], d_out = p.d_out[l], N = p.N;
+  const int cchunks = (d_in + 255) / 256;
+  const int bx = local % cchunks, by = local / cchunks;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cq = wave & 3, rh = wave >> 2;
+  const int l16 = lane & 15, kg = lane >> 4;
+  const int jbase = by * MIDO_ROWS;
+  // stage delta^T [n][row] and a [n][256 columns]
+  for (int e = tid; e < NP * MIDO_ROWS; e += 512) {
+    const int n = e / MIDO_ROWS, jj = e - n * MIDO_ROWS;
+    s_dT[n * LDR + jj] = mid_delta_at<NT>(p.md[l], n, jbase + jj, N, d_out);
+  }
+  for (int e = tid; e < NP * 64; e += 512) {
+    const int n = e >> 6, c4 = (e & 63) * 4;
+    const int i = bx * 256 + c4;
+    float4 v = zero4();
+    if (n < N && i < d_in) v = ld4(p.a_prev[l] + (long)n * d_in + i);
+    *reinterpret_cast<float4 *>(&s_a[n * 256 + c4]) = v;
+  }
+  __syncthreads();
+  if (p.out_b[l] && bx == 0 && tid < MIDO_ROWS && jbase + tid < d_out) {
+    float sb = 0.f;
+    for (int n = 0; n < NP; ++n) sb += s_dT[n * LDR + tid];
+    float *pb = p.out_b[l] + jbase + tid;
+    *pb = (ACCUM ? p.beta * *pb : 0.f) + p.alpha * sb;
+  }
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[rt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NP / 4; ++s) {
+    const float4 bv = *reinterpret_cast<const float4 *>(&s_a[(4 * s + kg) * 256 + cq * 64 + l16 * 4]);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float av = s_dT[(4 * s + kg) * LDR + rh * 32 + rt * 16 + l16];
+      acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[rt][0], 0, 0, 0);
+      acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[rt][1], 0, 0, 0);
+      acc[rt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[rt][2], 0, 0, 0);
+      acc[rt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.w, acc[rt][3], 0, 0, 0);
+    }
+  }
+  // D[row = 4 q + r][column l16 of component e] -> out_W[jbase + rh 32 + rt 16 + 4 q + r][i0 + e]
+  const int i0 = bx * 256 + cq * 64 + l16 * 4;
+  if (i0 >= d_in) return;
+  const int q = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = jbase + rh * 32 + rt * 16 + q * 4 + r;
+      if (j < d_out) {
+        float4 v = make_float4(p.alpha * acc[rt][0][r], p.alpha * acc[rt][1][r], p.alpha * acc[rt][2][r],
+                               p.alpha * acc[rt][3][r]);
+        float *po = p.out_W[l] + (long)j * d_in + i0;
+        if (ACCUM) {
+          const float4 od = ld4(po);
+          v.x += p.beta * od.x; v.y += p.beta * od.y; v.z += p.beta * od.z; v.w += p.beta * od.w;
+        }
+        CLO_STW(po, v);
+      }
+    }
+}
+
+// head_bwd_kernel for more than NB rows, one block per (256-column chunk, NB-row chunk): merge the head
+// partials of the chunk, loss Hessian per sample -> delta_L rows (written to dL [N][HEAD_CMAX] for the
+// outer-product launch, which also forms out_W_L / out_b_L) and the chunk's rows of delta_{L-1}.
+__global__ __launch_bounds__(256) void head_bwd_rows_kernel(const HeadBwdArgs p, float *__restrict__ dL) {
+  __shared__ float s_f[NB][HEAD_CMAX], s_u[NB][HEAD_CMAX], s_dl[NB][HEAD_CMAX];
+  const int tid = threadIdx.x;
+  const int N = p.N, C = p.C;
+  const int i = blockIdx.x * 256 + tid;
+  const int ic = i < p.d ? i : 0;
+  const int n0 = blockIdx.y * NB, nn = min(NB, N - n0);
+  float wcol[HEAD_CMAX], dpp[NB];
+#pragma unroll
+  for (int c = 0; c < HEAD_CMAX; ++c) wcol[c] = c < C ? p.WL[(long)c * p.d + ic] : 0.f;
+#pragma unroll
+  for (int n = 0; n < NB; ++n) dpp[n] = p.dphi_prev[(long)(n0 + (n < nn ? n : 0)) * p.d + ic];
+  {  // merge the head partials of this chunk: thread = (n, which in {z, dz}, c)
+    const int n = tid >> 5, r = tid & 31, c = r & (HEAD_CMAX - 1);
+    float acc = 0.f;
+    if (n < nn && c < C) {
+      const float *bias = (r < HEAD_CMAX) ? p.bL : p.VbL;
+      acc = bias ? bias[c] : 0.f;
+      const float *q = p.hp + ((long)(n0 + n) * p.nblk * 2) * HEAD_CMAX + r;
+      for (int k0 = 0; k0 < p.nblk; k0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = q[(long)min(k0 + k, p.nblk - 1) * 2 * HEAD_CMAX];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (k0 + k < p.nblk) ? t[k] : 0.f;
+      }
+    }
+    if (r < HEAD_CMAX) s_f[n][c] = acc; else s_u[n][c] = acc;
+  }
+  __syncthreads();
+  if (tid < NB) {  // loss Hessian per sample
+    const int n = tid;
+    for (int c = 0; c < HEAD_CMAX; ++c) s_dl[n][c] = 0.f;
+    if (n < nn) {
+      if (p.kind == CLO_LOSS_MSE) {
+        for (int c = 0; c < C; ++c) s_dl[n][c] = p.scale * s_u[n][c];
+      } else if (p.kind == CLO_LOSS_BCE) {
+        for (int c = 0; c < C; ++c) {
+          const float sg = 1.f / (1.f + __expf(-s_f[n][c]));
+          s_dl[n][c] = p.scale * sg * (1.f - sg) * s_u[n][c];
+        }
+      } else if (p.kind == CLO_LOSS_CE) {
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, s_f[n][c]);
+        float se = 0.f, spu = 0.f;
+        for (int c = 0; c < C; ++c) {
+          const float e = __expf(s_f[n][c] - mx);
+          se += e;
+          spu += e * s_u[n][c];
+        }
+        const float inv = 1.f / se, pu = spu * inv;
+        for (int c = 0; c < C; ++c) {
+          const float pc = __expf(s_f[n][c] - mx) * inv;
+          s_dl[n][c] = p.scale * pc * (s_u[n][c] - pu);
+        }
+      } else {
+        for (int m = 0; m < p.aux_rank; ++m) {
+          const float *g = p.aux + ((long)(n0 + n) * p.aux_rank + m) * C;
+          float sdot = 0.f;
+          for (int c = 0; c < C; ++c) sdot += g[c] * s_u[n][c];
+          for (int c = 0; c < C; ++c) s_dl[n][c] += p.scale * g[c] * sdot;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < NB * HEAD_CMAX && (tid >> 4) < nn)
+    dL[(long)(n0 + (tid >> 4)) * HEAD_CMAX + (tid & 15)] = s_dl[tid >> 4][tid & 15];
+  if (i < p.d && p.delta_prev) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < HEAD_CMAX; ++c) acc = fmaf(s_dl[n][c], wcol[c], acc);
+      if (n < nn) p.delta_prev[(long)(n0 + n) * p.d + i] = acc * dpp[n];
     }
   }
 }
@@ -2027,6 +2464,161 @@ extern "C" int clo_mlp_bwd_layer(const float *W, const float *delta, const float
   return CLO_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// 9 ... 32 rows, narrow linear head, float4-complete layers: the MFMA streaming chain (mid_* kernels).
+// Scratch comes out of the GEMM slab area `gws` (unused on this path): forward slabs | head partials |
+// two regions of delta slabs (ping-pong over the layers).
+// ------------------------------------------------------------------------------------------
+constexpr int MID_MAX_N = 32;
+
+static bool mid_chain_ok(int L, const int *dims, const float *const *W, const float *const *VW,
+                         float *const *OW, int N) {
+  static const bool off = getenv("CLO_MLP_NO_MID") != nullptr;
+  if (off || N <= NB || N > MID_MAX_N || L < 2 || L > OUTER_MAXL) return false;
+  for (int l = 1; l <= L - 1; ++l)
+    if (dims[l - 1] % 4 != 0 || dims[l] % 4 != 0 || dims[l - 1] < 16 || !aligned16(W[l - 1]) ||
+        !aligned16(VW[l - 1]) || !aligned16(OW[l - 1]))
+      return false;
+  return aligned16(OW[L - 1]);  // out_W_L is written by the float4 outer-product kernel
+}
+
+template <int NT>
+static int mid_chain(int L, const int *dims, const int *acts, const float *const *W,
+                     const float *const *b, const float *const *VW, const float *const *Vb,
+                     float *const *OW, float *const *Ob, int N, int loss_kind, const float *aux,
+                     int aux_rank, float scale, float beta, float *const *a, float *const *da,
+                     float *const *dphi, float *const *dl, float *gws, long gws_sz, hipStream_t st) {
+  constexpr int NP = 16 * NT;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  const int C = dims[L], dh = dims[L - 1];
+  const int head_nblk = (int)cdiv(dh, 256);
+  // carve gws
+  float *fslab = gws;
+  const long fslab_sz = 32L * 2 * NP * dmax;          // up to 32 K ranges
+  float *hp = fslab + fslab_sz;
+  const long hp_sz = (long)N * head_nblk * 2 * HEAD_CMAX + 64;
+  float *dLbuf = hp + hp_sz;                          // [N][HEAD_CMAX] delta of the head
+  const long dL_sz = (long)NP * HEAD_CMAX;
+  float *dslab[2] = {dLbuf + dL_sz, dLbuf + dL_sz + 24L * NP * dmax};
+  if (fslab_sz + hp_sz + dL_sz + 2 * 24L * NP * dmax > gws_sz) return CLO_EUNSUP;
+  int rc;
+  // ---- forward + JVP: hidden layers 1 .. L-1
+  for (int l = 1; l <= L - 1; ++l) {
+    const int di = dims[l - 1], dout = dims[l];
+    const bool has_da = l > 1;
+    const int cols = (has_da ? 2 : 1) * NP;
+    // Besides the weights a launch moves the activations every block stages (row blocks x cols x d_in) and
+    // the split-K slabs (written here, read by the finish): both cost like weight bytes.  Pick waves per
+    // block (4 / 8 = 64 / 128 features) and the K split that minimise them at >= ~0.8 blocks per CU.
+    const long kpb_max = std::min<long>(MF_KB_MAX, ((65536 / (4 * cols) - 4) / 32) * 32);
+    int wv = 4;
+    long ksplit = 1, kpb = 32;
+    double best = 1e300;
+    for (int w : {4, 8}) {
+      const long rb = cdiv(dout, w * 16);
+      for (long ks = 1; ks <= 32; ++ks) {
+        const long kp = cdiv(cdiv(di, ks), 32) * 32;
+        if (kp > kpb_max) continue;
+        const long kse = cdiv(di, kp);
+        const long blocks = rb * kse;
+        if (blocks * 5 < kNumCU * 4 && !(ks == 32 && best == 1e300)) continue;
+        const double traffic = (double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout;
+        if (traffic < best) { best = traffic; wv = w; ksplit = kse; kpb = kp; }
+      }
+    }
+    if (best == 1e300 || ksplit > 32) return CLO_EUNSUP;
+    const long row_blocks = cdiv(dout, wv * 16);
+    const size_t smem = (size_t)cols * (kpb + 4) * sizeof(float);
+    dim3 grid((unsigned)row_blocks, (unsigned)ksplit), block(wv * 64);
+    {
+      ProfScope prof(0, 8.0 * di * dout, st);
+#define CLO_MIDF(DA, WVV)                                                                                  \
+  hipLaunchKernelGGL((mid_fwd_kernel<NT, DA, WVV>), grid, block, smem, st, W[l - 1], VW[l - 1], a[l - 1],  \
+                     DA ? da[l - 1] : nullptr, fslab, N, di, dout, (int)kpb)
+      if (has_da) { if (wv == 8) CLO_MIDF(true, 8); else CLO_MIDF(true, 4); }
+      else { if (wv == 8) CLO_MIDF(false, 8); else CLO_MIDF(false, 4); }
+#undef CLO_MIDF
+      CLO_CHECK_LAUNCH("mid_fwd_kernel");
+    }
+    if (l < L - 1) {
+      ProfScope pf(3, 0.0, st);
+      hipLaunchKernelGGL(fwd_finish_kernel, dim3(ew_grid((long)N * dout)), dim3(256), 0, st, fslab, (int)ksplit,
+                         b ? b[l - 1] : nullptr, Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dout,
+                         acts[l - 1], NP);
+      CLO_CHECK_LAUNCH("fwd_finish_kernel");
+    } else {  // last hidden layer: finish + partial products of the head
+      HeadFwdArgs fa{};
+      fa.part = fslab; fa.ksplit = (int)ksplit; fa.part_rows = NP;
+      fa.b = b ? b[l - 1] : nullptr; fa.Vb = Vb ? Vb[l - 1] : nullptr;
+      fa.a = a[l]; fa.da = da[l]; fa.dphi = dphi[l];
+      fa.N = N; fa.d = dout; fa.act = acts[l - 1];
+      fa.WL = W[L - 1]; fa.VL = VW[L - 1]; fa.C = C; fa.hp = hp;
+      ProfScope pf(3, 0.0, st);
+      hipLaunchKernelGGL(head_fwd_kernel, dim3(head_nblk, N), dim3(256), 0, st, fa);
+      CLO_CHECK_LAUNCH("head_fwd_kernel");
+    }
+  }
+  // ---- head: loss Hessian, out_W_L / out_b_L, delta_{L-1}
+  {
+    HeadBwdArgs ba{};
+    ba.hp = hp; ba.nblk = head_nblk;
+    ba.bL = b ? b[L - 1] : nullptr; ba.VbL = Vb ? Vb[L - 1] : nullptr;
+    ba.kind = loss_kind; ba.aux = aux; ba.aux_rank = aux_rank; ba.scale = scale;
+    ba.WL = W[L - 1]; ba.a_prev = a[L - 1]; ba.dphi_prev = dphi[L - 1];
+    ba.out_W = nullptr; ba.out_b = nullptr; ba.delta_prev = dl[L - 1];  // out_W_L / out_b_L: mid_outer_kernel
+    ba.beta = beta; ba.N = N; ba.d = dh; ba.C = C;
+    ProfScope pf(1, 4.0 * dh * C, st);
+    hipLaunchKernelGGL(head_bwd_rows_kernel, dim3(head_nblk, (unsigned)cdiv(N, NB)), dim3(256), 0, st, ba, dLbuf);
+    CLO_CHECK_LAUNCH("head_bwd_rows_kernel");
+  }
+  // ---- data chain: delta_{l-1} for l = L-1 .. 2
+  MidDelta md[OUTER_MAXL + 2];
+  md[L - 1] = MidDelta{dl[L - 1], nullptr, nullptr, 0, 0};
+  for (int l = L - 1; l >= 2; --l) {
+    const int di = dims[l - 1], dout = dims[l];
+    long JB = cdiv(kNumCU, cdiv(di, 256));
+    JB = std::min<long>({JB, cdiv(dout, 64), 24L});
+    JB = std::max<long>(JB, cdiv(dout, 512));
+    const int rpb = (int)(cdiv(cdiv(dout, JB), 8) * 8);
+    const int JBe = (int)cdiv(dout, rpb);
+    if (JBe > 24) return CLO_EUNSUP;
+    float *slab = dslab[l & 1];
+    const size_t smem = ((size_t)((rpb + 7) & ~7) * MID_LDD + NT * 4096) * sizeof(float);
+    rc = set_smem(mid_dprev_kernel<NT>, smem);
+    if (rc != CLO_OK) return rc;
+    const int fin = JBe == 1 ? 1 : 0;
+    ProfScope prof(2, 4.0 * di * dout, st);
+    hipLaunchKernelGGL((mid_dprev_kernel<NT>), dim3((unsigned)cdiv(di, 256), (unsigned)JBe), dim3(512), smem, st,
+                       W[l - 1], md[l], dphi[l - 1], fin ? dl[l - 1] : slab, N, di, dout, rpb, fin);
+    CLO_CHECK_LAUNCH("mid_dprev_kernel");
+    md[l - 1] = fin ? MidDelta{dl[l - 1], nullptr, nullptr, 0, 0} : MidDelta{nullptr, slab, dphi[l - 1], JBe, 0};
+  }
+  // ---- all outer products of the hidden layers in one launch
+  {
+    MidOuterArgs oa{};
+    oa.nlayers = L; oa.alpha = 1.f; oa.beta = beta; oa.N = N;
+    md[L] = MidDelta{dLbuf, nullptr, nullptr, 0, HEAD_CMAX};  // the head's delta, [N][HEAD_CMAX]
+    int nb = 0;
+    double bytes = 0;
+    for (int l = 1; l <= L; ++l) {
+      const int k = l - 1;
+      oa.first_block[k] = nb;
+      oa.md[k] = md[l]; oa.a_prev[k] = a[l - 1];
+      oa.out_W[k] = OW[l - 1]; oa.out_b[k] = Ob ? Ob[l - 1] : nullptr;
+      oa.d_in[k] = dims[l - 1]; oa.d_out[k] = dims[l];
+      nb += (int)(cdiv(dims[l - 1], 256) * cdiv(dims[l], MIDO_ROWS));
+      bytes += 4.0 * dims[l - 1] * dims[l] * (beta != 0.f ? 2 : 1);
+    }
+    oa.first_block[L] = nb;
+    ProfScope prof(4, bytes, st);
+    if (beta != 0.f) hipLaunchKernelGGL((mid_outer_kernel<NT, true>), dim3(nb), dim3(512), 0, st, oa);
+    else hipLaunchKernelGGL((mid_outer_kernel<NT, false>), dim3(nb), dim3(512), 0, st, oa);
+    CLO_CHECK_LAUNCH("mid_outer_kernel");
+  }
+  return CLO_OK;
+}
+
 // Workspace layout of clo_mlp_ggn_matvec (floats):
 //   per layer l = 1..L : a_l, da_l, dphi_l, each [N][d_l]
 //   delta ping/pong    : 2 x [N][dmax]
@@ -2115,6 +2707,13 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   const int Lf = narrow ? L - 1 : L;  // layers run by the generic forward loop
   float *hp = nullptr;
   int head_nblk = 0;
+  if (narrow && mid_chain_ok(L, dims, W, VW, OW, N)) {
+    rc = N <= 16 ? mid_chain<1>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank,
+                                loss_scale * alpha, beta, a, da, dphi, dl, gws, gws_sz, st)
+                 : mid_chain<2>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank,
+                                loss_scale * alpha, beta, a, da, dphi, dl, gws, gws_sz, st);
+    if (rc != CLO_EUNSUP) return rc;
+  }
   // ---- forward + JVP
   for (int l = 1; l <= Lf; ++l) {
     const int di = dims[l - 1], dout = dims[l];

@@ -299,6 +299,33 @@ def test_ggn_matvec_large_layers(hip, N):
     assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
 
 
+@pytest.mark.parametrize("loss", ["mse", "ce", "bce"])
+@pytest.mark.parametrize("N", [9, 12, 16, 17, 25, 32])
+def test_ggn_matvec_mid_rows_chain(hip, N, loss):
+    """9 ... 32 rows: the MFMA streaming chain (mid_fwd / head / mid_dprev / mid_outer kernels) against
+    the float64 oracle on a 4-layer net (two finished hidden layers, slab ping-pong in the data chain,
+    a layer without bias), plain and accumulating (beta = 1) products."""
+    g = np.random.default_rng(100 * N + len(loss))
+    dims, acts = [64, 96, 80, 48, 7], ["tanh", "relu", "sigmoid", "identity"]
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(4)]
+    bs = [g.random(dims[1]) - 0.5, None, g.random(dims[3]) - 0.5, g.random(dims[4]) - 0.5]
+    vWs = [g.random(W.shape) - 0.5 for W in Ws]
+    vbs = [None if b is None else g.random(b.shape) - 0.5 for b in bs]
+    X = g.random((N, dims[0]))
+    y = g.integers(0, dims[-1], N) if loss == "ce" else (g.integers(0, 2, (N, dims[-1])).astype(float) if loss == "bce"
+                                                         else g.random((N, dims[-1])))
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", vWs, vbs)
+    c = O.reduction_factor(loss, "mean", N, dims[-1])
+    scale = (2.0 if loss == "mse" else 1.0) * c
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 1.0, 0.0)
+    assert rel_err(O.flatten_params(gW, gb), O.flatten_params(rW, rb)) < 1e-4
+    out0 = ([g.random(W.shape) for W in Ws], [None if b is None else g.random(b.shape) for b in bs])
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 0.5, 1.0, out0=out0)
+    ref = O.flatten_params([0.5 * r + o for r, o in zip(rW, out0[0])],
+                           [None if r is None else 0.5 * r + o for r, o in zip(rb, out0[1])])
+    assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
+
+
 def _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, Vbk, loss_kind, scale, alpha, beta, out0=None,
                          aux=None, pad=0):
     """K columns through clo_mlp_ggn_matmat: VWk[l] is [d_out, d_in, K], Vbk[l] is [d_out, K]; `pad`
