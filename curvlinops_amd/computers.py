@@ -317,6 +317,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
     _SUPPORTED_FISHER_TYPE = FisherType
     _SUPPORTED_KFAC_APPROX = KFACType
     NEEDS_NUM_PER_EXAMPLE_LOSS_TERMS: bool = True
+    _REQUIRES_MODULE: bool = True
 
     def __init__(
         self,
@@ -339,7 +340,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
         """``distributed=True``: ``data`` is this rank's shard, ``num_data`` the GLOBAL count; the
         factors (and EKFAC's corrected eigenvalues) are summed over ranks with one packed
         all-reduce each (``curvlinops_amd.dist``).  All other arguments as in the reference."""
-        if not isinstance(model_func, Module):
+        if self._REQUIRES_MODULE and not isinstance(model_func, Module):
             raise ValueError(
                 "The hooks-based backends require model_func to be an nn.Module."
             )

@@ -189,9 +189,17 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
 
     @staticmethod
     def _native_cost(n: int) -> float:
-        """Relative time of one native product over ``n`` rows (measured on C2: 8 rows 55 us on the
-        streaming kernels; beyond that the GEMM path, ~100 us of launches plus ~0.85 us per row)."""
-        return 1.0 if n <= 8 else 1.8 + n / 65.0
+        """Relative time of one native product over ``n`` rows (measured on C2,
+        profiles/r02_c2_batch_sweep.txt: 8 rows 52 us on the streaming kernels, 9-16 rows 64 us and
+        17-32 rows 88 us on their MFMA variants; beyond that the GEMM path, 141 us at 33 rows plus
+        ~0.8 us per row)."""
+        if n <= 8:
+            return 1.0
+        if n <= 16:
+            return 1.22
+        if n <= 32:
+            return 1.68
+        return 2.2 + n / 65.0
 
     def _merge_native_batches(self, entries: list[tuple]) -> list[tuple]:
         """``entries``: ``(X, kind, scale, aux, norm)`` per mini-batch.  The curvature is a sum over

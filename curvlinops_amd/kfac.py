@@ -18,6 +18,7 @@ from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss, Module, MSELoss
 
 from curvlinops_amd import linalg_native
 from curvlinops_amd.canonical import FromCanonicalLinearOperator, ParamGroup, ToCanonicalLinearOperator
+from curvlinops_amd.collector import CollectorEKFACComputer, CollectorKFACComputer
 from curvlinops_amd.computers import HipEKFACComputer, HipKFACComputer
 from curvlinops_amd.enums import FisherType, KFACType
 from curvlinops_amd.kronecker import (
@@ -31,7 +32,11 @@ from curvlinops_amd.linop import _ChainPyTorchLinearOperator
 class KFACLinearOperator(_ChainPyTorchLinearOperator):
     """Kronecker-factored approximate curvature ``(A_l (x) G_l)`` per layer."""
 
-    _BACKENDS: dict[str, type] = {"hip": HipKFACComputer, "hooks": HipKFACComputer}
+    # "hip" / "hooks": module hooks (one use per parameter); "collector" / "make_fx": taps the affine
+    # operations of the eager forward pass -- functional models and weight tying (reference's second
+    # backend, `kfac.py:89-92`)
+    _BACKENDS: dict[str, type] = {"hip": HipKFACComputer, "hooks": HipKFACComputer,
+                                  "collector": CollectorKFACComputer, "make_fx": CollectorKFACComputer}
     SELF_ADJOINT: bool = True
 
     def __init__(
@@ -141,7 +146,8 @@ class KFACLinearOperator(_ChainPyTorchLinearOperator):
 class EKFACLinearOperator(KFACLinearOperator):
     """Eigenvalue-corrected KFAC: ``(Q_g (x) Q_a) diag(lambda) (Q_g (x) Q_a)^T`` per layer."""
 
-    _BACKENDS: dict[str, type] = {"hip": HipEKFACComputer, "hooks": HipEKFACComputer}
+    _BACKENDS: dict[str, type] = {"hip": HipEKFACComputer, "hooks": HipEKFACComputer,
+                                  "collector": CollectorEKFACComputer, "make_fx": CollectorEKFACComputer}
 
     @staticmethod
     def _compute_canonical_op(computer) -> tuple[BlockDiagonalLinearOperator, list[ParamGroup]]:
