@@ -193,7 +193,8 @@ long clo_mlp_bwd_ws_floats(int N, int d_in, int d_out);
  *   W,b,VW,Vb,OW,Ob  host arrays of L device pointers (b/Vb/Ob entries may be NULL)
  *   X [N][d_0]   input batch;  loss_kind/aux/loss_scale as clo_loss_hessian_apply
  *   ws           workspace of clo_mlp_ggn_ws_floats(L, dims, N) floats
- * Works for any N (N > 16 runs the MFMA GEMM path). */
+ * Works for any N: <= 8 rows on the VALU/MFMA streaming chain, 9 ... 32 rows on its all-MFMA variant
+ * (narrow head, float4-complete layers), otherwise on the MFMA GEMM engine. */
 int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
                        const float *const *W, const float *const *b,
                        const float *const *VW, const float *const *Vb,
@@ -203,14 +204,6 @@ int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
                        float *ws, void *stream);
 long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
 
-/* K probe columns in one call (reference: vmap over the trailing K axis, _torch_base.py:946-989):
- *   out[.., k] = beta * out[.., k] + alpha * (J^T H J) V[.., k],   k = 0..K-1
- * VW[l] / OW[l] point at element (0, 0, 0) of a [d_out][d_in][K] block whose rows (one per weight)
- * are ldk floats apart -- the rows of the reference's [D, K] matrix; Vb[l] / Ob[l] likewise
- * [d_out][K].  The tangent weights are streamed once in that layout, W is shared by all columns.
- * Returns CLO_EUNSUP unless K % 4 == 0, 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0, aux_rank
- * <= 16 and all operands are 16-byte aligned (the caller then loops clo_mlp_ggn_matvec over columns).
- * ws: clo_mlp_ggn_matmat_ws_floats(L, dims, N, K) floats. */
 /* Jacobian and transposed-Jacobian products of an MLP (reference jacobian.py:14-358): the
  * forward+JVP half and the VJP half of the GGN product.
  *   clo_mlp_jvp: JV [N][d_L] = J v          (CLO_EUNSUP unless dims[0..L-1] % 4 == 0, aligned)
@@ -238,6 +231,14 @@ int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, const float 
                            int loss_kind, const float *aux, int aux_rank, float loss_scale, float alpha,
                            float beta, float *ws, void *stream);
 
+/* K probe columns in one call (reference: vmap over the trailing K axis, _torch_base.py:946-989):
+ *   out[.., k] = beta * out[.., k] + alpha * (J^T H J) V[.., k],   k = 0..K-1
+ * VW[l] / OW[l] point at element (0, 0, 0) of a [d_out][d_in][K] block whose rows (one per weight)
+ * are ldk floats apart -- the rows of the reference's [D, K] matrix; Vb[l] / Ob[l] likewise
+ * [d_out][K].  The tangent weights are streamed once in that layout, W is shared by all columns.
+ * Returns CLO_EUNSUP unless K % 4 == 0, 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0, aux_rank
+ * <= 16 and all operands are 16-byte aligned (the caller then loops clo_mlp_ggn_matvec over columns).
+ * ws: clo_mlp_ggn_matmat_ws_floats(L, dims, N, K) floats. */
 long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int K);
 int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *const *W,
                        const float *const *b, const float *const *VW, const float *const *Vb,
