@@ -179,6 +179,66 @@ def cpu_baseline(batch: int) -> dict:
     return out
 
 
+def secondary_configs(device) -> dict:
+    """Driver-visible numbers for the remaining BASELINE configs (rank 0, N = 1, outside the timed region):
+    EKFAC phases on C4 (reference phases `benchmark_utils.py:139-143`) and C5 = 12-layer d = 768 encoder,
+    `EFLinearOperator` matvec + `hutchpp_trace` with 96 products (three K = 32 probe blocks)."""
+    import curvlinops_amd as C
+    from benchmarks.models import Encoder, ResNet18, kfac_params
+    from curvlinops_amd import linalg_native
+
+    def timed(fn, repeats):
+        fn()
+        torch.cuda.synchronize()
+        best, out = float("inf"), None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return 1e3 * best, out
+
+    out = {}
+    torch.manual_seed(0)
+    model = ResNet18().to(device).eval()
+    params = kfac_params(model)
+    B = 512
+    X, y = torch.rand(B, 3, 32, 32, device=device), torch.randint(0, 10, (B,), device=device)
+    kw = dict(fisher_type="mc", separate_weight_and_bias=False, check_deterministic=False, num_data=B)
+    K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw)
+    facs = [S for blk in K[1] for S in blk]
+    ek = {"rows": B}
+    ek["eigh_ms"], _ = timed(lambda: linalg_native.eigh_many(facs), 1)
+    ek["ekfac_total_ms"], E = timed(lambda: C.EKFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw), 1)
+    v = torch.rand(E.shape[1], device=device)
+    ek["ekfac_matvec_ms"], _ = timed(lambda: E @ v, 3)
+    ek["note"] = ("EKFAC = factors + eigendecompositions of the 42 factors (rocSOLVER through torch.linalg.eigh, "
+                  "batched by size on 4 streams) + eigenvalue-correction sweep")
+    out["c4_ekfac_resnet18"] = ek
+    del K, E, facs, model, params
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    enc = Encoder().to(device).eval()
+    p5 = dict(enc.named_parameters())
+    X5, y5 = torch.rand(8, 128, 768, device=device), torch.randint(0, 10, (8,), device=device)
+    EF = C.EFLinearOperator(enc, nn.CrossEntropyLoss(), p5, [(X5, y5)], check_deterministic=False, num_data=8)
+    D5 = EF.shape[1]
+    v5 = torch.rand(D5, device=device)
+    c5 = {"D": D5, "rows": 8, "seq_len": 128}
+    c5["ef_matvec_ms"], _ = timed(lambda: EF @ v5, 2)
+    t0 = time.perf_counter()
+    C.hutchpp_trace(EF, num_matvecs=96)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    tr = C.hutchpp_trace(EF, num_matvecs=96)
+    torch.cuda.synchronize()
+    c5["hutchpp_96_ms"] = 1e3 * min(t1 - t0, time.perf_counter() - t1)
+    c5["hutchpp_trace"] = float(tr)
+    c5["note"] = "general net: torch.func products on the GPU; probes, Gram-route range basis and reductions native"
+    out["c5_encoder_ef_hutchpp"] = c5
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # KFAC factor build (BASELINE config C4): the second half of the metric
 # --------------------------------------------------------------------------------------------
@@ -450,6 +510,10 @@ def main() -> None:
         }
         result["cpu_baseline"] = cpu_baseline(args.batch)
         result["other_points"] = other_points(model, params, device, D)
+        try:
+            result["other_points"].update(secondary_configs(device))
+        except Exception as e:  # noqa: BLE001
+            result["other_points"]["secondary_configs_error"] = repr(e)
 
     if not args.no_extras:
         # ---- second half of the metric: KFAC factor build ms/batch (every rank takes part)
