@@ -326,6 +326,30 @@ def test_ggn_matvec_mid_rows_chain(hip, N, loss):
     assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
 
 
+@pytest.mark.parametrize("dims,acts", [([20, 36, 10], ["relu", "identity"]),            # one hidden layer, ragged widths
+                                       ([32, 16, 16], ["tanh", "identity"]),            # C = 16 (widest narrow head)
+                                       ([300, 520, 260, 3], ["sigmoid", "relu", "identity"])])
+@pytest.mark.parametrize("N", [11, 16, 29])
+def test_ggn_matvec_mid_rows_shapes_and_rank1(hip, dims, acts, N):
+    """The 9 ... 32-row chain on ragged / minimal shapes, and with the rank-M output curvature of the
+    empirical Fisher (`aux`), against the float64 oracle."""
+    g = np.random.default_rng(N + dims[1])
+    L = len(dims) - 1
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(L)]
+    bs = [g.random(dims[i + 1]) - 0.5 for i in range(L)]
+    vWs = [g.random(W.shape) - 0.5 for W in Ws]
+    vbs = [g.random(b.shape) - 0.5 for b in bs]
+    X, y = g.random((N, dims[0])), g.random((N, dims[-1]))
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, "mse", "sum", vWs, vbs)
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 0, 2.0, 1.0, 0.0)
+    assert rel_err(O.flatten_params(gW, gb), O.flatten_params(rW, rb)) < 1e-4
+    rW, rb = O.ef_matvec_batch(Ws, bs, acts, X, y, "mse", "sum", vWs, vbs)
+    f = O.forward(Ws, bs, acts, X)[0][-1]
+    aux = dev(2.0 * (f - y)).reshape(N, 1, dims[-1]).contiguous()  # per-sample gradients of the sum-MSE
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 3, 1.0, 1.0, 0.0, aux=aux)
+    assert rel_err(O.flatten_params(gW, gb), O.flatten_params(rW, rb)) < 1e-4
+
+
 def _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, Vbk, loss_kind, scale, alpha, beta, out0=None,
                          aux=None, pad=0):
     """K columns through clo_mlp_ggn_matmat: VWk[l] is [d_out, d_in, K], Vbk[l] is [d_out, K]; `pad`
