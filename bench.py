@@ -508,8 +508,14 @@ def main() -> None:
                             "rocprof_avg_kernel_us from profiles/r02_c2_n8_bench_kernel_stats.txt (same command)",
             "kernel_us_per_matvec_hip_events": sum(k["us_per_matvec"] for k in kernels.values()),
         }
-        result["cpu_baseline"] = cpu_baseline(args.batch)
-        result["other_points"] = other_points(model, params, device, D)
+        try:  # the headline line must be printed whatever happens in the untimed legs
+            result["cpu_baseline"] = cpu_baseline(args.batch)
+        except Exception as e:  # noqa: BLE001
+            result["cpu_baseline"] = {"error": repr(e)}
+        try:
+            result["other_points"] = other_points(model, params, device, D)
+        except Exception as e:  # noqa: BLE001
+            result["other_points"] = {"error": repr(e)}
         try:
             result["other_points"].update(secondary_configs(device))
         except Exception as e:  # noqa: BLE001
