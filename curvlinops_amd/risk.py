@@ -46,7 +46,9 @@ class EmpiricalRiskMixin:
         num_per_example_loss_terms: int | None = None,
         check_deterministic: bool = True,
     ):
-        if isinstance(next(iter(data))[0], MutableMapping) and batch_size_fn is None:
+        first = next(iter(data), None)  # None: an empty shard of a data-parallel run (needs num_data and
+        #                                   num_per_example_loss_terms from the caller)
+        if first is not None and isinstance(first[0], MutableMapping) and batch_size_fn is None:
             raise ValueError("When using dict-like custom data, `batch_size_fn` is required.")
         if not isinstance(params, dict):
             raise TypeError(

@@ -74,6 +74,15 @@ def _worker(rank: int, world: int, port: int, ret):
             # exchanged with packed broadcasts, the EKFAC bases come from the sharded eigh
             ok &= _check(failed, 5, torch.allclose(KR.inverse(damping=1e-2) @ v, K1.inverse(damping=1e-2) @ v, rtol=1e-8, atol=1e-10))
 
+        # a rank without any mini-batch still takes part in both factor collectives (zero contribution)
+        lopsided = data if rank == 0 else []
+        K1 = C.KFACLinearOperator(model, loss, params, data, fisher_type="empirical", check_deterministic=False,
+                                  separate_weight_and_bias=False)
+        KR = C.KFACLinearOperator(model, loss, params, lopsided, fisher_type="empirical", num_data=N,
+                                  num_per_example_loss_terms=1, check_deterministic=False,
+                                  separate_weight_and_bias=False, distributed=True)
+        ok &= _check(failed, 9, torch.allclose(KR @ v, K1 @ v, rtol=1e-8, atol=1e-10))
+
         # the sharding helpers themselves
         from curvlinops_amd import linalg_native
         from curvlinops_amd.dist import partition_by_cost, sharded_factor_map
