@@ -37,6 +37,7 @@ _SIGNATURES = {
          c_float, _PF, c_long, c_long, c_int, c_int, _PF, c_void_p],
     ),
     "clo_gemm_suggest_splitk": (c_int, [c_int, c_int, c_int, c_int]),
+    "clo_syrk_suggest_splitk": (c_int, [c_int, c_long]),
     "clo_gemm_sqsum_f32": (
         c_int,
         [c_int, c_int, c_int, c_float, _PF, c_long, c_long, c_long, _PF, c_long, c_long, c_long,
@@ -288,8 +289,9 @@ def gemm_sqsum(A: Tensor, B: Tensor, out: Tensor, alpha: float = 1.0, beta: floa
 
 
 def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones_col: bool = False,
-               splitk: int | None = None) -> Tensor:
-    """``C = beta*C + alpha * [X|1]^T [X|1]`` for row-major ``X[rows, d]`` (view with stride ok)."""
+               splitk: int | None = None, force_gram_tall: bool = False) -> Tensor:
+    """``C = beta*C + alpha * [X|1]^T [X|1]`` for row-major ``X[rows, d]`` (view with stride ok).
+    ``force_gram_tall``: run the streaming tall-skinny kernel whatever the dispatch policy says (tests)."""
     lib = load()
     if X.dim() != 2 or (X.shape[1] > 1 and X.stride(1) != 1):
         raise ValueError("X must be 2-D with unit column stride")
@@ -298,7 +300,9 @@ def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones
     if C.shape != (dd, dd) or C.stride(1) != 1:
         raise ValueError(f"C must be [{dd},{dd}] row-major, got {tuple(C.shape)}")
     ldx = X.stride(0) if rows > 1 else max(d, 1)
-    if splitk is None and lib.clo_gram_tall_supported(rows, d, int(ones_col)):
+    if force_gram_tall and not (1 <= dd <= 128):
+        raise ValueError("the tall-skinny Gram kernel needs 1 <= d + ones_col <= 128")
+    if force_gram_tall or (splitk is None and lib.clo_gram_tall_supported(rows, d, int(ones_col))):
         # tall and skinny (conv-layer factors, Hutch++ Gram passes): the streaming Gram kernel
         ws = torch.empty(lib.clo_gram_tall_ws_floats(rows, d, int(ones_col)), device=X.device, dtype=torch.float32)
         rc = lib.clo_gram_tall_f32(_p(C), C.stride(0), _p(X), rows, d, ldx, int(ones_col), alpha, beta, _p(ws),
@@ -306,7 +310,7 @@ def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones
         _check(rc, "clo_gram_tall_f32")
         return C
     if splitk is None:
-        splitk = lib.clo_gemm_suggest_splitk(dd, dd, rows, 1)
+        splitk = lib.clo_syrk_suggest_splitk(dd, rows)
     ws = torch.empty(splitk * dd * dd, device=X.device, dtype=torch.float32) if splitk > 1 else None
     rc = lib.clo_syrk_accum_f32(_p(C), C.stride(0), _p(X), rows, d, ldx, int(ones_col), alpha, beta,
                                 splitk, _p(ws), _stream())
@@ -341,7 +345,7 @@ def im2col_syrk_accum(C: Tensor, x: Tensor, kernel_size, stride, padding, dilati
     if C.shape != (dd, dd) or C.stride(1) != 1:
         raise ValueError(f"C must be a row-major [{dd}, {dd}] matrix, got {tuple(C.shape)}")
     rows = B * OH * OW
-    splitk = lib.clo_gemm_suggest_splitk(dd, dd, rows, 1) if rows > 0 else 1
+    splitk = lib.clo_syrk_suggest_splitk(dd, rows) if rows > 0 else 1
     ws = torch.empty(splitk * dd * dd, device=x.device, dtype=torch.float32) if splitk > 1 else None
     rc = lib.clo_im2col_syrk_accum_f32(_p(C), C.stride(0), _pc(x.contiguous()), B, C_, H, W, KH, KW, SH, SW,
                                        PH, PW, DH, DW, OH, OW, int(ones_col), alpha, beta, splitk, _p(ws),

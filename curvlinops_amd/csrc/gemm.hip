@@ -1111,6 +1111,20 @@ static int suggest_splitk_for(int M, int N, int K, long b, bool aligned, long ca
                                    (double)cfg.bm * cfg.bn / (128.0 * 128.0), cfg.bk == 64 ? 4 : 8, cap);
 }
 
+// Symmetric product C = X^T X (d x d from `rows` rows): only the upper-triangular tiles are computed
+// (and only they write slabs), so the split that fills the chip is about twice the one of the full
+// d x d product.  Measured (tools/probe_syrk_mid.py): 32768 x 576: 281 us at the full-product split 6,
+// 177 us at 16; 8192 x 1152: 221 -> 183 us; 2048 x 2304: 197 -> 167 us.
+extern "C" int clo_syrk_suggest_splitk(int d, long rows) {
+  if (d <= 0 || rows <= 0) return 1;
+  const int K = (int)std::min<long>(rows, 1L << 30);
+  const bool aligned = d % 4 == 0;
+  const V2Config cfg = aligned ? v2_config(d, d, K, 1, 1) : V2Config{128, 128, 32};
+  const long t = cdiv(d, cfg.bm);
+  return clo::suggest_splitk_tiles(t * (t + 1) / 2, K, (long)d * d * 6 / 10,
+                                   (double)cfg.bm * cfg.bn / (128.0 * 128.0), cfg.bk == 64 ? 4 : 8, 64);
+}
+
 extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
   // without the operands: float4-complete extents are taken as "aligned"
   return suggest_splitk_for(M, N, K, batch > 0 ? batch : 1, M % 4 == 0 && N % 4 == 0 && K % 4 == 0);

@@ -202,10 +202,19 @@ static int gram_pad(int dd) { return dd <= 16 ? 16 : 32 * (int)cdiv(dd, 32); }
 
 using namespace clo;
 
-// Worth it when the matrix is tall: rows >= 32 (d + 1) and d + 1 <= 128.
+// Worth it when the matrix is tall (rows >= 32 (d + 1), d + 1 <= 128) AND the aligned symmetric GEMM with
+// its (now symmetric-aware) split-K would not be faster.  Measured (tools/probe_gram_vs_gemm.py): up to 32
+// columns the streaming kernel wins at every height (131072 x 16: 25 vs 67 us); at 48 / 64 columns only
+// beyond ~300 k rows (131072 x 64: 122 vs 71 us; 524288 x 64: 149 vs 248 us); from 96 columns the GEMM wins
+// (131072 x 128: 278 vs 81 us).  Widths the aligned engine cannot take (d % 4 != 0, or a bias column on top
+// of an aligned d) stay here: their alternative is the scalar-load engine.
 extern "C" int clo_gram_tall_supported(long rows, int d, int ones_col) {
   const int dd = d + (ones_col ? 1 : 0);
-  return dd >= 1 && dd <= 128 && rows >= 32L * dd;
+  if (!(dd >= 1 && dd <= 128 && rows >= 32L * dd)) return 0;
+  const bool gemm_aligned = d % 4 == 0 && d >= 4;   // [X | 1] with d % 4 == 0 is also fine for the v2 loader
+  if (!gemm_aligned || dd <= 32) return 1;
+  if (dd <= 64 + 1) return rows >= 300000 ? 1 : 0;
+  return 0;
 }
 extern "C" long clo_gram_tall_ws_floats(long rows, int d, int ones_col) {
   const int dd = d + (ones_col ? 1 : 0);

@@ -70,6 +70,9 @@ int clo_gemm_f32(int M, int N, int K, float alpha,
 
 /* Suggested split-K factor for a (M,N,K,batch) problem (1 = none). */
 int clo_gemm_suggest_splitk(int M, int N, int K, int batch);
+/* The same for the symmetric product of clo_syrk_accum_f32 / clo_im2col_syrk_accum_f32 (upper-triangular
+ * tiles only: about twice the split of the full d x d product fills the chip). */
+int clo_syrk_suggest_splitk(int d, long rows);
 
 /* EKFAC eigenvalue correction (computers/ekfac_hooks.py:206-236, per-example-gradient
  * strategy without materialising the [batch, d_out, d_in] tensor):
