@@ -610,6 +610,12 @@ def compute_eigenvalue_correction(g: Tensor, Qg: Tensor, a: Tensor | None, Qa: T
         else:
             g_rot = _hip.gemm(g.reshape(V * B * S, d1).contiguous(), Qg).view(V, B, S, d1)
             a_rot = _hip.gemm(a.reshape(B * S, d2).contiguous(), Qa).view(B, S, d2)
+        if S == 1:
+            # no weight sharing: the per-example gradient is the outer product g_n a_n^T, its square the
+            # outer product of the squares -- sum_{v,n} = (sum_v g_vn^2)^T (a_n^2), ONE GEMM with K = B
+            # instead of B rank-1 products (ResNet-18 layer4 / fc, every Linear layer of an MLP)
+            g2 = g_rot.view(V, B, d1).square().sum(dim=0)
+            return _hip.gemm(g2.T, a_rot.view(B, d2).square())
         out = torch.zeros(d1, d2, device=g.device, dtype=torch.float32)
         for v in range(V):
             # per-example products P_n = g_rot_n^T a_rot_n, squared and summed over n, fused
@@ -617,6 +623,8 @@ def compute_eigenvalue_correction(g: Tensor, Qg: Tensor, a: Tensor | None, Qa: T
         return out
     g_rot = g if identity else g @ Qg
     a_rot = a if identity else a @ Qa
+    if S == 1:
+        return (g_rot.reshape(V, B, d1).square().sum(dim=0)).T @ a_rot.reshape(B, d2).square()
     per_example = torch.einsum("vnsi,nsj->vnij", g_rot, a_rot)
     return per_example.square_().sum(dim=(0, 1))
 
