@@ -13,6 +13,7 @@ from torch import nn
 
 import curvlinops_amd as C
 
+WIDE = float(os.environ.get("CLO_FUZZ_WIDE", "0.0"))  # fraction of cases with layers up to 1600 wide
 ACTS = [nn.ReLU, nn.Tanh, nn.Sigmoid, None]
 LOSSES = {"mse": nn.MSELoss, "ce": nn.CrossEntropyLoss, "bce": nn.BCEWithLogitsLoss}
 
@@ -20,7 +21,11 @@ LOSSES = {"mse": nn.MSELoss, "ce": nn.CrossEntropyLoss, "bce": nn.BCEWithLogitsL
 def _one_case(case: int, rng, dev, failures: list) -> float:
     L = int(rng.integers(1, 5))
     align = rng.random() < 0.5
-    dims = [int(rng.integers(1, 40)) * 4 if align else int(rng.integers(2, 150)) for _ in range(L + 1)]
+    wide = rng.random() < WIDE
+    if wide:  # wide layers: several K ranges / split-K slabs per kernel
+        dims = [int(rng.integers(4, 400)) * 4 for _ in range(L + 1)]
+    else:
+        dims = [int(rng.integers(1, 40)) * 4 if align else int(rng.integers(2, 150)) for _ in range(L + 1)]
     if rng.random() < 0.5:
         dims[-1] = int(rng.integers(1, 17))
     bias = bool(rng.random() < 0.8)
@@ -38,7 +43,7 @@ def _one_case(case: int, rng, dev, failures: list) -> float:
     loss = LOSSES[lossname](reduction=red)
     data = []
     for _ in range(int(rng.integers(1, 4))):
-        N = int(rng.choice([1, 3, 8, 9, 16, 17, 24, 33, 64, 70]))
+        N = int(rng.choice([1, 3, 8, 9, 13, 16, 17, 24, 31, 32, 33, 64, 70]))
         X = torch.rand(N, dims[0], device=dev) - 0.5
         y = torch.randint(0, dims[-1], (N,), device=dev) if lossname == "ce" else torch.rand(N, dims[-1], device=dev)
         data.append((X, y))
