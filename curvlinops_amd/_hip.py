@@ -50,6 +50,8 @@ _SIGNATURES = {
     "clo_cholesky_inverse_batched_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                                  _PF, c_void_p, c_void_p]),
     "clo_cholesky_inverse_batched_ws_floats": (c_long, [c_int, c_int]),
+    "clo_sytrd_f32": (c_int, [_PF, c_long, c_int, _PF, _PF, _PF, _PF, c_long, c_void_p]),
+    "clo_sytrd_ws_bytes": (c_long, [c_int]),
     "clo_im2col_syrk_accum_f32": (
         c_int,
         [_PF, c_long, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -407,6 +409,22 @@ def cholesky_inverse_batched_into(As: list[Tensor], dampings: list[float], outs:
     rc = lib.clo_cholesky_inverse_batched_f32(a_ptrs, ldas, o_ptrs, ldos, n, nb, damps, _p(ws), status.data_ptr(),
                                               _stream())
     _check(rc, "clo_cholesky_inverse_batched_f32")
+
+
+def sytrd_(A: Tensor, n: int) -> tuple[Tensor, Tensor, Tensor]:
+    """In-place Householder tridiagonalisation of the symmetric matrix in ``A[:n, :n]`` (``clo_sytrd_f32``).
+    ``A``: fp32 GPU tensor ``[>= n, ld]`` with ``ld % 4 == 0`` and zero padding columns.  Returns
+    ``(D, E, tau)``; afterwards ``A`` holds the Householder vectors in LAPACK's ``uplo='L'`` layout of
+    the column-major matrix."""
+    lib = load()
+    D = torch.empty(n, device=A.device, dtype=torch.float32)
+    E = torch.empty(n, device=A.device, dtype=torch.float32)
+    tau = torch.empty(n, device=A.device, dtype=torch.float32)
+    nbytes = lib.clo_sytrd_ws_bytes(n)
+    ws = torch.zeros(nbytes // 4, device=A.device, dtype=torch.float32)
+    rc = lib.clo_sytrd_f32(_p(A), A.stride(0), n, _p(D), _p(E), _p(tau), _p(ws), nbytes, _stream())
+    _check(rc, "clo_sytrd_f32")
+    return D, E, tau
 
 
 def not_pd_error(pivot: int, n: int) -> RuntimeError:

@@ -8,12 +8,14 @@ factorisation fails.  ``eigh`` replaces ``torch.linalg.eigh`` at ``kronecker.py:
 
 fp32 GPU inputs: the Cholesky inverse runs on the hand-written kernels (``csrc/linalg.hip`` for
 the diagonal blocks, the MFMA GEMM of ``csrc/gemm.hip`` for every O(n^3) step; driver
-``_hip.cholesky_inverse``).  The symmetric eigensolver is NOT native yet: ``eigh`` calls
-``torch.linalg.eigh`` on the tensor's device (rocSOLVER on the GPU) -- see DESIGN.md, open items.
+``_hip.cholesky_inverse``).  The symmetric eigensolver defaults to ``torch.linalg.eigh`` (rocSOLVER);
+``eigh_sytrd`` is the same decomposition on the hand-written Householder reduction
+(``csrc/sytrd.hip``), selected with ``CLO_EIGH=sytrd|auto`` -- measured in DESIGN.md section 7.
 """
 
 from __future__ import annotations
 
+import os
 from contextlib import contextmanager
 from warnings import warn
 
@@ -277,10 +279,41 @@ def damped_cholesky_inverse(A: Tensor, damping: float, retry_double_precision: b
         return _torch_damped_cholesky_inverse(A.to(torch.float64), damping).to(A.dtype)
 
 
+# Which solver :func:`eigh` uses for fp32 GPU matrices: "rocsolver" (torch.linalg.eigh; default), "sytrd" (the
+# hand-written tridiagonalisation clo_sytrd_f32 + rocSOLVER's tridiagonal divide & conquer and
+# back-transformation) or "auto" (own reduction where it measured faster: single matrices of order
+# 256..2400).
+_EIGH_MODE = os.environ.get("CLO_EIGH", "rocsolver").lower()
+_SYTRD_MAX_N = 8184
+
+
+def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
+    """Symmetric eigendecomposition with the hand-written Householder reduction: ``clo_sytrd_f32`` (one launch
+    per column) -> rocSOLVER ``sstedc`` on the tridiagonal matrix -> ``sormtr``.  fp32 GPU matrices of order
+    3..8184; same conventions as ``torch.linalg.eigh`` (ascending eigenvalues, eigenvectors in columns)."""
+    from . import _rocsolver
+
+    n = A.shape[0]
+    if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == n and 3 <= n <= _SYTRD_MAX_N):
+        raise ValueError(f"eigh_sytrd: need a square fp32 GPU matrix of order 3..{_SYTRD_MAX_N}, got {tuple(A.shape)} {A.dtype}")
+    ld = (n + 3) // 4 * 4
+    work = torch.zeros(n, ld, device=A.device, dtype=torch.float32)   # zero padding columns
+    work[:, :n].copy_(A)
+    D, E, tau = _hip.sytrd_(work, n)
+    Z = torch.empty(n, ld, device=A.device, dtype=torch.float32)      # column-major eigenvectors
+    info = _rocsolver.stedc_(D, E, Z, n)
+    _rocsolver.ormtr_(work, tau, Z, n)
+    if int(info) != 0:
+        raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
+    return D, Z[:, :n].T
+
+
 def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
     """Eigenvalues (ascending) and orthonormal eigenvectors (columns) of symmetric ``A``."""
-    if is_native_tensor(A) and _hip.has("clo_eigh_f32"):
-        return _hip.eigh(A)
+    if _EIGH_MODE != "rocsolver" and A.is_cuda and A.dtype == torch.float32 and A.dim() == 2:
+        n = A.shape[0]
+        if 3 <= n <= _SYTRD_MAX_N and (_EIGH_MODE == "sytrd" or 256 <= n <= 2400):
+            return eigh_sytrd(A)
     res = torch.linalg.eigh(A)
     return res.eigenvalues, res.eigenvectors
 
@@ -315,7 +348,7 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
     units.sort(key=lambda u: -len(u) * mats[u[0]].shape[0] ** 3)
 
     def run(unit: list[int]) -> None:
-        if len(unit) == 1 or _hip.has("clo_eigh_f32"):
+        if len(unit) == 1:
             for i in unit:
                 out[i] = eigh(mats[i])
             return

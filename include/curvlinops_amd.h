@@ -150,6 +150,18 @@ int clo_cholesky_inverse_batched_f32(const float *const *A, const long *lda, flo
                                      float *ws, int *status, void *stream);
 long clo_cholesky_inverse_batched_ws_floats(int n, int batch);
 
+/* Householder reduction of a symmetric matrix to tridiagonal form, the 85 % of the reference's
+ * torch.linalg.eigh (kronecker.py:294-301 eigendecomposed Kronecker factors; ekfac.py's eigenbases) that
+ * rocSOLVER runs as ~5 dependent kernels per column; here one launch per column plus one MFMA rank-128
+ * update per 64 columns.  A: row-major [n][lda] FULL symmetric matrix, 16-byte aligned rows zero-padded to a
+ * multiple of 4 columns; overwritten.  On return, LAPACK ssytrd(uplo='L') storage of the column-major
+ * (== row-major, symmetric) matrix: row j, columns j+2.. = Householder vector j (unit entry at j+1 implied),
+ * D[n] / E[n-1] the tridiagonal matrix, tau[n-1] the reflector scales -- the inputs of sstedc / sormtr.
+ * 3 <= n <= 8184.  ws: clo_sytrd_ws_bytes(n) bytes, 16-byte aligned. */
+int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, float *tau, float *ws, long ws_bytes,
+                  void *stream);
+long clo_sytrd_ws_bytes(int n);
+
 /* ------------------------------------------------------------------------- *
  * MLP fast path (Sequential of Linear + elementwise activation), one mini-batch,
  * K = 1 column.  All activations are row-major [N][d].

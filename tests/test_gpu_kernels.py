@@ -589,3 +589,110 @@ def test_im2col_syrk_fused_matches_materialised(B, C_, H, W, k, s, p, d, ones):
     assert rel_err(Cf.cpu(), Cm.double().cpu().numpy()) < 2e-5
     _hip.im2col_syrk_accum(Cf, x, k, s, p, d, alpha=0.25, beta=1.0, ones_col=ones)
     assert rel_err(Cf.cpu(), (0.75 * ref).cpu().numpy()) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# Householder tridiagonalisation (clo_sytrd_f32) and the eigensolver built on it
+# ---------------------------------------------------------------------------------------------
+def _sym_case(kind: str, n: int, dev):
+    g = torch.Generator(device="cpu").manual_seed(1000 + n)
+    if kind == "full":
+        X = torch.randn(n + 5, n, generator=g, dtype=torch.float64)
+        A = X.T @ X / (n + 5)
+    elif kind == "lowrank":   # a Kronecker factor of a batch with fewer rows than features
+        r = max(2, n // 5)
+        X = torch.randn(r, n, generator=g, dtype=torch.float64) * torch.logspace(0, -3, n, dtype=torch.float64)
+        A = X.T @ X / r
+    elif kind == "indefinite":
+        X = torch.randn(n, n, generator=g, dtype=torch.float64)
+        A = 0.5 * (X + X.T)
+    elif kind == "diagonal":
+        A = torch.diag(torch.linspace(-1.0, 2.0, n, dtype=torch.float64))
+    elif kind == "zero":
+        A = torch.zeros(n, n, dtype=torch.float64)
+    else:
+        raise ValueError(kind)
+    return A
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["full", "lowrank", "indefinite", "diagonal", "zero"])
+@pytest.mark.parametrize("n", [3, 4, 7, 64, 66, 67, 130, 333, 1030])
+def test_eigh_sytrd(hip, kind, n):
+    """eigh_sytrd (clo_sytrd_f32 -> sstedc -> sormtr) against float64 LAPACK: eigenvalues, residual
+    |A Q - Q diag(lam)| and orthogonality |Q^T Q - I|, all <= 1e-5 relative to |A| (the tolerance the
+    fp32 rocSOLVER path of torch.linalg.eigh meets on the same matrices)."""
+    from curvlinops_amd.linalg_native import eigh_sytrd
+
+    dev = torch.device("cuda:0")
+    A64 = _sym_case(kind, n, dev)
+    A = A64.to(dev, torch.float32)
+    lam, Q = eigh_sytrd(A)
+    ref = torch.linalg.eigvalsh(A64)
+    scale = max(float(A64.abs().max()), 1e-30) if kind != "zero" else 1.0
+    lam64, Q64 = lam.double().cpu(), Q.double().cpu()
+    assert torch.all(lam64[1:] >= lam64[:-1] - 1e-6 * scale)
+    assert float((lam64 - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), scale)
+    assert float((A64 @ Q64 - Q64 * lam64).abs().max()) <= 1e-5 * scale * max(1.0, n ** 0.5 / 8)
+    assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-5
+    # the input is not modified
+    assert torch.equal(A.cpu(), A64.float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [24, 200, 1500])
+def test_sytrd_is_a_similarity_transform(hip, n):
+    """The tridiagonal matrix (d, e) of clo_sytrd_f32 has the spectrum of the input (the entries themselves
+    are not forward-stable for later columns, only the first ones are compared with rocSOLVER's ssytrd,
+    which follows the same LAPACK sign convention)."""
+    import ctypes
+
+    from curvlinops_amd import _rocsolver
+
+    dev = torch.device("cuda:0")
+    A64 = _sym_case("indefinite", n, dev)
+    ld = (n + 3) // 4 * 4
+
+    def padded():
+        P = torch.zeros(n, ld, device=dev)
+        P[:, :n] = A64.float().to(dev)
+        return P
+
+    A = padded()
+    D, E, tau = hip.sytrd_(A, n)
+    T = torch.diag(D.double().cpu()) + torch.diag(E[: n - 1].double().cpu(), 1) + torch.diag(E[: n - 1].double().cpu(), -1)
+    ref = torch.linalg.eigvalsh(A64)
+    assert float((torch.linalg.eigvalsh(T) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float(tau[: n - 2].min()) >= 0.0 and float(tau[: n - 2].max()) <= 2.0   # reflector scales
+    _, rs = _rocsolver._load()
+    rs.rocsolver_ssytrd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    Ar = padded()
+    Dr, Er, taur = (torch.empty(n, device=dev) for _ in range(3))
+    assert rs.rocsolver_ssytrd(_rocsolver._handle(dev), 122, n, Ar.data_ptr(), ld, Dr.data_ptr(), Er.data_ptr(),
+                               taur.data_ptr()) == 0
+    torch.cuda.synchronize()
+    sc = float(A64.abs().max())
+    k = 8
+    assert float((D[:k] - Dr[:k]).abs().max()) <= 1e-4 * sc
+    assert float((E[:k] - Er[:k]).abs().max()) <= 1e-4 * sc
+    assert float((tau[:k] - taur[:k]).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_eigh_mode_switch(hip, monkeypatch):
+    """CLO_EIGH=sytrd routes linalg_native.eigh through the hand-written reduction; the default stays on
+    torch.linalg.eigh.  Both give the same spectrum."""
+    from curvlinops_amd import linalg_native as L
+
+    dev = torch.device("cuda:0")
+    A = _sym_case("lowrank", 300, dev).to(dev, torch.float32)
+    lam0, _ = L.eigh(A)
+    monkeypatch.setattr(L, "_EIGH_MODE", "sytrd")
+    calls = []
+    real = L.eigh_sytrd
+    monkeypatch.setattr(L, "eigh_sytrd", lambda M: (calls.append(1), real(M))[1])
+    lam1, Q1 = L.eigh(A)
+    assert calls == [1]
+    assert float((lam0 - lam1).abs().max()) <= 1e-5 * float(lam0.abs().max())
+    assert float((A @ Q1 - Q1 * lam1).abs().max()) <= 1e-5 * float(A.abs().max())
