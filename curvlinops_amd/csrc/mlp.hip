@@ -1192,9 +1192,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// 9 ... 32 batch rows: the weight-streaming chain with MFMA tiles in EVERY kernel (the VALU backward
+// 9 ... 64 batch rows: the weight-streaming chain with MFMA tiles in EVERY kernel (the VALU backward
 // kernels above keep 8 rows of accumulators per lane and stop there; the GEMM engine needs a dozen
-// launches on 128-wide tiles that are mostly padding at these sizes).  Npad = 16 NT rows, NT = 1, 2.
+// launches on 128-wide tiles that are mostly padding at these sizes).  Npad = 16 NT rows, NT = 1 ... 4.
 //   mid_fwd_kernel        forward + JVP: A = [8 rows of W ; 8 rows of V] straight from global memory,
 //                         B = 16 batch rows of a (and of da) from LDS: acc1 = [W a ; V a], acc2 = [W da ; -]
 //   head_fwd_kernel       slab sum + bias / activation (+ partial products of a narrow head)
@@ -1202,7 +1202,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
 //   mid_dprev_kernel      delta_{l-1} slabs: A = delta^T from LDS, B = 4 rows x 64 columns of W per load
 //   mid_outer_kernel      out_W_l = beta out_W_l + delta_l^T a_{l-1} for all layers, 16 x 64 MFMA tiles
 // ------------------------------------------------------------------------------------------
-constexpr int MID_LDD = 48;  // row stride of [row][Npad] delta tiles in LDS (conflict-free ds_read_b32)
+// row stride of [row][Npad] delta tiles in LDS: Npad + 16 (conflict-free ds_read_b32 across the 4 k-groups)
+constexpr int mid_ldd(int NT) { return NT <= 2 ? 48 : 80; }
 
 template <int NT, bool HAS_DA, int WV>
 __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
@@ -1327,7 +1328,7 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
     }
 }
 
-// delta_{l-1} slabs for up to 32 rows: P[by][n][i] = sum_{j in rows(by)} delta[n][j] W[j][i].
+// delta_{l-1} slabs for up to 64 rows: P[by][n][i] = sum_{j in rows(by)} delta[n][j] W[j][i].
 // grid = (column chunks of 256, JB row ranges); 8 waves = 4 column quarters x 2 row halves (merged in LDS).
 struct MidDelta {            // where delta_l comes from
   const float *delta;        // [N][ld] final (ld = d_out unless ld_delta is set), or null
@@ -1361,7 +1362,7 @@ template <int NT>
 __global__ __launch_bounds__(512) void mid_dprev_kernel(
     const float *__restrict__ W, const MidDelta md, const float *__restrict__ dphi_prev,
     float *__restrict__ dst, int N, int d_in, int d_out, int rows_per_block, int final_write) {
-  constexpr int NP = 16 * NT;
+  constexpr int NP = 16 * NT, MID_LDD = mid_ldd(NT);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_d = smem;                                  // [rows_per_block (padded to 8)][MID_LDD]
   const int rpad = (rows_per_block + 7) & ~7;
@@ -1453,7 +1454,7 @@ __global__ __launch_bounds__(512) void mid_dprev_kernel(
     }
 }
 
-// All outer products of a matvec for up to 32 rows: out_W_l = beta out_W_l + alpha delta_l^T a_{l-1}, bias
+// All outer products of a matvec for up to 64 rows: out_W_l = beta out_W_l + alpha delta_l^T a_{l-1}, bias
 // gradients = column sums of delta_l.  Block = 64 rows x 256 columns, 8 waves = 4 column quarters x 2
 // row halves, each wave 2 x (16 x 64) MFMA tiles with K = the batch rows.
 constexpr int MIDO_ROWS = 64;
@@ -1468,21 +1469,25 @@ struct MidOuterArgs {
   float alpha, beta;
   int N;
 };
-template <int NT, bool ACCUM>
+// CW = columns per block (256: 4 column quarters x 2 row halves of two 16-row tiles; 128 beyond 32 batch rows
+// -- 2 column halves x 4 row quarters of one tile -- so that three blocks still fit a CU's LDS).
+template <int NT, bool ACCUM, int CW>
 __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
   constexpr int NP = 16 * NT;
+  constexpr int NCQ = CW / 64, NRH = 8 / NCQ, RT = MIDO_ROWS / (16 * NRH);
   constexpr int LDR = MIDO_ROWS + 16;  // [NP][rows + 16]: conflict-free A-operand reads
-  __shared__ __attribute__((aligned(16))) float s_dT[NP * LDR];
-  __shared__ __attribute__((aligned(16))) float s_a[NP * 256];
+  extern __shared__ __attribute__((aligned(16))) float smem_o[];
+  float *s_dT = smem_o;              // [NP][LDR]
+  float *s_a = smem_o + NP * LDR;    // [NP][CW]
   int l = 0;
   while (l + 1 < p.nlayers && (int)blockIdx.x >= p.first_block[l + 1]) ++l;
   const int local = blockIdx.x - p.first_block[l];
   const int d_in = p.d_in[l], d_out = p.d_out[l], N = p.N;
-  const int cchunks = (d_in + 255) / 256;
+  const int cchunks = (d_in + CW - 1) / CW;
   const int bx = local % cchunks, by = local / cchunks;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cq = wave & 3, rh = wave >> 2;
+  const int cq = wave % NCQ, rh = wave / NCQ;
   const int l16 = lane & 15, kg = lane >> 4;
   const int jbase = by * MIDO_ROWS;
   // stage delta^T [n][row] and a [n][256 columns]
@@ -1490,12 +1495,12 @@ __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
     const int n = e / MIDO_ROWS, jj = e - n * MIDO_ROWS;
     s_dT[n * LDR + jj] = mid_delta_at<NT>(p.md[l], n, jbase + jj, N, d_out);
   }
-  for (int e = tid; e < NP * 64; e += 512) {
-    const int n = e >> 6, c4 = (e & 63) * 4;
-    const int i = bx * 256 + c4;
+  for (int e = tid; e < NP * (CW / 4); e += 512) {
+    const int n = e / (CW / 4), c4 = (e % (CW / 4)) * 4;
+    const int i = bx * CW + c4;
     float4 v = zero4();
     if (n < N && i < d_in) v = ld4(p.a_prev[l] + (long)n * d_in + i);
-    *reinterpret_cast<float4 *>(&s_a[n * 256 + c4]) = v;
+    *reinterpret_cast<float4 *>(&s_a[n * CW + c4]) = v;
   }
   __syncthreads();
   if (p.out_b[l] && bx == 0 && tid < MIDO_ROWS && jbase + tid < d_out) {
@@ -1504,17 +1509,17 @@ __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
     float *pb = p.out_b[l] + jbase + tid;
     *pb = (ACCUM ? p.beta * *pb : 0.f) + p.alpha * sb;
   }
-  f32x4 acc[2][4];
+  f32x4 acc[RT][4];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[rt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < NP / 4; ++s) {
-    const float4 bv = *reinterpret_cast<const float4 *>(&s_a[(4 * s + kg) * 256 + cq * 64 + l16 * 4]);
+    const float4 bv = *reinterpret_cast<const float4 *>(&s_a[(4 * s + kg) * CW + cq * 64 + l16 * 4]);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const float av = s_dT[(4 * s + kg) * LDR + rh * 32 + rt * 16 + l16];
+    for (int rt = 0; rt < RT; ++rt) {
+      const float av = s_dT[(4 * s + kg) * LDR + (rh * RT + rt) * 16 + l16];
       acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[rt][0], 0, 0, 0);
       acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[rt][1], 0, 0, 0);
       acc[rt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[rt][2], 0, 0, 0);
@@ -1522,14 +1527,14 @@ __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
     }
   }
   // D[row = 4 q + r][column l16 of component e] -> out_W[jbase + rh 32 + rt 16 + 4 q + r][i0 + e]
-  const int i0 = bx * 256 + cq * 64 + l16 * 4;
+  const int i0 = bx * CW + cq * 64 + l16 * 4;
   if (i0 >= d_in) return;
   const int q = lane >> 4;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j = jbase + rh * 32 + rt * 16 + q * 4 + r;
+      const int j = jbase + (rh * RT + rt) * 16 + q * 4 + r;
       if (j < d_out) {
         float4 v = make_float4(p.alpha * acc[rt][0][r], p.alpha * acc[rt][1][r], p.alpha * acc[rt][2][r],
                                p.alpha * acc[rt][3][r]);
@@ -1541,6 +1546,23 @@ __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
         CLO_STW(po, v);
       }
     }
+}
+
+// delta_l [N][d] = (sum of the row-range slabs of mid_dprev_kernel) x act'(z_l): beyond 32 batch rows the
+// consumers (the next mid_dprev launch and mid_outer_kernel, one block per column chunk each) would
+// otherwise re-add the slabs d_in / 256 times over.
+__global__ __launch_bounds__(256) void mid_delta_finish_kernel(const float *__restrict__ slabs, int njb,
+                                                               long slab_stride, const float *__restrict__ dphi,
+                                                               float *__restrict__ out, long total4) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total4) return;
+  float4 acc = zero4();
+  for (int jb = 0; jb < njb; ++jb) {
+    const float4 v = ld4(slabs + (long)jb * slab_stride + 4 * e);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const float4 dp = ld4(dphi + 4 * e);
+  st4(out + 4 * e, make_float4(acc.x * dp.x, acc.y * dp.y, acc.z * dp.z, acc.w * dp.w));
 }
 
 // head_bwd_kernel for more than NB rows, one block per (256-column chunk, NB-row chunk): merge the head
@@ -2465,11 +2487,11 @@ extern "C" int clo_mlp_bwd_layer(const float *W, const float *delta, const float
 }
 
 // ------------------------------------------------------------------------------------------
-// 9 ... 32 rows, narrow linear head, float4-complete layers: the MFMA streaming chain (mid_* kernels).
+// 9 ... 64 rows, narrow linear head, float4-complete layers: the MFMA streaming chain (mid_* kernels).
 // Scratch comes out of the GEMM slab area `gws` (unused on this path): forward slabs | head partials |
 // two regions of delta slabs (ping-pong over the layers).
 // ------------------------------------------------------------------------------------------
-constexpr int MID_MAX_N = 32;
+constexpr int MID_MAX_N = 64;
 
 static bool mid_chain_ok(int L, const int *dims, const float *const *W, const float *const *VW,
                          float *const *OW, int N) {
@@ -2495,13 +2517,16 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   const int head_nblk = (int)cdiv(dh, 256);
   // carve gws
   float *fslab = gws;
-  const long fslab_sz = 32L * 2 * NP * dmax;          // up to 32 K ranges
+  // the GEMM workspace this chain borrows holds 4096 dmax floats: 32 K ranges / 24 row ranges of up to 32
+  // padded rows, half as many of 48 / 64
+  constexpr long KS_MAX = NT <= 2 ? 32 : 16, JB_MAX = NT <= 2 ? 24 : 12;
+  const long fslab_sz = KS_MAX * 2 * NP * dmax;
   float *hp = fslab + fslab_sz;
   const long hp_sz = (long)N * head_nblk * 2 * HEAD_CMAX + 64;
   float *dLbuf = hp + hp_sz;                          // [N][HEAD_CMAX] delta of the head
   const long dL_sz = (long)NP * HEAD_CMAX;
-  float *dslab[2] = {dLbuf + dL_sz, dLbuf + dL_sz + 24L * NP * dmax};
-  if (fslab_sz + hp_sz + dL_sz + 2 * 24L * NP * dmax > gws_sz) return CLO_EUNSUP;
+  float *dslab[2] = {dLbuf + dL_sz, dLbuf + dL_sz + JB_MAX * NP * dmax};
+  if (fslab_sz + hp_sz + dL_sz + 2 * JB_MAX * NP * dmax > gws_sz) return CLO_EUNSUP;
   int rc;
   // ---- forward + JVP: hidden layers 1 .. L-1
   for (int l = 1; l <= L - 1; ++l) {
@@ -2511,33 +2536,36 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     // Besides the weights a launch moves the activations every block stages (row blocks x cols x d_in) and
     // the split-K slabs (written here, read by the finish): both cost like weight bytes.  Pick waves per
     // block (4 / 8 = 64 / 128 features) and the K split that minimise them at >= ~0.8 blocks per CU.
-    const long kpb_max = std::min<long>(MF_KB_MAX, ((65536 / (4 * cols) - 4) / 32) * 32);
+    const long lds_b = NT <= 2 ? 65536 : 131072;   // the staged activations: one block per CU beyond 32 rows
+    const long kpb_max = std::min<long>(MF_KB_MAX, ((lds_b / (4 * cols) - 4) / 32) * 32);
     int wv = 4;
     long ksplit = 1, kpb = 32;
     double best = 1e300;
     for (int w : {4, 8}) {
       const long rb = cdiv(dout, w * 16);
-      for (long ks = 1; ks <= 32; ++ks) {
+      for (long ks = 1; ks <= KS_MAX; ++ks) {
         const long kp = cdiv(cdiv(di, ks), 32) * 32;
         if (kp > kpb_max) continue;
         const long kse = cdiv(di, kp);
         const long blocks = rb * kse;
-        if (blocks * 5 < kNumCU * 4 && !(ks == 32 && best == 1e300)) continue;
+        if (blocks * 5 < kNumCU * 4 && !(ks == KS_MAX && best == 1e300)) continue;
         const double traffic = (double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout;
         if (traffic < best) { best = traffic; wv = w; ksplit = kse; kpb = kp; }
       }
     }
-    if (best == 1e300 || ksplit > 32) return CLO_EUNSUP;
+    if (best == 1e300 || ksplit > KS_MAX) return CLO_EUNSUP;
     const long row_blocks = cdiv(dout, wv * 16);
     const size_t smem = (size_t)cols * (kpb + 4) * sizeof(float);
     dim3 grid((unsigned)row_blocks, (unsigned)ksplit), block(wv * 64);
     {
       ProfScope prof(0, 8.0 * di * dout, st);
 #define CLO_MIDF(DA, WVV)                                                                                  \
+  rc = set_smem(mid_fwd_kernel<NT, DA, WVV>, smem);                                                        \
+  if (rc != CLO_OK) return rc;                                                                             \
   hipLaunchKernelGGL((mid_fwd_kernel<NT, DA, WVV>), grid, block, smem, st, W[l - 1], VW[l - 1], a[l - 1],  \
                      DA ? da[l - 1] : nullptr, fslab, N, di, dout, (int)kpb)
-      if (has_da) { if (wv == 8) CLO_MIDF(true, 8); else CLO_MIDF(true, 4); }
-      else { if (wv == 8) CLO_MIDF(false, 8); else CLO_MIDF(false, 4); }
+      if (has_da) { if (wv == 8) { CLO_MIDF(true, 8); } else { CLO_MIDF(true, 4); } }
+      else { if (wv == 8) { CLO_MIDF(false, 8); } else { CLO_MIDF(false, 4); } }
 #undef CLO_MIDF
       CLO_CHECK_LAUNCH("mid_fwd_kernel");
     }
@@ -2578,13 +2606,13 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   for (int l = L - 1; l >= 2; --l) {
     const int di = dims[l - 1], dout = dims[l];
     long JB = cdiv(kNumCU, cdiv(di, 256));
-    JB = std::min<long>({JB, cdiv(dout, 64), 24L});
-    JB = std::max<long>(JB, cdiv(dout, 512));
+    JB = std::min<long>({JB, cdiv(dout, 64), JB_MAX});
+    JB = std::max<long>(JB, cdiv(dout, NT <= 2 ? 512 : 256));   // LDS: rows x (Npad + 16) delta + merge buffer
     const int rpb = (int)(cdiv(cdiv(dout, JB), 8) * 8);
     const int JBe = (int)cdiv(dout, rpb);
-    if (JBe > 24) return CLO_EUNSUP;
+    if (JBe > JB_MAX) return CLO_EUNSUP;
     float *slab = dslab[l & 1];
-    const size_t smem = ((size_t)((rpb + 7) & ~7) * MID_LDD + NT * 4096) * sizeof(float);
+    const size_t smem = ((size_t)((rpb + 7) & ~7) * mid_ldd(NT) + NT * 4096) * sizeof(float);
     rc = set_smem(mid_dprev_kernel<NT>, smem);
     if (rc != CLO_OK) return rc;
     const int fin = JBe == 1 ? 1 : 0;
@@ -2592,10 +2620,19 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     hipLaunchKernelGGL((mid_dprev_kernel<NT>), dim3((unsigned)cdiv(di, 256), (unsigned)JBe), dim3(512), smem, st,
                        W[l - 1], md[l], dphi[l - 1], fin ? dl[l - 1] : slab, N, di, dout, rpb, fin);
     CLO_CHECK_LAUNCH("mid_dprev_kernel");
-    md[l - 1] = fin ? MidDelta{dl[l - 1], nullptr, nullptr, 0, 0} : MidDelta{nullptr, slab, dphi[l - 1], JBe, 0};
+    if (!fin && NT > 2) {   // one pass over the slabs instead of one per consumer block
+      const long total4 = (long)N * di / 4;
+      hipLaunchKernelGGL(mid_delta_finish_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st, slab, JBe,
+                         (long)NP * di, dphi[l - 1], dl[l - 1], total4);
+      CLO_CHECK_LAUNCH("mid_delta_finish_kernel");
+      md[l - 1] = MidDelta{dl[l - 1], nullptr, nullptr, 0, 0};
+    } else {
+      md[l - 1] = fin ? MidDelta{dl[l - 1], nullptr, nullptr, 0, 0} : MidDelta{nullptr, slab, dphi[l - 1], JBe, 0};
+    }
   }
   // ---- all outer products of the hidden layers in one launch
   {
+    constexpr int OCW = NT <= 2 ? 256 : 128;
     MidOuterArgs oa{};
     oa.nlayers = L; oa.alpha = 1.f; oa.beta = beta; oa.N = N;
     md[L] = MidDelta{dLbuf, nullptr, nullptr, 0, HEAD_CMAX};  // the head's delta, [N][HEAD_CMAX]
@@ -2607,13 +2644,17 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
       oa.md[k] = md[l]; oa.a_prev[k] = a[l - 1];
       oa.out_W[k] = OW[l - 1]; oa.out_b[k] = Ob ? Ob[l - 1] : nullptr;
       oa.d_in[k] = dims[l - 1]; oa.d_out[k] = dims[l];
-      nb += (int)(cdiv(dims[l - 1], 256) * cdiv(dims[l], MIDO_ROWS));
+      nb += (int)(cdiv(dims[l - 1], OCW) * cdiv(dims[l], MIDO_ROWS));
       bytes += 4.0 * dims[l - 1] * dims[l] * (beta != 0.f ? 2 : 1);
     }
     oa.first_block[L] = nb;
     ProfScope prof(4, bytes, st);
-    if (beta != 0.f) hipLaunchKernelGGL((mid_outer_kernel<NT, true>), dim3(nb), dim3(512), 0, st, oa);
-    else hipLaunchKernelGGL((mid_outer_kernel<NT, false>), dim3(nb), dim3(512), 0, st, oa);
+    const size_t osmem = (size_t)NP * (MIDO_ROWS + 16 + OCW) * sizeof(float);
+    rc = beta != 0.f ? set_smem(mid_outer_kernel<NT, true, OCW>, osmem)
+                     : set_smem(mid_outer_kernel<NT, false, OCW>, osmem);
+    if (rc != CLO_OK) return rc;
+    if (beta != 0.f) hipLaunchKernelGGL((mid_outer_kernel<NT, true, OCW>), dim3(nb), dim3(512), osmem, st, oa);
+    else hipLaunchKernelGGL((mid_outer_kernel<NT, false, OCW>), dim3(nb), dim3(512), osmem, st, oa);
     CLO_CHECK_LAUNCH("mid_outer_kernel");
   }
   return CLO_OK;
@@ -2708,10 +2749,13 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   float *hp = nullptr;
   int head_nblk = 0;
   if (narrow && mid_chain_ok(L, dims, W, VW, OW, N)) {
-    rc = N <= 16 ? mid_chain<1>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank,
-                                loss_scale * alpha, beta, a, da, dphi, dl, gws, gws_sz, st)
-                 : mid_chain<2>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank,
-                                loss_scale * alpha, beta, a, da, dphi, dl, gws, gws_sz, st);
+#define CLO_MID_CHAIN(T)                                                                              \
+  mid_chain<T>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank, loss_scale * alpha, beta, \
+               a, da, dphi, dl, gws, gws_sz, st)
+    static const int mid_max = getenv("CLO_MLP_MID_MAX") ? atoi(getenv("CLO_MLP_MID_MAX")) : MID_MAX_N;
+    rc = N > mid_max ? CLO_EUNSUP
+         : N <= 16 ? CLO_MID_CHAIN(1) : N <= 32 ? CLO_MID_CHAIN(2) : N <= 48 ? CLO_MID_CHAIN(3) : CLO_MID_CHAIN(4);
+#undef CLO_MID_CHAIN
     if (rc != CLO_EUNSUP) return rc;
   }
   // ---- forward + JVP

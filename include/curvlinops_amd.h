@@ -208,7 +208,7 @@ long clo_mlp_bwd_ws_floats(int N, int d_in, int d_out);
  *   W,b,VW,Vb,OW,Ob  host arrays of L device pointers (b/Vb/Ob entries may be NULL)
  *   X [N][d_0]   input batch;  loss_kind/aux/loss_scale as clo_loss_hessian_apply
  *   ws           workspace of clo_mlp_ggn_ws_floats(L, dims, N) floats
- * Works for any N: <= 8 rows on the VALU/MFMA streaming chain, 9 ... 32 rows on its all-MFMA variant
+ * Works for any N: <= 8 rows on the VALU/MFMA streaming chain, 9 ... 64 rows on its all-MFMA variant
  * (narrow head, float4-complete layers), otherwise on the MFMA GEMM engine. */
 int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
                        const float *const *W, const float *const *b,

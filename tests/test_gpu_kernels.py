@@ -298,9 +298,9 @@ def test_ggn_matvec_large_layers(hip, N):
 
 
 @pytest.mark.parametrize("loss", ["mse", "ce", "bce"])
-@pytest.mark.parametrize("N", [9, 12, 16, 17, 25, 32])
+@pytest.mark.parametrize("N", [9, 12, 16, 17, 25, 32, 33, 40, 48, 49, 57, 64])
 def test_ggn_matvec_mid_rows_chain(hip, N, loss):
-    """9 ... 32 rows: the MFMA streaming chain (mid_fwd / head / mid_dprev / mid_outer kernels) against
+    """9 ... 64 rows: the MFMA streaming chain (mid_fwd / head / mid_dprev / mid_outer kernels) against
     the float64 oracle on a 4-layer net (two finished hidden layers, slab ping-pong in the data chain,
     a layer without bias), plain and accumulating (beta = 1) products."""
     g = np.random.default_rng(100 * N + len(loss))
@@ -327,9 +327,9 @@ def test_ggn_matvec_mid_rows_chain(hip, N, loss):
 @pytest.mark.parametrize("dims,acts", [([20, 36, 10], ["relu", "identity"]),            # one hidden layer, ragged widths
                                        ([32, 16, 16], ["tanh", "identity"]),            # C = 16 (widest narrow head)
                                        ([300, 520, 260, 3], ["sigmoid", "relu", "identity"])])
-@pytest.mark.parametrize("N", [11, 16, 29])
+@pytest.mark.parametrize("N", [11, 16, 29, 37, 64])
 def test_ggn_matvec_mid_rows_shapes_and_rank1(hip, dims, acts, N):
-    """The 9 ... 32-row chain on ragged / minimal shapes, and with the rank-M output curvature of the
+    """The 9 ... 64-row chain on ragged / minimal shapes, and with the rank-M output curvature of the
     empirical Fisher (`aux`), against the float64 oracle."""
     g = np.random.default_rng(N + dims[1])
     L = len(dims) - 1

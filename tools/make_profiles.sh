@@ -14,7 +14,7 @@ cd $R
 cp $OUT/r02_c2_n8_pmc_traffic.json $OUT/r02_c2_n8_bench_kernel_stats.txt profiles/   # the bench's traffic / rocprof legs read these
 python bench.py > $OUT/r02_bench_n1.json 2> $OUT/bench_stderr.txt
 tail -c 1500 $OUT/r02_bench_n1.json
-python tools/probe_c2.py 1 8 9 16 32 64 128 256 512 1024 2>&1 | grep "N=" > $OUT/r02_c2_batch_sweep.txt
+python tools/probe_c2.py 1 8 9 16 32 33 48 64 65 128 256 512 1024 2>&1 | grep "N=" > $OUT/r02_c2_batch_sweep.txt
 python benchmarks/bench_kfac.py resnet18 --ekfac 2>/dev/null > $OUT/r02_kfac_resnet18_b512.json
 python benchmarks/bench_kfac.py lenet 2>/dev/null > $OUT/r02_kfac_lenet_b1024.json
 python benchmarks/bench_kfac.py lenet --fisher type-2 2>/dev/null > $OUT/r02_kfac_lenet_b1024_type2.json
