@@ -347,14 +347,23 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
     float acc[RPW];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) acc[rr] = 0.f;
+    // three pipeline stages: the loads of step s + 2 are issued while step s is consumed
+    float4 nxt[RPW][UN];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+      for (int t = 0; t < UN; ++t) {
+        const int q = 64 * UN + lane + 64 * t;
+        nxt[rr][t] = (rv[rr] && q < nq) ? ar[rr][q] : zero4;
+      }
     for (int q0 = 0; q0 < ((p.dbg & 4) ? 1 : nq); q0 += 64 * UN) {
-      float4 nxt[RPW][UN];
+      float4 nx2[RPW][UN];
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
         for (int t = 0; t < UN; ++t) {
-          const int q = q0 + 64 * UN + lane + 64 * t;
-          nxt[rr][t] = (rv[rr] && q < nq) ? ar[rr][q] : zero4;
+          const int q = q0 + 2 * 64 * UN + lane + 64 * t;
+          nx2[rr][t] = (rv[rr] && q < nq) ? ar[rr][q] : zero4;
         }
 #pragma unroll
       for (int t = 0; t < UN; ++t) {
@@ -366,7 +375,10 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-        for (int t = 0; t < UN; ++t) cur[rr][t] = nxt[rr][t];
+        for (int t = 0; t < UN; ++t) {
+          cur[rr][t] = nxt[rr][t];
+          nxt[rr][t] = nx2[rr][t];
+        }
     }
     float y[RPW], pw[RPW], bs[RPW], Vk[RPW], Wk[RPW];
     bool ok[RPW];
