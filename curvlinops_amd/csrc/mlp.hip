@@ -1328,6 +1328,115 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
     }
 }
 
+// First layer of the 9 ... 64-row chain (no incoming tangent): fwd_mfma_first_kernel's scheme with all 16
+// B columns of a tile carrying batch rows -- the 8 waves of a block split K among themselves for the same
+// RG x 8 features, B straight from global memory (x is L2-resident), merge through LDS, bias / activation in
+// the same launch: no split-K slabs, no finish launch.
+template <int NT, int U>
+__global__ __launch_bounds__(512) void mid_first_kernel(
+    const float *__restrict__ W, const float *__restrict__ b, const float *__restrict__ VW,
+    const float *__restrict__ Vb, const float *__restrict__ a_in, float *__restrict__ a_out,
+    float *__restrict__ da_out, float *__restrict__ dphi_out, int N, int d_in, int d_out, int act,
+    int k_per_wave, int fpb) {
+  constexpr int WAVES = 8, RG = 2;
+  extern __shared__ __attribute__((aligned(16))) float s_mf[];   // [WAVES][RG][NT][4][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = lane & 15, s4 = (lane >> 4) * 4;
+  const int kb0 = min(wave * k_per_wave, d_in);
+  const int klen = min(d_in, kb0 + k_per_wave) - kb0;  // multiple of 4, may be 0
+  const int j0 = blockIdx.x * fpb;
+  const int jlast = min(j0 + fpb, d_out) - 1;
+  const float *pA[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int row = min(j0 + g * 8 + (idx & 7), jlast);
+    pA[g] = ((idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
+  }
+  const float *pB[NT];
+  unsigned bmask[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = t * 16 + idx;
+    bmask[t] = n < N ? 0xffffffffu : 0u;
+    pB[t] = a_in + (long)min(n, N - 1) * d_in + kb0 + s4;
+  }
+  f32x4 acc[RG][NT];
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mm = [&](const float4 (&av)[RG], const float4 (&bv)[NT], unsigned ok) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const unsigned m = bmask[t] & ok;
+      const float bx = __uint_as_float(__float_as_uint(bv[t].x) & m);
+      const float by = __uint_as_float(__float_as_uint(bv[t].y) & m);
+      const float bz = __uint_as_float(__float_as_uint(bv[t].z) & m);
+      const float bw = __uint_as_float(__float_as_uint(bv[t].w) & m);
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].x, bx, acc[g][t], 0, 0, 0);
+        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].y, by, acc[g][t], 0, 0, 0);
+        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].z, bz, acc[g][t], 0, 0, 0);
+        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].w, bw, acc[g][t], 0, 0, 0);
+      }
+    }
+  };
+  const int nfull = klen >> 4;
+  int step = 0;
+  for (; step + U <= nfull; step += U) {
+    float4 av[U][RG], bv[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) av[u][g] = CLO_LDW(pA[g] + (step + u) * 16);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[u][t] = ld4(pB[t] + (step + u) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load of the group is issued before the first MFMA waits
+#pragma unroll
+    for (int u = 0; u < U; ++u) mm(av[u], bv[u], 0xffffffffu);
+  }
+  for (; step * 16 < klen; ++step) {  // leftover full steps and the partial one
+    const bool ok = step * 16 + s4 < klen;
+    float4 av[RG], bv[NT];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) av[g] = ld4(pA[g] + (ok ? step * 16 : 0));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = ld4(pB[t] + (ok ? step * 16 : 0));
+    mm(av, bv, ok ? 0xffffffffu : 0u);
+  }
+  // ---- merge the waves' K ranges; then (wave g, tile t) pairs are finished by waves 0 .. RG NT - 1
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_mf[((((wave * RG + g) * NT + t) * 4) + r) * 64 + lane] = acc[g][t][r];
+  __syncthreads();
+  for (int job = wave; job < RG * NT; job += WAVES) {
+    const int g = job / NT, t = job % NT;
+    const int q = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += s_mf[((((w * RG + g) * NT + t) * 4) + r) * 64 + lane];
+      // D rows 0..7 = W rows (z), rows 8..15 = V rows (the tangent): lanes q < 2 pair with lane + 32
+      const float up = __shfl(v, (lane + 32) & 63, 64);
+      const int n = t * 16 + col, j = j0 + g * 8 + q * 4 + r;
+      if (q < 2 && n < N && j <= jlast) {
+        float dphi;
+        const float aval = act_apply(act, v + (b ? b[j] : 0.f), dphi);
+        a_out[(long)n * d_out + j] = aval;
+        dphi_out[(long)n * d_out + j] = dphi;
+        da_out[(long)n * d_out + j] = dphi * (up + (Vb ? Vb[j] : 0.f));
+      }
+    }
+  }
+}
+
 // delta_{l-1} slabs for up to 64 rows: P[by][n][i] = sum_{j in rows(by)} delta[n][j] W[j][i].
 // grid = (column chunks of 256, JB row ranges); 8 waves = 4 column quarters x 2 row halves (merged in LDS).
 struct MidDelta {            // where delta_l comes from
@@ -2532,6 +2641,29 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   for (int l = 1; l <= L - 1; ++l) {
     const int di = dims[l - 1], dout = dims[l];
     const bool has_da = l > 1;
+    static const bool no_first = getenv("CLO_MLP_NO_MID_FIRST") != nullptr;
+    if (l == 1 && l < L - 1 && !no_first && di >= 256 && cdiv(dout, 16) >= kNumCU / 2) {
+      // first layer, finished in the launch itself (in-block split-K over the 8 waves)
+      const int kpw = (int)cdiv(cdiv(di, 8), 16) * 16;
+      const int fpb = (int)std::min<long>(16, std::max<long>(4, cdiv(dout, kNumCU)));
+      const size_t smem = (size_t)8 * 2 * NT * 4 * 64 * sizeof(float);
+      ProfScope prof(0, 8.0 * di * dout, st);
+      if (kpw == 128 && di % 128 == 0 && NT <= 2) {
+        rc = set_smem(mid_first_kernel<NT, 8>, smem);
+        if (rc != CLO_OK) return rc;
+        hipLaunchKernelGGL((mid_first_kernel<NT, 8>), dim3((unsigned)cdiv(dout, fpb)), dim3(512), smem, st, W[0],
+                           b ? b[0] : nullptr, VW[0], Vb ? Vb[0] : nullptr, a[0], a[1], da[1], dphi[1], N, di, dout,
+                           acts[0], kpw, fpb);
+      } else {
+        rc = set_smem(mid_first_kernel<NT, 4>, smem);
+        if (rc != CLO_OK) return rc;
+        hipLaunchKernelGGL((mid_first_kernel<NT, 4>), dim3((unsigned)cdiv(dout, fpb)), dim3(512), smem, st, W[0],
+                           b ? b[0] : nullptr, VW[0], Vb ? Vb[0] : nullptr, a[0], a[1], da[1], dphi[1], N, di, dout,
+                           acts[0], kpw, fpb);
+      }
+      CLO_CHECK_LAUNCH("mid_first_kernel");
+      continue;
+    }
     const int cols = (has_da ? 2 : 1) * NP;
     // Besides the weights a launch moves the activations every block stages (row blocks x cols x d_in) and
     // the split-K slabs (written here, read by the finish): both cost like weight bytes.  Pick waves per

@@ -190,19 +190,19 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
     @staticmethod
     def _native_cost(n: int) -> float:
         """Relative time of one native product over ``n`` rows (measured on C2,
-        profiles/r02_c2_batch_sweep.txt: 8 rows 52 us on the streaming kernels; 9-16 rows 64 us, 17-32 rows
-        88 us, 33-48 rows 120 us and 49-64 rows 141 us on their MFMA variants; beyond that the GEMM path,
+        profiles/r02_c2_batch_sweep.txt: 8 rows 52 us on the streaming kernels; 9-16 rows 62 us, 17-32 rows
+        87 us, 33-48 rows 117 us and 49-64 rows 137 us on their MFMA variants; beyond that the GEMM path,
         ~180 us at 65 rows plus ~0.8 us per row)."""
         if n <= 8:
             return 1.0
         if n <= 16:
-            return 1.22
+            return 1.19
         if n <= 32:
-            return 1.68
+            return 1.66
         if n <= 48:
-            return 2.3
+            return 2.23
         if n <= 64:
-            return 2.72
+            return 2.62
         return 2.2 + n / 65.0
 
     def _merge_native_batches(self, entries: list[tuple]) -> list[tuple]:

@@ -348,6 +348,24 @@ def test_ggn_matvec_mid_rows_shapes_and_rank1(hip, dims, acts, N):
     assert rel_err(O.flatten_params(gW, gb), O.flatten_params(rW, rb)) < 1e-4
 
 
+@pytest.mark.parametrize("d_in,N", [(1024, 12), (1024, 31), (1024, 40), (260, 16), (260, 64), (400, 9)])
+def test_ggn_matvec_mid_rows_first_layer_kernel(hip, d_in, N):
+    """A first layer wide enough for mid_first_kernel (>= 2048 features: in-block split-K, no slabs, no finish
+    launch; K ranges of 128 per wave and ragged ones), followed by two more hidden layers, against the
+    float64 oracle."""
+    g = np.random.default_rng(N + d_in)
+    dims, acts = [d_in, 2064, 48, 32, 5], ["tanh", "relu", "sigmoid", "identity"]
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(4)]
+    bs = [g.random(dims[1]) - 0.5, None, g.random(dims[3]) - 0.5, g.random(dims[4]) - 0.5]
+    vWs = [g.random(W.shape) - 0.5 for W in Ws]
+    vbs = [None if b is None else g.random(b.shape) - 0.5 for b in bs]
+    X, y = g.random((N, dims[0])), g.random((N, dims[-1]))
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, "mse", "mean", vWs, vbs)
+    scale = 2.0 * O.reduction_factor("mse", "mean", N, dims[-1])
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 0, scale, 1.0, 0.0)
+    assert rel_err(O.flatten_params(gW, gb), O.flatten_params(rW, rb)) < 1e-4
+
+
 def _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, Vbk, loss_kind, scale, alpha, beta, out0=None,
                          aux=None, pad=0):
     """K columns through clo_mlp_ggn_matmat: VWk[l] is [d_out, d_in, K], Vbk[l] is [d_out, K]; `pad`
