@@ -1328,18 +1328,18 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
     }
 }
 
-// First layer of the 9 ... 64-row chain (no incoming tangent): fwd_mfma_first_kernel's scheme with all 16
-// B columns of a tile carrying batch rows -- the 8 waves of a block split K among themselves for the same
-// RG x 8 features, B straight from global memory (x is L2-resident), merge through LDS, bias / activation in
-// the same launch: no split-K slabs, no finish launch.
-template <int NT, int U>
-__global__ __launch_bounds__(512) void mid_first_kernel(
+// Forward + JVP of a layer of the 9 ... 64-row chain WITHOUT split-K slabs: fwd_mfma_first_kernel's scheme
+// with all 16 B columns of a tile carrying batch rows -- the 8 waves of a block split K among themselves for
+// the same RG x 8 features, B (= a and, beyond the first layer, da) straight from global memory (the
+// activations are L2-resident), merge through LDS, bias / activation in the same launch.
+template <int NT, bool HAS_DA, int U>
+__global__ __launch_bounds__(512) void mid_full_kernel(
     const float *__restrict__ W, const float *__restrict__ b, const float *__restrict__ VW,
-    const float *__restrict__ Vb, const float *__restrict__ a_in, float *__restrict__ a_out,
-    float *__restrict__ da_out, float *__restrict__ dphi_out, int N, int d_in, int d_out, int act,
-    int k_per_wave, int fpb) {
+    const float *__restrict__ Vb, const float *__restrict__ a_in, const float *__restrict__ da_in,
+    float *__restrict__ a_out, float *__restrict__ da_out, float *__restrict__ dphi_out, int N, int d_in,
+    int d_out, int act, int k_per_wave, int fpb) {
   constexpr int WAVES = 8, RG = 2;
-  extern __shared__ __attribute__((aligned(16))) float s_mf[];   // [WAVES][RG][NT][4][64]
+  extern __shared__ __attribute__((aligned(16))) float s_mf[];   // [WAVES][RG][NT][2 (z, dz)][4][32]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int idx = lane & 15, s4 = (lane >> 4) * 4;
@@ -1353,85 +1353,108 @@ __global__ __launch_bounds__(512) void mid_first_kernel(
     const int row = min(j0 + g * 8 + (idx & 7), jlast);
     pA[g] = ((idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
   }
-  const float *pB[NT];
+  long offB[NT];
   unsigned bmask[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int n = t * 16 + idx;
     bmask[t] = n < N ? 0xffffffffu : 0u;
-    pB[t] = a_in + (long)min(n, N - 1) * d_in + kb0 + s4;
+    offB[t] = (long)min(n, N - 1) * d_in + kb0 + s4;
   }
-  f32x4 acc[RG][NT];
+  f32x4 acc1[RG][NT], acc2[RG][NT];
 #pragma unroll
   for (int g = 0; g < RG; ++g)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mm = [&](const float4 (&av)[RG], const float4 (&bv)[NT], unsigned ok) {
+    for (int t = 0; t < NT; ++t) {
+      acc1[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  auto masked = [](float4 v, unsigned m) {
+    return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                       __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+  };
+  auto mm = [&](const float4 (&av)[RG], const float4 (&bv)[NT], const float4 (&bd)[NT], unsigned ok) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const unsigned m = bmask[t] & ok;
-      const float bx = __uint_as_float(__float_as_uint(bv[t].x) & m);
-      const float by = __uint_as_float(__float_as_uint(bv[t].y) & m);
-      const float bz = __uint_as_float(__float_as_uint(bv[t].z) & m);
-      const float bw = __uint_as_float(__float_as_uint(bv[t].w) & m);
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].x, bx, acc[g][t], 0, 0, 0);
-        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].y, by, acc[g][t], 0, 0, 0);
-        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].z, bz, acc[g][t], 0, 0, 0);
-        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].w, bw, acc[g][t], 0, 0, 0);
-      }
+      const float4 x = masked(bv[t], bmask[t] & ok);
+      float4 dx = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_DA) dx = masked(bd[t], bmask[t] & ok);
+#define CLO_MIDF_MM(E)                                                                                  \
+  _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                     \
+    acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].E, x.E, acc1[g][t], 0, 0, 0);              \
+    if (HAS_DA) acc2[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].E, dx.E, acc2[g][t], 0, 0, 0); \
+  }
+      CLO_MIDF_MM(x) CLO_MIDF_MM(y) CLO_MIDF_MM(z) CLO_MIDF_MM(w)
+#undef CLO_MIDF_MM
     }
   };
   const int nfull = klen >> 4;
   int step = 0;
   for (; step + U <= nfull; step += U) {
-    float4 av[U][RG], bv[U][NT];
+    float4 av[U][RG], bv[U][NT], bd[U][NT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int g = 0; g < RG; ++g) av[u][g] = CLO_LDW(pA[g] + (step + u) * 16);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[u][t] = ld4(pB[t] + (step + u) * 16);
+      for (int t = 0; t < NT; ++t) {
+        bv[u][t] = ld4(a_in + offB[t] + (step + u) * 16);
+        if (HAS_DA) bd[u][t] = ld4(da_in + offB[t] + (step + u) * 16);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);  // every load of the group is issued before the first MFMA waits
 #pragma unroll
-    for (int u = 0; u < U; ++u) mm(av[u], bv[u], 0xffffffffu);
+    for (int u = 0; u < U; ++u) mm(av[u], bv[u], bd[u], 0xffffffffu);
   }
   for (; step * 16 < klen; ++step) {  // leftover full steps and the partial one
     const bool ok = step * 16 + s4 < klen;
-    float4 av[RG], bv[NT];
+    float4 av[RG], bv[NT], bd[NT];
 #pragma unroll
     for (int g = 0; g < RG; ++g) av[g] = ld4(pA[g] + (ok ? step * 16 : 0));
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = ld4(pB[t] + (ok ? step * 16 : 0));
-    mm(av, bv, ok ? 0xffffffffu : 0u);
+    for (int t = 0; t < NT; ++t) {
+      bv[t] = ld4(a_in + offB[t] + (ok ? step * 16 : 0));
+      if (HAS_DA) bd[t] = ld4(da_in + offB[t] + (ok ? step * 16 : 0));
+    }
+    mm(av, bv, bd, ok ? 0xffffffffu : 0u);
   }
-  // ---- merge the waves' K ranges; then (wave g, tile t) pairs are finished by waves 0 .. RG NT - 1
+  // ---- per wave: z = D1 rows 0..7, dz = D1 rows 8..15 (V a) + D2 rows 0..7 (W da), held by lanes q < 2;
+  // merge the waves' K ranges through LDS; (group, tile) pairs are finished by waves 0 .. RG NT - 1
+  const int q = lane >> 4, col = lane & 15;
 #pragma unroll
   for (int g = 0; g < RG; ++g)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s_mf[((((wave * RG + g) * NT + t) * 4) + r) * 64 + lane] = acc[g][t][r];
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc1[g][t][r];
+        const float up = __shfl(v, (lane + 32) & 63, 64);
+        if (q < 2) {
+          float *dst = s_mf + ((((wave * RG + g) * NT + t) * 2) * 4 + r) * 32 + lane;
+          dst[0] = v;
+          dst[4 * 32] = up + (HAS_DA ? acc2[g][t][r] : 0.f);
+        }
+      }
   __syncthreads();
+  if (q >= 2) return;
   for (int job = wave; job < RG * NT; job += WAVES) {
     const int g = job / NT, t = job % NT;
-    const int q = lane >> 4, col = lane & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = 0.f;
+      float z = 0.f, dz = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) v += s_mf[((((w * RG + g) * NT + t) * 4) + r) * 64 + lane];
-      // D rows 0..7 = W rows (z), rows 8..15 = V rows (the tangent): lanes q < 2 pair with lane + 32
-      const float up = __shfl(v, (lane + 32) & 63, 64);
+      for (int w = 0; w < WAVES; ++w) {
+        const float *src = s_mf + ((((w * RG + g) * NT + t) * 2) * 4 + r) * 32 + lane;
+        z += src[0];
+        dz += src[4 * 32];
+      }
       const int n = t * 16 + col, j = j0 + g * 8 + q * 4 + r;
-      if (q < 2 && n < N && j <= jlast) {
+      if (n < N && j <= jlast) {
         float dphi;
-        const float aval = act_apply(act, v + (b ? b[j] : 0.f), dphi);
+        const float aval = act_apply(act, z + (b ? b[j] : 0.f), dphi);
         a_out[(long)n * d_out + j] = aval;
         dphi_out[(long)n * d_out + j] = dphi;
-        da_out[(long)n * d_out + j] = dphi * (up + (Vb ? Vb[j] : 0.f));
+        da_out[(long)n * d_out + j] = dphi * (dz + (Vb ? Vb[j] : 0.f));
       }
     }
   }
@@ -2641,27 +2664,42 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   for (int l = 1; l <= L - 1; ++l) {
     const int di = dims[l - 1], dout = dims[l];
     const bool has_da = l > 1;
-    static const bool no_first = getenv("CLO_MLP_NO_MID_FIRST") != nullptr;
-    if (l == 1 && l < L - 1 && !no_first && di >= 256 && cdiv(dout, 16) >= kNumCU / 2) {
-      // first layer, finished in the launch itself (in-block split-K over the 8 waves)
+    // Layers without an incoming tangent (the first one) finish in their own launch (in-block split-K over the
+    // 8 waves: no slabs, no finish launch: -2...4 us).  With a tangent the kernel issues twice the B loads per
+    // weight load and measured slower than the slab route (C2 layer 2: 24.8 vs 17.9 us at 16 rows, 67 vs 46 us
+    // at 64); CLO_MLP_MID_FULL_DA=1 forces it.
+    static const bool no_full = getenv("CLO_MLP_NO_MID_FULL") != nullptr;
+    static const bool full_da = getenv("CLO_MLP_MID_FULL_DA") != nullptr;
+    if (!no_full && (!has_da || full_da) && di >= 256 && cdiv(dout, 16) >= kNumCU / 2) {
       const int kpw = (int)cdiv(cdiv(di, 8), 16) * 16;
       const int fpb = (int)std::min<long>(16, std::max<long>(4, cdiv(dout, kNumCU)));
-      const size_t smem = (size_t)8 * 2 * NT * 4 * 64 * sizeof(float);
-      ProfScope prof(0, 8.0 * di * dout, st);
-      if (kpw == 128 && di % 128 == 0 && NT <= 2) {
-        rc = set_smem(mid_first_kernel<NT, 8>, smem);
-        if (rc != CLO_OK) return rc;
-        hipLaunchKernelGGL((mid_first_kernel<NT, 8>), dim3((unsigned)cdiv(dout, fpb)), dim3(512), smem, st, W[0],
-                           b ? b[0] : nullptr, VW[0], Vb ? Vb[0] : nullptr, a[0], a[1], da[1], dphi[1], N, di, dout,
-                           acts[0], kpw, fpb);
-      } else {
-        rc = set_smem(mid_first_kernel<NT, 4>, smem);
-        if (rc != CLO_OK) return rc;
-        hipLaunchKernelGGL((mid_first_kernel<NT, 4>), dim3((unsigned)cdiv(dout, fpb)), dim3(512), smem, st, W[0],
-                           b ? b[0] : nullptr, VW[0], Vb ? Vb[0] : nullptr, a[0], a[1], da[1], dphi[1], N, di, dout,
-                           acts[0], kpw, fpb);
+      const size_t smem = (size_t)8 * 2 * NT * 2 * 4 * 32 * sizeof(float);
+      {
+        ProfScope prof(0, 8.0 * di * dout, st);
+#define CLO_MIDFULL(DA, UU)                                                                                   \
+  rc = set_smem(mid_full_kernel<NT, DA, UU>, smem);                                                           \
+  if (rc != CLO_OK) return rc;                                                                                \
+  hipLaunchKernelGGL((mid_full_kernel<NT, DA, UU>), dim3((unsigned)cdiv(dout, fpb)), dim3(512), smem, st,     \
+                     W[l - 1], b ? b[l - 1] : nullptr, VW[l - 1], Vb ? Vb[l - 1] : nullptr, a[l - 1],         \
+                     DA ? da[l - 1] : nullptr, a[l], da[l], dphi[l], N, di, dout, acts[l - 1], kpw, fpb)
+        if (!has_da) {
+          if (kpw == 128 && di % 128 == 0 && NT <= 2) { CLO_MIDFULL(false, 8); } else { CLO_MIDFULL(false, 4); }
+        } else {
+          if (NT <= 2) { CLO_MIDFULL(true, 4); } else { CLO_MIDFULL(true, 2); }
+        }
+#undef CLO_MIDFULL
+        CLO_CHECK_LAUNCH("mid_full_kernel");
       }
-      CLO_CHECK_LAUNCH("mid_first_kernel");
+      if (l == L - 1) {   // partial products of the head from the finished activations
+        HeadFwdArgs fa{};
+        fa.part = nullptr; fa.ksplit = 1; fa.part_rows = NP;
+        fa.a = a[l]; fa.da = da[l]; fa.dphi = dphi[l];
+        fa.N = N; fa.d = dout; fa.act = acts[l - 1];
+        fa.WL = W[L - 1]; fa.VL = VW[L - 1]; fa.C = C; fa.hp = hp;
+        ProfScope pf(3, 0.0, st);
+        hipLaunchKernelGGL(head_fwd_kernel, dim3(head_nblk, N), dim3(256), 0, st, fa);
+        CLO_CHECK_LAUNCH("head_fwd_kernel");
+      }
       continue;
     }
     const int cols = (has_da ? 2 : 1) * NP;

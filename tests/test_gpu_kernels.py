@@ -350,7 +350,7 @@ def test_ggn_matvec_mid_rows_shapes_and_rank1(hip, dims, acts, N):
 
 @pytest.mark.parametrize("d_in,N", [(1024, 12), (1024, 31), (1024, 40), (260, 16), (260, 64), (400, 9)])
 def test_ggn_matvec_mid_rows_first_layer_kernel(hip, d_in, N):
-    """A first layer wide enough for mid_first_kernel (>= 2048 features: in-block split-K, no slabs, no finish
+    """A first layer wide enough for mid_full_kernel (>= 2048 features: in-block split-K, no slabs, no finish
     launch; K ranges of 128 per wave and ragged ones), followed by two more hidden layers, against the
     float64 oracle."""
     g = np.random.default_rng(N + d_in)
