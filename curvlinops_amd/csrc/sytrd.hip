@@ -20,6 +20,7 @@
 // sstedc / sormtr (or any LAPACK-compatible back-transformation) take over from there.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "clo_common.h"
 
@@ -509,7 +510,15 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
   float *tv[2] = {part[1] + (long)TD_GMAX * TD_NPART, part[1] + (long)TD_GMAX * TD_NPART + TD_NB};
 
   const size_t lds = (2 * n4 + TD_WAVES * TD_NPART + 4 * TD_NB + 5 * TD_WAVES + 16) * sizeof(float);
-  static size_t lds_set = 0;
+  // several host threads may run reductions at once (linalg_native.eigh_many): the attribute must be in
+  // place for every instantiation before any of them launches with the larger size
+  static std::mutex lds_mutex;
+  static size_t lds_set_dev[64] = {0};   // per device: function attributes are per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  {
+  std::lock_guard<std::mutex> lds_lock(lds_mutex);
+  size_t &lds_set = lds_set_dev[dev];
   if (lds > lds_set) {
     const void *fns[8] = {reinterpret_cast<const void *>(sytrd_col_kernel<1>),
                           reinterpret_cast<const void *>(sytrd_col_kernel<2>),
@@ -525,6 +534,7 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
       if (rc != CLO_OK) return rc;
     }
     lds_set = lds;
+  }
   }
   static const int dbg = getenv("CLO_TD_DEBUG") ? atoi(getenv("CLO_TD_DEBUG")) : 0;
   int g_prev = 1, flip = 0;
