@@ -600,8 +600,9 @@ class MLPPlan:
         _check(rc, "clo_mlp_vjp")
 
     def hessian_supported(self) -> bool:
-        """Shape conditions of ``clo_mlp_hessian_matvec`` (alignment is checked by the library)."""
-        return all(d % 4 == 0 for d in self._dims_list[:-1])
+        """Shape conditions of ``clo_mlp_hessian_matvec``: none any more (layer inputs that are not multiples
+        of 4 run on the scalar-load kernel variants / the unaligned GEMM tile loader)."""
+        return True
 
     def hessian_matvec(self, W, b, VW, Vb, OW, Ob, X, G, loss_kind: int, loss_scale: float, alpha: float,
                        beta: float, aux=None) -> None:

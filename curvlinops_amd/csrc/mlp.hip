@@ -2830,6 +2830,34 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   return CLO_OK;
 }
 
+// Forward + JVP of one layer on the GEMM engine: a_l = act(a W^T + b) with act' as second output,
+// da_l = act' * (a VW^T + da W^T + Vb).  Preferred: one fused pass over W_l and V_l (three MFMA products per
+// tile, gemm_fwd3_kernel); unaligned operands (layer inputs % 4 != 0): two or three plain products with bias /
+// activation / derivative fused into whichever kernel writes C, the tangent's two products chained along K
+// where the aligned engine allows it.
+static int fwd_jvp_gemm(const float *a_in, const float *da_in, const float *Wl, const float *Vl, const float *bl,
+                        const float *vbl, float *a_out, float *da_out, float *dphi_out, int N, int di, int dout,
+                        int act, float *gws, long gws_sz, hipStream_t st) {
+  int rc = launch_mlp_fwd3(a_in, da_in, Wl, Vl, bl, vbl, a_out, da_out, dphi_out, N, di, dout, act, gws, gws_sz, st);
+  if (rc != CLO_EUNSUP) return rc;
+  GemmArgs g1 = gemm_problem(N, dout, di, a_in, di, 1, Wl, 1, di, 0.f, a_out, dout);
+  g1.epi = EPI_ACT; g1.e_act = act; g1.e_vec = bl; g1.e_out2 = dphi_out;
+  rc = launch_gemm_auto(g1, gws, gws_sz, st);
+  if (rc != CLO_OK) return rc;
+  GemmArgs g2 = gemm_problem(N, dout, di, a_in, di, 1, Vl, 1, di, 0.f, da_out, dout);
+  g2.epi = EPI_MUL; g2.e_vec = vbl; g2.e_mul = dphi_out; g2.ld_mul = dout;
+  if (!da_in) return launch_gemm_auto(g2, gws, gws_sz, st);
+  GemmArgs gc = g2;
+  gc.K = 2 * di; gc.K1 = di; gc.A2 = da_in; gc.B2 = Wl;
+  if (di % 32 == 0 && gemm_v2_eligible(gc, 1)) return launch_gemm_auto(gc, gws, gws_sz, st);
+  g2.epi = EPI_NONE;
+  rc = launch_gemm_auto(g2, gws, gws_sz, st);
+  if (rc != CLO_OK) return rc;
+  GemmArgs g3 = gemm_problem(N, dout, di, da_in, di, 1, Wl, 1, di, 1.f, da_out, dout);
+  g3.epi = EPI_MUL; g3.e_vec = vbl; g3.e_mul = dphi_out; g3.ld_mul = dout;
+  return launch_gemm_auto(g3, gws, gws_sz, st);
+}
+
 // Workspace layout of clo_mlp_ggn_matvec (floats):
 //   per layer l = 1..L : a_l, da_l, dphi_l, each [N][d_l]
 //   delta ping/pong    : 2 x [N][dmax]
@@ -2949,32 +2977,8 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
       // da W^T + Vb): two launches, bias / activation / derivative fused into whichever kernel
       // writes C, the tangent's two products chained along K in one pass
       // preferred: one fused pass over W_l and V_l (three MFMA products per tile, gemm_fwd3_kernel)
-      rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], bl, vbl, a[l], da[l], dphi[l], N, di,
-                           dout, acts[l - 1], gws, gws_sz, st);
-      if (rc == CLO_OK) continue;
-      if (rc != CLO_EUNSUP) return rc;
-      GemmArgs g1 = gemm_problem(N, dout, di, a[l - 1], di, 1, W[l - 1], 1, di, 0.f, a[l], dout);
-      g1.epi = EPI_ACT; g1.e_act = acts[l - 1]; g1.e_vec = bl; g1.e_out2 = dphi[l];
-      rc = launch_gemm_auto(g1, gws, gws_sz, st);
-      if (rc != CLO_OK) return rc;
-      GemmArgs g2 = gemm_problem(N, dout, di, a[l - 1], di, 1, VW[l - 1], 1, di, 0.f, da[l], dout);
-      g2.epi = EPI_MUL; g2.e_vec = vbl; g2.e_mul = dphi[l]; g2.ld_mul = dout;
-      if (da[l - 1]) {
-        GemmArgs gc = g2;
-        gc.K = 2 * di; gc.K1 = di; gc.A2 = da[l - 1]; gc.B2 = W[l - 1];
-        if (di % 32 == 0 && gemm_v2_eligible(gc, 1)) {
-          rc = launch_gemm_auto(gc, gws, gws_sz, st);
-        } else {
-          g2.epi = EPI_NONE;
-          rc = launch_gemm_auto(g2, gws, gws_sz, st);
-          if (rc != CLO_OK) return rc;
-          GemmArgs g3 = gemm_problem(N, dout, di, da[l - 1], di, 1, W[l - 1], 1, di, 1.f, da[l], dout);
-          g3.epi = EPI_MUL; g3.e_vec = vbl; g3.e_mul = dphi[l]; g3.ld_mul = dout;
-          rc = launch_gemm_auto(g3, gws, gws_sz, st);
-        }
-      } else {
-        rc = launch_gemm_auto(g2, gws, gws_sz, st);
-      }
+      rc = fwd_jvp_gemm(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], bl, vbl, a[l], da[l], dphi[l], N, di, dout,
+                        acts[l - 1], gws, gws_sz, st);
       if (rc != CLO_OK) return rc;
     }
   }
@@ -3309,8 +3313,8 @@ extern "C" long clo_mlp_hessian_ws_floats(int L, const int *dims, int N) {
 
 // out = beta out + alpha H v for one mini-batch.  G [N][C]: gradient of the (reduced) mini-batch
 // loss w.r.t. the model output; loss_kind / aux / loss_scale describe its Hessian as in
-// clo_mlp_ggn_matvec.  Needs dims[0..L-1] % 4 == 0 and 16-byte aligned operands (CLO_EUNSUP
-// otherwise).
+// clo_mlp_ggn_matvec.  Any widths (float4-complete layer inputs and 16-byte aligned operands take the fast
+// kernel variants).
 extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, const float *const *W,
                                       const float *const *b, const float *const *VW,
                                       const float *const *Vb, float *const *OW, float *const *Ob,
@@ -3320,17 +3324,13 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
   CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW, "clo_mlp_hessian_matvec: bad layer table");
   CLO_REQUIRE(N >= 1 && X && G && ws, "clo_mlp_hessian_matvec: bad batch / gradient / workspace");
   CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_hessian_matvec: unknown loss kind %d", loss_kind);
-  bool ok = aligned16(X) && aligned16(ws);
   for (int l = 0; l <= L; ++l) CLO_REQUIRE(dims[l] > 0, "clo_mlp_hessian_matvec: dims[%d] <= 0", l);
   for (int l = 0; l < L; ++l) {
     CLO_REQUIRE(acts[l] >= 0 && acts[l] <= 3, "clo_mlp_hessian_matvec: unknown activation");
     CLO_REQUIRE(W[l] && VW[l] && OW[l], "clo_mlp_hessian_matvec: null weight pointer in layer %d", l);
-    ok = ok && dims[l] % 4 == 0 && aligned16(W[l]) && aligned16(VW[l]);
   }
-  if (!ok) {
-    set_error("clo_mlp_hessian_matvec: needs layer inputs %% 4 == 0 and 16-byte aligned operands");
-    return CLO_EUNSUP;
-  }
+  // (layer inputs that are not multiples of 4 / operands that are not 16-byte aligned: every kernel below
+  // picks its scalar-load variant, the GEMM engine its unaligned tile loader)
   hipStream_t st = (hipStream_t)stream;
   int dmax = 0;
   for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
@@ -3368,9 +3368,9 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
       rc = fwd_pass(W[l - 1], b ? b[l - 1] : nullptr, VW[l - 1], Vb ? Vb[l - 1] : nullptr, a[l - 1], da[l - 1],
                     a[l], da[l], dphi[l], N, dims[l - 1], dims[l], acts[l - 1], part, false, nullptr, st);
     else
-      rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
-                           Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l],
-                           acts[l - 1], gws, gws_sz, st);
+      rc = fwd_jvp_gemm(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
+                        Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l], acts[l - 1], gws,
+                        gws_sz, st);
     if (rc != CLO_OK) return rc;
   }
   // ---- output layer: dA = alpha G, T = alpha s H(f) Jv  ->  d_L, Rd_L

@@ -100,7 +100,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         _hip.load()  # a GPU fp32 MLP must run natively: fail loudly if the library is absent
         native = NativeMLP(structure, self._params)
         if self._NATIVE_KIND == "hessian" and not native.plan.hessian_supported():
-            return  # layer widths not float4-complete: the R-operator kernels do not apply
+            return
         self._native = native
 
     @property

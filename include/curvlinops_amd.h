@@ -237,8 +237,8 @@ int clo_mlp_vjp(int L, const int *dims, const int *acts, const float *const *W, 
  * the gradient signal AND its directional derivative; every product on the MFMA GEMM engine.
  *   G [N][C]   gradient of the (reduced) mini-batch loss w.r.t. the model output f
  *   loss_kind / aux / aux_rank / loss_scale: the loss Hessian w.r.t. f as in clo_mlp_ggn_matvec
- * out = beta * out + alpha * H v.  Returns CLO_EUNSUP unless dims[0..L-1] % 4 == 0 and the operands
- * are 16-byte aligned.  ws: clo_mlp_hessian_ws_floats(L, dims, N) floats. */
+ * out = beta * out + alpha * H v.  Any layer widths (dims[0..L-1] % 4 == 0 with 16-byte aligned operands
+ * take the vectorised kernel variants).  ws: clo_mlp_hessian_ws_floats(L, dims, N) floats. */
 long clo_mlp_hessian_ws_floats(int L, const int *dims, int N);
 int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, const float *const *W,
                            const float *const *b, const float *const *VW, const float *const *Vb,

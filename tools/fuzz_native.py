@@ -48,9 +48,7 @@ def _one_case(case: int, rng, dev, failures: list) -> float:
         y = torch.randint(0, dims[-1], (N,), device=dev) if lossname == "ce" else torch.rand(N, dims[-1], device=dev)
         data.append((X, y))
     worst = 0.0
-    classes = [C.GGNLinearOperator, C.EFLinearOperator]
-    if all(d % 4 == 0 for d in dims[:-1]):
-        classes.append(C.HessianLinearOperator)
+    classes = [C.GGNLinearOperator, C.EFLinearOperator, C.HessianLinearOperator]
     for cls in classes:
         nat = cls(model, loss, params, data, check_deterministic=False)
         assert nat.uses_native_kernels, (dims, lossname)
