@@ -3463,22 +3463,16 @@ extern "C" long clo_mlp_jac_ws_floats(int L, const int *dims, int N) {
   return total + 2L * N * dmax + gemm_ws_floats(N, dmax) + 256;
 }
 
-// JV[n][c] = (J_theta f(x_n) v)[c]: tangent forward pass (one fused launch per layer).  Needs
-// dims[0..L-1] % 4 == 0 and 16-byte aligned operands (CLO_EUNSUP otherwise).
+// JV[n][c] = (J_theta f(x_n) v)[c]: tangent forward pass (one fused launch per layer; layers whose inputs are
+// not float4-complete: two or three plain products).  Any widths / alignment.
 extern "C" int clo_mlp_jvp(int L, const int *dims, const int *acts, const float *const *W,
                            const float *const *b, const float *const *VW, const float *const *Vb,
                            const float *X, int N, float *JV, float *ws, void *stream) {
   CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW, "clo_mlp_jvp: bad layer table");
   CLO_REQUIRE(N >= 1 && X && JV && ws, "clo_mlp_jvp: bad batch / output / workspace");
-  bool ok = aligned16(X) && aligned16(ws);
   for (int l = 0; l < L; ++l) {
     CLO_REQUIRE(dims[l] > 0 && dims[l + 1] > 0 && acts[l] >= 0 && acts[l] <= 3, "clo_mlp_jvp: bad layer %d", l);
     CLO_REQUIRE(W[l] && VW[l], "clo_mlp_jvp: null weight pointer in layer %d", l);
-    ok = ok && dims[l] % 4 == 0 && aligned16(W[l]) && aligned16(VW[l]);
-  }
-  if (!ok) {
-    set_error("clo_mlp_jvp: needs layer inputs %% 4 == 0 and 16-byte aligned operands");
-    return CLO_EUNSUP;
   }
   hipStream_t st = (hipStream_t)stream;
   int dmax = 0;
@@ -3495,9 +3489,9 @@ extern "C" int clo_mlp_jvp(int L, const int *dims, const int *acts, const float 
   float *gws = p;
   const long gws_sz = gemm_ws_floats(N, dmax);
   for (int l = 1; l <= L; ++l) {
-    int rc = launch_mlp_fwd3(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
-                             Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l],
-                             acts[l - 1], gws, gws_sz, st);
+    int rc = fwd_jvp_gemm(a[l - 1], da[l - 1], W[l - 1], VW[l - 1], b ? b[l - 1] : nullptr,
+                          Vb ? Vb[l - 1] : nullptr, a[l], da[l], dphi[l], N, dims[l - 1], dims[l], acts[l - 1], gws,
+                          gws_sz, st);
     if (rc != CLO_OK) return rc;
   }
   return CLO_OK;

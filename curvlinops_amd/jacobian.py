@@ -109,8 +109,6 @@ class JacobianLinearOperator(_JacobianBase):
 
     def _matmat_native(self, M: list[Tensor]) -> list[Tensor] | None:
         nat = self._native
-        if not nat.plan.hessian_supported():  # same float4 condition as the tangent forward kernel
-            return None
         batches = self._native_batches()
         if batches is None:
             return None

@@ -221,7 +221,7 @@ long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
 
 /* Jacobian and transposed-Jacobian products of an MLP (reference jacobian.py:14-358): the
  * forward+JVP half and the VJP half of the GGN product.
- *   clo_mlp_jvp: JV [N][d_L] = J v          (CLO_EUNSUP unless dims[0..L-1] % 4 == 0, aligned)
+ *   clo_mlp_jvp: JV [N][d_L] = J v                             (any widths)
  *   clo_mlp_vjp: out = beta out + alpha J^T U,  U [N][d_L]     (any widths)
  * ws: clo_mlp_jac_ws_floats(L, dims, N) floats for either. */
 long clo_mlp_jac_ws_floats(int L, const int *dims, int N);

@@ -110,3 +110,34 @@ def test_jacobian_c2_size_gpu():
     assert abs(lhs - rhs) / abs(lhs) < 1e-4
     G = C.GGNLinearOperator(model, nn.MSELoss(reduction="sum"), params, data, check_deterministic=False)
     assert rel_err(2.0 * (JT @ Jv), (G @ v).double().cpu().numpy()) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [[7, 13, 5, 3], [33, 50, 21, 6], [10, 130, 77, 4]])
+def test_jacobian_odd_widths_native_gpu(dims):
+    """Layer widths that are not multiples of 4 stay on the native kernels (plain GEMM products instead of the
+    fused tangent-forward launch) and agree with the torch.func path on the same device."""
+    from torch import nn
+
+    import curvlinops_amd as C
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(dims))
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(nn.Tanh())
+    model = nn.Sequential(*layers).to(dev)
+    params = dict(model.named_parameters())
+    data = [(torch.rand(n, dims[0], device=dev), torch.rand(n, dims[-1], device=dev)) for n in (9, 40)]
+    J = C.JacobianLinearOperator(model, params, data)
+    JT = C.TransposedJacobianLinearOperator(model, params, data)
+    assert J.uses_native_kernels and JT.uses_native_kernels
+    J_ref = C.JacobianLinearOperator(model, params, data)
+    JT_ref = C.TransposedJacobianLinearOperator(model, params, data)
+    J_ref._native = JT_ref._native = None
+    V = torch.rand(J.shape[1], 5, device=dev)
+    U = torch.rand(J.shape[0], 3, device=dev)
+    assert rel_err(J @ V, (J_ref @ V).cpu().numpy()) < 1e-5
+    assert rel_err(JT @ U, (JT_ref @ U).cpu().numpy()) < 1e-5
