@@ -190,6 +190,27 @@ class TestC2FullSize:
         assert rel_err(nat @ v, (ref @ v).double().cpu().numpy()) < 2e-4
 
 
+    @pytest.mark.parametrize("N,cls,loss", [(13, "ggn", "mse"), (40, "ggn", "ce"), (64, "ef", "mse"), (48, "ggn", "mse"),
+                                            (100, "ggn", "ce")])
+    def test_row_regimes_against_autograd(self, setup, N, cls, loss):
+        """Full-size net at the row counts of every kernel regime (9-16, 33-48, 49-64 rows on the MFMA streaming
+        chain incl. its slab-free first-layer kernel, > 64 on the GEMM engine) against the torch.func path."""
+        dev, model, params, _, _ = setup
+        torch.manual_seed(N)
+        X = torch.rand(N, 1024, device=dev)
+        if loss == "ce":
+            y, lf = torch.randint(0, 10, (N,), device=dev), nn.CrossEntropyLoss()
+        else:
+            y, lf = torch.rand(N, 10, device=dev), nn.MSELoss()
+        Op = C.GGNLinearOperator if cls == "ggn" else C.EFLinearOperator
+        nat = Op(model, lf, params, [(X, y)], check_deterministic=False)
+        ref = Op(model, lf, params, [(X, y)], check_deterministic=False)
+        assert nat.uses_native_kernels
+        ref._native = None
+        v = torch.rand(nat.shape[1], device=dev) - 0.5
+        assert rel_err(nat @ v, (ref @ v).double().cpu().numpy()) < 2e-4
+
+
 # ----------------------------------------------------------------------------- structured ops
 @pytest.mark.parametrize("name", ["rect", "sq", "one", "three"])
 def test_kronecker_gpu(dev, golden_linops, name):
