@@ -20,4 +20,4 @@ for _ in range(5):
     t = time.perf_counter(); build(); ts.append(time.perf_counter() - t)
 print(f"build: min {min(ts)*1e3:.2f} ms")
 pr = cProfile.Profile(); pr.enable(); build(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats("computers.py|_hip.py|streams.py|kfac_utils|kfac_math", 30)
