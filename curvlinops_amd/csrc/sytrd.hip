@@ -64,8 +64,8 @@ struct TdArgs {
   const float *part_prev;  // [g_prev][TD_NPART]
   int g_prev;
   float *part_cur;
-  const float *t_prev;     // [TD_NB]: the finished W[j][:] (row j+1 of column j-1's launch)
-  float *t_cur;
+  float *gam;              // [TD_NB]: gamma_k of the panel's finished columns (W_k = w0_k + gamma_k v_k); the panel
+                           // in memory keeps w0_k until the panel ends, every reader adds the gamma term
   float *D, *E, *tau;
 };
 
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
   float *s_t2 = s_t1 + TD_NB;      // [64] V^T v
   float *s_wj1 = s_t2 + TD_NB;     // [64] W[j+1][:]
   float *s_vj1 = s_wj1 + TD_NB;    // [64] V[j+1][:]
-  float *s_slotA = s_vj1 + TD_NB;  // [TD_WAVES][4]
+  float *s_gam = s_vj1 + TD_NB;    // [64] gamma_k (this launch's for k = c-1)
+  float *s_slotA = s_gam + TD_NB;  // [TD_WAVES][4]
   float *s_slotB = s_slotA + 4 * TD_WAVES;   // [TD_WAVES]
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -126,14 +127,13 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
   float4 u4[TD_VEC], vp4[TD_VEC], row4[TD_VEC];
   const float *rowj1 = p.A + (long)r0 * p.lda;
   // (b) rows j and j+1 of the panels
-  float wk0 = 0.f, wk1 = 0.f, vk0 = 0.f, vk1 = 0.f;
+  float wk0 = 0.f, wk1 = 0.f, vk0 = 0.f, vk1 = 0.f, gk = 0.f;
   if (tid < c) {
-    // row j of W: columns < c-1 were finished by the previous launch (kept in t_prev, the panel in
-    // memory still holds the unfinished value for that one row); column c-1 is unfinished by design
-    wk0 = tid < cp ? p.t_prev[tid] : p.Wp[(long)j * TD_NB + tid];
+    wk0 = p.Wp[(long)j * TD_NB + tid];    // w0 parts; the gamma terms are added once gamma_{c-1} is known
     wk1 = p.Wp[(long)r0 * TD_NB + tid];
     vk0 = p.Vp[(long)j * TD_NB + tid];
     vk1 = p.Vp[(long)r0 * TD_NB + tid];
+    if (tid < cp) gk = p.gam[tid];
   }
   const float tau_prev = c > 0 ? p.tau[j - 1] : 0.f;
   const float ajj = p.A[(long)j * p.lda + j];
@@ -270,15 +270,17 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
   }
   // ---- panel dot products t1 = W^T v, t2 = V^T v from the sums of the previous launch ----
   if (tid < TD_NB) {
-    float t1 = 0.f, t2 = 0.f, wj1 = 0.f, vj1 = 0.f;
+    float t1 = 0.f, t2 = 0.f, wj1 = 0.f, vj1 = 0.f, g = 0.f;
+    if (tid < c) {
+      g = tid == cp ? gamma : gk;
+      wk0 += g * vk0;             // finished W[j][k]
+      wj1 = wk1 + g * vk1;        // finished W[j+1][k]
+      vj1 = vk1;
+    }
     if (tid < cp) {
-      t1 = wk1 + s * (pwu - 2.f * gamma * pwv);
+      t1 = wj1 + s * (pwu - 2.f * gamma * pwv);
       t2 = vk1 + s * (pvu - 2.f * gamma * pvv);
-      wj1 = wk1;
-      vj1 = vk1;
     } else if (tid == cp) {
-      wj1 = wk1 + gamma * vk1;   // the finished W[j+1][c-1]
-      vj1 = vk1;
       t1 = wj1 + s * (S_wu - 2.f * gamma * S_wv2 + gamma * S_uv - 2.f * gamma * gamma * S_vv);
       t2 = vk1 + s * (S_uv - 2.f * gamma * S_vv);
     }
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
     s_t2[tid] = t2;
     s_wj1[tid] = wj1;
     s_vj1[tid] = vj1;
+    s_gam[tid] = g;
   }
   yj1 = wave_sum_dpp(yj1);
   if (lane == 0) s_slotB[wave] = yj1;
@@ -301,8 +304,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
     if (lane < c)
       for (int i = r0 + wave; i < n; i += TD_WAVES) {
         const float V = p.Vp[(long)i * TD_NB + lane];
-        float W = p.Wp[(long)i * TD_NB + lane];
-        if (lane == cp) W += gamma * V;
+        const float W = p.Wp[(long)i * TD_NB + lane] + s_gam[lane] * V;   // finished entries
         const float vi = s_v[i - m0];
         a1 += W * vi;
         a2 += V * vi;
@@ -322,12 +324,12 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
     }
     __syncthreads();
   }
-  const float t1l = s_t1[lane], t2l = s_t2[lane], wj1l = s_wj1[lane], vj1l = s_vj1[lane];
+  const float t1l = s_t1[lane], t2l = s_t2[lane], wj1l = s_wj1[lane], vj1l = s_vj1[lane], gl = s_gam[lane];
   // unfinished w at row j+1 (every wave computes it)
   const float w0j1 = tau * (yj1 - wave_sum_dpp(lane < c ? vj1l * t1l + wj1l * t2l : 0.f));
   if (blockIdx.x == 0 && wave == 0) {
     // d_j = A[j][j] - 2 sum_k V[j][k] W[j][k] with the finished W[j][c-1] = w0 + gamma (V[j][c-1] = 1)
-    const float x = wave_sum_dpp(lane < c ? vk0 * (lane == cp ? wk0 + gamma : wk0) : 0.f);
+    const float x = wave_sum_dpp(lane < c ? vk0 * wk0 : 0.f);
     if (lane == 0) {
       p.D[j] = ajj - 2.f * x;
       p.E[j] = beta;
@@ -335,8 +337,8 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
       p.Vp[(long)r0 * TD_NB + c] = 1.f;
       p.Wp[(long)r0 * TD_NB + c] = w0j1;
       p.vcur[r0] = 1.f;
+      if (c > 0) p.gam[cp] = gamma;   // read by the launches after this one
     }
-    if (lane < c) p.t_cur[lane] = wj1l;   // finished W[j+1][0:c] (other blocks still read the panel)
   }
 
   // ---- rows i >= j+2:  y_i = A[i][:] v,  w0_i,  next column's u0_i,  partial sums ----
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
     bool ok[RPW];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-      if (lane == cp) Wik[rr] += gamma * Vik[rr];   // finish column c-1 of W for this row
+      Wik[rr] += gl * Vik[rr];   // finished entries W = w0 + gamma_k v (the panel keeps w0)
       Vk[rr] = Vik[rr];
       Wk[rr] = Wik[rr];
       ok[rr] = rv[rr];
@@ -398,7 +400,6 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
     for (int rr = 0; rr < RPW; ++rr) {
       if (!ok[rr]) continue;
       const int i = ibase + rr;
-      if (lane == cp) p.Wp[(long)i * TD_NB + lane] = Wk[rr];
       const float vi = s_v[i - m0];
       const float w0 = tau * (y[rr] - pw[rr]);
       const float un = s_row[i - m0] - bs[rr] - vi * w0j1 - w0;
@@ -444,17 +445,20 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
   }
 }
 
-// End of a panel whose last column is jl (index cl inside the panel, panel origin i0):
-// finish the last column of W (rows >= jl+1) and move the Householder vectors into the rows of A.
+// End of a panel whose last column is jl (index cl inside the panel, panel origin i0): finish W for the rows of
+// the trailing update (W_k = w0_k + gamma_k v_k, rows >= jl+1) and move the Householder vectors into the rows
+// of A.
 __global__ __launch_bounds__(256) void sytrd_panel_end_kernel(float *A, long lda, int n, int i0, int ncol,
                                                               const float *Vp, float *Wp,
                                                               const float *part, int g, const float *tau,
-                                                              const float *t_last) {
+                                                              const float *gam) {
   __shared__ float s_part[256];
+  __shared__ float s_g[TD_NB];
   const int jl = i0 + ncol - 1, cl = ncol - 1;
   float sacc = 0.f;
   for (int b = threadIdx.x; b < g; b += 256) sacc += part[(long)b * TD_NPART + TD_SC];
   s_part[threadIdx.x] = sacc;
+  if ((int)threadIdx.x < TD_NB) s_g[threadIdx.x] = (int)threadIdx.x < cl ? gam[threadIdx.x] : 0.f;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
@@ -463,9 +467,9 @@ __global__ __launch_bounds__(256) void sytrd_panel_end_kernel(float *A, long lda
   const float gamma = -0.5f * tau[jl] * s_part[0];
   const int i = blockIdx.x * 256 + threadIdx.x;   // matrix row
   if (i < n && i > i0) {
-    if (i >= jl + 1) Wp[(long)i * TD_NB + cl] += gamma * Vp[(long)i * TD_NB + cl];
-    // the one entry of the trailing rows the column launches leave unfinished in the panel
-    if (i == jl + 1 && cl > 0) Wp[(long)i * TD_NB + cl - 1] = t_last[cl - 1];
+    if (i >= jl + 1)
+      for (int k = 0; k < ncol; ++k)
+        Wp[(long)i * TD_NB + k] += (k == cl ? gamma : s_g[k]) * Vp[(long)i * TD_NB + k];
     // reflector k of the panel lives in rows >= i0+k+2 of column (matrix row) i0+k
     const int kmax = min(ncol, i - i0 - 1);
     for (int k = 0; k < kmax; ++k) A[(long)(i0 + k) * lda + i] = Vp[(long)i * TD_NB + k];
@@ -507,9 +511,9 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
   float *u0[2] = {Wp + (long)n * TD_NB, Wp + (long)n * TD_NB + n4};
   float *vv[2] = {u0[1] + n4, u0[1] + 2 * n4};
   float *part[2] = {vv[1] + n4, vv[1] + n4 + (long)TD_GMAX * TD_NPART};
-  float *tv[2] = {part[1] + (long)TD_GMAX * TD_NPART, part[1] + (long)TD_GMAX * TD_NPART + TD_NB};
+  float *gam = part[1] + (long)TD_GMAX * TD_NPART;   // [TD_NB]
 
-  const size_t lds = (2 * n4 + TD_WAVES * TD_NPART + 4 * TD_NB + 5 * TD_WAVES + 16) * sizeof(float);
+  const size_t lds = (2 * n4 + TD_WAVES * TD_NPART + 5 * TD_NB + 5 * TD_WAVES + 16) * sizeof(float);
   // several host threads may run reductions at once (linalg_native.eigh_many): the attribute must be in
   // place for every instantiation before any of them launches with the larger size
   static std::mutex lds_mutex;
@@ -554,8 +558,7 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
       a.vcur = vv[flip ^ 1];
       a.part_prev = part[flip]; a.g_prev = g_prev;
       a.part_cur = part[flip ^ 1];
-      a.t_prev = tv[flip];
-      a.t_cur = tv[flip ^ 1];
+      a.gam = gam;
       a.D = D; a.E = E; a.tau = tau;
       a.rpw = rpw;
       a.dbg = dbg;
@@ -572,7 +575,7 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
     }
     CLO_CHECK_LAUNCH("sytrd_col_kernel");
     hipLaunchKernelGGL(sytrd_panel_end_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, A, lda, n, i0,
-                       ncol, Vp, Wp, part[flip], g_prev, tau, tv[flip]);
+                       ncol, Vp, Wp, part[flip], g_prev, tau, gam);
     CLO_CHECK_LAUNCH("sytrd_panel_end_kernel");
     // trailing update A[t:, t:] -= V W^T + W V^T on the MFMA GEMM engine (full square: the column
     // kernel reads complete rows)

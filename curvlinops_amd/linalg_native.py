@@ -287,6 +287,28 @@ _EIGH_MODE = os.environ.get("CLO_EIGH", "rocsolver").lower()
 _SYTRD_MAX_N = 8184
 
 
+def _unit_scale(A: Tensor) -> tuple[Tensor, Tensor]:
+    """``(A / s, s)`` with ``s = max |A|`` per matrix (1 for a zero matrix), no host synchronisation.
+    rocSOLVER's tridiagonal divide & conquer (``sstedc``, also inside ``torch.linalg.eigh``) applies an ABSOLUTE
+    tolerance: fp32 matrices of norm 1e-5 come back with eigenvalue errors of 6 % of the largest one, norm 1e-6
+    with 30 % (``tools/diag_eigh_scale.py``; the Householder reduction before it is scale-invariant).  Gradient
+    covariances of mean-reduced losses live at exactly those scales, so every GPU eigensolver call here runs
+    on the normalised matrix and scales the eigenvalues back (what LAPACK's ``syev`` does for norms outside
+    its safe range)."""
+    s = A.abs().amax(dim=(-2, -1), keepdim=True)
+    s = torch.where(s > 0, s, torch.ones_like(s))
+    return A / s, s
+
+
+def _torch_eigh_scaled(A: Tensor) -> tuple[Tensor, Tensor]:
+    if not A.is_cuda:
+        res = torch.linalg.eigh(A)
+        return res.eigenvalues, res.eigenvectors
+    An, s = _unit_scale(A)
+    res = torch.linalg.eigh(An)
+    return res.eigenvalues * s.squeeze(-1), res.eigenvectors
+
+
 def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
     """Symmetric eigendecomposition with the hand-written Householder reduction: ``clo_sytrd_f32`` (one launch
     per column) -> rocSOLVER ``sstedc`` on the tridiagonal matrix -> ``sormtr``.  fp32 GPU matrices of order
@@ -297,15 +319,16 @@ def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
     if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == n and 3 <= n <= _SYTRD_MAX_N):
         raise ValueError(f"eigh_sytrd: need a square fp32 GPU matrix of order 3..{_SYTRD_MAX_N}, got {tuple(A.shape)} {A.dtype}")
     ld = (n + 3) // 4 * 4
+    An, scale = _unit_scale(A)
     work = torch.zeros(n, ld, device=A.device, dtype=torch.float32)   # zero padding columns
-    work[:, :n].copy_(A)
+    work[:, :n].copy_(An)
     D, E, tau = _hip.sytrd_(work, n)
     Z = torch.empty(n, ld, device=A.device, dtype=torch.float32)      # column-major eigenvectors
     info = _rocsolver.stedc_(D, E, Z, n)
     _rocsolver.ormtr_(work, tau, Z, n)
     if int(info) != 0:
         raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
-    return D, Z[:, :n].T
+    return D * scale.reshape(()), Z[:, :n].T
 
 
 def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
@@ -314,8 +337,7 @@ def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
         n = A.shape[0]
         if 3 <= n <= _SYTRD_MAX_N and (_EIGH_MODE == "sytrd" or 256 <= n <= 2400):
             return eigh_sytrd(A)
-    res = torch.linalg.eigh(A)
-    return res.eigenvalues, res.eigenvectors
+    return _torch_eigh_scaled(A)
 
 
 def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Tensor]]:
@@ -352,9 +374,9 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
             for i in unit:
                 out[i] = eigh(mats[i])
             return
-        res = torch.linalg.eigh(torch.stack([mats[i] for i in unit]))
+        lam, vec = _torch_eigh_scaled(torch.stack([mats[i] for i in unit]))
         for k, i in enumerate(unit):
-            out[i] = (res.eigenvalues[k], res.eigenvectors[k])
+            out[i] = (lam[k], vec[k])
 
     if len(units) < 2 or num_streams < 2:
         for unit in units:

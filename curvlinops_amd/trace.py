@@ -46,7 +46,10 @@ def _gram_orthonormal_basis(X: Tensor, rel_tol: float = 1e-5) -> Tensor:
         n = Q.shape[1]
         gram = torch.empty(n, n, device=Q.device, dtype=torch.float32)
         _hip.syrk_accum(gram, Q, alpha=1.0, beta=0.0)
-        lam, V = torch.linalg.eigh(gram.double())
+        # (normalised: rocSOLVER's tridiagonal solver applies an absolute tolerance, linalg_native._unit_scale)
+        gscale = gram.abs().amax().clamp_min(torch.finfo(torch.float32).tiny).double()
+        lam, V = torch.linalg.eigh(gram.double() / gscale)
+        lam = lam * gscale
         keep = lam > lam.max() * (rel_tol if it == 0 else 1e-12)
         if not bool(keep.any()):
             return torch.zeros(Q.shape[0], 1, device=Q.device, dtype=Q.dtype)

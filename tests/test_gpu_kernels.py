@@ -714,3 +714,54 @@ def test_eigh_mode_switch(hip, monkeypatch):
     assert calls == [1]
     assert float((lam0 - lam1).abs().max()) <= 1e-5 * float(lam0.abs().max())
     assert float((A @ Q1 - Q1 * lam1).abs().max()) <= 1e-5 * float(A.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("power", [-8, -6, -3, 0, 4, 7])
+@pytest.mark.parametrize("mode", ["rocsolver", "sytrd", "many"])
+def test_eigh_is_scale_invariant(hip, monkeypatch, power, mode):
+    """Factors of tiny norm (gradient covariances of mean-reduced losses) and of huge norm: rocSOLVER's
+    tridiagonal solver applies an absolute tolerance (fp32 matrices of norm 1e-6: 30 % eigenvalue error through
+    plain torch.linalg.eigh), so every GPU entry point normalises first.  Relative accuracy must not depend on
+    the scale."""
+    from curvlinops_amd import linalg_native as L
+
+    dev = torch.device("cuda:0")
+    n = 97
+    A64 = _sym_case("indefinite", n, dev) * 10.0 ** power
+    A = A64.to(dev, torch.float32)
+    A64 = A.double().cpu()
+    if mode == "many":
+        B64 = _sym_case("lowrank", n, dev) * 10.0 ** (power - 1)
+        B = B64.to(dev, torch.float32)
+        (lam, Q), (lam_b, Q_b) = L.eigh_many([A, B])     # equal sizes: the stacked batched call
+        refb = torch.linalg.eigvalsh(B.double().cpu())
+        assert float((lam_b.double().cpu() - refb).abs().max()) <= 1e-5 * float(refb.abs().max())
+    else:
+        monkeypatch.setattr(L, "_EIGH_MODE", mode)
+        lam, Q = L.eigh(A)
+    ref = torch.linalg.eigvalsh(A64)
+    scale = float(A64.abs().max())
+    lam64, Q64 = lam.double().cpu(), Q.double().cpu()
+    assert float((lam64 - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((A64 @ Q64 - Q64 * lam64).abs().max()) <= 2e-5 * scale
+    assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_sytrd_is_deterministic(hip):
+    """Rank-deficient factors take the per-block panel pass in many columns: no block may observe another
+    block's updates of the panel (a race here showed up as run-to-run differences of 1e-2)."""
+    dev = torch.device("cuda:0")
+    n = 777
+    A64 = _sym_case("lowrank", n, dev)
+    ld = (n + 3) // 4 * 4
+    outs = []
+    for _ in range(4):
+        P = torch.zeros(n, ld, device=dev)
+        P[:, :n] = A64.float().to(dev)
+        D, E, tau = hip.sytrd_(P, n)
+        outs.append((D.clone(), E.clone(), tau.clone()))
+    for D, E, tau in outs[1:]:
+        assert torch.equal(D, outs[0][0]) and torch.equal(E[: n - 1], outs[0][1][: n - 1])
+        assert torch.equal(tau[: n - 2], outs[0][2][: n - 2])
