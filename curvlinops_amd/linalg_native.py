@@ -300,44 +300,129 @@ def _unit_scale(A: Tensor) -> tuple[Tensor, Tensor]:
     return A / s, s
 
 
+_ORTH_TOL = 1e-4   # healthy float32 eigenvectors: |Q^T Q - I| <= 2e-5 up to order 8000
+
+
+def _orth_defect(Q: Tensor) -> Tensor:
+    """``max |Q^T Q - I|`` per matrix (device tensor)."""
+    n = Q.shape[-1]
+    G = Q.mT @ Q
+    G.diagonal(dim1=-2, dim2=-1).sub_(1.0)
+    return G.abs().amax(dim=(-2, -1)) if n > 0 else G.new_zeros(G.shape[:-2])
+
+
 def _torch_eigh_scaled(A: Tensor) -> tuple[Tensor, Tensor]:
+    """``torch.linalg.eigh`` on the normalised matrices; on the GPU in float32 the eigenvectors are VERIFIED:
+    rocSOLVER's ``ssyevd`` returns non-orthogonal eigenvectors (|Q^T Q - I| = 0.07 ... 0.27, residual fine) for
+    some covariances of ReLU features with dead units and repeated rows (found by tools/fuzz_kfac.py, factor
+    kept in tests/golden/eigh_regression.npz).  A matrix that fails the check is decomposed again with the
+    hand-written reduction (``eigh_sytrd``), and in float64 if that is not applicable."""
     if not A.is_cuda:
         res = torch.linalg.eigh(A)
         return res.eigenvalues, res.eigenvectors
     An, s = _unit_scale(A)
     res = torch.linalg.eigh(An)
-    return res.eigenvalues * s.squeeze(-1), res.eigenvectors
+    lam, Q = res.eigenvalues, res.eigenvectors
+    if A.dtype == torch.float32 and A.shape[-1] > 1:
+        bad = (~(_orth_defect(Q) <= _ORTH_TOL)).reshape(-1).nonzero().flatten().tolist()   # (also catches NaN)
+        if bad:
+            batch_shape = An.shape[:-2]
+            An2, lam2, Q2 = An.reshape(-1, *An.shape[-2:]), lam.reshape(-1, lam.shape[-1]).clone(), Q.reshape(-1, *Q.shape[-2:]).clone()
+            for b in bad:
+                lam2[b], Q2[b] = _eigh_unit_checked(An2[b])
+            lam, Q = lam2.reshape(*batch_shape, -1), Q2.reshape(*batch_shape, *Q.shape[-2:])
+    return lam * s.squeeze(-1), Q
+
+
+def _eigh_unit_checked(An: Tensor) -> tuple[Tensor, Tensor]:
+    """Second opinion for ONE normalised float32 GPU matrix: own reduction, then float64."""
+    n = An.shape[0]
+    if 3 <= n <= _SYTRD_MAX_N:
+        lam, Q = _eigh_sytrd_unit(An)
+        if bool(_orth_defect(Q) <= _ORTH_TOL):
+            return lam, Q
+    res = torch.linalg.eigh(An.double())
+    return res.eigenvalues.float(), res.eigenvectors.float()
+
+
+def _eigh_sytrd_unit(An: Tensor) -> tuple[Tensor, Tensor]:
+    """``clo_sytrd_f32`` -> ``sstedc`` -> ``sormtr`` on a normalised matrix (no checks)."""
+    from . import _rocsolver
+
+    n = An.shape[0]
+    ld = (n + 3) // 4 * 4
+    work = torch.zeros(n, ld, device=An.device, dtype=torch.float32)   # zero padding columns
+    work[:, :n].copy_(An)
+    D, E, tau = _hip.sytrd_(work, n)
+    Z = torch.empty(n, ld, device=An.device, dtype=torch.float32)      # column-major eigenvectors
+    info = _rocsolver.stedc_(D, E, Z, n)
+    _rocsolver.ormtr_(work, tau, Z, n)
+    if int(info) != 0:
+        raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
+    return D, Z[:, :n].T
 
 
 def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
     """Symmetric eigendecomposition with the hand-written Householder reduction: ``clo_sytrd_f32`` (one launch
     per column) -> rocSOLVER ``sstedc`` on the tridiagonal matrix -> ``sormtr``.  fp32 GPU matrices of order
     3..8184; same conventions as ``torch.linalg.eigh`` (ascending eigenvalues, eigenvectors in columns)."""
-    from . import _rocsolver
-
     n = A.shape[0]
     if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == n and 3 <= n <= _SYTRD_MAX_N):
         raise ValueError(f"eigh_sytrd: need a square fp32 GPU matrix of order 3..{_SYTRD_MAX_N}, got {tuple(A.shape)} {A.dtype}")
-    ld = (n + 3) // 4 * 4
     An, scale = _unit_scale(A)
-    work = torch.zeros(n, ld, device=A.device, dtype=torch.float32)   # zero padding columns
-    work[:, :n].copy_(An)
-    D, E, tau = _hip.sytrd_(work, n)
-    Z = torch.empty(n, ld, device=A.device, dtype=torch.float32)      # column-major eigenvectors
-    info = _rocsolver.stedc_(D, E, Z, n)
-    _rocsolver.ormtr_(work, tau, Z, n)
-    if int(info) != 0:
-        raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
-    return D * scale.reshape(()), Z[:, :n].T
+    lam, Q = _eigh_sytrd_unit(An)
+    if not bool(_orth_defect(Q) <= _ORTH_TOL):   # same verification as the rocSOLVER route
+        res = torch.linalg.eigh(An.double())
+        lam, Q = res.eigenvalues.float(), res.eigenvectors.float()
+    return lam * scale.reshape(()), Q
 
 
-def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
-    """Eigenvalues (ascending) and orthonormal eigenvectors (columns) of symmetric ``A``."""
+def _nonzero_rows(A: Tensor) -> Tensor | None:
+    """Indices of the rows (= columns) of symmetric ``A`` that are not entirely zero, or None if all are.
+    Covariances of ReLU features have exactly-zero rows for dead units (ResNet-18, 512 CIFAR-sized inputs: 4180
+    of the 4608 patch features of a layer4 convolution): the eigenproblem splits exactly into the nonzero
+    principal submatrix and unit vectors with eigenvalue 0, which is both much smaller and the input class on
+    which rocSOLVER's ``ssyevd`` loses orthogonality (|Q^T Q - I| = 0.59 on that factor)."""
+    nz = (A != 0).any(dim=1)
+    m = int(nz.sum())
+    return None if m == A.shape[0] else nz.nonzero().flatten()
+
+
+def _embed_deflated(n: int, idx: Tensor, lam_s: Tensor, Q_s: Tensor) -> tuple[Tensor, Tensor]:
+    """Eigenpairs of the full matrix from those of its nonzero principal submatrix (rows ``idx``)."""
+    m = idx.numel()
+    dev, dt = lam_s.device, lam_s.dtype
+    lam = torch.cat([lam_s, lam_s.new_zeros(n - m)])
+    Q = torch.zeros(n, n, device=dev, dtype=dt)
+    if m:
+        Q[idx.unsqueeze(1), torch.arange(m, device=dev).unsqueeze(0)] = Q_s
+    dead = torch.ones(n, dtype=torch.bool, device=dev)
+    dead[idx] = False
+    dead_idx = dead.nonzero().flatten()
+    Q[dead_idx, m + torch.arange(n - m, device=dev)] = 1.0
+    order = torch.sort(lam, stable=True).indices
+    return lam[order], Q[:, order]
+
+
+def _eigh_full(A: Tensor) -> tuple[Tensor, Tensor]:
+    """One matrix without zero rows (or a CPU / non-float32 one): solver selection as documented at _EIGH_MODE."""
     if _EIGH_MODE != "rocsolver" and A.is_cuda and A.dtype == torch.float32 and A.dim() == 2:
         n = A.shape[0]
         if 3 <= n <= _SYTRD_MAX_N and (_EIGH_MODE == "sytrd" or 256 <= n <= 2400):
             return eigh_sytrd(A)
     return _torch_eigh_scaled(A)
+
+
+def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
+    """Eigenvalues (ascending) and orthonormal eigenvectors (columns) of symmetric ``A``."""
+    if A.is_cuda and A.dim() == 2 and A.shape[0] > 1:
+        idx = _nonzero_rows(A)
+        if idx is not None:
+            if idx.numel() == 0:
+                return A.new_zeros(A.shape[0]), torch.eye(A.shape[0], device=A.device, dtype=A.dtype)
+            sub = A.index_select(0, idx).index_select(1, idx)
+            return _embed_deflated(A.shape[0], idx, *_eigh_full(sub))
+    return _eigh_full(A)
 
 
 def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Tensor]]:
@@ -349,13 +434,32 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
       409 -> 258 ms), and
     * the groups are spread, largest first, over a few worker threads that each own a HIP stream
       (the solver synchronises with the host in between)."""
-    gpu = [i for i, A in enumerate(mats) if A.is_cuda]
     out: list = [None] * len(mats)
     for i, A in enumerate(mats):
         if not A.is_cuda:
             out[i] = eigh(A)
+    # exactly-zero rows (dead ReLU features) split off: the solvers see the nonzero principal submatrices
+    full_mats, deflated = mats, {}
+    mats = list(mats)
+    for i, A in enumerate(full_mats):
+        if A.is_cuda and A.dim() == 2 and A.shape[0] > 1:
+            idx = _nonzero_rows(A)
+            if idx is not None:
+                if idx.numel() == 0:
+                    out[i] = (A.new_zeros(A.shape[0]), torch.eye(A.shape[0], device=A.device, dtype=A.dtype))
+                else:
+                    deflated[i] = idx
+                    mats[i] = A.index_select(0, idx).index_select(1, idx)
+    gpu = [i for i, A in enumerate(mats) if A.is_cuda and out[i] is None]
     if not gpu:
         return out
+    out = _eigh_many_gpu(mats, gpu, out, num_streams)
+    for i, idx in deflated.items():
+        out[i] = _embed_deflated(full_mats[i].shape[0], idx, *out[i])
+    return out
+
+
+def _eigh_many_gpu(mats: list[Tensor], gpu: list[int], out: list, num_streams: int) -> list:
     groups: dict = {}
     for i in gpu:
         groups.setdefault((mats[i].shape[0], mats[i].dtype), []).append(i)
@@ -372,7 +476,7 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
     def run(unit: list[int]) -> None:
         if len(unit) == 1:
             for i in unit:
-                out[i] = eigh(mats[i])
+                out[i] = _eigh_full(mats[i])
             return
         lam, vec = _torch_eigh_scaled(torch.stack([mats[i] for i in unit]))
         for k, i in enumerate(unit):

@@ -765,3 +765,79 @@ def test_sytrd_is_deterministic(hip):
     for D, E, tau in outs[1:]:
         assert torch.equal(D, outs[0][0]) and torch.equal(E[: n - 1], outs[0][1][: n - 1])
         assert torch.equal(tau[: n - 2], outs[0][2][: n - 2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["eigh", "eigh_many", "eigh_sytrd"])
+def test_eigh_orthogonal_on_dead_relu_factor(hip, entry):
+    """A real KFAC input covariance (845 flattened ReLU features of a small conv net, 338 dead units, repeated
+    rows; produced by tools/fuzz_kfac.py seed 3 case 59) on which rocSOLVER's ssyevd -- plain torch.linalg.eigh --
+    returns eigenvectors with |Q^T Q - I| = 0.07 (0.27 on the normalised matrix) on this platform.  Every
+    entry point of the package must return an orthogonal basis (verified + decomposed again when needed)."""
+    from curvlinops_amd import linalg_native as L
+
+    dev = torch.device("cuda:0")
+    A = torch.as_tensor(load_golden("eigh_regression")["dead_relu_845"]["factor"]).to(dev)
+    n = A.shape[0]
+    if entry == "eigh":
+        lam, Q = L.eigh(A)
+    elif entry == "eigh_sytrd":
+        lam, Q = L.eigh_sytrd(A)
+    else:
+        (lam, Q), (lam2, Q2) = L.eigh_many([A, 2.0 * A])   # equal sizes: the stacked batched call
+        assert float((Q2.T @ Q2 - torch.eye(n, device=dev)).abs().max()) <= 2e-5
+    A64, Q64, l64 = A.double().cpu(), Q.double().cpu(), lam.double().cpu()
+    assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 2e-5
+    assert float((A64 @ Q64 - Q64 * l64).abs().max()) <= 1e-4 * float(A64.abs().max())
+    ref = torch.linalg.eigvalsh(A64)
+    assert float((l64 - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_fuzz_eigh(hip):
+    """Random orders / spectra / scales through both eigensolver routes (tools/fuzz_eigh.py)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_eigh
+
+    worst, failures = fuzz_eigh.run(seed=5, ncase=60)
+    assert not failures, "\n".join(failures)
+    os.environ["CLO_FUZZ_EIGH_DEFAULT"] = "1"
+    try:
+        worst, failures = fuzz_eigh.run(seed=6, ncase=60)
+    finally:
+        del os.environ["CLO_FUZZ_EIGH_DEFAULT"]
+    assert not failures, "\n".join(failures)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dead", [(64, 0.5), (300, 0.9), (845, 0.3), (97, 1.0), (33, 0.0)])
+@pytest.mark.parametrize("entry", ["eigh", "eigh_many"])
+def test_eigh_deflates_zero_rows(hip, n, dead, entry):
+    """Exactly-zero rows / columns (dead ReLU features) are split off before the solver runs: the result is a
+    complete orthonormal eigenbasis of the full matrix with ascending eigenvalues (indefinite input, so the zero
+    eigenvalues sit in the middle of the spectrum)."""
+    from curvlinops_amd import linalg_native as L
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    A64 = _sym_case("indefinite", n, dev)
+    kill = torch.rand(n, generator=g) < dead
+    A64[kill, :] = 0.0
+    A64[:, kill] = 0.0
+    A = A64.to(dev, torch.float32)
+    if entry == "eigh":
+        lam, Q = L.eigh(A)
+    else:
+        (lam, Q), (lam2, Q2) = L.eigh_many([A, _sym_case("full", n, dev).to(dev, torch.float32)])
+        assert float((Q2.T @ Q2 - torch.eye(n, device=dev)).abs().max()) <= 2e-5
+    A32, l64, Q64 = A.double().cpu(), lam.double().cpu(), Q.double().cpu()
+    ref = torch.linalg.eigvalsh(A32)
+    scale = max(float(A32.abs().max()), 1.0)
+    assert torch.all(l64[1:] >= l64[:-1])
+    assert float((l64 - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-30) + 1e-12
+    assert float((A32 @ Q64 - Q64 * l64).abs().max()) <= 2e-5 * scale
+    assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 2e-5
+    assert int((l64 == 0).sum()) >= int(kill.sum())

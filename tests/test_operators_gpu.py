@@ -593,3 +593,18 @@ def test_grouped_kronecker_blocks_see_inplace_factor_updates(dev):
         blocks[2][0].mul_(0.5).add_(torch.eye(6, device=dev))
     dense = torch.block_diag(*[torch.kron(b[0], b[1]) for b in blocks])
     assert rel_err(bd @ x, (dense @ x).cpu().numpy()) < TOL
+
+
+def test_fuzz_kfac_operators_gpu():
+    """30 random small nets (conv / linear stacks, losses, Fisher types, expand / reduce, joint / separate bias,
+    input scales 1e-2 ... 1e2): KFAC / EKFAC products and damped inverses in float32 on the GPU against this
+    package's float64 CPU path (pinned to the reference by the goldens) -- tools/fuzz_kfac.py."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_kfac
+
+    worst, failures = fuzz_kfac.run(seed=3, ncase=60)   # seed 3 holds the dead-ReLU factor rocSOLVER mishandles
+    assert not failures, "\\n".join(failures)
+    assert worst < 5e-3
