@@ -212,8 +212,9 @@ def secondary_configs(device) -> dict:
     ek["ekfac_total_ms"], E = timed(lambda: C.EKFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw), 1)
     v = torch.rand(E.shape[1], device=device)
     ek["ekfac_matvec_ms"], _ = timed(lambda: E @ v, 3)
-    ek["note"] = ("EKFAC = factors + eigendecompositions of the 42 factors (rocSOLVER through torch.linalg.eigh, "
-                  "batched by size on 4 streams) + eigenvalue-correction sweep")
+    ek["note"] = ("EKFAC = factors + eigendecompositions of the 42 factors (dead-feature rows deflated, normalised, "
+                  "rocSOLVER batched by size on 4 streams, orthogonality verified with fallback to the hand-written "
+                  "tridiagonalisation) + eigenvalue-correction sweep")
     out["c4_ekfac_resnet18"] = ek
     del K, E, facs, model, params
     torch.cuda.empty_cache()
