@@ -605,6 +605,6 @@ def test_fuzz_kfac_operators_gpu():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_kfac
 
-    worst, failures = fuzz_kfac.run(seed=3, ncase=60)   # seed 3 holds the dead-ReLU factor rocSOLVER mishandles
+    worst, failures = fuzz_kfac.run(seed=3, ncase=60)
     assert not failures, "\\n".join(failures)
     assert worst < 5e-3

@@ -10,10 +10,26 @@ from torch import nn
 import curvlinops_amd as C
 
 
+class MeanPool(nn.Module):
+    """[B, T, d] -> [B, d]: ends the weight-sharing part of a sequence model."""
+
+    def forward(self, x):
+        return x.mean(dim=1)
+
+
 def make_model(rng):
-    conv = rng.random() < 0.5
+    kind = rng.random()
+    conv = kind < 0.4
     layers = []
-    if conv:
+    if kind >= 0.8:   # sequence model: Linear layers applied to [B, T, d] (weight sharing over T), then pooled
+        T, d = int(rng.integers(2, 6)), int(rng.integers(2, 8))
+        shape = (T, d)
+        for _ in range(int(rng.integers(1, 3))):
+            do = int(rng.integers(2, 8))
+            layers += [nn.Linear(d, do, bias=bool(rng.random() < 0.8)), nn.Tanh() if rng.random() < 0.5 else nn.ReLU()]
+            d = do
+        layers.append(MeanPool())
+    elif conv:
         c, h = int(rng.integers(1, 4)), int(rng.integers(6, 12))
         shape = (c, h, h)
         for _ in range(int(rng.integers(1, 3))):
@@ -51,15 +67,16 @@ def run(seed, ncase):
         model64, shape, out = make_model(rng)
         model64 = model64.double()
         model32 = copy.deepcopy(model64).float().to(dev)
-        lossname = str(rng.choice(["mse", "ce"]))
+        lossname = str(rng.choice(["mse", "ce", "bce"]))
         red = str(rng.choice(["mean", "sum"]))
-        loss = (nn.MSELoss if lossname == "mse" else nn.CrossEntropyLoss)(reduction=red)
+        loss = {"mse": nn.MSELoss, "ce": nn.CrossEntropyLoss, "bce": nn.BCEWithLogitsLoss}[lossname](reduction=red)
         scale = 10.0 ** rng.uniform(-2, 2)
         data64 = []
         for _ in range(int(rng.integers(1, 3))):
             n = int(rng.integers(2, 9))
             X = torch.rand(n, *shape, dtype=torch.float64) * scale
-            y = torch.randint(0, out, (n,)) if lossname == "ce" else torch.rand(n, out, dtype=torch.float64)
+            y = (torch.randint(0, out, (n,)) if lossname == "ce" else
+                 torch.randint(0, 2, (n, out)).double() if lossname == "bce" else torch.rand(n, out, dtype=torch.float64))
             data64.append((X, y))
         data32 = [(X.float().to(dev), y.to(dev) if y.dtype == torch.int64 else y.float().to(dev)) for X, y in data64]
         kw = dict(fisher_type=str(rng.choice(["empirical", "type-2"])), kfac_approx=str(rng.choice(["expand", "reduce"])),

@@ -20,15 +20,16 @@ def run(seed, ncase):
         model64, shape, out = make_model(rng)
         model64 = model64.double()
         model32 = copy.deepcopy(model64).float().to(dev)
-        lossname = str(rng.choice(["mse", "ce"]))
+        lossname = str(rng.choice(["mse", "ce", "bce"]))
         red = str(rng.choice(["mean", "sum"]))
-        loss = (nn.MSELoss if lossname == "mse" else nn.CrossEntropyLoss)(reduction=red)
+        loss = {"mse": nn.MSELoss, "ce": nn.CrossEntropyLoss, "bce": nn.BCEWithLogitsLoss}[lossname](reduction=red)
         scale = 10.0 ** rng.uniform(-1, 1)
         data64 = []
         for _ in range(int(rng.integers(1, 3))):
             n = int(rng.integers(2, 9))
             X = torch.rand(n, *shape, dtype=torch.float64) * scale
-            y = torch.randint(0, out, (n,)) if lossname == "ce" else torch.rand(n, out, dtype=torch.float64)
+            y = (torch.randint(0, out, (n,)) if lossname == "ce" else
+                 torch.randint(0, 2, (n, out)).double() if lossname == "bce" else torch.rand(n, out, dtype=torch.float64))
             data64.append((X, y))
         data32 = [(X.float().to(dev), y.to(dev) if y.dtype == torch.int64 else y.float().to(dev)) for X, y in data64]
         p64, p32 = dict(model64.named_parameters()), dict(model32.named_parameters())
