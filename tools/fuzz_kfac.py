@@ -83,7 +83,7 @@ def run(seed, ncase):
                   separate_weight_and_bias=bool(rng.random() < 0.5), check_deterministic=False)
         what = f"case {case}: {[type(m).__name__ for m in model64]} shape {shape} loss {lossname}/{red} scale {scale:.1e} {kw}"
         try:
-            has_conv = any(isinstance(m, nn.Conv2d) for m in model64)
+            has_conv = any(isinstance(m, (nn.Conv2d, MeanPool)) for m in model64)   # any weight sharing
             for cls in (C.KFACLinearOperator, C.EKFACLinearOperator):
                 if cls is C.EKFACLinearOperator and has_conv and kw["kfac_approx"] == "reduce":
                     # the eigenvalues are re-fitted on EXPAND-format patches (ekfac_hooks.py:435-440) in the
