@@ -311,6 +311,14 @@ def _orth_defect(Q: Tensor) -> Tensor:
     return G.abs().amax(dim=(-2, -1)) if n > 0 else G.new_zeros(G.shape[:-2])
 
 
+_RES_TOL = 1e-3    # |A Q - Q diag(lam)| on the normalised matrix (healthy: <= 4e-5 up to order 8000)
+
+
+def _residual_defect(An: Tensor, lam: Tensor, Q: Tensor) -> Tensor:
+    """``max |A Q - Q diag(lam)|`` per matrix (device tensor), ``A`` normalised to ``max |A| = 1``."""
+    return (An @ Q - Q * lam.unsqueeze(-2)).abs().amax(dim=(-2, -1))
+
+
 def _torch_eigh_scaled(A: Tensor) -> tuple[Tensor, Tensor]:
     """``torch.linalg.eigh`` on the normalised matrices; on the GPU in float32 the eigenvectors are VERIFIED:
     rocSOLVER's ``ssyevd`` returns non-orthogonal eigenvectors (|Q^T Q - I| = 0.07 ... 0.27, residual fine) for
@@ -324,7 +332,8 @@ def _torch_eigh_scaled(A: Tensor) -> tuple[Tensor, Tensor]:
     res = torch.linalg.eigh(An)
     lam, Q = res.eigenvalues, res.eigenvectors
     if A.dtype == torch.float32 and A.shape[-1] > 1:
-        bad = (~(_orth_defect(Q) <= _ORTH_TOL)).reshape(-1).nonzero().flatten().tolist()   # (also catches NaN)
+        ok = (_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL)   # (NaN fails both)
+        bad = (~ok).reshape(-1).nonzero().flatten().tolist()
         if bad:
             batch_shape = An.shape[:-2]
             An2, lam2, Q2 = An.reshape(-1, *An.shape[-2:]), lam.reshape(-1, lam.shape[-1]).clone(), Q.reshape(-1, *Q.shape[-2:]).clone()
@@ -339,7 +348,7 @@ def _eigh_unit_checked(An: Tensor) -> tuple[Tensor, Tensor]:
     n = An.shape[0]
     if 3 <= n <= _SYTRD_MAX_N:
         lam, Q = _eigh_sytrd_unit(An)
-        if bool(_orth_defect(Q) <= _ORTH_TOL):
+        if bool((_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL)):
             return lam, Q
     res = torch.linalg.eigh(An.double())
     return res.eigenvalues.float(), res.eigenvectors.float()
@@ -371,7 +380,7 @@ def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
         raise ValueError(f"eigh_sytrd: need a square fp32 GPU matrix of order 3..{_SYTRD_MAX_N}, got {tuple(A.shape)} {A.dtype}")
     An, scale = _unit_scale(A)
     lam, Q = _eigh_sytrd_unit(An)
-    if not bool(_orth_defect(Q) <= _ORTH_TOL):   # same verification as the rocSOLVER route
+    if not bool((_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL)):   # verified like the rocSOLVER route
         res = torch.linalg.eigh(An.double())
         lam, Q = res.eigenvalues.float(), res.eigenvectors.float()
     return lam * scale.reshape(()), Q
