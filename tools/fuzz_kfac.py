@@ -17,6 +17,9 @@ class MeanPool(nn.Module):
         return x.mean(dim=1)
 
 
+BIG = os.environ.get("CLO_FUZZ_BIG") is not None   # wider layers / more rows: more kernel paths (split-K, tall-skinny Gram)
+
+
 def make_model(rng):
     kind = rng.random()
     conv = kind < 0.4
@@ -30,10 +33,10 @@ def make_model(rng):
             d = do
         layers.append(MeanPool())
     elif conv:
-        c, h = int(rng.integers(1, 4)), int(rng.integers(6, 12))
+        c, h = int(rng.integers(1, 12 if BIG else 4)), int(rng.integers(6, 20 if BIG else 12))
         shape = (c, h, h)
         for _ in range(int(rng.integers(1, 3))):
-            co = int(rng.integers(2, 6))
+            co = int(rng.integers(2, 40 if BIG else 6))
             k = int(rng.integers(1, 4))
             s, p = int(rng.integers(1, 3)), int(rng.integers(0, 2))
             if (h + 2 * p - k) // s + 1 < 1:
@@ -43,10 +46,10 @@ def make_model(rng):
         layers.append(nn.Flatten())
         d = c * h * h
     else:
-        d = int(rng.integers(2, 12))
+        d = int(rng.integers(2, 300 if BIG else 12))
         shape = (d,)
     for _ in range(int(rng.integers(0, 3))):
-        do = int(rng.integers(2, 10))
+        do = int(rng.integers(2, 200 if BIG else 10))
         layers += [nn.Linear(d, do, bias=bool(rng.random() < 0.8)), nn.Sigmoid() if rng.random() < 0.5 else nn.ReLU()]
         d = do
     out = int(rng.integers(2, 6))
@@ -73,7 +76,7 @@ def run(seed, ncase):
         scale = 10.0 ** rng.uniform(-2, 2)
         data64 = []
         for _ in range(int(rng.integers(1, 3))):
-            n = int(rng.integers(2, 9))
+            n = int(rng.integers(2, 70 if BIG else 9))
             X = torch.rand(n, *shape, dtype=torch.float64) * scale
             y = (torch.randint(0, out, (n,)) if lossname == "ce" else
                  torch.randint(0, 2, (n, out)).double() if lossname == "bce" else torch.rand(n, out, dtype=torch.float64))
