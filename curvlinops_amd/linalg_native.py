@@ -279,11 +279,12 @@ def damped_cholesky_inverse(A: Tensor, damping: float, retry_double_precision: b
         return _torch_damped_cholesky_inverse(A.to(torch.float64), damping).to(A.dtype)
 
 
-# Which solver :func:`eigh` uses for fp32 GPU matrices: "rocsolver" (torch.linalg.eigh; default), "sytrd" (the
-# hand-written tridiagonalisation clo_sytrd_f32 + rocSOLVER's tridiagonal divide & conquer and
-# back-transformation) or "auto" (own reduction where it measured faster: single matrices of order
-# 256..2400).
-_EIGH_MODE = os.environ.get("CLO_EIGH", "rocsolver").lower()
+# Which solver :func:`eigh` uses for fp32 GPU matrices: "auto" (default: the hand-written tridiagonalisation
+# clo_sytrd_f32 + rocSOLVER's tridiagonal divide & conquer and back-transformation where it measured faster --
+# single matrices of order 256..2400 -- and torch.linalg.eigh elsewhere), "sytrd" (own reduction for every order
+# 3..8184) or "rocsolver" (torch.linalg.eigh only).  All routes are verified, see _torch_eigh_scaled; DESIGN.md
+# section 7.
+_EIGH_MODE = os.environ.get("CLO_EIGH", "auto").lower()
 _SYTRD_MAX_N = 8184
 
 

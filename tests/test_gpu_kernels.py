@@ -699,8 +699,8 @@ def test_sytrd_is_a_similarity_transform(hip, n):
 
 @pytest.mark.gpu
 def test_eigh_mode_switch(hip, monkeypatch):
-    """CLO_EIGH=sytrd routes linalg_native.eigh through the hand-written reduction; the default stays on
-    torch.linalg.eigh.  Both give the same spectrum."""
+    """CLO_EIGH=sytrd routes every linalg_native.eigh through the hand-written reduction (the default, "auto",
+    does so for single matrices of order 256..2400).  Same spectrum either way."""
     from curvlinops_amd import linalg_native as L
 
     dev = torch.device("cuda:0")
