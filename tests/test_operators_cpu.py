@@ -356,3 +356,32 @@ def test_composites_never_mutate_the_operand(K):
     Y = I @ X
     Y.mul_(2.0)  # even the plain product is the caller's to modify
     assert torch.equal(X, X0)
+
+
+def test_eigh_zero_row_deflation_logic_cpu():
+    """The host logic of the GPU eigensolver wrapper (linalg_native): exactly-zero rows are split off, the
+    eigenpairs of the nonzero principal submatrix are embedded with unit vectors for the dead rows, eigenvalues
+    stay ascending (indefinite input: the zeros land in the middle)."""
+    from curvlinops_amd import linalg_native as L
+
+    g = torch.Generator().manual_seed(0)
+    n = 23
+    A = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = A + A.T
+    dead = torch.tensor([1, 4, 5, 17, 22])
+    A[dead, :] = 0.0
+    A[:, dead] = 0.0
+    idx = L._nonzero_rows(A)
+    assert idx.tolist() == [i for i in range(n) if i not in dead.tolist()]
+    sub = A.index_select(0, idx).index_select(1, idx)
+    lam, Q = L._embed_deflated(n, idx, *torch.linalg.eigh(sub))
+    assert torch.all(lam[1:] >= lam[:-1]) and int((lam == 0).sum()) == dead.numel()
+    assert torch.allclose(Q.T @ Q, torch.eye(n, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(A @ Q, Q * lam, atol=1e-12)
+    assert L._nonzero_rows(torch.eye(4)) is None
+    # scaling / verification helpers
+    An, s = L._unit_scale(1e-7 * A)
+    assert abs(float(An.abs().max()) - 1.0) < 1e-12 and torch.allclose(An * s, 1e-7 * A)
+    assert float(L._orth_defect(Q)) < 1e-12 and float(L._residual_defect(A, lam, Q)) < 1e-12
+    Z, sz = L._unit_scale(torch.zeros(3, 3))
+    assert float(sz) == 1.0 and not torch.isnan(Z).any()
