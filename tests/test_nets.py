@@ -327,3 +327,27 @@ def test_resnet18_fp32_native_against_fp64_torch_path_gpu():
             got = K32.inverse(damping=1e-2, **mode) @ v
             ref = K64.inverse(damping=1e-2, **mode) @ v.double()
             assert rel_err(got, ref.cpu().numpy()) < 1e-3, (cls.__name__, mode)
+
+
+@pytest.mark.gpu
+def test_encoder_fp32_native_against_fp64_torch_path_gpu():
+    """BASELINE C5's model at full size (12 layers, d = 768, 85 M parameters; 4 sequences of 32 tokens, weight
+    sharing over the sequence): KFAC / EKFAC of the Linear layers, float32 native path against the float64 torch
+    path on the same device.  Products 1e-4; the damped inverses see factors of rank 128 in 769 / 3073 dimensions
+    (condition number ~1e4 after damping), hence 5e-3 there."""
+    import copy
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m32 = Encoder().to(dev).eval()
+    m64 = copy.deepcopy(m32).double()
+    X, y = torch.rand(4, 32, 768, device=dev), torch.randint(0, 10, (4,), device=dev)
+    kw = dict(fisher_type="empirical", separate_weight_and_bias=False, check_deterministic=False)
+    lf = nn.CrossEntropyLoss()
+    for cls in (C.KFACLinearOperator, C.EKFACLinearOperator):
+        K32 = cls(m32, lf, kfac_params(m32), [(X, y)], **kw)
+        K64 = cls(m64, lf, kfac_params(m64), [(X.double(), y)], **kw)
+        v = torch.rand(K32.shape[1], 2, device=dev) - 0.5
+        assert rel_err(K32 @ v, (K64 @ v.double()).cpu().numpy()) < 1e-4
+        got, ref = K32.inverse(damping=1e-2) @ v, K64.inverse(damping=1e-2) @ v.double()
+        assert rel_err(got, ref.cpu().numpy()) < 5e-3, cls.__name__
