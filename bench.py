@@ -351,6 +351,27 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this script as N ranks of one node under
+    ``torch.distributed.run`` (rendezvous on 127.0.0.1, a free port), one rank per GPU.  Fewer visible
+    devices than ranks is an error unless the gloo dry-run backend was asked for."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()
+    if ndev < n and os.environ.get("CLO_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"bench.py: --gpus {n} requested but only {ndev} device(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,9 +381,18 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, RCCL); rank 0 of the children prints the JSON line
+        sys.exit(self_launch(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per requested GPU")
+    if world > 1 and os.environ.get("CLO_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} device(s) visible")
     # one process per GPU (the modulo only matters for the single-GPU dry run of the N > 1 code path)
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
@@ -375,8 +405,6 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     import curvlinops_amd as C
     from curvlinops_amd import _hip
