@@ -87,6 +87,7 @@ _SIGNATURES = {
          c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
     ),
     "clo_mlp_ggn_ws_floats": (c_long, [c_int, POINTER(c_int), c_int]),
+    "clo_mlp_ggn_ws_init": (c_int, [c_int, POINTER(c_int), c_int, _PF, c_void_p]),
     "clo_mlp_ggn_matmat": (
         c_int,
         [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
@@ -509,6 +510,12 @@ class MLPPlan:
         if ws is None:
             n = load().clo_mlp_ggn_ws_floats(self.L, self.dims, N)
             ws = torch.empty(n, device=device, dtype=torch.float32)
+            # counters of the persistent <= 8-row kernel (zeroed once; the kernel maintains them)
+            with torch.cuda.device(ws.device):
+                rc = load().clo_mlp_ggn_ws_init(self.L, self.dims, N, ws.data_ptr(),
+                                                torch.cuda.current_stream(ws.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"clo_mlp_ggn_ws_init failed: {load().clo_last_error().decode(errors='replace')}")
             self._ws = {k: v for k, v in self._ws.items() if k[0] in ("mm", "hess", "jac")}  # keep only the latest batch size
             self._ws[key] = ws
         return ws

@@ -2544,6 +2544,18 @@ static int launch_loss(int kind, const float *f, const float *aux, int aux_rank,
   return CLO_OK;
 }
 
+// mlp_mega.hip: the <= 8-row matvec of a three-layer net in one persistent launch
+bool mega_shape_ok(int L, const int *dims, int N);
+bool mega_ok(int L, const int *dims, const float *const *W, const float *const *VW, float *const *OW,
+             const float *X, int N);
+int mega_launch(const int *dims, const int *acts, const float *const *W, const float *const *b,
+                const float *const *VW, const float *const *Vb, float *const *OW, float *const *Ob,
+                const float *X, int N, int loss_kind, const float *aux, int aux_rank, float scale,
+                float beta, float *xch, unsigned *sync, hipStream_t st);
+long mega_xch_floats(int d1, int d2);
+long mega_sync_words();
+long mega_debug_floats();
+
 }  // namespace clo
 
 using namespace clo;
@@ -2863,7 +2875,25 @@ static int fwd_jvp_gemm(const float *a_in, const float *da_in, const float *Wl, 
 //   delta ping/pong    : 2 x [N][dmax]
 //   slabs              : max over layers of the fwd split-K / bwd row-range partial slabs
 //   GEMM split-K slabs : only when N > SKINNY_MAX_N
+static long ggn_ws_core_floats(int L, const int *dims, int N);
+// the persistent kernel's exchange area and counters sit behind everything else (64-float aligned)
+static long ggn_ws_mega_offset(int L, const int *dims, int N) {
+  return cdiv(ggn_ws_core_floats(L, dims, N), 64) * 64;
+}
 extern "C" long clo_mlp_ggn_ws_floats(int L, const int *dims, int N) {
+  if (L <= 0 || !dims || N < 0) return 0;
+  if (!mega_shape_ok(L, dims, N)) return ggn_ws_core_floats(L, dims, N);
+  return ggn_ws_mega_offset(L, dims, N) + cdiv(mega_xch_floats(dims[1], dims[2]), 64) * 64 + mega_sync_words() +
+         mega_debug_floats();
+}
+extern "C" int clo_mlp_ggn_ws_init(int L, const int *dims, int N, float *ws, void *stream) {
+  CLO_REQUIRE(L >= 1 && dims && N >= 0 && ws, "clo_mlp_ggn_ws_init: bad arguments");
+  if (!mega_shape_ok(L, dims, N)) return CLO_OK;  // nothing to initialise
+  float *sync = ws + ggn_ws_mega_offset(L, dims, N) + cdiv(mega_xch_floats(dims[1], dims[2]), 64) * 64;
+  return check_hip(hipMemsetAsync(sync, 0, (size_t)mega_sync_words() * 4, (hipStream_t)stream),
+                   "hipMemsetAsync(matvec counters)");
+}
+static long ggn_ws_core_floats(int L, const int *dims, int N) {
   if (L <= 0 || !dims || N < 0) return 0;
   long total = 0;
   int dmax = 0;
@@ -2946,6 +2976,12 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   const int Lf = narrow ? L - 1 : L;  // layers run by the generic forward loop
   float *hp = nullptr;
   int head_nblk = 0;
+  if (head && mega_ok(L, dims, W, VW, OW, X, N)) {
+    float *xch = ws + ggn_ws_mega_offset(L, dims, N);
+    unsigned *sync = reinterpret_cast<unsigned *>(xch + cdiv(mega_xch_floats(dims[1], dims[2]), 64) * 64);
+    return mega_launch(dims, acts, W, b, VW, Vb, OW, Ob, X, N, loss_kind, aux, aux_rank, loss_scale * alpha, beta,
+                       xch, sync, st);
+  }
   if (narrow && mid_chain_ok(L, dims, W, VW, OW, N)) {
 #define CLO_MID_CHAIN(T)                                                                              \
   mid_chain<T>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank, loss_scale * alpha, beta, \

@@ -26,6 +26,8 @@ checked by comparing R-rank results with the 1-rank result on identical data.
 
 from __future__ import annotations
 
+import os
+
 from collections.abc import Iterable, Sequence
 
 import torch
@@ -177,7 +179,20 @@ class AllReducedLinearOperator(PyTorchLinearOperator):
         not block the host) makes ``Y`` the reduced product.  Consecutive independent products --
         probe vectors of a trace estimator, the steps of the benchmark -- overlap the 4 D K-byte
         all-reduce of one product with the kernels of the next."""
-        Y = self._op @ X
+        if is_distributed():
+            # the collective of the previous product may still hold CUs: a persistent grid that needs every CU
+            # of the chip (csrc/mlp_mega.hip) would spin beside it, so overlapped products take the launch chain
+            prev = os.environ.get("CLO_MLP_MEGA")
+            os.environ["CLO_MLP_MEGA"] = "0"
+            try:
+                Y = self._op @ X
+            finally:
+                if prev is None:
+                    os.environ.pop("CLO_MLP_MEGA", None)
+                else:
+                    os.environ["CLO_MLP_MEGA"] = prev
+        else:
+            Y = self._op @ X
         if not Y.is_contiguous():
             Y = Y.contiguous()
         work = dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self._group, async_op=True) if is_distributed() else None

@@ -208,8 +208,9 @@ long clo_mlp_bwd_ws_floats(int N, int d_in, int d_out);
  *   W,b,VW,Vb,OW,Ob  host arrays of L device pointers (b/Vb/Ob entries may be NULL)
  *   X [N][d_0]   input batch;  loss_kind/aux/loss_scale as clo_loss_hessian_apply
  *   ws           workspace of clo_mlp_ggn_ws_floats(L, dims, N) floats
- * Works for any N: <= 8 rows on the VALU/MFMA streaming chain, 9 ... 64 rows on its all-MFMA variant
- * (narrow head, float4-complete layers), otherwise on the MFMA GEMM engine. */
+ * Works for any N: <= 8 rows in one persistent launch (three layers, narrow head, widths as in
+ * mlp_mega.hip; needs clo_mlp_ggn_ws_init) or on the VALU/MFMA streaming chain, 9 ... 64 rows on its
+ * all-MFMA variant (narrow head, float4-complete layers), otherwise on the MFMA GEMM engine. */
 int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
                        const float *const *W, const float *const *b,
                        const float *const *VW, const float *const *Vb,
@@ -218,6 +219,11 @@ int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
                        float loss_scale, float alpha, float beta,
                        float *ws, void *stream);
 long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
+/* Must run once on a freshly allocated workspace before its first clo_mlp_ggn_matvec (and again if other
+ * code wrote into it): three-layer nets with a narrow head and <= 8 rows run as ONE persistent launch whose
+ * workgroups synchronise through counters at the end of `ws`; this call zeroes them (hipMemsetAsync on
+ * `stream`).  The kernel keeps them consistent from call to call by itself.  No-op for other shapes. */
+int clo_mlp_ggn_ws_init(int L, const int *dims, int N, float *ws, void *stream);
 
 /* Jacobian and transposed-Jacobian products of an MLP (reference jacobian.py:14-358): the
  * forward+JVP half and the VJP half of the GGN product.

@@ -324,6 +324,91 @@ def test_ggn_matvec_mid_rows_chain(hip, N, loss):
     assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
 
 
+def _mega_case(g, dims, acts, N, loss, bias=(True, True, True)):
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [g.random(dims[i + 1]) - 0.5 if bias[i] else None for i in range(3)]
+    vWs = [g.random(W.shape) - 0.5 for W in Ws]
+    vbs = [None if b is None else g.random(b.shape) - 0.5 for b in bs]
+    X = g.random((N, dims[0]))
+    C = dims[-1]
+    y = g.integers(0, C, N) if loss == "ce" else (g.integers(0, 2, (N, C)).astype(float) if loss == "bce"
+                                                  else g.random((N, C)))
+    return Ws, bs, vWs, vbs, X, y
+
+
+@pytest.mark.parametrize("loss", ["mse", "ce", "bce"])
+@pytest.mark.parametrize("N", [1, 5, 8])
+@pytest.mark.parametrize("dims,acts,bias", [
+    ([64, 256, 512, 10], ["relu", "tanh", "identity"], (True, True, True)),          # one k-step per range, empty slices
+    ([128, 272, 520, 3], ["sigmoid", "relu", "identity"], (True, False, True)),      # ragged K ranges / feature blocks
+    ([16, 2816, 2688, 16], ["tanh", "relu", "identity"], (False, True, False)),      # the widest tile, C = 16
+    ([1024, 1024, 1024, 1], ["relu", "identity", "identity"], (True, True, True)),   # C = 1
+])
+def test_ggn_matvec_persistent_kernel(hip, monkeypatch, dims, acts, bias, N, loss):
+    """Round 3: the <= 8-row matvec of a three-layer net as ONE persistent launch (mlp_mega.hip) against the
+    float64 oracle, plain and accumulating, and against the six-launch chain."""
+    monkeypatch.setenv("CLO_MLP_MEGA", "1")
+    g = np.random.default_rng(7 * N + len(loss) + dims[1])
+    Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, loss, bias)
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", vWs, vbs)
+    scale = (2.0 if loss == "mse" else 1.0) * O.reduction_factor(loss, "mean", N, dims[-1])
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 1.0, 0.0)
+    for k, (got, ref) in enumerate(zip(gW + gb, rW + rb)):  # every parameter block on its own scale
+        if ref is not None:
+            assert rel_err(got, ref) < 1e-4, f"block {k}"
+    out0 = ([g.random(W.shape) for W in Ws], [None if b is None else g.random(b.shape) for b in bs])
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 0.5, 1.0, out0=out0)
+    ref = O.flatten_params([0.5 * r + o for r, o in zip(rW, out0[0])],
+                           [None if r is None else 0.5 * r + o for r, o in zip(rb, out0[1])])
+    assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
+    monkeypatch.setenv("CLO_MLP_MEGA", "0")
+    oW, ob = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 0.5, 1.0, out0=out0)
+    assert rel_err(O.flatten_params(gW, gb), O.flatten_params(oW, ob)) < 2e-5
+
+
+@pytest.mark.parametrize("N,loss", [(8, "mse"), (5, "ce"), (8, "bce")])
+def test_ggn_matvec_persistent_kernel_c2(hip, monkeypatch, N, loss):
+    """The benchmark network itself (1024-2688-2688-10, ReLU) through the persistent kernel: float64 oracle,
+    every parameter block on its own scale; 20 products on ONE workspace are bit-for-bit identical (fixed
+    summation orders, the counters recycle correctly from call to call)."""
+    monkeypatch.setenv("CLO_MLP_MEGA", "1")
+    g = np.random.default_rng(N)
+    dims, acts = [1024, 2688, 2688, 10], ["relu", "relu", "identity"]
+    Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, loss)
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", vWs, vbs)
+    scale = (2.0 if loss == "mse" else 1.0) * O.reduction_factor(loss, "mean", N, dims[-1])
+    plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    dW, db = [dev(W) for W in Ws], [dev(b) for b in bs]
+    dVW, dVb = [dev(v) for v in vWs], [dev(v) for v in vbs]
+    dX = dev(X)
+    first = None
+    for it in range(20):
+        oW = [torch.full_like(w, float("nan")) for w in dW]
+        ob = [torch.full_like(b, float("nan")) for b in db]
+        plan.ggn_matvec(dW, db, dVW, dVb, oW, ob, dX, LOSS_KIND[loss], scale, 1.0, 0.0)
+        torch.cuda.synchronize()
+        got = [t.cpu().numpy() for t in oW + ob]
+        if first is None:
+            first = got
+            for k, (a, r) in enumerate(zip(got, rW + rb)):
+                assert rel_err(a, r) < 1e-4, f"block {k}"
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(got, first)), f"call {it} differs"
+
+
+def test_ggn_matvec_persistent_kernel_rank1(hip, monkeypatch):
+    """Empirical-Fisher / MC output curvature (rank-M) through the persistent kernel."""
+    g = np.random.default_rng(3)
+    dims, acts, N, M = [64, 256, 512, 10], ["relu", "tanh", "identity"], 6, 3
+    Ws, bs, vWs, vbs, X, _ = _mega_case(g, dims, acts, N, "mse")
+    aux = g.random((N, M, dims[-1])) - 0.5
+    monkeypatch.setenv("CLO_MLP_MEGA", "1")
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 3, 0.25, 1.0, 0.0, aux=dev(aux))
+    monkeypatch.setenv("CLO_MLP_MEGA", "0")
+    oW, ob = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 3, 0.25, 1.0, 0.0, aux=dev(aux))
+    assert rel_err(O.flatten_params(gW, gb), O.flatten_params(oW, ob)) < 2e-5
+
+
 @pytest.mark.parametrize("dims,acts", [([20, 36, 10], ["relu", "identity"]),            # one hidden layer, ragged widths
                                        ([32, 16, 16], ["tanh", "identity"]),            # C = 16 (widest narrow head)
                                        ([300, 520, 260, 3], ["sigmoid", "relu", "identity"])])

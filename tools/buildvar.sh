@@ -1,9 +1,9 @@
-# usage: buildvar.sh name "-DFLAGS"
+# usage: buildvar.sh name "-DFLAGS"   -> curvlinops_amd/lib/variants/libclo_<name>.so (load with CLO_HIP_LIB=<path>)
 set -e
 cd /root/repo/curvlinops_amd/csrc
 name=$1; shift
-mkdir -p /tmp/obj_$name
-for f in gemm mlp stream_ops linalg conv gram sytrd; do
+mkdir -p /tmp/obj_$name ../lib/variants
+for f in gemm mlp mlp_mega stream_ops linalg conv gram sytrd; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $f.hip -o /tmp/obj_$name/$f.o ) &
 done
 wait

@@ -28,7 +28,7 @@ def run(n):
     return 1e6 * (t1 - t0) / n, 1e6 * (time.perf_counter() - t0) / n
 
 
-variants = [v.split(",") for v in os.environ.get("VARIANTS", "CLO_MLP_CHAIN4=0;CLO_MLP_CHAIN4=1").split(";")]
+variants = [v.split(",") for v in os.environ.get("VARIANTS", "CLO_MLP_MEGA=0;CLO_MLP_MEGA=1").split(";")]
 for rnd in range(3):
     for var in variants:
         for kv in var:
