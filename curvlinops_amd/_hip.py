@@ -150,8 +150,28 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+            if res is c_int and args and args[-1] is c_void_p:   # status-returning entry points that take a stream
+                setattr(lib, name, _device_safe(fn))
         _lib = lib
     return _lib
+
+
+def _device_safe(fn):
+    """`_stream()` may have made another device current for the duration of the foreign call and `_check()`
+    switches back; if the call itself raises (ctypes argument conversion), nothing would -- restore here."""
+
+    def call(*args):
+        try:
+            return fn(*args)
+        except BaseException:
+            prev = getattr(_tls, "restore", None)
+            if prev is not None:
+                _tls.restore = None
+                torch.cuda.set_device(prev)
+            raise
+
+    call.__name__ = getattr(fn, "__name__", "clo_call")
+    return call
 
 
 def has(symbol: str) -> bool:
@@ -170,7 +190,7 @@ def prof_collect() -> dict[str, dict[str, float]]:
     by = (ctypes.c_double * 8)()
     _check(load().clo_prof_collect(ms, cnt, by), "clo_prof_collect")
     # tags of csrc/clo_common.h:ProfScope as used by mlp.hip
-    names = ["fwd_mfma", "loss_head_bwd", "bwd_dprev", "finish_head_fwd", "outer_all", "other", "t6", "t7"]
+    names = ["fwd_mfma", "loss_head_bwd", "bwd_dprev", "finish_head_fwd", "outer_all", "other", "persistent", "t7"]
     return {n: {"ms": ms[i], "launches": int(cnt[i]), "alg_bytes": by[i]} for i, n in enumerate(names) if cnt[i]}
 
 

@@ -5,7 +5,7 @@ API (ctypes on the copy PyTorch ships, so no second rocBLAS is loaded):
 * ``sormtr``  -- multiplication by the Householder reflectors of the reduction (12.9 ms).
 
 The reduction itself (85 % of ``torch.linalg.eigh``'s time) is ``clo_sytrd_f32``.  One rocBLAS handle
-per host thread; each call binds the handle to the thread's current HIP stream.
+per (device, HIP stream), kept for the life of the process.
 """
 
 from __future__ import annotations
@@ -19,7 +19,6 @@ import torch
 _P, _I = ctypes.c_void_p, ctypes.c_int
 _FILL_LOWER, _SIDE_LEFT, _OP_NONE, _EVECT_TRIDIAGONAL = 122, 141, 111, 212
 _libs = None
-_tls = threading.local()
 _lock = threading.Lock()
 
 
@@ -47,23 +46,32 @@ def available() -> bool:
         return False
 
 
+_handles: dict = {}   # (device index, HIP stream) -> rocBLAS handle, process-wide
+
+
 def _handle(device: torch.device):
+    """One rocBLAS handle per (device, HIP stream), created once and kept for the life of the process.
+    The worker threads of ``linalg_native`` are started per call but their HIP streams persist, so keying the
+    handles by stream (not by thread, as rounds 1-2 did) bounds their number -- and the >= 32 MB of device
+    workspace each one owns -- by the number of streams instead of leaking one per worker thread per
+    refresh.  Work of one stream is ordered by the stream, so its handle (and workspace) is never used by
+    two kernels at once."""
     rocblas, _ = _load()
-    handles = getattr(_tls, "handles", None)
-    if handles is None:
-        handles = _tls.handles = {}
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    h = handles.get(key)
-    if h is None:
-        h = _P()
-        with torch.cuda.device(key):
-            status = rocblas.rocblas_create_handle(ctypes.byref(h))
-        if status != 0:
-            raise RuntimeError(f"rocblas_create_handle failed with status {status}")
-        handles[key] = h
-    status = rocblas.rocblas_set_stream(h, _P(torch.cuda.current_stream(device).cuda_stream))
-    if status != 0:
-        raise RuntimeError(f"rocblas_set_stream failed with status {status}")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    key = (idx, stream)
+    with _lock:
+        h = _handles.get(key)
+        if h is None:
+            h = _P()
+            with torch.cuda.device(idx):
+                status = rocblas.rocblas_create_handle(ctypes.byref(h))
+            if status != 0:
+                raise RuntimeError(f"rocblas_create_handle failed with status {status}")
+            status = rocblas.rocblas_set_stream(h, _P(stream))
+            if status != 0:
+                raise RuntimeError(f"rocblas_set_stream failed with status {status}")
+            _handles[key] = h
     return h
 
 

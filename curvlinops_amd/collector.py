@@ -51,8 +51,13 @@ class _AffineTap(TorchFunctionMode):
         if not isinstance(t, Tensor):
             return None
         hit = self._names.get(id(t))
-        if hit is None and t._base is not None:  # e.g. `W.T.T`-style no-op views keep the identity of the base
-            return None
+        if hit is None and t._base is not None and id(t._base) in self._names:
+            # `W.T`, `W.view(...)`, slices: the factor contract is defined for the parameter itself
+            # (`layer_io.py:128-336` matches parameters, not their views) -- dropping such a use silently
+            # would give wrong factors under weight tying
+            raise NotImplementedError(
+                f"collector backend: a view of tracked parameter {self._names[id(t._base)]!r} is used as the weight / "
+                "bias of an affine operation; pass the parameter itself (views of tied weights are not supported)")
         return hit
 
     def __torch_function__(self, func, types, args=(), kwargs=None):

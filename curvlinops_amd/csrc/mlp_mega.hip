@@ -818,7 +818,7 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
   }
   const double D = (double)dims[0] * dims[1] + (double)dims[1] * dims[2] + (double)dims[2] * dims[3];
   {
-    ProfScope prof(0, 12.0 * D, st);
+    ProfScope prof(6, 12.0 * D, st);
     if (v) hipLaunchKernelGGL(mlp_mega_kernel<true>, dim3(MG_G), dim3(MG_T), smem, st, a);
     else hipLaunchKernelGGL(mlp_mega_kernel<false>, dim3(MG_G), dim3(MG_T), smem, st, a);
     CLO_CHECK_LAUNCH("mlp_mega_kernel");

@@ -348,9 +348,12 @@ def _eigh_unit_checked(An: Tensor) -> tuple[Tensor, Tensor]:
     """Second opinion for ONE normalised float32 GPU matrix: own reduction, then float64."""
     n = An.shape[0]
     if 3 <= n <= _SYTRD_MAX_N:
-        lam, Q = _eigh_sytrd_unit(An)
-        if bool((_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL)):
-            return lam, Q
+        try:
+            lam, Q = _eigh_sytrd_unit(An)
+            if bool((_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL)):
+                return lam, Q
+        except (RuntimeError, OSError):   # solver did not converge / library or LDS attribute unavailable
+            pass
     res = torch.linalg.eigh(An.double())
     return res.eigenvalues.float(), res.eigenvectors.float()
 
@@ -366,9 +369,9 @@ def _eigh_sytrd_unit(An: Tensor) -> tuple[Tensor, Tensor]:
     D, E, tau = _hip.sytrd_(work, n)
     Z = torch.empty(n, ld, device=An.device, dtype=torch.float32)      # column-major eigenvectors
     info = _rocsolver.stedc_(D, E, Z, n)
-    _rocsolver.ormtr_(work, tau, Z, n)
-    if int(info) != 0:
+    if int(info) != 0:   # checked BEFORE the back-transformation is queued on an unconverged Z
         raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
+    _rocsolver.ormtr_(work, tau, Z, n)
     return D, Z[:, :n].T
 
 
@@ -380,8 +383,12 @@ def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
     if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == n and 3 <= n <= _SYTRD_MAX_N):
         raise ValueError(f"eigh_sytrd: need a square fp32 GPU matrix of order 3..{_SYTRD_MAX_N}, got {tuple(A.shape)} {A.dtype}")
     An, scale = _unit_scale(A)
-    lam, Q = _eigh_sytrd_unit(An)
-    if not bool((_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL)):   # verified like the rocSOLVER route
+    try:
+        lam, Q = _eigh_sytrd_unit(An)
+        ok = bool((_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL))   # verified like the rocSOLVER route
+    except (RuntimeError, OSError):   # a recoverable solver failure must not abort a KFAC build
+        ok = False
+    if not ok:
         res = torch.linalg.eigh(An.double())
         lam, Q = res.eigenvalues.float(), res.eigenvectors.float()
     return lam * scale.reshape(()), Q
@@ -451,15 +458,19 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
     # exactly-zero rows (dead ReLU features) split off: the solvers see the nonzero principal submatrices
     full_mats, deflated = mats, {}
     mats = list(mats)
-    for i, A in enumerate(full_mats):
-        if A.is_cuda and A.dim() == 2 and A.shape[0] > 1:
-            idx = _nonzero_rows(A)
-            if idx is not None:
-                if idx.numel() == 0:
-                    out[i] = (A.new_zeros(A.shape[0]), torch.eye(A.shape[0], device=A.device, dtype=A.dtype))
-                else:
-                    deflated[i] = idx
-                    mats[i] = A.index_select(0, idx).index_select(1, idx)
+    cand = [i for i, A in enumerate(full_mats) if A.is_cuda and A.dim() == 2 and A.shape[0] > 1 and out[i] is None]
+    masks = {i: (full_mats[i] != 0).any(dim=1) for i in cand}
+    # one device -> host read for all factors (a read per factor stalled the launch stream ~40 times per refresh)
+    counts = dict(zip(cand, torch.stack([masks[i].sum() for i in cand]).tolist())) if cand else {}
+    for i in cand:
+        A = full_mats[i]
+        if counts[i] == A.shape[0]:
+            continue
+        if counts[i] == 0:
+            out[i] = (A.new_zeros(A.shape[0]), torch.eye(A.shape[0], device=A.device, dtype=A.dtype))
+        else:
+            idx = deflated[i] = masks[i].nonzero().flatten()
+            mats[i] = A.index_select(0, idx).index_select(1, idx)
     gpu = [i for i, A in enumerate(mats) if A.is_cuda and out[i] is None]
     if not gpu:
         return out

@@ -195,3 +195,67 @@ def test_collector_backend_gpu(case):
                 for f, fac in enumerate(block):
                     assert rel_err(fac, rec[f"{tag}/block{b}_factor{f}"]) < 1e-4, (case, tag, b, f)
             assert rel_err(K @ V, rec[f"{tag}/KV"]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("sep", [True, False])
+def test_weight_tying_fp32_gpu(bias, sep):
+    """The reference's weight-tying test (`test/test_kfac.py:273-360`) in float32 on the device: the collector
+    backend's factors come from the HIP SYRK kernels; with one datum type-2 KFAC / EKFAC equal the exact
+    block-diagonal GGN (float64 CPU) to fp32 accuracy."""
+    from curvlinops_amd import _hip
+
+    _hip.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    D = 4
+    model64 = SplitConcat(D, bias).to(F64)
+    params64 = dict(model64.named_parameters())
+    X, y = torch.rand(1, 2 * D, dtype=F64), torch.rand(1, 2 * D, dtype=F64)
+    mapping = ([{"W": "linear.weight"}, {"b": "linear.bias"}] if sep and bias else
+               [{"W": "linear.weight", "b": "linear.bias"}] if bias else [{"W": "linear.weight"}])
+    for reduction in ("mean", "sum"):
+        loss = nn.MSELoss(reduction=reduction)
+        ref = block_diagonal_ggn(model64, loss, params64, [(X, y)], mapping).numpy()
+        model = SplitConcat(D, bias).to(dev)
+        model.load_state_dict({k: v.float() for k, v in model64.state_dict().items()})
+        params = dict(model.named_parameters())
+        data = [(X.float().to(dev), y.float().to(dev))]
+        eye = torch.eye(ref.shape[0], device=dev)
+        K = C.KFACLinearOperator(model, loss, params, data, fisher_type="type-2", kfac_approx="expand",
+                                 separate_weight_and_bias=sep, backend="collector")
+        assert rel_err(K @ eye, ref) < 1e-4, reduction
+        E = C.EKFACLinearOperator(model, loss, params, data, fisher_type="type-2", separate_weight_and_bias=sep,
+                                  backend="collector")
+        assert rel_err(E @ eye, ref) < 1e-3, reduction
+        # two tied modules with different bias settings (`test/utils.py:380-414`), joint and separate
+    model64 = TiedSplitConcat(D, True, False).to(F64)
+    params64 = dict(model64.named_parameters())
+    mapping = [{"W": "linear1.weight"}, {"b": "linear1.bias"}] if sep else [{"W": "linear1.weight", "b": "linear1.bias"}]
+    loss = nn.MSELoss()
+    ref = block_diagonal_ggn(model64, loss, params64, [(X, y)], mapping).numpy()
+    model = TiedSplitConcat(D, True, False).to(dev)
+    model.load_state_dict({k: v.float() for k, v in model64.state_dict().items()})
+    model.linear2.weight = model.linear1.weight
+    K = C.KFACLinearOperator(model, loss, dict(model.named_parameters()), [(X.float().to(dev), y.float().to(dev))],
+                             fisher_type="type-2", separate_weight_and_bias=sep, backend="collector")
+    assert rel_err(K @ torch.eye(ref.shape[0], device=dev), ref) < 1e-4
+
+
+def test_view_of_tracked_parameter_is_refused():
+    """A transposed / viewed tied weight must not be dropped silently (it would be missing from the factors)."""
+
+    class TransposedTie(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc = nn.Linear(4, 4, bias=False)
+
+        def forward(self, x):
+            return F.linear(self.enc(x), self.enc.weight.T)
+
+    model = TransposedTie().to(F64)
+    data = [(torch.rand(2, 4, dtype=F64), torch.rand(2, 4, dtype=F64))]
+    with pytest.raises(NotImplementedError, match="view of tracked parameter"):
+        C.KFACLinearOperator(model, nn.MSELoss(), dict(model.named_parameters()), data, fisher_type="type-2",
+                             backend="collector")

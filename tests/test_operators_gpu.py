@@ -358,6 +358,12 @@ def test_trace_estimators_gpu(dev):
         p12 = pool[:, :12].contiguous()
         assert rel_err(C.hutchinson_diag(op, 12, dist, probes=p12), rec[f"{dist}/hutch_diag"]) < TOL
         assert rel_err(C.hutchinson_squared_fro(op, 12, dist, probes=p12), rec[f"{dist}/hutch_fro2"]) < TOL
+        # XTrace / XDiag (reference `trace/epperly2024xtrace.py:15-101`, `diagonal/epperly2024xtrace.py`) with the
+        # replayed probes: fp32 on the device against the reference's float64 values
+        p8 = pool[:, :8].contiguous()
+        assert rel_err(C.xtrace(op, 16, dist, probes=p8), rec[f"{dist}/xtrace"]) < 1e-3
+        if dist == "rademacher":
+            assert rel_err(C.xdiag(op, 16, probes=p8), rec[f"{dist}/xdiag"]) < 1e-3
     torch.manual_seed(0)
     ests = torch.stack([C.hutchinson_trace(op, 29) for _ in range(200)])
     assert abs(ests.mean() - A.trace()) / A.trace() < 0.05
