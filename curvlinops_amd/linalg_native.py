@@ -279,13 +279,20 @@ def damped_cholesky_inverse(A: Tensor, damping: float, retry_double_precision: b
         return _torch_damped_cholesky_inverse(A.to(torch.float64), damping).to(A.dtype)
 
 
-# Which solver :func:`eigh` uses for fp32 GPU matrices: "auto" (default: the hand-written tridiagonalisation
-# clo_sytrd_f32 + rocSOLVER's tridiagonal divide & conquer and back-transformation where it measured faster --
-# single matrices of order 256..2400 -- and torch.linalg.eigh elsewhere), "sytrd" (own reduction for every order
-# 3..8184) or "rocsolver" (torch.linalg.eigh only).  All routes are verified, see _torch_eigh_scaled; DESIGN.md
-# section 7.
-_EIGH_MODE = os.environ.get("CLO_EIGH", "auto").lower()
+# Which solver :func:`eigh` uses for fp32 GPU matrices:
+#   "native" (default)  hand-written end to end for every order up to 8184: clo_sytrd_f32 (Householder reduction),
+#                       divide & conquer on the tridiagonal matrix and block-reflector back-transformation
+#                       (eigh_native.py); matrices of equal size are separate units on the worker streams;
+#   "hybrid"            rounds 1-2: the own route for single matrices of order 256..2400, rocSOLVER
+#                       (torch.linalg.eigh, batched by size) elsewhere -- ~20 % faster on ResNet-18's factors;
+#   "sytrd"             = "native" (kept as an alias); "rocsolver": torch.linalg.eigh only.
+# All routes are verified (orthogonality, residual) with a float64 retry, see _torch_eigh_scaled; DESIGN.md section 7.
+_EIGH_MODE = {"sytrd": "native", "auto": "native"}.get(os.environ.get("CLO_EIGH", "native").lower(),
+                                                         os.environ.get("CLO_EIGH", "native").lower())
 _SYTRD_MAX_N = 8184
+# What follows the own reduction: "native" (default) = the hand-written divide & conquer on the tridiagonal
+# matrix and block-reflector back-transformation of eigh_native.py; "rocsolver" = sstedc / sormtr (rounds 1-2).
+_EIGH_VENDOR_TAIL = os.environ.get("CLO_EIGH_TAIL", "native").lower() == "rocsolver"
 
 
 def _unit_scale(A: Tensor) -> tuple[Tensor, Tensor]:
@@ -368,11 +375,20 @@ def _eigh_sytrd_unit(An: Tensor) -> tuple[Tensor, Tensor]:
     work[:, :n].copy_(An)
     D, E, tau = _hip.sytrd_(work, n)
     Z = torch.empty(n, ld, device=An.device, dtype=torch.float32)      # column-major eigenvectors
-    info = _rocsolver.stedc_(D, E, Z, n)
-    if int(info) != 0:   # checked BEFORE the back-transformation is queued on an unconverged Z
-        raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
-    _rocsolver.ormtr_(work, tau, Z, n)
-    return D, Z[:, :n].T
+    if _EIGH_VENDOR_TAIL:
+        info = _rocsolver.stedc_(D, E, Z, n)
+        if int(info) != 0:   # checked BEFORE the back-transformation is queued on an unconverged Z
+            raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
+        _rocsolver.ormtr_(work, tau, Z, n)
+        return D, Z[:, :n].T
+    # hand-written tail: divide & conquer on the tridiagonal matrix, block-reflector back-transformation
+    from . import eigh_native
+
+    lam, Qt = eigh_native.stedc_native(D, E, n)
+    Z.zero_()
+    Z[:, :n] = Qt.T
+    eigh_native.ormtr_native(work, tau, Z, n)
+    return lam, Z[:, :n].T
 
 
 def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
@@ -425,8 +441,14 @@ def _eigh_full(A: Tensor) -> tuple[Tensor, Tensor]:
     """One matrix without zero rows (or a CPU / non-float32 one): solver selection as documented at _EIGH_MODE."""
     if _EIGH_MODE != "rocsolver" and A.is_cuda and A.dtype == torch.float32 and A.dim() == 2:
         n = A.shape[0]
-        if 3 <= n <= _SYTRD_MAX_N and (_EIGH_MODE == "sytrd" or 256 <= n <= 2400):
+        if 3 <= n <= _SYTRD_MAX_N and (_EIGH_MODE == "native" or 256 <= n <= 2400):
             return eigh_sytrd(A)
+        if _EIGH_MODE == "native" and n == 2:   # already tridiagonal: the leaf solver alone
+            from . import eigh_native
+
+            An, scale = _unit_scale(A)
+            lam, Q = eigh_native.stedc_native(An.diagonal().contiguous(), An[1, :1].contiguous(), 2)
+            return lam * scale.reshape(()), Q
     return _torch_eigh_scaled(A)
 
 
@@ -488,6 +510,9 @@ def _eigh_many_gpu(mats: list[Tensor], gpu: list[int], out: list, num_streams: i
     total = sum(float(mats[i].shape[0]) ** 3 for i in gpu)
     share = total / max(num_streams, 1)  # a group worth more than one worker's share is split
     for (n, dtype), idx in groups.items():
+        if _EIGH_MODE == "native" and dtype == torch.float32 and 2 <= n <= _SYTRD_MAX_N:
+            units.extend([i] for i in idx)   # the hand-written route works on one matrix per call
+            continue
         per = 8 * max(n, 1) ** 2 * mats[idx[0]].element_size()  # stacked input + vectors + solver workspace
         parts = max(1, min(len(idx), round(len(idx) * float(n) ** 3 / max(share, 1.0))))
         chunk = max(1, min((8 << 30) // per, -(-len(idx) // parts)))

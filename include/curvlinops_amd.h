@@ -299,6 +299,28 @@ int clo_cg_update_f32(float *x, float *r, const float *p, const float *ap, long 
 int clo_cg_direction_f32(float *p, const float *z, long n, const float *num, const float *den,
                          void *stream);
 
+/* ---- symmetric eigensolver behind clo_sytrd_f32 (csrc/eigh.hip; replaces rocSOLVER sstedc / sormtr behind
+ * torch.linalg.eigh at computers/_base.py:355-372, kronecker.py:292-300).  The host side
+ * (curvlinops_amd/eigh_native.py) drives them level by level; every O(n^3) product is a clo_gemm_f32.
+ *   clo_larft_f32       : T factors (nb x nb, upper triangular) of `np` block reflectors from G = V^T V and tau
+ *   clo_tql2_batched_f32: eigen-decomposition of `batch` symmetric tridiagonal matrices of order L <= 64
+ *                         (implicit QL in float64, one wave each): lam ascending, eigenvectors in columns
+ *   clo_dc_*            : one merge level of Cuppen's divide & conquer, batched over `nodes` of size s:
+ *                         deflation scan (in place on D, z), secular roots (float64 bisection on the shifted
+ *                         variable) + Gu-Eisenstat weights, eigenvector matrix MT [nodes][s][s] (transposed),
+ *                         Givens rotations of the deflation. */
+int clo_larft_f32(const float *G, const float *tau, float *T, int np, int nb, void *stream);
+int clo_tql2_batched_f32(const float *d, const float *e, float *lam, float *Q, int L, int batch, int *status,
+                         void *stream);
+int clo_dc_deflate(double *D, double *z, const double *rho, int *type, int *rot_p, double *rot_c, double *rot_s,
+                   int *K, int s, int nodes, double eps, void *stream);
+int clo_dc_secular(const double *dk, const double *zk, const double *rho, const int *K, int *org, double *mu,
+                   double *zh, int s, int nodes, int kmax, void *stream);
+int clo_dc_build(const double *dk, const int *K, const int *org, const double *mu, const double *zh,
+                 const int *spos, float *MT, int s, int nodes, int kmax, void *stream);
+int clo_dc_rotate(float *MT, const int *rot_p, const double *rot_c, const double *rot_s, int s, int nodes,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

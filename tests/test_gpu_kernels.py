@@ -722,9 +722,9 @@ def _sym_case(kind: str, n: int, dev):
 @pytest.mark.parametrize("kind", ["full", "lowrank", "indefinite", "diagonal", "zero"])
 @pytest.mark.parametrize("n", [3, 4, 7, 64, 66, 67, 130, 333, 1030])
 def test_eigh_sytrd(hip, kind, n):
-    """eigh_sytrd (clo_sytrd_f32 -> sstedc -> sormtr) against float64 LAPACK: eigenvalues, residual
-    |A Q - Q diag(lam)| and orthogonality |Q^T Q - I|, all <= 1e-5 relative to |A| (the tolerance the
-    fp32 rocSOLVER path of torch.linalg.eigh meets on the same matrices)."""
+    """eigh_sytrd (clo_sytrd_f32 -> hand-written divide & conquer -> block-reflector back-transformation) against
+    float64 LAPACK: eigenvalues, residual |A Q - Q diag(lam)| and orthogonality |Q^T Q - I|, all <= 1e-5 relative
+    to |A| (the tolerance the fp32 rocSOLVER path of torch.linalg.eigh meets on the same matrices)."""
     from curvlinops_amd.linalg_native import eigh_sytrd
 
     dev = torch.device("cuda:0")
@@ -784,14 +784,15 @@ def test_sytrd_is_a_similarity_transform(hip, n):
 
 @pytest.mark.gpu
 def test_eigh_mode_switch(hip, monkeypatch):
-    """CLO_EIGH=sytrd routes every linalg_native.eigh through the hand-written reduction (the default, "auto",
-    does so for single matrices of order 256..2400).  Same spectrum either way."""
+    """The default policy ("native") routes every fp32 GPU eigh through the hand-written solver; "hybrid" /
+    "rocsolver" keep torch.linalg.eigh where it is faster / everywhere.  Same spectrum either way."""
     from curvlinops_amd import linalg_native as L
 
     dev = torch.device("cuda:0")
     A = _sym_case("lowrank", 300, dev).to(dev, torch.float32)
+    monkeypatch.setattr(L, "_EIGH_MODE", "rocsolver")
     lam0, _ = L.eigh(A)
-    monkeypatch.setattr(L, "_EIGH_MODE", "sytrd")
+    monkeypatch.setattr(L, "_EIGH_MODE", "native")
     calls = []
     real = L.eigh_sytrd
     monkeypatch.setattr(L, "eigh_sytrd", lambda M: (calls.append(1), real(M))[1])
@@ -803,7 +804,7 @@ def test_eigh_mode_switch(hip, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("power", [-8, -6, -3, 0, 4, 7])
-@pytest.mark.parametrize("mode", ["rocsolver", "sytrd", "many"])
+@pytest.mark.parametrize("mode", ["rocsolver", "native", "hybrid", "many"])
 def test_eigh_is_scale_invariant(hip, monkeypatch, power, mode):
     """Factors of tiny norm (gradient covariances of mean-reduced losses) and of huge norm: rocSOLVER's
     tridiagonal solver applies an absolute tolerance (fp32 matrices of norm 1e-6: 30 % eigenvalue error through
@@ -831,6 +832,83 @@ def test_eigh_is_scale_invariant(hip, monkeypatch, power, mode):
     assert float((lam64 - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     assert float((A64 @ Q64 - Q64 * lam64).abs().max()) <= 2e-5 * scale
     assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["random", "toeplitz", "clustered", "graded", "decoupled"])
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 130, 577, 1500])
+def test_tridiagonal_divide_and_conquer(hip, kind, n):
+    """eigh_native.stedc_native (leaves by implicit QL, merges with deflation / float64 secular equation /
+    Gu-Eisenstat weights, one batched GEMM pair per level) against float64 LAPACK on tridiagonal matrices:
+    well separated, clustered (deflation), graded and block-decoupled spectra."""
+    from curvlinops_amd import eigh_native
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7 * n + len(kind))
+    if kind == "random":
+        d, e = torch.rand(n, generator=g) - 0.5, torch.rand(n, generator=g) - 0.5
+    elif kind == "toeplitz":
+        d, e = torch.full((n,), 2.0), torch.full((n,), -1.0)
+    elif kind == "clustered":
+        d = torch.cat([torch.ones(n // 2), torch.rand(n - n // 2, generator=g)])
+        e = torch.rand(n, generator=g) * 1e-6
+    elif kind == "graded":
+        d = torch.logspace(0, -6, n)
+        e = torch.logspace(0, -6, n) * 0.3
+    else:
+        d, e = torch.rand(n, generator=g), torch.rand(n, generator=g)
+        e[::7] = 0.0
+    T = torch.diag(d.double()) + torch.diag(e[: n - 1].double(), 1) + torch.diag(e[: n - 1].double(), -1)
+    ref = torch.linalg.eigvalsh(T)
+    lam, Q = eigh_native.stedc_native(d.to(dev), e.to(dev), n)
+    lam64, Q64 = lam.double().cpu(), Q.double().cpu()
+    scale = max(float(T.abs().max()), 1e-30)
+    assert torch.all(lam64[1:] >= lam64[:-1])
+    assert float((lam64 - ref).abs().max()) <= 5e-6 * scale
+    assert float((T @ Q64 - Q64 * lam64).abs().max()) <= 2e-5 * scale
+    assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 64, 65, 200, 1030])
+def test_block_reflector_back_transformation(hip, n):
+    """eigh_native.ormtr_native applies Q = H_0 ... H_{n-2} of clo_sytrd_f32: Q T Q^T reproduces the input and
+    Q is orthogonal (applied to the identity)."""
+    from curvlinops_amd import eigh_native
+
+    dev = torch.device("cuda:0")
+    A64 = _sym_case("indefinite", n, dev)
+    ld = (n + 3) // 4 * 4
+    work = torch.zeros(n, ld, device=dev)
+    work[:, :n] = A64.float().to(dev)
+    D, E, tau = hip.sytrd_(work, n)
+    Zr = torch.zeros(n, ld, device=dev)
+    Zr[:, :n] = torch.eye(n, device=dev)
+    eigh_native.ormtr_native(work, tau, Zr, n)          # rows of Zr = columns of Q ...
+    Q = Zr[:, :n].T.double().cpu()
+    T = torch.diag(D.double().cpu()) + torch.diag(E[: n - 1].double().cpu(), 1) + torch.diag(E[: n - 1].double().cpu(), -1)
+    sc = float(A64.abs().max())
+    assert float((Q.T @ Q - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-5
+    assert float((Q @ T @ Q.T - A64).abs().max()) <= 2e-5 * sc * max(1.0, n ** 0.5 / 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 577, 1153, 2305, 4609])
+def test_native_eigh_at_the_factor_sizes_of_the_benchmarks(hip, n):
+    """The hand-written solver end to end (no torch.linalg.eigh / rocSOLVER on the way) at the factor orders of
+    ResNet-18 / the encoder: |Q^T Q - I| <= 1e-5 and Q diag(lam) Q^T against the float64 matrix <= 1e-4."""
+    from curvlinops_amd import linalg_native as L
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    X = torch.rand(max(16, n // 3), n, generator=g, dtype=torch.float64)      # rank-deficient covariance
+    A64 = X.T @ X / X.shape[0]
+    A = A64.to(dev, torch.float32)
+    assert L._EIGH_MODE == "native" and not L._EIGH_VENDOR_TAIL
+    lam, Q = L.eigh(A)
+    Qd, ld_ = Q.double().cpu(), lam.double().cpu()
+    assert float((Qd.T @ Qd - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-5
+    assert float(((Qd * ld_) @ Qd.T - A.double().cpu()).abs().max()) <= 1e-4 * float(A64.abs().max())
 
 
 @pytest.mark.gpu

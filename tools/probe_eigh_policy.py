@@ -1,0 +1,26 @@
+"""ResNet-18 (C4, 512 rows) EKFAC bases under the three solver policies: eigh_many time and orthogonality."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch import nn
+import curvlinops_amd as C
+from curvlinops_amd import linalg_native as L
+from benchmarks.models import ResNet18, kfac_params
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = ResNet18().to(dev).eval()
+params = kfac_params(model)
+X, y = torch.rand(512, 3, 32, 32, device=dev), torch.randint(0, 10, (512,), device=dev)
+K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], fisher_type="mc",
+                         separate_weight_and_bias=False, check_deterministic=False, num_data=512)
+facs = [S for blk in K[1] for S in blk]
+for mode in ("native", "hybrid", "rocsolver", "native"):
+    L._EIGH_MODE = mode
+    L.eigh_many(facs); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter(); out = L.eigh_many(facs); torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    orth = max(float(L._orth_defect(q)) for _, q in out)
+    print(f"{mode:10s} eigh_many {1e3*best:7.1f} ms   max |Q^T Q - I| {orth:.2e}")
