@@ -125,6 +125,8 @@ _SIGNATURES = {
     "clo_rowscale_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_int, c_float, c_void_p]),
     "clo_pack_probes_f32": (c_int, [_PF, c_long, c_long, c_uint64, c_int, c_void_p]),
     "clo_larft_f32": (c_int, [_PF, _PF, _PF, c_int, c_int, c_void_p]),
+    "clo_ormtr_ws_floats": (c_long, [c_int, c_int]),
+    "clo_ormtr_f32": (c_int, [_PF, c_long, _PF, _PF, c_long, c_int, c_int, _PF, c_long, c_void_p]),
     "clo_tql2_batched_f32": (c_int, [_PF, _PF, _PF, _PF, c_int, c_int, _PF, c_void_p]),
     "clo_dc_deflate": (c_int, [_PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, ctypes.c_double, c_void_p]),
     "clo_dc_secular": (c_int, [_PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, c_int, c_void_p]),

@@ -11,7 +11,10 @@
 //                          matrix of the rank-one update, Givens rotations of the deflation
 //
 // Everything O(n^3) -- the merges Q_children @ M -- is a batched GEMM on gemm.hip.
+#include <algorithm>
+
 #include "clo_common.h"
+#include "gemm.h"
 
 namespace clo {
 
@@ -323,6 +326,23 @@ __global__ void dc_rotate_kernel(float *__restrict__ MT, const int *__restrict__
   }
 }
 
+// explicit reflector rows for the back-transformation: Vt[i][k] = v_i[k] (unit entry at k = i + 1, zero left of
+// it and in the padding; rows >= n - 1 are zero), from LAPACK's 'L' storage in the rows of `work`
+__global__ void ormtr_vt_kernel(const float *__restrict__ work, long ldw, float *__restrict__ Vt, long ldv, int n,
+                                int rows) {
+  const long total = (long)rows * ldv;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(e / ldv), k = (int)(e - (long)i * ldv);
+    float v = 0.f;
+    if (i < n - 1 && k < n) v = k >= i + 2 ? work[(long)i * ldw + k] : (k == i + 1 ? 1.f : 0.f);
+    Vt[e] = v;
+  }
+}
+__global__ void ormtr_tau_kernel(const float *__restrict__ tau, float *__restrict__ tp, int n, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) tp[i] = i < n - 1 ? tau[i] : 0.f;
+}
+
 }  // namespace clo
 using namespace clo;
 
@@ -388,5 +408,59 @@ extern "C" int clo_dc_rotate(float *MT, const int *rot_p, const double *rot_c, c
   hipLaunchKernelGGL(dc_rotate_kernel, dim3((unsigned)cdiv(s, 64), (unsigned)nodes), dim3(64), 0, (hipStream_t)stream,
                      MT, rot_p, rot_c, rot_s, s);
   CLO_CHECK_LAUNCH("dc_rotate_kernel");
+  return CLO_OK;
+}
+
+// ---- back-transformation  Z <- Z Q^T  (every ROW of Z [m][ldz >= pad4(n)] times Q = H_0 ... H_{n-2}, the
+// reflectors clo_sytrd_f32 left in `work` / `tau`): blocks of 64 reflectors as I - V T^T V^T, three GEMMs each.
+static inline long ormtr_pad4(long n) { return (n + 3) & ~3L; }
+extern "C" long clo_ormtr_ws_floats(int m, int n) {
+  if (n < 3 || m < 1) return 64;
+  const long ldv = ormtr_pad4(n), npan = cdiv(n - 1, 64), R = npan * 64;
+  return R * ldv + 2 * npan * 4096 + R + 2L * m * 64 + 8L * std::max<long>(m, 64) * 64 + 256;
+}
+extern "C" int clo_ormtr_f32(const float *work, long ldw, const float *tau, float *Z, long ldz, int m, int n,
+                             float *ws, long ws_floats, void *stream) {
+  CLO_REQUIRE(work && tau && Z && ws && m >= 1 && n >= 1, "clo_ormtr_f32: bad arguments");
+  if (n < 3) return CLO_OK;
+  const long ldv = ormtr_pad4(n);
+  CLO_REQUIRE(ldz >= ldv && ldz % 4 == 0 && ldw >= n && aligned16(Z) && aligned16(ws),
+              "clo_ormtr_f32: Z needs a 16-byte aligned base and a leading dimension >= pad4(n), multiple of 4");
+  CLO_REQUIRE(ws_floats >= clo_ormtr_ws_floats(m, n), "clo_ormtr_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int npan = (int)cdiv(n - 1, 64), R = npan * 64;
+  float *Vt = ws, *G = Vt + (long)R * ldv, *T = G + (long)npan * 4096, *tp = T + (long)npan * 4096;
+  float *W = tp + R, *W2 = W + (long)m * 64, *gws = W2 + (long)m * 64;
+  const long gws_floats = ws_floats - (gws - ws);
+  hipLaunchKernelGGL(ormtr_vt_kernel, dim3((unsigned)std::min<long>(cdiv((long)R * ldv, 256), 4096)), dim3(256), 0, st,
+                     work, ldw, Vt, ldv, n, R);
+  CLO_CHECK_LAUNCH("ormtr_vt_kernel");
+  hipLaunchKernelGGL(ormtr_tau_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, tau, tp, n, R);
+  CLO_CHECK_LAUNCH("ormtr_tau_kernel");
+  auto gemm = [&](int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k, long sa_b, const float *B,
+                  long sb_k, long sb_n, long sb_b, float beta, float *C, long ldc, long sc_b, int batch) {
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+    g.A = A; g.sa_m = sa_m; g.sa_k = sa_k; g.sa_b = sa_b;
+    g.B = B; g.sb_k = sb_k; g.sb_n = sb_n; g.sb_b = sb_b;
+    g.C = C; g.ldc = ldc; g.sc_b = sc_b;
+    return launch_gemm_auto(g, gws, gws_floats, st, batch);
+  };
+  int rc = gemm(64, 64, (int)ldv, 1.f, Vt, ldv, 1, 64 * ldv, Vt, 1, ldv, 64 * ldv, 0.f, G, 64, 4096, npan);
+  if (rc != CLO_OK) return rc;
+  hipLaunchKernelGGL(larft_kernel, dim3(npan), dim3(64), 0, st, G, tp, T, 64);
+  CLO_CHECK_LAUNCH("larft_kernel");
+  for (int p = npan - 1; p >= 0; --p) {
+    const long c0 = 64L * p;
+    const int w = (int)(ldv - c0);
+    const float *Vp = Vt + c0 * ldv + c0;   // rows 64 p .., columns c0 ..
+    float *Zs = Z + c0;
+    rc = gemm(m, 64, w, 1.f, Zs, ldz, 1, 0, Vp, 1, ldv, 0, 0.f, W, 64, 0, 1);           // W  = Zs Vp^T
+    if (rc != CLO_OK) return rc;
+    rc = gemm(m, 64, 64, 1.f, W, 64, 1, 0, T + (long)p * 4096, 1, 64, 0, 0.f, W2, 64, 0, 1);   // W2 = W T^T
+    if (rc != CLO_OK) return rc;
+    rc = gemm(m, w, 64, -1.f, W2, 64, 1, 0, Vp, ldv, 1, 0, 1.f, Zs, ldz, 0, 1);         // Zs -= W2 Vp
+    if (rc != CLO_OK) return rc;
+  }
   return CLO_OK;
 }

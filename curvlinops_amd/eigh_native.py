@@ -43,47 +43,59 @@ def _run(name: str, dev: torch.device, *args) -> None:
 # tridiagonal divide & conquer
 # ----------------------------------------------------------------------------------------------
 def stedc_native(d: Tensor, e: Tensor, n: int) -> tuple[Tensor, Tensor]:
-    """Eigenvalues (ascending, float32 ``[n]``) and eigenvectors (``[n, n]``, in COLUMNS) of the symmetric
-    tridiagonal matrix with diagonal ``d[:n]`` and sub-diagonal ``e[:n-1]`` (float32 GPU tensors)."""
+    """Eigenvalues (ascending, float32) and eigenvectors (in COLUMNS) of symmetric tridiagonal matrices with
+    diagonal ``d[..., :n]`` and sub-diagonal ``e[..., :n-1]`` (float32 GPU tensors).  ``d``/``e`` of shape ``[>= n]``
+    give ``([n], [n, n])``; a leading batch dimension ``[B, >= n]`` (matrices of one order: the factors of repeated
+    layer shapes) gives ``([B, n], [B, n, n])`` with every tree level of ALL matrices in one batch."""
+    single = d.dim() == 1
+    d2 = d.reshape(1, -1) if single else d
+    e2 = e.reshape(1, -1) if single else e
+    lam, Q = _stedc_batched(d2, e2, n)
+    return (lam[0], Q[0]) if single else (lam, Q)
+
+
+def _stedc_batched(d: Tensor, e: Tensor, n: int) -> tuple[Tensor, Tensor]:
     dev = d.device
+    B = d.shape[0]
     if n == 1:
-        return d[:1].clone(), torch.ones(1, 1, device=dev, dtype=torch.float32)
+        return d[:, :1].clone(), torch.ones(B, 1, 1, device=dev, dtype=torch.float32)
     k = max(0, math.ceil(math.log2(n / _LEAF)))
     L = -(-n // (1 << k))
     L = (L + 3) // 4 * 4            # multiples of 4 keep every block 16-byte aligned for the GEMM engine
     nleaf = 1 << k
     N = L * nleaf
-    dp = torch.zeros(N, device=dev, dtype=torch.float64)
-    ep = torch.zeros(N, device=dev, dtype=torch.float64)
-    dp[:n] = d[:n].double()
-    ep[: n - 1] = e[: n - 1].double()
+    dp = torch.zeros(B, N, device=dev, dtype=torch.float64)
+    ep = torch.zeros(B, N, device=dev, dtype=torch.float64)
+    dp[:, :n] = d[:, :n].double()
+    ep[:, : n - 1] = e[:, : n - 1].double()
     if N > n:  # decoupled padding: distinct values above the spectrum (they deflate in every merge)
-        big = 4.0 * (dp[:n].abs().max() + 2.0 * ep.abs().max()) + 1.0
-        dp[n:] = big * (1.0 + 0.01 * torch.arange(1, N - n + 1, device=dev, dtype=torch.float64))
+        big = 4.0 * (dp[:, :n].abs().amax(dim=1) + 2.0 * ep.abs().amax(dim=1)) + 1.0
+        dp[:, n:] = big[:, None] * (1.0 + 0.01 * torch.arange(1, N - n + 1, device=dev, dtype=torch.float64))[None, :]
     # tear at every leaf boundary c: T = diag(T1', T2') + beta (e_{c-1} + theta e_c)(...)^T with rho = |beta|
     cuts = torch.arange(1, nleaf, device=dev) * L
-    beta = ep[cuts - 1].clone()
-    dp[cuts - 1] -= beta.abs()
-    dp[cuts] -= beta.abs()
-    ep[cuts - 1] = 0.0
-    beta_full = torch.zeros(N, device=dev, dtype=torch.float64)   # beta_full[c] = beta of the cut at row c
-    beta_full[cuts] = beta
+    beta = ep[:, cuts - 1].clone()
+    dp[:, cuts - 1] -= beta.abs()
+    dp[:, cuts] -= beta.abs()
+    ep[:, cuts - 1] = 0.0
+    beta_full = torch.zeros(B, N, device=dev, dtype=torch.float64)   # beta_full[:, c] = beta of the cut at row c
+    beta_full[:, cuts] = beta
     # ---- leaves
-    lam = torch.empty(nleaf, L, device=dev, dtype=torch.float32)
-    Q = torch.empty(nleaf, L, L, device=dev, dtype=torch.float32)
+    lam = torch.empty(B * nleaf, L, device=dev, dtype=torch.float32)
+    Q = torch.empty(B * nleaf, L, L, device=dev, dtype=torch.float32)
     status = torch.zeros(1, device=dev, dtype=torch.int32)
     d32, e32 = dp.float().contiguous(), ep.float().contiguous()
     # (float32 copies for the kernel interface; the tearing itself was done in float64)
-    _run("clo_tql2_batched_f32", dev, _ptr(d32), _ptr(e32), _ptr(lam), _ptr(Q), L, nleaf, _ptr(status))
+    _run("clo_tql2_batched_f32", dev, _ptr(d32), _ptr(e32), _ptr(lam), _ptr(Q), L, B * nleaf, _ptr(status))
     lam = lam.double()
-    # ---- merges, all nodes of a level at once
+    # ---- merges, all nodes of a level (of all matrices) at once
     h = L
     while h < N:
         s = 2 * h
-        nodes = N // s
+        per = N // s                   # nodes per matrix
+        nodes = B * per
         Qc = Q.reshape(2 * nodes, h, h)
-        starts = torch.arange(nodes, device=dev) * s
-        b = beta_full[starts + h]
+        starts = torch.arange(per, device=dev) * s
+        b = beta_full[:, starts + h].reshape(nodes)
         theta = torch.where(b < 0, -torch.ones_like(b), torch.ones_like(b))
         rho = (2.0 * b.abs()).contiguous()
         z = torch.cat([Qc[0::2][:, h - 1, :].double(), theta[:, None] * Qc[1::2][:, 0, :].double()], dim=1) / math.sqrt(2.0)
@@ -106,9 +118,8 @@ def stedc_native(d: Tensor, e: Tensor, n: int) -> tuple[Tensor, Tensor]:
         mu = torch.zeros(nodes, s, device=dev, dtype=torch.float64)
         zh = torch.zeros(nodes, s, device=dev, dtype=torch.float64)
         MT = torch.zeros(nodes, s, s, device=dev, dtype=torch.float32)
-        if kmax > 0:
-            _run("clo_dc_secular", dev, _ptr(dk), _ptr(zk), _ptr(rho), _ptr(K), _ptr(org), _ptr(mu), _ptr(zh), s, nodes, kmax)
-            _run("clo_dc_build", dev, _ptr(dk), _ptr(K), _ptr(org), _ptr(mu), _ptr(zh), _ptr(spos), _ptr(MT), s, nodes, kmax)
+        _run("clo_dc_secular", dev, _ptr(dk), _ptr(zk), _ptr(rho), _ptr(K), _ptr(org), _ptr(mu), _ptr(zh), s, nodes, kmax)
+        _run("clo_dc_build", dev, _ptr(dk), _ptr(K), _ptr(org), _ptr(mu), _ptr(zh), _ptr(spos), _ptr(MT), s, nodes, kmax)
         col = torch.arange(s, device=dev)[None, :].expand(nodes, s)
         defl = col >= K[:, None]                                       # columns K.. = deflated entries
         # unit entries of the deflated columns: MT[node, c, order[c]] += 1 for c >= K (adds 0 elsewhere; no mask
@@ -128,40 +139,22 @@ def stedc_native(d: Tensor, e: Tensor, n: int) -> tuple[Tensor, Tensor]:
     # a leaf that did not converge (status != 0; not observed) poisons the result instead of costing a host read
     # here: every caller verifies orthogonality / residual and falls back to float64
     poison = torch.where(status != 0, float("nan"), 0.0).to(torch.float32)[0]
-    return lam.reshape(N)[:n].float() + poison, Q.reshape(N, N)[:n, :n]
+    return lam.reshape(B, N)[:, :n].float() + poison, Q.reshape(B, N, N)[:, :n, :n]
 
 
 # ----------------------------------------------------------------------------------------------
 # back-transformation
 # ----------------------------------------------------------------------------------------------
-def ormtr_native(work: Tensor, tau: Tensor, Zr: Tensor, n: int, nb: int = 64) -> None:
-    """``Zr <- Zr Q^T`` in place, i.e. every ROW of ``Zr [m, >= n]`` (an eigenvector of the tridiagonal matrix) is
-    multiplied by ``Q = H_0 H_1 ... H_{n-2}``, the product of the Householder reflectors ``clo_sytrd_f32`` left in
-    ``work`` (row i holds v_i in columns i+2.., unit entry at column i+1 implied) and ``tau``.
-    Blocks of ``nb`` reflectors are applied as ``I - V T^T V^T`` (reverse order), three GEMMs per block."""
+def ormtr_native(work: Tensor, tau: Tensor, Zr: Tensor, n: int) -> None:
+    """``Zr <- Zr Q^T`` in place, i.e. every ROW of ``Zr [m, ld]`` (an eigenvector of the tridiagonal matrix;
+    ``ld >= pad4(n)``, multiple of 4, zero padding columns) is multiplied by ``Q = H_0 H_1 ... H_{n-2}``, the product
+    of the Householder reflectors ``clo_sytrd_f32`` left in ``work`` (row i holds v_i in columns i+2.., unit entry at
+    column i+1 implied) and ``tau``.  ONE foreign call (``clo_ormtr_f32``): blocks of 64 reflectors are applied as
+    ``I - V T^T V^T`` in reverse order, three GEMMs per block on the MFMA engine."""
     if n < 3:
-        if n == 2:
-            pass  # H_0 has v = e_1: tau_0 = 0 for n = 2 in LAPACK's convention (nothing to apply)
         return
-    dev = work.device
-    nref = n - 1
-    npan = -(-nref // nb)
-    ld = work.shape[1]
-    Vt = torch.zeros(npan * nb, ld, device=dev, dtype=torch.float32)
-    Vt[:nref, :n] = torch.triu(work[:nref, :n], diagonal=2)
-    idx = torch.arange(nref, device=dev)
-    Vt[idx, idx + 1] = 1.0
-    tau_p = torch.zeros(npan * nb, device=dev, dtype=torch.float32)
-    tau_p[:nref] = tau[:nref]
-    V3 = Vt.view(npan, nb, ld)
-    G = _hip.gemm(V3, V3.mT)                                           # [npan, nb, nb] Gram matrices
-    T = torch.empty(npan, nb, nb, device=dev, dtype=torch.float32)
-    _run("clo_larft_f32", dev, _ptr(G), _ptr(tau_p), _ptr(T), npan, nb)
+    lib = _hip.load()
     m = Zr.shape[0]
-    for p in reversed(range(npan)):
-        c0 = p * nb                                                    # reflectors of the block vanish left of c0 + 1
-        Vp = V3[p][:, c0:n]
-        Zs = Zr[:, c0:n]
-        W = _hip.gemm(Zs, Vp.T)                                        # [m, nb]
-        W2 = _hip.gemm(W, T[p].T)
-        _hip.gemm(W2, Vp, out=Zs, alpha=-1.0, beta=1.0)
+    nws = lib.clo_ormtr_ws_floats(m, n)
+    ws = torch.empty(nws, device=Zr.device, dtype=torch.float32)
+    _run("clo_ormtr_f32", Zr.device, _ptr(work), work.stride(0), _ptr(tau), _ptr(Zr), Zr.stride(0), m, n, _ptr(ws), nws)

@@ -8,9 +8,10 @@ factorisation fails.  ``eigh`` replaces ``torch.linalg.eigh`` at ``kronecker.py:
 
 fp32 GPU inputs: the Cholesky inverse runs on the hand-written kernels (``csrc/linalg.hip`` for
 the diagonal blocks, the MFMA GEMM of ``csrc/gemm.hip`` for every O(n^3) step; driver
-``_hip.cholesky_inverse``).  The symmetric eigensolver defaults to ``torch.linalg.eigh`` (rocSOLVER);
-``eigh_sytrd`` is the same decomposition on the hand-written Householder reduction
-(``csrc/sytrd.hip``), selected with ``CLO_EIGH=sytrd|auto`` -- measured in DESIGN.md section 7.
+``_hip.cholesky_inverse``).  The symmetric eigensolver is hand-written end to end by default
+(``CLO_EIGH=native``): Householder reduction ``csrc/sytrd.hip``, tridiagonal divide & conquer and
+block-reflector back-transformation ``csrc/eigh.hip`` / ``eigh_native.py``; ``CLO_EIGH=hybrid|rocsolver``
+keep ``torch.linalg.eigh`` (rocSOLVER) where it is faster / everywhere -- measured in DESIGN.md section 7.
 """
 
 from __future__ import annotations
@@ -398,6 +399,8 @@ def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
     n = A.shape[0]
     if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == n and 3 <= n <= _SYTRD_MAX_N):
         raise ValueError(f"eigh_sytrd: need a square fp32 GPU matrix of order 3..{_SYTRD_MAX_N}, got {tuple(A.shape)} {A.dtype}")
+    if not _EIGH_VENDOR_TAIL:
+        return _eigh_native_group([A])[0]
     An, scale = _unit_scale(A)
     try:
         lam, Q = _eigh_sytrd_unit(An)
@@ -408,6 +411,42 @@ def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
         res = torch.linalg.eigh(An.double())
         lam, Q = res.eigenvalues.float(), res.eigenvectors.float()
     return lam * scale.reshape(()), Q
+
+
+def _eigh_native_group(As: list[Tensor]) -> list[tuple[Tensor, Tensor]]:
+    """Hand-written route for several fp32 GPU matrices of ONE order n >= 3 (repeated layer shapes): one reduction
+    per matrix (``clo_sytrd_f32``: a chain of n launches inside one foreign call), then ONE divide & conquer whose
+    tree levels carry all matrices (``eigh_native.stedc_native`` with a batch dimension), one back-transformation
+    call per matrix, and a batched verification (own GEMMs) with the float64 retry of the other routes."""
+    from . import eigh_native
+
+    n, B = As[0].shape[0], len(As)
+    dev = As[0].device
+    An, scale = _unit_scale(torch.stack(As))
+    ld = (n + 3) // 4 * 4
+    work = torch.zeros(B, n, ld, device=dev, dtype=torch.float32)
+    work[:, :, :n] = An
+    DEt = [_hip.sytrd_(work[b], n) for b in range(B)]
+    lam, Qt = eigh_native.stedc_native(torch.stack([x[0] for x in DEt]), torch.stack([x[1] for x in DEt]), n)
+    Z = torch.zeros(B, n, ld, device=dev, dtype=torch.float32)
+    Z[:, :, :n] = Qt.mT
+    for b in range(B):
+        eigh_native.ormtr_native(work[b], DEt[b][2], Z[b], n)
+    Q = Z[:, :, :n].mT
+    # verification on the engine: |Q^T Q - I| and |A Q - Q diag(lam)| per matrix, one host read for the group
+    Zc = Z[:, :, :n]
+    G = _hip.gemm(Zc, Zc.mT)                                  # rows of Z are the eigenvectors
+    G.diagonal(dim1=-2, dim2=-1).sub_(1.0)
+    R = _hip.gemm(An, Q) - Q * lam.unsqueeze(-2)
+    ok = ((G.abs().amax(dim=(-2, -1)) <= _ORTH_TOL) & (R.abs().amax(dim=(-2, -1)) <= _RES_TOL)).tolist()
+    out = []
+    for b in range(B):
+        if ok[b]:
+            out.append((lam[b] * scale[b].reshape(()), Q[b]))
+        else:
+            res = torch.linalg.eigh(An[b].double())
+            out.append((res.eigenvalues.float() * scale[b].reshape(()), res.eigenvectors.float()))
+    return out
 
 
 def _nonzero_rows(A: Tensor) -> Tensor | None:
@@ -510,9 +549,6 @@ def _eigh_many_gpu(mats: list[Tensor], gpu: list[int], out: list, num_streams: i
     total = sum(float(mats[i].shape[0]) ** 3 for i in gpu)
     share = total / max(num_streams, 1)  # a group worth more than one worker's share is split
     for (n, dtype), idx in groups.items():
-        if _EIGH_MODE == "native" and dtype == torch.float32 and 2 <= n <= _SYTRD_MAX_N:
-            units.extend([i] for i in idx)   # the hand-written route works on one matrix per call
-            continue
         per = 8 * max(n, 1) ** 2 * mats[idx[0]].element_size()  # stacked input + vectors + solver workspace
         parts = max(1, min(len(idx), round(len(idx) * float(n) ** 3 / max(share, 1.0))))
         chunk = max(1, min((8 << 30) // per, -(-len(idx) // parts)))
@@ -523,6 +559,11 @@ def _eigh_many_gpu(mats: list[Tensor], gpu: list[int], out: list, num_streams: i
         if len(unit) == 1:
             for i in unit:
                 out[i] = _eigh_full(mats[i])
+            return
+        A0 = mats[unit[0]]
+        if _EIGH_MODE == "native" and A0.dtype == torch.float32 and 3 <= A0.shape[0] <= _SYTRD_MAX_N:
+            for i, res in zip(unit, _eigh_native_group([mats[i] for i in unit])):
+                out[i] = res
             return
         lam, vec = _torch_eigh_scaled(torch.stack([mats[i] for i in unit]))
         for k, i in enumerate(unit):

@@ -310,6 +310,12 @@ int clo_cg_direction_f32(float *p, const float *z, long n, const float *num, con
  *                         variable) + Gu-Eisenstat weights, eigenvector matrix MT [nodes][s][s] (transposed),
  *                         Givens rotations of the deflation. */
 int clo_larft_f32(const float *G, const float *tau, float *T, int np, int nb, void *stream);
+/* Back-transformation Z <- Z Q^T: every ROW of Z [m][ldz] (ldz >= pad4(n), multiple of 4, 16-byte aligned) is
+ * multiplied by Q = H_0 ... H_{n-2}, the reflectors clo_sytrd_f32 left in the rows of `work` [n][ldw] and `tau`
+ * (LAPACK sormtr, side = left on the column-major eigenvector matrix).  ws: clo_ormtr_ws_floats(m, n) floats. */
+long clo_ormtr_ws_floats(int m, int n);
+int clo_ormtr_f32(const float *work, long ldw, const float *tau, float *Z, long ldz, int m, int n, float *ws,
+                  long ws_floats, void *stream);
 int clo_tql2_batched_f32(const float *d, const float *e, float *lam, float *Q, int L, int batch, int *status,
                          void *stream);
 int clo_dc_deflate(double *D, double *z, const double *rho, int *type, int *rot_p, double *rot_c, double *rot_s,
