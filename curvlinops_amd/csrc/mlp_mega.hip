@@ -86,6 +86,7 @@ struct MegaArgs {
   const float *aux;
   int aux_rank;
   float scale, beta;
+  const float *a1g, *da1g, *dphi1g;   // L1 = false: outputs of the separate layer-1 launch
   float *xch;       // exchange area, see mega_xch_floats
   unsigned *sync;   // counters, see mega_sync_words
 };
@@ -142,7 +143,9 @@ __device__ __forceinline__ void mg_st4nt(float *p, const float4 &v) {
 }
 __device__ __forceinline__ float mg_and(float x, unsigned m) { return __uint_as_float(__float_as_uint(x) & m); }
 
-template <bool ACCUM>
+// L1 = false: layer 1 ran as its own launch before (fwd_mfma_first_kernel of mlp.hip); a1 / da1 / phi'1 are read from
+// p.a1g / p.da1g / p.dphi1g ([N][d1]) -- no first seam, and the whole layer-2 tile is requested at once.
+template <bool ACCUM, bool L1>
 __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_w = smem + MG_OFF_W, *s_b = smem + MG_OFF_B, *s_sl = smem + MG_OFF_SL, *s_d2 = smem + MG_OFF_D2;
@@ -197,29 +200,30 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   const int klen = min(d0, kb0 + kpw) - kb0;
   const int kbs = klen > 0 ? kb0 : 0;                          // a wave without a K range loads valid dummies
   const int jlast1 = jA + nf1 - 1;
-  const float *pA1[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int row = max(0, min(jA + g * 8 + (idx & 7), jlast1));   // an empty slice (nf1 == 0) loads valid dummies
-    pA1[g] = ((idx >= 8) ? p.V1 : p.W1) + (long)row * d0 + kbs + s4;
-  }
-  // B of layer 1 = x[:, K range of the wave]: loaded once per wave with linear 16-byte loads (issued FIRST), kept
-  // in a private LDS slice [8][kpw + 4] (rows >= N and columns beyond the range zero)
   float *s_xw = smem + MG_OFF_XW + wave * (MG_NB * (16 * MG_P1S + 4));
   const int xq = kpw >> 2;  // float4 per row
-  float4 xv[MG_P1S / 2];
+  float4 xv[MG_P1S / 2], a1v[MG_P1S][2];
+  if constexpr (L1) {
+    const float *pA1[2];
 #pragma unroll
-  for (int i = 0; i < MG_P1S / 2; ++i) {
-    const int e = i * 64 + lane, n = e / xq, c4 = (e - n * xq) * 4;
-    const bool ok = n < N && c4 < klen;
-    xv[i] = mg_ld4(p.X + (ok ? (long)n * d0 + kbs + c4 : 0));
-  }
-  float4 a1v[MG_P1S][2];
+    for (int g = 0; g < 2; ++g) {
+      const int row = max(0, min(jA + g * 8 + (idx & 7), jlast1));   // an empty slice (nf1 == 0) loads valid dummies
+      pA1[g] = ((idx >= 8) ? p.V1 : p.W1) + (long)row * d0 + kbs + s4;
+    }
+    // B of layer 1 = x[:, K range of the wave]: loaded once per wave with linear 16-byte loads (issued FIRST), kept
+    // in a private LDS slice [8][kpw + 4] (rows >= N and columns beyond the range zero)
 #pragma unroll
-  for (int s = 0; s < MG_P1S; ++s) {
-    const bool ok = s * 16 + s4 < klen;
+    for (int i = 0; i < MG_P1S / 2; ++i) {
+      const int e = i * 64 + lane, n = e / xq, c4 = (e - n * xq) * 4;
+      const bool ok = n < N && c4 < klen;
+      xv[i] = mg_ld4(p.X + (ok ? (long)n * d0 + kbs + c4 : 0));
+    }
 #pragma unroll
-    for (int g = 0; g < 2; ++g) a1v[s][g] = mg_ld4(pA1[g] + (ok ? s * 16 : 0));
+    for (int s = 0; s < MG_P1S; ++s) {
+      const bool ok = s * 16 + s4 < klen;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) a1v[s][g] = mg_ld4(pA1[g] + (ok ? s * 16 : 0));
+    }
   }
   if (wave == MG_CWAVES) {  // W3 / V3 columns of the finished slice -> LDS (needed in phase 3)
     for (int e = lane; e < 2 * MG_CMAX * 16; e += 64) {
@@ -239,27 +243,44 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     const int row = j0 + gl * 8 + (idx & 7);
     pA2[g] = ((idx >= 8) ? p.V2 : p.W2) + (long)row * d1 + k0 + s4;
   }
+  if (!L1 && wave == MG_CWAVES) {
+    // [a1 ; da1] of the K range and phi'1 of the layer-1 slice from the separate launch (requested BEFORE the tile)
+    const int q4 = kr >> 2;
+    for (int e = lane; e < 16 * q4; e += 64) {
+      const int c = e / q4, kk = (e - c * q4) * 4, n = c & 7;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) v = mg_ld4((c < 8 ? p.a1g : p.da1g) + (long)n * d1 + k0 + kk);
+      *reinterpret_cast<float4 *>(&s_b[c * MG_LDB + kk]) = v;
+    }
+    for (int e = lane; e < MG_NB * 16; e += 64) {
+      const int n = e >> 4, f = e & 15;
+      s_m[MG_M_PHI1 + e] = (n < N && f < nf1) ? p.dphi1g[(long)n * d1 + jA + f] : 0.f;
+    }
+  }
   if (wave < MG_CWAVES) {
 #pragma unroll
-    for (int s = 0; s < MG_PRE; ++s) {
+    for (int s = 0; s < (L1 ? MG_PRE : MG_MAXS); ++s) {
       if (s < ns) {
 #pragma unroll
         for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
       }
     }
   }
+  if constexpr (L1) {
 #pragma unroll
-  for (int i = 0; i < MG_P1S / 2; ++i) {
-    const int e = i * 64 + lane, n = e / xq, c4 = (e - n * xq) * 4;
-    if (n < MG_NB) {
-      const bool ok = n < N && c4 < klen;
-      *reinterpret_cast<float4 *>(&s_xw[n * (16 * MG_P1S + 4) + c4]) = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < MG_P1S / 2; ++i) {
+      const int e = i * 64 + lane, n = e / xq, c4 = (e - n * xq) * 4;
+      if (n < MG_NB) {
+        const bool ok = n < N && c4 < klen;
+        *reinterpret_cast<float4 *>(&s_xw[n * (16 * MG_P1S + 4) + c4]) = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
   MG_STAMP(1);
 
+  if constexpr (L1) {
   // =====================================================================================
   // phase 1: layer 1 for features [jA, jA + nf1): in-block split-K over the 8 waves
   // =====================================================================================
@@ -344,6 +365,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       *reinterpret_cast<f32x4 *>(&s_b[c * MG_LDB + kk]) = v;
     }
   }
+  }
   wg_barrier();
   MG_STAMP(4);
 
@@ -352,11 +374,13 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   // =====================================================================================
   if (wave < MG_CWAVES) {
     // the rest of the tile (its loads queue behind nothing but the first part now)
+    if constexpr (L1) {
 #pragma unroll
-    for (int s = MG_SPLIT; s < MG_MAXS; ++s) {
-      if (s < ns) {
+      for (int s = MG_SPLIT; s < MG_MAXS; ++s) {
+        if (s < ns) {
 #pragma unroll
-        for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
+          for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
+        }
       }
     }
     f32x4 acc[MG_MAXG];
@@ -772,7 +796,8 @@ bool mega_ok(int L, const int *dims, const float *const *W, const float *const *
 int mega_launch(const int *dims, const int *acts, const float *const *W, const float *const *b,
                 const float *const *VW, const float *const *Vb, float *const *OW, float *const *Ob,
                 const float *X, int N, int loss_kind, const float *aux, int aux_rank, float scale,
-                float beta, float *xch, unsigned *sync, hipStream_t st) {
+                float beta, float *xch, unsigned *sync, hipStream_t st, const float *a1g, const float *da1g,
+                const float *dphi1g) {
   MegaArgs a{};
   a.W1 = W[0]; a.V1 = VW[0]; a.W2 = W[1]; a.V2 = VW[1]; a.W3 = W[2]; a.V3 = VW[2];
   a.b1 = b ? b[0] : nullptr; a.b2 = b ? b[1] : nullptr; a.b3 = b ? b[2] : nullptr;
@@ -783,13 +808,16 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
   a.act1 = acts[0]; a.act2 = acts[1];
   a.kind = loss_kind; a.aux = aux; a.aux_rank = aux_rank; a.scale = scale; a.beta = beta;
   a.xch = xch; a.sync = sync;
+  a.a1g = a1g; a.da1g = da1g; a.dphi1g = dphi1g;
   const size_t smem = (size_t)MG_LDS_FLOATS * sizeof(float);
-  static bool attr_done[2] = {false, false};
-  const int v = beta != 0.f ? 1 : 0;
+  static bool attr_done[4] = {false, false, false, false};
+  const int v = (beta != 0.f ? 1 : 0) + (a1g ? 2 : 0);
+  const void *fns[4] = {reinterpret_cast<const void *>(mlp_mega_kernel<false, true>),
+                        reinterpret_cast<const void *>(mlp_mega_kernel<true, true>),
+                        reinterpret_cast<const void *>(mlp_mega_kernel<false, false>),
+                        reinterpret_cast<const void *>(mlp_mega_kernel<true, false>)};
   if (!attr_done[v]) {
-    const void *fn = v ? reinterpret_cast<const void *>(mlp_mega_kernel<true>)
-                       : reinterpret_cast<const void *>(mlp_mega_kernel<false>);
-    int rc = check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
+    int rc = check_hip(hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
                        "hipFuncSetAttribute(mlp_mega_kernel)");
     if (rc != CLO_OK) return rc;
     attr_done[v] = true;
@@ -819,8 +847,10 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
   const double D = (double)dims[0] * dims[1] + (double)dims[1] * dims[2] + (double)dims[2] * dims[3];
   {
     ProfScope prof(6, 12.0 * D, st);
-    if (v) hipLaunchKernelGGL(mlp_mega_kernel<true>, dim3(MG_G), dim3(MG_T), smem, st, a);
-    else hipLaunchKernelGGL(mlp_mega_kernel<false>, dim3(MG_G), dim3(MG_T), smem, st, a);
+    if (v == 0) hipLaunchKernelGGL((mlp_mega_kernel<false, true>), dim3(MG_G), dim3(MG_T), smem, st, a);
+    else if (v == 1) hipLaunchKernelGGL((mlp_mega_kernel<true, true>), dim3(MG_G), dim3(MG_T), smem, st, a);
+    else if (v == 2) hipLaunchKernelGGL((mlp_mega_kernel<false, false>), dim3(MG_G), dim3(MG_T), smem, st, a);
+    else hipLaunchKernelGGL((mlp_mega_kernel<true, false>), dim3(MG_G), dim3(MG_T), smem, st, a);
     CLO_CHECK_LAUNCH("mlp_mega_kernel");
   }
   if (c.multi) {
