@@ -37,6 +37,7 @@ _SIGNATURES = {
          c_float, _PF, c_long, c_long, c_int, c_int, _PF, c_void_p],
     ),
     "clo_gemm_suggest_splitk": (c_int, [c_int, c_int, c_int, c_int]),
+    "clo_gemm_streamk_ws_floats": (c_long, []),
     "clo_syrk_suggest_splitk": (c_int, [c_int, c_long]),
     "clo_gemm_sqsum_f32": (
         c_int,
@@ -291,6 +292,8 @@ def gemm(A: Tensor, B: Tensor, out: Tensor | None = None, alpha: float = 1.0, be
     ws = None
     if splitk > 1:
         ws = torch.empty(nb * splitk * M * N, device=A.device, dtype=torch.float32)
+    elif splitk < 0:  # stream-K schedule: partial tiles are finished inside the kernel
+        ws = torch.empty(lib.clo_gemm_streamk_ws_floats(), device=A.device, dtype=torch.float32)
     ldc = O3.stride(1) if M > 1 else max(N, O3.stride(1))
     rc = lib.clo_gemm_f32(
         M, N, K, alpha, _p(A3), A3.stride(1), A3.stride(2), sa_b, _p(B3), B3.stride(1),

@@ -51,12 +51,37 @@ struct GemmArgs {
   // im2col matrix of a [B][C][H][W] tensor, X[(b, oh, ow)][(c, kh, kw)], generated in the tile loader
   // -- it is never written to memory.  A == B == the input tensor; M == N == C*KH*KW (+ ones).
   int patch;
+  // stream-K request (LDS-DMA engine): ws holds gemm_streamk_ws_floats() floats (besides whatever splitk needs); the
+  // engine decides whether the schedule pays (then no split-K reduction runs)
+  int streamk;
   int cvC, cvH, cvW, cvKH, cvKW, cvSH, cvSW, cvPH, cvPW, cvDH, cvDW, cvOH, cvOW;
 };
 enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2, EPI_MUL_T = 3 };
 enum { TRI_KGE_M = 1, TRI_KLT_M = 2, TRI_KGE_N = 4, TRI_KLT_N = 8 };
 
+// final value of C[row][col] from the accumulated product `acc`
+__device__ __forceinline__ void store_final(const GemmArgs &p, float *c, int row, int col, float acc,
+                                            float alpha, float beta) {
+  float v = alpha * acc;
+  if (beta != 0.f) v += beta * *c;
+  if (p.epi == EPI_ACT) {
+    float dphi;
+    v = act_apply(p.e_act, v + (p.e_vec ? p.e_vec[col] : 0.f), dphi);
+    if (p.e_out2) p.e_out2[(c - p.C)] = dphi;
+  } else if (p.epi == EPI_MUL) {
+    v = (v + (p.e_vec ? p.e_vec[col] : 0.f)) * p.e_mul[(long)row * p.ld_mul + col];
+  } else if (p.epi == EPI_MUL_T) {
+    v *= p.e_mul[(long)(col / p.e_div) * p.ld_mul + row];
+  }
+  *c = v;
+}
+
 bool gemm_v2_eligible(const GemmArgs &a, int batch);
+// LDS-DMA engine (gemm_v3.hip): 128 x 128 x 32 tiles, optional stream-K schedule
+bool gemm_v3_eligible(const GemmArgs &a, int batch);
+bool gemm_v3_would_streamk(long tiles, int K);
+long gemm_streamk_ws_floats();
+int launch_gemm_v3(const GemmArgs &a, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk);
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream);
 int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int batch = 1);
 int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float *V, const float *b,

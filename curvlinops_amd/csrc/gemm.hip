@@ -31,23 +31,6 @@ enum LoadMode { MODE_OC_VEC = 0, MODE_KC_VEC = 1, MODE_OC_SCALAR = 2, MODE_KC_SC
 
 
 
-// final value of C[row][col] from the accumulated product `acc`
-__device__ __forceinline__ void store_final(const GemmArgs &p, float *c, int row, int col, float acc,
-                                            float alpha, float beta) {
-  float v = alpha * acc;
-  if (beta != 0.f) v += beta * *c;
-  if (p.epi == EPI_ACT) {
-    float dphi;
-    v = act_apply(p.e_act, v + (p.e_vec ? p.e_vec[col] : 0.f), dphi);
-    if (p.e_out2) p.e_out2[(c - p.C)] = dphi;
-  } else if (p.epi == EPI_MUL) {
-    v = (v + (p.e_vec ? p.e_vec[col] : 0.f)) * p.e_mul[(long)row * p.ld_mul + col];
-  } else if (p.epi == EPI_MUL_T) {
-    v *= p.e_mul[(long)(col / p.e_div) * p.ld_mul + row];
-  }
-  *c = v;
-}
-
 // Load one [BK x 128] operand tile into 8 registers per thread.
 // Element (o, k) lives at P[o*so + k*sk]; o in [o0, o0+128), k in [k0, k0+16).
 // `ones` (outer-contiguous modes only): outer index O-1 is an implicit column of ones.
@@ -979,7 +962,14 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   else if (b_kc) CLO_V2(false, true, BKV, BMV, BNV, WM_, WN_)           \
   else CLO_V2(false, false, BKV, BMV, BNV, WM_, WN_)
     const long nblocks = (long)grid.x * grid.y;
-    if (a.patch) {
+    if (cfg.bm == 128 && cfg.bk == 32 && gemm_v3_eligible(a, batch)) {
+      // LDS-DMA engine (gemm_v3.hip); with a stream-K workspace it may finish the split tiles itself
+      bool used_streamk = false;
+      int rc3 = launch_gemm_v3(a, batch, a_kc, b_kc, stream, &used_streamk);
+      if (rc3 != CLO_OK) return rc3;
+      if (used_streamk) a.splitk = 1;
+    }
+    else if (a.patch) {
       if (cfg.bk == 64) CLO_V2X(false, false, 64, 64, 64, 2, 2, true)
       else if (nblocks < 2L * kNumCU) CLO_V2X(false, false, 32, 128, 128, 2, 4, true)
       else CLO_V2X(false, false, 32, 128, 128, 2, 2, true)
@@ -1125,10 +1115,19 @@ extern "C" int clo_syrk_suggest_splitk(int d, long rows) {
                                    (double)cfg.bm * cfg.bn / (128.0 * 128.0), cfg.bk == 64 ? 4 : 8, 64);
 }
 
+// -1: ask for the stream-K schedule of the LDS-DMA engine (workspace of clo_gemm_streamk_ws_floats() floats)
 extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
   // without the operands: float4-complete extents are taken as "aligned"
-  return suggest_splitk_for(M, N, K, batch > 0 ? batch : 1, M % 4 == 0 && N % 4 == 0 && K % 4 == 0);
+  const bool aligned = M % 4 == 0 && N % 4 == 0 && K % 4 == 0;
+  const long b = batch > 0 ? batch : 1;
+  if (aligned && M > 0 && N > 0) {
+    const V2Config cfg = v2_config(M, N, K, b, 0);
+    if (cfg.bm == 128 && cfg.bk == 32 && clo::gemm_v3_would_streamk(cdiv(M, 128) * cdiv(N, 128) * b, K)) return -1;
+  }
+  return suggest_splitk_for(M, N, K, b, aligned);
 }
+
+extern "C" long clo_gemm_streamk_ws_floats(void) { return clo::gemm_streamk_ws_floats(); }
 
 extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, long sa_m, long sa_k,
                             long sa_b, const float *B, long sb_k, long sb_n, long sb_b, float beta,
@@ -1144,6 +1143,11 @@ extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, lo
   a.B = B; a.sb_k = sb_k; a.sb_n = sb_n; a.sb_b = sb_b;
   a.C = C; a.ldc = ldc; a.sc_b = sc_b;
   a.splitk = splitk; a.ws = ws; a.sym = 0;
+  if (splitk < 0) {  // stream-K request; an engine that cannot honour it runs unsplit
+    CLO_REQUIRE(ws, "clo_gemm_f32: splitk = -1 (stream-K) needs a workspace of clo_gemm_streamk_ws_floats() floats");
+    a.splitk = 1;
+    a.streamk = 1;
+  }
   return launch_gemm(a, batch, (hipStream_t)stream);
 }
 
@@ -1230,6 +1234,7 @@ int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int 
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws;
+  a.streamk = ws && ws_floats >= gemm_streamk_ws_floats();
   return launch_gemm(a, batch, st);
 }
 

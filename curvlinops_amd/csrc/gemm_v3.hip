@@ -1,0 +1,585 @@
+// fp32 MFMA GEMM, LDS-DMA engine (gfx950) -- the 128 x 128 x 32 tile loop of the aligned engine of gemm.hip rebuilt
+// around `buffer_load_dwordx4 ... lds`:
+//   * operand tiles go global -> LDS directly (no staging registers, no ds_write pass) into a ring of NST stages, so
+//     NST - 1 k tiles are in flight across the ONE barrier per k tile; completion is counted (`s_waitcnt vmcnt(N)`),
+//     never drained, and out-of-range k is zero-filled by the buffer range check (no select after the load);
+//   * the LDS images are linear (the DMA writes wave-base + 16 lane); bank conflicts are avoided by a swizzle that is
+//     applied on the SOURCE address of the lane that owns a slot and again on the fragment read;
+//   * every non-MFMA instruction of the loop (fragment reads of the next 8-k group, the DMA pieces of the tile three
+//     ahead) is placed behind one MFMA, so it issues while the matrix pipe is busy with that MFMA.
+// Measured against the register-staged loop it replaces (one MI355X, tools/ubench/gemm_v3_probe): 4096^3 115-129 ->
+// 141 TFLOP/s, 2048^3 104-111 -> 113-131, and the loop alone runs at 93 % of a loop with the MFMAs only.
+//
+// Scheduling: either one output tile per workgroup (`blockIdx.y` = batch x split-K slab, as in gemm.hip), or
+// STREAM-K: the (tile, k tile) units of the whole problem are cut into `workers` equal contiguous ranges, one per
+// workgroup (<= one per CU).  A range that ends inside a tile leaves its partial accumulator in a slot of the
+// workspace and raises a flag; the workgroup whose range contains the tile's LAST k tile adds the partials of the
+// workgroups before it (fixed order: the result does not depend on timing) and runs the epilogue.  Every workgroup
+// walks its range from the last tile to the first, so the partial somebody waits for is written FIRST and the tile that
+// needs other workgroups' partials is finished LAST: nobody waits in practice.  Ranges are laid out XCD by XCD (the
+// workgroups of one XCD hold neighbouring tiles, which share operand rows in that XCD's L2).
+#include "clo_common.h"
+#include "gemm.h"
+
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace clo {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+using i32x4v = __attribute__((ext_vector_type(4))) int;
+using u32x4v = __attribute__((ext_vector_type(4))) unsigned int;
+
+constexpr int V3_BK = 32;
+constexpr int V3_BM = 128, V3_BN = 128, V3_WVM = 2, V3_WVN = 4, V3_NST = 4;
+constexpr int V3_NTHR = V3_WVM * V3_WVN * 64;
+constexpr int V3_FLAG_STRIDE = 16;       // unsigned per flag (64 bytes apart)
+constexpr unsigned V3_SPIN = 1u << 24;   // polls before a waiting workgroup gives up (trap)
+constexpr long V3_SK_MAX_TILES = 1024;   // stream-K below this many output tiles
+constexpr int V3_SK_MAX_PARTS = 8;       // partial accumulators one finisher adds, at most (about)
+
+struct V3Sched {
+  int streamk;        // 0: one tile per workgroup; 1: stream-K
+  int nkt;            // stream-K: k tiles per output tile
+  int workers;        // stream-K: grid.x
+  long units;         // stream-K: tiles x nkt
+  int tiles_per_mat;  // output tiles of one matrix of the batch
+  float *slots;       // stream-K: workers x (BM BN) partial accumulators
+  unsigned *flags;    // stream-K: one per worker; a worker publishes its partial by storing `epoch`
+  unsigned epoch;     // stream-K: unique per launch on this (device, stream)
+};
+
+__device__ __forceinline__ i32x4v v3_srd(const float *p) {
+  const unsigned long u = (unsigned long)p;
+  i32x4v r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+  r.z = 0x7ffffff0;   // the loader clamps its own addresses; an offset >= 2^31 is out of range: the lane gets zeros
+  r.w = 0x00020000;
+  return r;
+}
+// one 1 KB piece: the 16 bytes at srd + voff of lane l land at LDS byte lds_dst + 16 l.  hipcc neither counts this
+// load nor knows that it writes LDS: the loop below waits for it by count.
+__device__ __forceinline__ void v3_dma16(i32x4v srd, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(srd), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void v3_wait_vm_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// Operand tile of T outer indices x 32 k as a LINEAR LDS image written in 1 KB pieces (T / 8 of them):
+//   KC (k contiguous in memory): [T][32]; the 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7), so the 16
+//      rows one ds_read_b128 pass touches cover all 64 banks;
+//   OC (outer contiguous):       [32][T]; element (k, o) sits at column o ^ (((k >> 2) & 1) << 5): the two half-waves
+//      of a fragment read (k and k + 4) hit different bank halves.
+template <bool KC, int T, int NW>
+struct V3Op {
+  static constexpr int PIECES = T / 8, PPW = PIECES / NW;
+  static_assert(PIECES % NW == 0, "pieces per wave");
+  unsigned voff[PPW];  // byte offset of this lane's 16 bytes relative to element (o0, k0) of the current k tile
+  int kq[PPW];         // k (inside the tile) the lane's chunk starts at
+  // stride = so (KC) or sk (OC), floats
+  __device__ __forceinline__ void init(long stride, int o0, int O, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int piece = wave + NW * q;
+      if (KC) {
+        const int row = 8 * piece + (lane >> 3), pc = lane & 7, lc = pc ^ ((row >> 1) & 7);
+        const int rr = min(o0 + row, O - 1) - o0;   // rows past the end repeat the last one (never stored)
+        voff[q] = (unsigned)(rr * stride * 4 + lc * 16);
+        kq[q] = 4 * lc;
+      } else {
+        const int idx = piece * 64 + lane, k = idx / (T / 4), pc = idx % (T / 4), lc = pc ^ (((k >> 2) & 1) << 3);
+        const int oc = min(o0 + 4 * lc, O - 4) - o0;
+        voff[q] = (unsigned)(k * stride * 4 + oc * 4);
+        kq[q] = k;
+      }
+    }
+  }
+  // lim = number of valid k in this tile (<= 0: the whole tile is zeros)
+  __device__ __forceinline__ void issue_one(int q, i32x4v srd, int lim, unsigned lds_byte, int wave) const {
+    const unsigned v = kq[q] < lim ? voff[q] : 0x80000000u;
+    v3_dma16(srd, v, lds_byte + (unsigned)(wave + NW * q) * 1024u);
+  }
+  // fragment values of one lane for the 8-k group g: v[m] feeds MFMA m (k = 8 g + 4 lh + m on both operands)
+  static __device__ __forceinline__ f32x4v frag(const float *S, int outer, int g, int lh) {
+    if (KC) return *reinterpret_cast<const f32x4v *>(S + outer * 32 + 4 * ((2 * g + lh) ^ ((outer >> 1) & 7)));
+    const float *p = S + (8 * g + 4 * lh) * T + (outer ^ (lh << 5));
+    f32x4v r;
+    r[0] = p[0]; r[1] = p[T]; r[2] = p[2 * T]; r[3] = p[3 * T];
+    return r;
+  }
+};
+
+struct V3Tile {
+  int bm, bn, m0, n0, batch, split, kb, ke, nk;
+};
+
+template <int BMt, int BNt>
+__device__ __forceinline__ void v3_tile(const GemmArgs &p, long lin, int y, bool sk, int tiles_per_mat, V3Tile &t) {
+  int tl = (int)lin;
+  if (sk) {
+    t.batch = (int)(lin / tiles_per_mat);
+    tl = (int)(lin - (long)t.batch * tiles_per_mat);
+    t.split = 0;
+  } else {
+    t.batch = y / p.splitk;
+    t.split = y % p.splitk;
+  }
+  if (p.sym) {
+    // upper-triangular tiles only, column by column: tl = bn (bn + 1) / 2 + bm
+    int bn = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
+    while ((bn + 1) * (bn + 2) / 2 <= tl) ++bn;
+    while (bn * (bn + 1) / 2 > tl) --bn;
+    t.bn = bn;
+    t.bm = tl - bn * (bn + 1) / 2;
+  } else {
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * p.tiles_n;
+    const int g = tl / per_group, first_m = g * GROUP, gsz = min(p.tiles_m - first_m, GROUP);
+    const int in_g = tl % per_group;
+    t.bm = first_m + in_g % gsz;
+    t.bn = in_g / gsz;
+  }
+  t.m0 = t.bm * BMt;
+  t.n0 = t.bn * BNt;
+  if (sk) {
+    t.kb = 0;
+    t.ke = p.K;
+  } else {
+    t.kb = t.split * p.k_per_split;
+    t.ke = min(p.K, t.kb + p.k_per_split);
+    if (p.tri) {  // triangular operands: only the k range of this tile that can be nonzero
+      int lo = 0, hi = p.K;
+      if (p.tri & TRI_KGE_M) lo = max(lo, t.m0);
+      if (p.tri & TRI_KGE_N) lo = max(lo, t.n0);
+      if (p.tri & TRI_KLT_M) hi = min(hi, t.m0 + BMt);
+      if (p.tri & TRI_KLT_N) hi = min(hi, t.n0 + BNt);
+      t.kb = max(t.kb, lo & ~(V3_BK - 1));
+      t.ke = min(t.ke, hi);
+    }
+  }
+  // (an empty k range -- triangular hint -- still owes beta C / a slab of zeros: one all-masked k tile)
+  t.nk = t.ke > t.kb ? (t.ke - t.kb + V3_BK - 1) / V3_BK : 1;
+}
+
+template <bool AKC, bool BKC, int BMt, int BNt, int WVM, int WVN, int NST, bool SK>
+__global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p, const V3Sched s) {
+  constexpr int NW = WVM * WVN, NTHR = NW * 64;
+  constexpr int WM = BMt / WVM, WNC = BNt / WVN, MT = WM / 32, NT = WNC / 32;
+  constexpr int A_FL = BMt * V3_BK, ST_FL = (BMt + BNt) * V3_BK;
+  using DA = V3Op<AKC, BMt, NW>;
+  using DB = V3Op<BKC, BNt, NW>;
+  constexpr int PER = DA::PPW + DB::PPW;  // DMA instructions per wave per k tile
+  static_assert(MT + NT + PER <= 4 * MT * NT, "one slot behind each MFMA");
+  static_assert(NST >= 3, "ring depth");
+  extern __shared__ __attribute__((aligned(1024))) float lds3[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WVN, wn = wave % WVN;
+  const int li = lane & 31, lh = lane >> 5;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds3;
+
+  // ---- this workgroup's units.  Stream-K walks the tiles of its range from the LAST to the first: the partial
+  // accumulator other workgroups wait for (the head of the last tile) is written first, and the tile this workgroup
+  // has to finish with the partials of the workgroups before it (the tail of the first tile) comes last.
+  long c_lin;        // linear index of the consumer's output tile
+  int c_kt, c_kend;  // the consumer's segment: next k tile and end (inside the tile's k tile range)
+  int n_units;       // units of this workgroup
+  long u0 = 0;       // (stream-K) first unit of the range
+  int w = blockIdx.x;  // (stream-K) worker = position of the range; neighbours in range order share operand tiles, so
+                       // they go to the same XCD (workgroup b runs on XCD b % 8)
+  if (SK) {
+    const int q = s.workers / kNumXCD, rem = s.workers % kNumXCD;
+    const int xcd = blockIdx.x % kNumXCD, idx = blockIdx.x / kNumXCD;
+    w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    u0 = (long)w * s.units / s.workers;
+    const long u1 = (long)(w + 1) * s.units / s.workers;
+    c_lin = (u1 - 1) / s.nkt;
+    c_kt = (int)(max(u0, c_lin * s.nkt) - c_lin * s.nkt);
+    c_kend = (int)(u1 - c_lin * s.nkt);
+    n_units = (int)(u1 - u0);
+  } else {
+    const int ntiles = s.tiles_per_mat;
+    if (p.sym || p.tri) {
+      c_lin = blockIdx.x;  // tiles of very different length: neighbours go to different XCDs
+    } else {
+      const int b = blockIdx.x, q = ntiles / kNumXCD, rem = ntiles % kNumXCD;
+      const int xcd = b % kNumXCD, idx = b / kNumXCD;
+      c_lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    c_kt = 0;
+    c_kend = 0;
+    n_units = 0;  // set from the tile below
+  }
+  V3Tile ct;
+  v3_tile<BMt, BNt>(p, c_lin, blockIdx.y, SK, s.tiles_per_mat, ct);
+  if (!SK) n_units = c_kend = ct.nk;
+  int seg_kt0 = c_kt;  // first k tile of the consumer's current segment
+
+  // ---- producer: runs NST - 1 units ahead of the consumer.  Its position is kept as the ADDRESSES of the next k tile of
+  // the two operands and the number of valid k left (`lim`), advanced by a constant per unit: a handful of scalar
+  // instructions in the loop.
+  const int K1 = p.A2 ? p.K1 : 0x7fffffff;
+  DA da;
+  DB db;
+  long p_lin = c_lin;
+  int p_kt = c_kt, p_kend = c_kend, p_kb = ct.kb, p_ke = ct.ke, issued = 0;
+  const long stepA = (AKC ? 1 : p.sa_k) * (long)(V3_BK * 4), stepB = (BKC ? 1 : p.sb_k) * (long)(V3_BK * 4);  // bytes
+  unsigned long Ab = 0, Bb = 0;   // element (m0 / n0, k = 0) of the producer's tile
+  unsigned long pa = 0, pb = 0;   // the k tile the producer issues next
+  int lim = 0;
+  auto rfl64 = [](unsigned long v) {
+    return ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+  };
+  auto prod_seek = [&]() {   // position = k tile p_kt of the tile's range (second K segment: its own operands)
+    const int k0 = p_kb + p_kt * V3_BK;
+    const bool s2 = k0 >= K1;
+    const int kr = s2 ? k0 - K1 : k0;
+    lim = (s2 ? p_ke - K1 : min(p_ke, K1)) - kr;
+    pa = rfl64(Ab + (s2 ? (unsigned long)(p.A2 - p.A) * 4 : 0ul) + (unsigned long)(kr / V3_BK) * stepA);
+    pb = rfl64(Bb + (s2 ? (unsigned long)(p.B2 - p.B) * 4 : 0ul) + (unsigned long)(kr / V3_BK) * stepB);
+  };
+  auto prod_setup = [&](const V3Tile &t) {
+    da.init(AKC ? p.sa_m : p.sa_k, t.m0, p.M, wave, lane);
+    db.init(BKC ? p.sb_n : p.sb_k, t.n0, p.N, wave, lane);
+    Ab = (unsigned long)(p.A + (long)t.batch * p.sa_b + (AKC ? (long)t.m0 * p.sa_m : (long)t.m0));
+    Bb = (unsigned long)(p.B + (long)t.batch * p.sb_b + (BKC ? (long)t.n0 * p.sb_n : (long)t.n0));
+    p_kb = t.kb; p_ke = t.ke;
+    prod_seek();
+  };
+  prod_setup(ct);
+  // SRDs of the unit the producer issues next and its number of valid k (<= 0: zeros; past the range: zeros)
+  i32x4v sa, sbd;
+  int lim_u;
+  auto prod_unit = [&]() {
+    sa = v3_srd(reinterpret_cast<const float *>(pa));
+    sbd = v3_srd(reinterpret_cast<const float *>(pb));
+    lim_u = __builtin_amdgcn_readfirstlane(issued < n_units ? lim : 0);
+  };
+  auto prod_advance = [&]() {
+    ++issued;
+    ++p_kt;
+    if (p_kt == p_kend && issued < n_units) {  // (stream-K only) on to the tile before this one
+      --p_lin;
+      p_kt = (int)max(u0 - p_lin * s.nkt, 0L);
+      p_kend = s.nkt;
+      V3Tile t;
+      v3_tile<BMt, BNt>(p, p_lin, 0, true, s.tiles_per_mat, t);
+      prod_setup(t);
+    } else if (p.A2 && p_kb + p_kt * V3_BK == K1) {
+      prod_seek();
+    } else {
+      pa += stepA;
+      pb += stepB;
+      lim -= V3_BK;
+    }
+  };
+  auto issue_all = [&](int stage) {
+    const unsigned sb = lds0 + (unsigned)stage * (ST_FL * 4);
+#pragma unroll
+    for (int q = 0; q < DA::PPW; ++q) da.issue_one(q, sa, lim_u, sb, wave);
+#pragma unroll
+    for (int q = 0; q < DB::PPW; ++q) db.issue_one(q, sbd, lim_u, sb + A_FL * 4, wave);
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t) {
+    prod_unit();
+    issue_all(t);
+    prod_advance();
+  }
+  v3_wait_vm_barrier<PER *(NST - 2)>();
+
+  f32x4v fa[2][MT], fb[2][NT];
+#define V3_SB __builtin_amdgcn_sched_barrier(0);
+  // One 8-k group: 4 MT NT MFMAs on fragment buffer BUF; behind MFMA m goes ONE other instruction -- a fragment read
+  // of group GN of stage SN (into the other buffer), with DMA set a piece of the unit NST - 1 ahead, or the scalar
+  // bookkeeping statement EXTRA (in the first free slot).
+#define V3_GROUP(BUF, SN, GN, DMA, EXTRA)                                                                      \
+  {                                                                                                          \
+    const float *as_ = lds3 + (SN) * ST_FL, *bs_ = as_ + A_FL;                                               \
+    _Pragma("unroll") for (int m = 0; m < 4 * MT * NT; ++m) {                                                \
+      const int e = m / (MT * NT), i = (m % (MT * NT)) / NT, j = m % NT;                                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][i][e], fb[BUF][j][e], acc[i][j], 0, 0, 0);   \
+      V3_SB                                                                                                  \
+      if (m < MT) fa[(BUF) ^ 1][m] = DA::frag(as_, wm * WM + m * 32 + li, GN, lh);                           \
+      else if (m < MT + NT) fb[(BUF) ^ 1][m - MT] = DB::frag(bs_, wn * WNC + (m - MT) * 32 + li, GN, lh);    \
+      else if (DMA && m - (MT + NT) < PER) {                                                                 \
+        const int q = m - (MT + NT);                                                                         \
+        if (q < DA::PPW) da.issue_one(q, sa, lim_u, sbyte, wave);                                            \
+        else db.issue_one(q - DA::PPW, sbd, lim_u, sbyte + A_FL * 4, wave);                                  \
+      } else if (!DMA && m == MT + NT) { EXTRA; }                                                            \
+      V3_SB                                                                                                  \
+    }                                                                                                        \
+  }
+
+  {
+    const float *as = lds3, *bs = as + A_FL;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[0][i] = DA::frag(as, wm * WM + i * 32 + li, 0, lh);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[0][j] = DB::frag(bs, wn * WNC + j * 32 + li, 0, lh);
+  }
+  int st = 0;  // stage of the consumer's unit
+  for (int u = 0; u < n_units; ++u) {
+    const int st_next = st + 1 == NST ? 0 : st + 1;
+    const int st_free = st == 0 ? NST - 1 : st - 1;  // stage of unit u - 1 = where unit u + NST - 1 goes
+    const unsigned sbyte = lds0 + (unsigned)st_free * (ST_FL * 4);
+    // (the producer's position moves past the unit issued in the previous iteration, then the SRDs of the next one
+    // are formed: scalar work, placed between MFMAs)
+    V3_GROUP(0, st, 1, false, if (u > 0) prod_advance())
+    V3_GROUP(1, st, 2, false, prod_unit())
+    V3_GROUP(0, st, 3, false, )
+    // unit u + 1: this wave's pieces have landed, the barrier makes everybody's visible (and tells that every wave is
+    // done reading unit u - 1, whose stage the DMA below overwrites)
+    v3_wait_vm_barrier<PER *(NST - 3)>();
+    V3_GROUP(1, st_next, 0, true, )
+    st = st_next;
+
+    // ---- end of a segment (last k tile of the output tile, or of this workgroup's range)?
+    if (c_kt + 1 == c_kend) {
+      const bool tile_done = c_kend == ct.nk;   // the segment contains the last k tile of the output tile
+      const bool whole_from_start = seg_kt0 == 0;
+      if (SK && !tile_done) {
+        // partial accumulator -> slot of this workgroup, then the flag (the data is complete in memory first)
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            s.slots + (long)w * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4v v;
+              v[0] = acc[i][j][4 * q]; v[1] = acc[i][j][4 * q + 1]; v[2] = acc[i][j][4 * q + 2]; v[3] = acc[i][j][4 * q + 3];
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rs,
+                                                     (unsigned)(((((i * NT + j) * 4 + q) * NTHR) + tid) * 16), 0, 16);
+            }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid == 0)
+          __hip_atomic_store(s.flags + (long)w * V3_FLAG_STRIDE, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (SK && !whole_from_start) {
+          // the workgroups before this one hold the first part of the tile's k range
+          const long tstart = c_lin * s.nkt;
+          for (int w2 = w - 1; w2 >= 0; --w2) {
+            if ((long)(w2 + 1) * s.units / s.workers <= tstart) break;
+            if (tid == 0) {
+              unsigned spins = 0;
+              while (__hip_atomic_load(s.flags + (long)w2 * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > V3_SPIN) __builtin_trap();   // fail loudly rather than add garbage
+              }
+            }
+            asm volatile("s_barrier" ::: "memory");
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                s.slots + (long)w2 * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const f32x4v v = __builtin_bit_cast(
+                      f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                  rs, (unsigned)(((((i * NT + j) * 4 + q) * NTHR) + tid) * 16), 0, 16));
+                  acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1];
+                  acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+                }
+          }
+        }
+        // ---- epilogue of the finished tile
+        const bool to_ws = !SK && p.splitk > 1;
+        const int z = blockIdx.y;
+        float *C = to_ws ? p.ws + (long)z * p.M * p.N : p.C + (long)ct.batch * p.sc_b;
+        const long ldc = to_ws ? p.N : p.ldc;
+        const float alpha = to_ws ? 1.f : p.alpha;
+        const float beta = to_ws ? 0.f : p.beta;
+        const bool mirror = p.sym && !to_ws && ct.bm != ct.bn;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int col = ct.n0 + wn * WNC + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = ct.m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (row < p.M && col < p.N) {
+                float *c = C + (long)row * ldc + col;
+                if (!to_ws && p.epi != EPI_NONE) {
+                  store_final(p, c, row, col, acc[mt][nt][r], alpha, beta);
+                  continue;
+                }
+                float v = alpha * acc[mt][nt][r];
+                if (beta != 0.f) v += beta * *c;
+                *c = v;
+                if (mirror) {
+                  float *ctp = C + (long)col * ldc + row;
+                  float vt = alpha * acc[mt][nt][r];
+                  if (beta != 0.f) vt += beta * *ctp;
+                  *ctp = vt;
+                }
+              }
+            }
+          }
+      }
+      if (u + 1 < n_units) {  // (stream-K only) on to the tile before this one
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        --c_lin;
+        v3_tile<BMt, BNt>(p, c_lin, 0, true, s.tiles_per_mat, ct);
+        c_kt = seg_kt0 = (int)max(u0 - c_lin * s.nkt, 0L);
+        c_kend = s.nkt;
+      }
+    } else {
+      ++c_kt;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero tiles issued past the end
+#undef V3_GROUP
+#undef V3_SB
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+long gemm_streamk_ws_floats() { return (long)kNumCU * V3_BM * V3_BN; }
+
+// Flags of the stream-K schedule: one array per (device, stream), zeroed when it is created.  Only the workgroup that
+// owns a flag ever writes it (the launch's epoch, a per-array counter that never repeats); the others poll for that
+// value.  Launches on one stream do not overlap, launches on different streams have different arrays.  A stream that
+// is being captured into a graph gets no stream-K launch (a replay would repeat the epoch).
+struct V3Flags { unsigned *ptr; unsigned epoch; };
+static int v3_flags(hipStream_t stream, unsigned **flags, unsigned *epoch) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, V3Flags> reg;
+  int dev = 0;
+  int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+  if (rc != CLO_OK) return rc;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = reg.find({dev, stream});
+  if (it == reg.end()) {
+    unsigned *f = nullptr;
+    const size_t bytes = (size_t)kNumCU * V3_FLAG_STRIDE * sizeof(unsigned);
+    if ((rc = check_hip(hipMalloc(&f, bytes), "hipMalloc(stream-K flags)")) != CLO_OK) return rc;
+    // zeroed ON THE LAUNCH STREAM: a hipMemset on the null stream is not ordered with a non-blocking stream and could
+    // land after the first kernel has raised its flags
+    if ((rc = check_hip(hipMemsetAsync(f, 0, bytes, stream), "hipMemsetAsync(stream-K flags)")) != CLO_OK) return rc;
+    it = reg.insert({{dev, stream}, V3Flags{f, 0u}}).first;
+  }
+  if (++it->second.epoch == 0u) ++it->second.epoch;
+  *flags = it->second.ptr;
+  *epoch = it->second.epoch;
+  return CLO_OK;
+}
+
+// the schedule decision for `tiles` output tiles (all matrices of the batch) of 128 x 128 and k extent K
+static long v3_streamk_workers(long tiles, int K) {
+  const int nkt = (int)cdiv(K, V3_BK);
+  if (nkt <= 0 || tiles <= 0 || tiles >= V3_SK_MAX_TILES || tiles % kNumCU == 0) return 0;
+  const long units = tiles * nkt;
+  long workers = std::min<long>({(long)kNumCU, units, tiles * V3_SK_MAX_PARTS});
+  // at least two k tiles per worker: a shorter range is all pipeline fill
+  workers = std::max<long>(1, std::min<long>(workers, units / 2));
+  if (workers <= tiles && tiles <= kNumCU) return 0;   // nothing to split: one tile per workgroup
+  if (const char *e = getenv("CLO_V3_SK_WORKERS")) workers = std::max<long>(1, std::min<long>(atol(e), std::min<long>(units, kNumCU)));
+  return workers;
+}
+bool gemm_v3_would_streamk(long tiles, int K) { return v3_streamk_workers(tiles, K) > 0; }
+
+bool gemm_v3_eligible(const GemmArgs &a, int batch) {
+  static const int off = getenv("CLO_GEMM_V3") ? !atoi(getenv("CLO_GEMM_V3")) : 0;
+  if (off || a.patch || a.ones || a.ones_b || a.col_out) return false;
+  if (a.A2 && (a.K1 % V3_BK != 0)) return false;
+  // 32-bit byte offsets inside one k tile of one output tile
+  const long lim = 1L << 29;
+  const long ra = (a.sa_k == 1 ? (long)V3_BM * a.sa_m : (long)V3_BK * a.sa_k + V3_BM);
+  const long rb = (a.sb_k == 1 ? (long)V3_BN * a.sb_n : (long)V3_BK * a.sb_k + V3_BN);
+  (void)batch;
+  return ra < lim && rb < lim;
+}
+
+// Launches the main kernel for `a` (tiles_m / tiles_n / k_per_split / splitk set by launch_gemm for 128 x 128 x 32
+// tiles).  a.streamk != 0 asks for the stream-K schedule with a.ws (>= gemm_streamk_ws_floats()) as its workspace;
+// *used_streamk tells the caller that no split-K reduction is due.
+int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk) {
+  GemmArgs a = a0;
+  V3Sched s{};
+  const long tiles_mat = a.sym ? (long)a.tiles_m * (a.tiles_m + 1) / 2 : (long)a.tiles_m * a.tiles_n;
+  s.tiles_per_mat = (int)tiles_mat;
+  const long tiles = tiles_mat * batch;
+  const int nkt = (int)cdiv(a.K, V3_BK);
+  static const int sk_off = getenv("CLO_GEMM_STREAMK") ? !atoi(getenv("CLO_GEMM_STREAMK")) : 0;
+  long workers = (a.streamk && a.ws && !a.tri && !sk_off) ? v3_streamk_workers(tiles, a.K) : 0;
+  if (workers > 0) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) workers = 0;
+  }
+  const bool sk = workers > 0;
+  if (sk) {
+    s.streamk = 1;
+    s.nkt = nkt;
+    s.workers = (int)workers;
+    s.units = tiles * nkt;
+    s.slots = a.ws;
+    const int rcf = v3_flags(stream, &s.flags, &s.epoch);
+    if (rcf != CLO_OK) return rcf;
+  }
+  *used_streamk = sk;
+  const size_t smem = (size_t)V3_NST * (V3_BM + V3_BN) * V3_BK * sizeof(float);
+  dim3 grid, block(V3_NTHR);
+  if (sk) {
+    a.splitk = 1;
+    grid = dim3((unsigned)s.workers, 1);
+  } else {
+    grid = dim3((unsigned)tiles_mat, (unsigned)(batch * a.splitk));
+  }
+#define CLO_V3(AK, BK_, SKV)                                                                                   \
+  {                                                                                                            \
+    auto kern = gemm_v3_kernel<AK, BK_, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST, SKV>;                            \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      int rc_ = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),          \
+                          "hipFuncSetAttribute");                                                              \
+      if (rc_ != CLO_OK) return rc_;                                                                           \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, a, s);                                                 \
+  }
+#define CLO_V3L(SKV)                                   \
+  if (a_kc && b_kc) CLO_V3(true, true, SKV)            \
+  else if (a_kc) CLO_V3(true, false, SKV)              \
+  else if (b_kc) CLO_V3(false, true, SKV)              \
+  else CLO_V3(false, false, SKV)
+  if (sk) { CLO_V3L(true) } else { CLO_V3L(false) }
+#undef CLO_V3L
+#undef CLO_V3
+  CLO_CHECK_LAUNCH("gemm_v3_kernel");
+  return CLO_OK;
+}
+
+}  // namespace clo

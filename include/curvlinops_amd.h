@@ -59,6 +59,9 @@ int clo_prof_collect(double *ms, long *count, double *alg_bytes);
  * an operand may be 1 (both layouts are loaded coalesced); arbitrary strides work
  * (slow path).  splitk > 1 splits K over grid.z: `ws` must then hold
  * batch*splitk*M*N floats and is reduced deterministically by a second kernel.
+ * splitk == -1 asks for the stream-K schedule of the LDS-DMA engine (gemm_v3.hip: the (tile, k tile) units of
+ * the whole problem in equal contiguous ranges, one per CU; split tiles are finished inside the kernel in a fixed
+ * order): `ws` must then hold clo_gemm_streamk_ws_floats() floats.  Operands the engine cannot take run unsplit.
  * Replaces torch.einsum / @ in kronecker.py:141-171, eigh.py:84-105 and the
  * Linear-layer GEMMs that torch.func.jvp/vjp issue for ggn.py:61-71.
  * ------------------------------------------------------------------------- */
@@ -68,8 +71,10 @@ int clo_gemm_f32(int M, int N, int K, float alpha,
                  float beta, float *C, long ldc, long sc_b,
                  int batch, int splitk, float *ws, void *stream);
 
-/* Suggested split-K factor for a (M,N,K,batch) problem (1 = none). */
+/* Suggested split-K factor for a (M,N,K,batch) problem (1 = none, -1 = stream-K, see clo_gemm_f32). */
 int clo_gemm_suggest_splitk(int M, int N, int K, int batch);
+/* Workspace (floats) of the stream-K schedule: one 128 x 128 partial accumulator and one flag per CU. */
+long clo_gemm_streamk_ws_floats(void);
 /* The same for the symmetric product of clo_syrk_accum_f32 / clo_im2col_syrk_accum_f32 (upper-triangular
  * tiles only: about twice the split of the full d x d product fills the chip). */
 int clo_syrk_suggest_splitk(int d, long rows);

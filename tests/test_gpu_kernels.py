@@ -75,6 +75,49 @@ def test_gemm_batched_and_broadcast(hip):
     assert rel_err(out.cpu(), A @ B3) < TOL
 
 
+# LDS-DMA engine (csrc/gemm_v3.hip; 128 x 128 x 32 tiles): one tile per workgroup, split-K slabs, stream-K (-1), with
+# ragged M / N / K, every operand layout, batches, alpha / beta
+@pytest.mark.parametrize("M,N,K", [(512, 2304, 1152), (516, 1156, 1000), (132, 128, 4096), (2048, 2048, 68),
+                                    (640, 640, 36), (300, 3000, 260), (4608, 512, 772)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("splitk", [None, 1, 3, -1])
+def test_gemm_lds_dma_engine(hip, M, N, K, ta, tb, splitk):
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 7 * K)
+    A = torch.rand((K, M) if ta else (M, K), generator=g, device="cuda") - 0.5
+    B = torch.rand((N, K) if tb else (K, N), generator=g, device="cuda") - 0.5
+    C0 = torch.rand(M, N, generator=g, device="cuda")
+    Av, Bv = (A.T if ta else A), (B.T if tb else B)
+    for alpha, beta in ((1.0, 0.0), (-0.5, 0.75)):
+        out = C0.clone()
+        hip.gemm(Av, Bv, out=out, alpha=alpha, beta=beta, splitk=splitk)
+        ref = alpha * (Av.double() @ Bv.double()) + beta * C0.double()
+        assert rel_err(out.cpu(), ref.cpu()) < TOL
+
+
+def test_gemm_stream_k_batched_and_repeatable(hip):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.rand(3, 384, 520, generator=g, device="cuda") - 0.5
+    B = torch.rand(3, 520, 640, generator=g, device="cuda") - 0.5
+    out = hip.gemm(A, B, splitk=-1)
+    assert rel_err(out.cpu(), (A.double() @ B.double()).cpu()) < TOL
+    # the partial accumulators of a tile are added in a fixed order: bitwise the same result every time
+    A2 = torch.rand(512, 2304, generator=g, device="cuda") - 0.5
+    B2 = torch.rand(2304, 1152, generator=g, device="cuda") - 0.5
+    r0 = hip.gemm(A2, B2, splitk=-1)
+    assert all(torch.equal(r0, hip.gemm(A2, B2, splitk=-1)) for _ in range(10))
+    # two streams at once: each has its own flags
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            outs.append(hip.gemm(A2, B2, splitk=-1))
+        with torch.cuda.stream(s2):
+            outs.append(hip.gemm(A2, B2, splitk=-1))
+    torch.cuda.synchronize()
+    assert all(torch.equal(r0, o) for o in outs)
+
+
 def test_gemm_unaligned_views(hip):
     g = torch.Generator().manual_seed(2)
     big = torch.rand(301, 203, generator=g, dtype=torch.float64) - 0.5
