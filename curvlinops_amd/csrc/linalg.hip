@@ -210,6 +210,182 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
   CLO_TICK(7)
 }
 
+// ---- 65 ... 128 rows: the same factorisation + triangular inverse by FOUR waves of one workgroup -------------------
+// Replaces, for every 128-row node of the recursion, two leaf launches and the four tiny products between them (each a
+// latency chain of its own: 2 x 23 + 4 x 8 us measured at n = 4608) by one launch.  The chain of 16 x 16 diagonal blocks
+// stays sequential on wave 0 (registers, as above); the panel, the trailing update and the columns of the inverse are
+// spread over the waves.  LDS: S (becomes L) and X = L^-1, 128 x 132 floats each; X^T is not kept -- the one product
+// that wants it reads X by columns (four ds_read_b32 instead of one b128).
+constexpr int QNB = 128, QLD = QNB + 4, QW = 4, QBLK = QNB / PSB;
+constexpr int QSMEM = (2 * QNB * QLD + QW * PSB * TLD) * (int)sizeof(float);
+
+__global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain, long ldin, float *A, long lda, int nb,
+                                                                float *__restrict__ Linv, long ldinv,
+                                                                int *__restrict__ status, int pivot_base,
+                                                                long batch_stride) {
+  Ain += blockIdx.x * batch_stride;
+  A += blockIdx.x * batch_stride;
+  Linv += blockIdx.x * batch_stride;
+  status += blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float qsm[];
+  float *S = qsm, *X = qsm + QNB * QLD, *TTall = X + QNB * QLD;
+  __shared__ int bad_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = lane & 15, s4 = (lane >> 4) * 4;
+  float *TT = TTall + wave * (PSB * TLD);
+  if (tid == 0) bad_sh = 0;
+  // load: thread t owns column t & 127 of half the rows; rows / columns beyond nb: identity
+  {
+    const int col = tid & (QNB - 1), r0 = (tid >> 7) * (QNB / 2);
+    const int cl = min(col, nb - 1);
+    float v[QNB / 2];
+#pragma unroll
+    for (int r = 0; r < QNB / 2; ++r) v[r] = Ain[(long)min(r0 + r, nb - 1) * ldin + cl];
+#pragma unroll
+    for (int r = 0; r < QNB / 2; ++r) {
+      const int row = r0 + r;
+      S[row * QLD + col] = (row < nb && col < nb) ? v[r] : ((row == col) ? 1.f : 0.f);
+      X[row * QLD + col] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  auto frag = [&](const float *M, int r0, int c0) {
+    return *reinterpret_cast<const float4 *>(M + (r0 + idx) * QLD + c0 + s4);
+  };
+  // the fragment of M^T: (M^T)[c0 + idx][r0 + s4 ..+3] = M[r0 + s4 + q][c0 + idx]
+  auto frag_t = [&](const float *M, int ld, int r0, int c0) {
+    const float *q = M + (r0 + s4) * ld + c0 + idx;
+    return make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]);
+  };
+  auto store = [&](float *M, int ld, int r0, int c0, const lf32x4 d, float scale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[(r0 + s4 + r) * ld + c0 + idx] = scale * d[r];
+  };
+
+#pragma unroll 1
+  for (int kb = 0; kb < QBLK; ++kb) {
+    const int o = kb * PSB;
+    if (wave == 0) {  // ---- diagonal block in registers (every group of 16 lanes runs the same rows)
+      float s[PSB], x[PSB];
+      const float *src = S + (o + idx) * QLD + o;
+#pragma unroll
+      for (int q = 0; q < PSB / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
+        s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
+      }
+      float my_inv = 1.f;
+      int bad = 0;
+#pragma unroll
+      for (int k = 0; k < PSB; ++k) {
+        const float d = read_lane(s[k], k);
+        bad = (bad == 0 && !(d > 0.f)) ? k + 1 : bad;
+        const float inv = __builtin_amdgcn_rsqf(d);
+        const float l = (idx == k) ? d * inv : s[k] * inv;
+        if (idx == k) my_inv = inv;
+        s[k] = l;
+#pragma unroll
+        for (int j = k + 1; j < PSB; ++j) s[j] = fmaf(-l, read_lane(l, j), s[j]);
+      }
+      if (bad && lane == 0) {
+        *status = pivot_base + o + bad;
+        bad_sh = 1;
+      }
+#pragma unroll
+      for (int r = 0; r < PSB; ++r) x[r] = (r == idx) ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < PSB; ++i) {
+        const float xi = x[i] * read_lane(my_inv, i);
+        x[i] = xi;  // X[i][idx]
+#pragma unroll
+        for (int r = i + 1; r < PSB; ++r) x[r] = fmaf(-read_lane(s[i], r), xi, x[r]);
+      }
+      if (lane < PSB) {
+        float *dst = S + (o + idx) * QLD + o;
+#pragma unroll
+        for (int j = 0; j < PSB; ++j) {
+          dst[j] = (j <= idx) ? s[j] : 0.f;
+          X[(o + j) * QLD + o + idx] = x[j];
+        }
+      }
+    }
+    __syncthreads();
+    if (bad_sh) return;  // uniform: a non-positive pivot ends the factorisation (the caller reads *status)
+    // ---- panel: L_ik = S_ik X_kk^T, block rows spread over the waves
+    {
+      const float4 b = frag(X, o, o);
+      for (int ib = kb + 1 + wave; ib < QBLK; ib += QW) {
+        const float4 a = frag(S, ib * PSB, o);
+        const lf32x4 d = mm16(a, b, lf32x4{0.f, 0.f, 0.f, 0.f});
+        store(S, QLD, ib * PSB, o, d, 1.f);
+      }
+    }
+    __syncthreads();
+    // ---- trailing update: S_ij -= L_ik L_jk^T (lower blocks), pairs spread over the waves
+    {
+      int pair = 0;
+      for (int ib = kb + 1; ib < QBLK; ++ib)
+        for (int jb = kb + 1; jb <= ib; ++jb, ++pair) {
+          if (pair % QW != wave) continue;
+          const lf32x4 d = mm16(frag(S, ib * PSB, o), frag(S, jb * PSB, o), lf32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[(ib * PSB + s4 + r) * QLD + jb * PSB + idx] -= d[r];
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- off-diagonal blocks of X = L^-1: X_ij = -X_ii sum_{j <= k < i} L_ik X_kj.  The block columns are independent
+  // chains: wave w takes columns w, w + 4 (the long chains are paired with the short ones).
+#pragma unroll 1
+  for (int c = 0; c < 2; ++c) {
+    const int jb = c == 0 ? wave : QBLK - 2 - wave;   // 0..3, then 6..3 (column 3 once)
+    if (c == 1 && jb <= QW - 1) continue;
+    if (jb > QBLK - 2) continue;
+#pragma unroll 1
+    for (int ib = jb + 1; ib < QBLK; ++ib) {
+      lf32x4 t{0.f, 0.f, 0.f, 0.f};
+      for (int k = jb; k < ib; ++k)  // (L_ik X_kj)[i][n] = sum_kk L_ik[i][kk] X_kj[kk][n]
+        t = mm16(frag(S, ib * PSB, k * PSB), frag_t(X, QLD, k * PSB, jb * PSB), t);
+      store(TT, TLD, 0, 0, t, 1.f);   // t as it is: TT[i][n]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes before its reads (other lanes' data)
+      // d = X_ii t: P = X_ii rows, Q rows = t^T rows = columns of TT
+      const lf32x4 d = mm16(frag(X, ib * PSB, ib * PSB), frag_t(TT, TLD, 0, 0), lf32x4{0.f, 0.f, 0.f, 0.f});
+      store(X, QLD, ib * PSB, jb * PSB, d, -1.f);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+
+  // coalesced stores (thread = column of half the rows): L lower triangle, L^-1 with its zeros
+  {
+    const int col = tid & (QNB - 1), r0 = (tid >> 7) * (QNB / 2);
+    if (col < nb) {
+      for (int r = r0; r < min(r0 + QNB / 2, nb); ++r) {
+        const float lv = S[r * QLD + col], xv = X[r * QLD + col];
+        Linv[(long)r * ldinv + col] = xv;
+        if (col <= r) A[(long)r * lda + col] = lv;
+      }
+    }
+  }
+}
+
+static int potrf_node128_launch(const float *Ain, long ldin, float *A, long lda, int nb, float *Linv, long ldinv,
+                                int *status, int pivot_base, long batch_stride, int batch, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_node128_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, QSMEM),
+                       "hipFuncSetAttribute(potrf_node128_kernel)");
+    if (rc != CLO_OK) return rc;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(potrf_node128_kernel, dim3(batch), dim3(QW * 64), QSMEM, st, Ain, ldin, A, lda, nb, Linv, ldinv,
+                     status, pivot_base, batch_stride);
+  CLO_CHECK_LAUNCH("potrf_node128_kernel");
+  return CLO_OK;
+}
+
 // S = (A + damping * I) (+) I ; L = 0 ; Li = 0.  The working matrices are np x np with
 // np = n rounded up to a multiple of 4 (identity on the padding): joint weight + bias factors have
 // odd sizes (577, 1153, 2305, 4609), and only float4-complete rows run on the aligned GEMM engine
@@ -284,6 +460,12 @@ static int chol_rec(const CholCtx &c, int o, int m) {
                        c.L + o * n + o, n, m, c.Li + o * n + o, n, c.status, o, c.stride);
     CLO_CHECK_LAUNCH("potrf_diag_kernel");
     return CLO_OK;
+  }
+  static const int node128 = getenv("CLO_CHOL_NODE128") ? atoi(getenv("CLO_CHOL_NODE128")) : 1;
+  if (m <= QNB && node128) {
+    int rcq = potrf_node128_launch(c.S + o * n + o, n, c.L + o * n + o, n, m, c.Li + o * n + o, n, c.status, o,
+                                   c.stride, c.batch, c.st);
+    return rcq;
   }
   const int m1 = ((m / 2 + PNB - 1) / PNB) * PNB, m2 = m - m1;
   const int a = o, b = o + m1;
@@ -407,8 +589,10 @@ extern "C" int clo_cholesky_inverse_f32(const float *A, long lda, float *out, lo
 
 extern "C" int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int *status,
                                   int pivot_base, void *stream) {
-  CLO_REQUIRE(nb >= 1 && nb <= PNB, "clo_potrf_diag_f32: nb must be in [1, %d], got %d", PNB, nb);
+  CLO_REQUIRE(nb >= 1 && nb <= QNB, "clo_potrf_diag_f32: nb must be in [1, %d], got %d", QNB, nb);
   CLO_REQUIRE(A && Linv && status && lda >= nb && ldinv >= nb, "clo_potrf_diag_f32: bad operand");
+  if (nb > PNB)  // 65 ... 128 rows: the four-wave kernel
+    return potrf_node128_launch(A, lda, A, lda, nb, Linv, ldinv, status, pivot_base, 0L, 1, (hipStream_t)stream);
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, lda, A, lda,
                      nb, Linv, ldinv, status, pivot_base, 0L);
   CLO_CHECK_LAUNCH("potrf_diag_kernel");

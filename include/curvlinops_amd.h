@@ -131,8 +131,8 @@ int clo_gram_tall_f32(float *C, long ldc, const float *X, long rows, int d, long
 /* ------------------------------------------------------------------------- *
  * Damped Cholesky inverse of a Kronecker factor (kronecker.py:328-373): the blocked algorithm
  * (panel solve, trailing update, triangular inverse, L^-T L^-1) runs on clo_gemm_f32; this entry
- * point factors ONE nb x nb (nb <= 64) diagonal block in place (lower) and writes the inverse of
- * its triangular factor to Linv.  *status (device int, caller-zeroed) receives pivot_base + k + 1
+ * point factors ONE nb x nb (nb <= 128; up to 64: one wave, 65 ... 128: four waves of one workgroup) diagonal
+ * block in place (lower) and writes the inverse of its triangular factor to Linv.  *status (device int, caller-zeroed) receives pivot_base + k + 1
  * if pivot k is not positive.  Driver: curvlinops_amd/_hip.py:cholesky_inverse.
  * ------------------------------------------------------------------------- */
 int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int *status,
@@ -140,7 +140,7 @@ int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long ldinv, int 
 /* Whole inverse in one call: out = (A + damping I)^-1 by the recursive blocked algorithm
  *   L11,L11^-1 = rec(A11); L21 = A21 L11^-T; S22 -= L21 L21^T; L22,L22^-1 = rec(S22);
  *   (L^-1)21 = -L22^-1 (L21 L11^-1);   A^-1 = L^-T L^-1
- * (leaves <= 64 in LDS, everything else GEMM/SYRK on the MFMA pipe).  A is not modified.
+ * (nodes of <= 128 rows in LDS, everything else GEMM/SYRK on the MFMA pipe).  A is not modified.
  * ws: clo_cholesky_inverse_ws_floats(n) floats; *status (device int) = 0 or the failing pivot. */
 int clo_cholesky_inverse_f32(const float *A, long lda, float *out, long ldo, int n, float damping,
                              float *ws, int *status, void *stream);

@@ -580,7 +580,41 @@ def test_ggn_matmat_unsupported_shapes_report(hip):
 
 
 # ------------------------------------------------------------------------ Cholesky inverse
-@pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 401, 1000])
+@pytest.mark.parametrize("nb", [1, 7, 16, 33, 64, 65, 80, 100, 127, 128])
+def test_potrf_diag_block(hip, nb):
+    """One diagonal block of the blocked inverse through the C ABI (clo_potrf_diag_f32): lower Cholesky factor in place
+    and the inverse of the triangular factor; up to 64 rows one wave, 65 ... 128 the four-wave kernel."""
+    import ctypes
+
+    lib = hip.load()
+    g = torch.Generator().manual_seed(nb)
+    B = torch.rand(nb, nb + 3, generator=g, dtype=torch.float64) - 0.5
+    A64 = B @ B.T / (nb + 3) + 0.05 * torch.eye(nb, dtype=torch.float64)
+    lda = nb + 5   # a view with a leading dimension of its own
+    buf = torch.full((nb, lda), 7.0, device="cuda")
+    buf[:, :nb] = A64.float().cuda()
+    Li = torch.full((nb, nb), 3.0, device="cuda")
+    status = torch.zeros(1, device="cuda", dtype=torch.int32)
+    rc = lib.clo_potrf_diag_f32(ctypes.c_void_p(buf.data_ptr()), lda, nb, ctypes.c_void_p(Li.data_ptr()), nb,
+                                ctypes.c_void_p(status.data_ptr()), 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and int(status.item()) == 0
+    L = torch.linalg.cholesky(A64)
+    got_L = torch.tril(buf[:, :nb]).double().cpu()
+    assert rel_err(got_L, L) < 1e-5
+    assert torch.equal(buf[:, nb:].cpu(), torch.full((nb, lda - nb), 7.0))          # nothing outside the block
+    assert rel_err(Li.double().cpu(), torch.linalg.inv(L)) < 2e-4
+    assert torch.equal(torch.triu(Li, 1).cpu(), torch.zeros(nb, nb))                 # exact zeros above the diagonal
+    # a non-positive pivot is reported with its 1-based index
+    bad = A64.clone().float().cuda().contiguous()
+    k = nb // 2
+    bad[k, k] = -1.0
+    status.zero_()
+    rc = lib.clo_potrf_diag_f32(ctypes.c_void_p(bad.data_ptr()), nb, nb, ctypes.c_void_p(Li.data_ptr()), nb,
+                                ctypes.c_void_p(status.data_ptr()), 100, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and int(status.item()) == 100 + k + 1
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 100, 128, 130, 192, 401, 1000])
 def test_cholesky_inverse(hip, n):
     g = torch.Generator().manual_seed(n)
     B = torch.rand(n, n + 3, generator=g, dtype=torch.float64) - 0.5
