@@ -119,6 +119,8 @@ struct V3Op {
   }
 };
 
+static_assert(alignof(V3Sched) == 8 && alignof(GemmArgs) == 8, "kernel-argument layout: V3Sched follows GemmArgs at the next multiple of 8");
+
 struct V3Tile {
   int bm, bn, m0, n0, batch, split, kb, ke, nk;
 };
@@ -359,10 +361,18 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
     if (c_kt + 1 == c_kend) {
       const bool tile_done = c_kend == ct.nk;   // the segment contains the last k tile of the output tile
       const bool whole_from_start = seg_kt0 == 0;
+      // What follows runs once per output tile and needs a dozen parameters (epilogue, slots, flags): they are re-read
+      // from the kernel-argument segment here (through a pointer the compiler cannot see through) instead of living in
+      // scalar registers across the k loop (60 scalar spills to VGPR lanes in the stream-K variant before, 6-8 now).
+      const __attribute__((address_space(4))) char *ka =
+          (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      const auto *pf = reinterpret_cast<const __attribute__((address_space(4))) GemmArgs *>(ka);
+      const auto *sf = reinterpret_cast<const __attribute__((address_space(4))) V3Sched *>(ka + ((sizeof(GemmArgs) + 7) & ~7ul));
       if (SK && !tile_done) {
         // partial accumulator -> slot of this workgroup, then the flag (the data is complete in memory first)
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            s.slots + (long)w * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
+            sf->slots + (long)w * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -376,23 +386,23 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
             }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid == 0)
-          __hip_atomic_store(s.flags + (long)w * V3_FLAG_STRIDE, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sf->flags + (long)w * V3_FLAG_STRIDE, sf->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         if (SK && !whole_from_start) {
           // the workgroups before this one hold the first part of the tile's k range
-          const long tstart = c_lin * s.nkt;
+          const long tstart = c_lin * sf->nkt;
           for (int w2 = w - 1; w2 >= 0; --w2) {
-            if ((long)(w2 + 1) * s.units / s.workers <= tstart) break;
+            if ((long)(w2 + 1) * sf->units / sf->workers <= tstart) break;
             if (tid == 0) {
               unsigned spins = 0;
-              while (__hip_atomic_load(s.flags + (long)w2 * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
+              while (__hip_atomic_load(sf->flags + (long)w2 * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sf->epoch) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > V3_SPIN) __builtin_trap();   // fail loudly rather than add garbage
               }
             }
             asm volatile("s_barrier" ::: "memory");
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                s.slots + (long)w2 * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
+                sf->slots + (long)w2 * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -408,13 +418,13 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
           }
         }
         // ---- epilogue of the finished tile
-        const bool to_ws = !SK && p.splitk > 1;
+        const bool to_ws = !SK && pf->splitk > 1;
         const int z = blockIdx.y;
-        float *C = to_ws ? p.ws + (long)z * p.M * p.N : p.C + (long)ct.batch * p.sc_b;
-        const long ldc = to_ws ? p.N : p.ldc;
-        const float alpha = to_ws ? 1.f : p.alpha;
-        const float beta = to_ws ? 0.f : p.beta;
-        const bool mirror = p.sym && !to_ws && ct.bm != ct.bn;
+        float *C = to_ws ? pf->ws + (long)z * pf->M * pf->N : pf->C + (long)ct.batch * pf->sc_b;
+        const long ldc = to_ws ? pf->N : pf->ldc;
+        const float alpha = to_ws ? 1.f : pf->alpha;
+        const float beta = to_ws ? 0.f : pf->beta;
+        const bool mirror = pf->sym && !to_ws && ct.bm != ct.bn;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -423,10 +433,11 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = ct.m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              if (row < p.M && col < p.N) {
+              if (row < pf->M && col < pf->N) {
                 float *c = C + (long)row * ldc + col;
-                if (!to_ws && p.epi != EPI_NONE) {
-                  store_final(p, c, row, col, acc[mt][nt][r], alpha, beta);
+                if (!to_ws && pf->epi != EPI_NONE) {
+                  const GemmArgs pl = *(const GemmArgs *)ka;   // (fused epilogues: the whole block, generic loads; rare path)
+                  store_final(pl, c, row, col, acc[mt][nt][r], alpha, beta);
                   continue;
                 }
                 float v = alpha * acc[mt][nt][r];
@@ -550,6 +561,11 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
   }
   *used_streamk = sk;
   const size_t smem = (size_t)V3_NST * (V3_BM + V3_BN) * V3_BK * sizeof(float);
+  int dev_ = 0;
+  {
+    const int rcd = check_hip(hipGetDevice(&dev_), "hipGetDevice");
+    if (rcd != CLO_OK) return rcd;
+  }
   dim3 grid, block(V3_NTHR);
   if (sk) {
     a.splitk = 1;
@@ -560,7 +576,8 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
 #define CLO_V3(AK, BK_, SKV)                                                                                   \
   {                                                                                                            \
     auto kern = gemm_v3_kernel<AK, BK_, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST, SKV>;                            \
-    static bool attr_set = false;                                                                              \
+    static bool attr_done[64] = {};  /* per device: the attribute belongs to the device's copy of the kernel */ \
+    bool &attr_set = attr_done[dev_ & 63];                                                                     \
     if (!attr_set) {                                                                                           \
       int rc_ = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),          \

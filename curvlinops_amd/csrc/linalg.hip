@@ -372,7 +372,11 @@ __global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain
 
 static int potrf_node128_launch(const float *Ain, long ldin, float *A, long lda, int nb, float *Linv, long ldinv,
                                 int *status, int pivot_base, long batch_stride, int batch, hipStream_t st) {
-  static bool attr_set = false;
+  static bool attr_done[64] = {};  // per device
+  int dev = 0;
+  int rcd = check_hip(hipGetDevice(&dev), "hipGetDevice");
+  if (rcd != CLO_OK) return rcd;
+  bool &attr_set = attr_done[dev & 63];
   if (!attr_set) {
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_node128_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, QSMEM),
