@@ -334,7 +334,8 @@ def test_encoder_fp32_native_against_fp64_torch_path_gpu():
     """BASELINE C5's model at full size (12 layers, d = 768, 85 M parameters; 4 sequences of 32 tokens, weight
     sharing over the sequence): KFAC / EKFAC of the Linear layers, float32 native path against the float64 torch
     path on the same device.  Products 1e-4; the damped inverses see factors of rank 128 in 769 / 3073 dimensions
-    (condition number ~1e4 after damping), hence 5e-3 there."""
+    (condition number ~1e4 after damping): 1e-3 for the EKFAC inverse (eigenbasis route, measured 3.6e-4), 5e-3 for the
+    KFAC inverse (fp32 Cholesky of the damped factors, measured 1.9e-3 -- kappa x eps of the factorisation itself)."""
     import copy
 
     dev = torch.device("cuda:0")
@@ -350,4 +351,4 @@ def test_encoder_fp32_native_against_fp64_torch_path_gpu():
         v = torch.rand(K32.shape[1], 2, device=dev) - 0.5
         assert rel_err(K32 @ v, (K64 @ v.double()).cpu().numpy()) < 1e-4
         got, ref = K32.inverse(damping=1e-2) @ v, K64.inverse(damping=1e-2) @ v.double()
-        assert rel_err(got, ref.cpu().numpy()) < 5e-3, cls.__name__
+        assert rel_err(got, ref.cpu().numpy()) < (1e-3 if cls is C.EKFACLinearOperator else 5e-3), cls.__name__
