@@ -272,14 +272,14 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
   auto prod_advance = [&]() {
     ++issued;
     ++p_kt;
-    if (p_kt == p_kend && issued < n_units) {  // (stream-K only) on to the tile before this one
+    if (__builtin_expect(p_kt == p_kend && issued < n_units, 0)) {  // (stream-K only) on to the tile before this one
       --p_lin;
       p_kt = (int)max(u0 - p_lin * s.nkt, 0L);
       p_kend = s.nkt;
       V3Tile t;
       v3_tile<BMt, BNt>(p, p_lin, 0, true, s.tiles_per_mat, t);
       prod_setup(t);
-    } else if (p.A2 && p_kb + p_kt * V3_BK == K1) {
+    } else if (__builtin_expect(p.A2 && p_kb + p_kt * V3_BK == K1, 0)) {
       prod_seek();
     } else {
       pa += stepA;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
     st = st_next;
 
     // ---- end of a segment (last k tile of the output tile, or of this workgroup's range)?
-    if (c_kt + 1 == c_kend) {
+    if (__builtin_expect(c_kt + 1 == c_kend, 0)) {   // cold: laid out behind the loop
       const bool tile_done = c_kend == ct.nk;   // the segment contains the last k tile of the output tile
       const bool whole_from_start = seg_kt0 == 0;
       // What follows runs once per output tile and needs a dozen parameters (epilogue, slots, flags): they are re-read
