@@ -53,7 +53,7 @@ struct GemmArgs {
   int patch;
   // stream-K request (LDS-DMA engine): ws holds gemm_streamk_ws_floats() floats (besides whatever splitk needs); the
   // engine decides whether the schedule pays (then no split-K reduction runs)
-  int streamk;
+  int streamk;   // 0: no; 1: ws >= gemm_streamk_ws_floats_square(); 2: ws >= gemm_streamk_ws_floats()
   int cvC, cvH, cvW, cvKH, cvKW, cvSH, cvSW, cvPH, cvPW, cvDH, cvDW, cvOH, cvOW;
 };
 enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2, EPI_MUL_T = 3 };
@@ -79,8 +79,9 @@ __device__ __forceinline__ void store_final(const GemmArgs &p, float *c, int row
 bool gemm_v2_eligible(const GemmArgs &a, int batch);
 // LDS-DMA engine (gemm_v3.hip): 128 x 128 x 32 tiles, optional stream-K schedule
 bool gemm_v3_eligible(const GemmArgs &a, int batch);
-bool gemm_v3_would_streamk(long tiles, int K);
-long gemm_streamk_ws_floats();
+bool gemm_v3_would_streamk(int M, int N, int K, long batch);
+long gemm_streamk_ws_floats();          // any tile configuration
+long gemm_streamk_ws_floats_square();   // 128 x 128 tiles only
 int launch_gemm_v3(const GemmArgs &a, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk);
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream);
 int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int batch = 1);

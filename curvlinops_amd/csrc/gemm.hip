@@ -1122,7 +1122,7 @@ extern "C" int clo_gemm_suggest_splitk(int M, int N, int K, int batch) {
   const long b = batch > 0 ? batch : 1;
   if (aligned && M > 0 && N > 0) {
     const V2Config cfg = v2_config(M, N, K, b, 0);
-    if (cfg.bm == 128 && cfg.bk == 32 && clo::gemm_v3_would_streamk(cdiv(M, 128) * cdiv(N, 128) * b, K)) return -1;
+    if (cfg.bm == 128 && cfg.bk == 32 && clo::gemm_v3_would_streamk(M, N, K, b)) return -1;
   }
   return suggest_splitk_for(M, N, K, b, aligned);
 }
@@ -1146,7 +1146,7 @@ extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, lo
   if (splitk < 0) {  // stream-K request; an engine that cannot honour it runs unsplit
     CLO_REQUIRE(ws, "clo_gemm_f32: splitk = -1 (stream-K) needs a workspace of clo_gemm_streamk_ws_floats() floats");
     a.splitk = 1;
-    a.streamk = 1;
+    a.streamk = 2;   // the workspace holds the partial tiles of any configuration
   }
   return launch_gemm(a, batch, (hipStream_t)stream);
 }
@@ -1234,7 +1234,7 @@ int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int 
   if (per > 0) s = std::min<long>(s, ws ? ws_floats / per : 1);
   a.splitk = (int)std::max<long>(1, s);
   a.ws = ws;
-  a.streamk = ws && ws_floats >= gemm_streamk_ws_floats();
+  a.streamk = !ws ? 0 : ws_floats >= gemm_streamk_ws_floats() ? 2 : ws_floats >= gemm_streamk_ws_floats_square() ? 1 : 0;
   return launch_gemm(a, batch, st);
 }
 

@@ -44,6 +44,7 @@ struct V3Sched {
   int streamk;        // 0: one tile per workgroup; 1: stream-K
   int nkt;            // stream-K: k tiles per output tile
   int workers;        // stream-K: grid.x
+  int team;           // stream-K: members per team (1: every workgroup has a range of its own)
   long units;         // stream-K: tiles x nkt
   int tiles_per_mat;  // output tiles of one matrix of the batch
   float *slots;       // stream-K: workers x (BM BN) partial accumulators
@@ -198,14 +199,29 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
   int c_kt, c_kend;  // the consumer's segment: next k tile and end (inside the tile's k tile range)
   int n_units;       // units of this workgroup
   long u0 = 0;       // (stream-K) first unit of the range
-  int w = blockIdx.x;  // (stream-K) worker = position of the range; neighbours in range order share operand tiles, so
-                       // they go to the same XCD (workgroup b runs on XCD b % 8)
+  int w = blockIdx.x;  // (stream-K) position of the range; neighbours in range order share operand tiles, so they go to
+                       // the same XCD (workgroup b runs on XCD b % 8)
+  // (stream-K) TEAMS: with G = s.team > 1 the tiles are taken as panels of G row tiles that share their B columns; the
+  // G members of a team own the same (panel, k tile) range, member g on row tile g, and run side by side on one XCD --
+  // the B tiles they stream are the same at the same time (one trip to memory instead of G).  Each member sequence is a
+  // stream-K problem of its own over the panels (its own slots, flags and finishers).
+  int g = 0, G = 1, W = 1;
+  long U = 0;
   if (SK) {
-    const int q = s.workers / kNumXCD, rem = s.workers % kNumXCD;
+    G = s.team;
+    W = s.workers / G;
+    U = s.units / G;
     const int xcd = blockIdx.x % kNumXCD, idx = blockIdx.x / kNumXCD;
-    w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    u0 = (long)w * s.units / s.workers;
-    const long u1 = (long)(w + 1) * s.units / s.workers;
+    if (G > 1) {   // s.workers is a multiple of 8 G
+      const int per_xcd = s.workers / kNumXCD / G;   // teams per XCD
+      w = xcd * per_xcd + idx / G;
+      g = idx % G;
+    } else {
+      const int q = s.workers / kNumXCD, rem = s.workers % kNumXCD;
+      w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    u0 = (long)w * U / W;
+    const long u1 = (long)(w + 1) * U / W;
     c_lin = (u1 - 1) / s.nkt;
     c_kt = (int)(max(u0, c_lin * s.nkt) - c_lin * s.nkt);
     c_kend = (int)(u1 - c_lin * s.nkt);
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
     n_units = 0;  // set from the tile below
   }
   V3Tile ct;
-  v3_tile<BMt, BNt>(p, c_lin, blockIdx.y, SK, s.tiles_per_mat, ct);
+  v3_tile<BMt, BNt>(p, SK ? c_lin * G + g : c_lin, blockIdx.y, SK, s.tiles_per_mat, ct);
   if (!SK) n_units = c_kend = ct.nk;
   int seg_kt0 = c_kt;  // first k tile of the consumer's current segment
 
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
       p_kt = (int)max(u0 - p_lin * s.nkt, 0L);
       p_kend = s.nkt;
       V3Tile t;
-      v3_tile<BMt, BNt>(p, p_lin, 0, true, s.tiles_per_mat, t);
+      v3_tile<BMt, BNt>(p, p_lin * G + g, 0, true, s.tiles_per_mat, t);
       prod_setup(t);
     } else if (__builtin_expect(p.A2 && p_kb + p_kt * V3_BK == K1, 0)) {
       prod_seek();
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
       if (SK && !tile_done) {
         // partial accumulator -> slot of this workgroup, then the flag (the data is complete in memory first)
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            sf->slots + (long)w * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
+            sf->slots + (long)(w * G + g) * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -386,23 +402,23 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
             }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid == 0)
-          __hip_atomic_store(sf->flags + (long)w * V3_FLAG_STRIDE, sf->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sf->flags + (long)(w * G + g) * V3_FLAG_STRIDE, sf->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         if (SK && !whole_from_start) {
           // the workgroups before this one hold the first part of the tile's k range
           const long tstart = c_lin * sf->nkt;
           for (int w2 = w - 1; w2 >= 0; --w2) {
-            if ((long)(w2 + 1) * sf->units / sf->workers <= tstart) break;
+            if ((long)(w2 + 1) * U / W <= tstart) break;
             if (tid == 0) {
               unsigned spins = 0;
-              while (__hip_atomic_load(sf->flags + (long)w2 * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sf->epoch) {
+              while (__hip_atomic_load(sf->flags + (long)(w2 * G + g) * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sf->epoch) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > V3_SPIN) __builtin_trap();   // fail loudly rather than add garbage
               }
             }
             asm volatile("s_barrier" ::: "memory");
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                sf->slots + (long)w2 * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
+                sf->slots + (long)(w2 * G + g) * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -461,7 +477,7 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         --c_lin;
-        v3_tile<BMt, BNt>(p, c_lin, 0, true, s.tiles_per_mat, ct);
+        v3_tile<BMt, BNt>(p, c_lin * G + g, 0, true, s.tiles_per_mat, ct);
         c_kt = seg_kt0 = (int)max(u0 - c_lin * s.nkt, 0L);
         c_kend = s.nkt;
       }
@@ -477,7 +493,9 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-long gemm_streamk_ws_floats() { return (long)kNumCU * V3_BM * V3_BN; }
+// (sized for the largest tile configuration, the tall 256 x 128 one)
+long gemm_streamk_ws_floats() { return (long)kNumCU * 256 * 128; }
+long gemm_streamk_ws_floats_square() { return (long)kNumCU * V3_BM * V3_BN; }
 
 // Flags of the stream-K schedule: one array per (device, stream), zeroed when it is created.  Only the workgroup that
 // owns a flag ever writes it (the launch's epoch, a per-array counter that never repeats); the others poll for that
@@ -519,7 +537,6 @@ static long v3_streamk_workers(long tiles, int K) {
   if (const char *e = getenv("CLO_V3_SK_WORKERS")) workers = std::max<long>(1, std::min<long>(atol(e), std::min<long>(units, kNumCU)));
   return workers;
 }
-bool gemm_v3_would_streamk(long tiles, int K) { return v3_streamk_workers(tiles, K) > 0; }
 
 bool gemm_v3_eligible(const GemmArgs &a, int batch) {
   static const int off = getenv("CLO_GEMM_V3") ? !atoi(getenv("CLO_GEMM_V3")) : 0;
@@ -527,24 +544,71 @@ bool gemm_v3_eligible(const GemmArgs &a, int batch) {
   if (a.A2 && (a.K1 % V3_BK != 0)) return false;
   // 32-bit byte offsets inside one k tile of one output tile
   const long lim = 1L << 29;
-  const long ra = (a.sa_k == 1 ? (long)V3_BM * a.sa_m : (long)V3_BK * a.sa_k + V3_BM);
+  const long ra = (a.sa_k == 1 ? 256L * a.sa_m : (long)V3_BK * a.sa_k + 256);
   const long rb = (a.sb_k == 1 ? (long)V3_BN * a.sb_n : (long)V3_BK * a.sb_k + V3_BN);
   (void)batch;
   return ra < lim && rb < lim;
 }
 
-// Launches the main kernel for `a` (tiles_m / tiles_n / k_per_split / splitk set by launch_gemm for 128 x 128 x 32
-// tiles).  a.streamk != 0 asks for the stream-K schedule with a.ws (>= gemm_streamk_ws_floats()) as its workspace;
-// *used_streamk tells the caller that no split-K reduction is due.
+// Tile configurations: 128 x 128 (8 waves of 64 x 32, four stages) and the TALL 256 x 128 (8 waves of 64 x 64, three
+// stages of 48 KB): half the re-reads of the B operand and 25 % fewer bytes into LDS per flop, for problems with
+// enough rows and enough tiles.
+constexpr int V3T_BM = 256, V3T_BN = 128, V3T_WVM = 4, V3T_WVN = 2, V3T_NST = 3;
+static bool v3_use_tall(const GemmArgs &a, int batch) {
+  static const int mode = getenv("CLO_GEMM_V3_TALL") ? atoi(getenv("CLO_GEMM_V3_TALL")) : 1;  // 0 never, 2 whenever legal
+  if (!mode || a.sym || a.M < V3T_BM) return false;
+  if (mode == 2) return true;
+  const long tall_tiles = cdiv(a.M, V3T_BM) * cdiv(a.N, V3T_BN) * batch;
+  // Measured (MI355X): +2-4 % on large squares (4096^3 NT 130.7 -> 135.4, 8192^3 136.4 -> 139.1 TFLOP/s); with stream-K
+  // the 128 KB partial tiles cost more than the operand traffic saves (512 x 4608 x 4608: 210 -> 220 us), so the tall
+  // tiles are used only where every CU gets at least two of them.
+  return tall_tiles >= 2L * kNumCU;
+}
+
+// Tile configuration and stream-K worker count (0: one tile per workgroup) for a problem; streamk_level as GemmArgs::streamk
+static long v3_plan(const GemmArgs &a, int batch, int streamk_level, bool *tall_out) {
+  bool tall = v3_use_tall(a, batch);
+  long workers = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bm = tall ? V3T_BM : V3_BM, bn = tall ? V3T_BN : V3_BN;
+    const long tm = cdiv(a.M, bm), tn = cdiv(a.N, bn);
+    const long tiles = (a.sym ? tm * (tm + 1) / 2 : tm * tn) * batch;
+    workers = (streamk_level >= 1 && !a.tri && !tall) ? v3_streamk_workers(tiles, a.K) : 0;
+    // the tall tiles without stream-K need enough tiles for every CU; otherwise fall back to the square ones
+    if (tall && workers == 0 && tiles < 2L * kNumCU && pass == 0) { tall = false; continue; }
+    break;
+  }
+  *tall_out = tall;
+  return workers;
+}
+bool gemm_v3_would_streamk(int M, int N, int K, long batch) {
+  GemmArgs a{};
+  a.M = M; a.N = N; a.K = K;
+  bool tall = false;
+  return v3_plan(a, (int)batch, 2, &tall) > 0;
+}
+
+// Launches the main kernel for `a` (k_per_split / splitk set by launch_gemm for 32-deep k tiles; the tile counts are
+// set here for the configuration that runs).  a.streamk != 0 asks for the stream-K schedule with a.ws as its workspace
+// (1: >= gemm_streamk_ws_floats(128 x 128 tiles) floats, 2: enough for the tall tiles too); *used_streamk tells the
+// caller that no split-K reduction is due.
 int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk) {
   GemmArgs a = a0;
   V3Sched s{};
-  const long tiles_mat = a.sym ? (long)a.tiles_m * (a.tiles_m + 1) / 2 : (long)a.tiles_m * a.tiles_n;
-  s.tiles_per_mat = (int)tiles_mat;
-  const long tiles = tiles_mat * batch;
-  const int nkt = (int)cdiv(a.K, V3_BK);
   static const int sk_off = getenv("CLO_GEMM_STREAMK") ? !atoi(getenv("CLO_GEMM_STREAMK")) : 0;
-  long workers = (a.streamk && a.ws && !a.tri && !sk_off) ? v3_streamk_workers(tiles, a.K) : 0;
+  const bool sk_ok = a.streamk && a.ws && !a.tri && !sk_off;
+  bool tall = false;
+  long workers = v3_plan(a, batch, sk_ok ? a.streamk : 0, &tall);
+  const int nkt = (int)cdiv(a.K, V3_BK);
+  {
+    const int bm = tall ? V3T_BM : V3_BM, bn = tall ? V3T_BN : V3_BN;
+    a.tiles_m = (int)cdiv(a.M, bm);
+    a.tiles_n = (int)cdiv(a.N, bn);
+    a.tbm = bm; a.tbn = bn;
+  }
+  const long tiles_mat = a.sym ? (long)a.tiles_m * (a.tiles_m + 1) / 2 : (long)a.tiles_m * a.tiles_n;
+  const long tiles = tiles_mat * batch;
+  s.tiles_per_mat = (int)tiles_mat;
   if (workers > 0) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) workers = 0;
@@ -556,26 +620,33 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
     s.workers = (int)workers;
     s.units = tiles * nkt;
     s.slots = a.ws;
+    // teams of G = tiles_m members when the row tiles are few (each panel = all row tiles of one block column)
+    static const int team_off = getenv("CLO_GEMM_SK_TEAM") ? !atoi(getenv("CLO_GEMM_SK_TEAM")) : 0;
+    s.team = 1;
+    const int G = a.tiles_m;
+    if (!team_off && !a.sym && batch == 1 && (G == 2 || G == 4 || G == 8) && s.workers % (kNumXCD * G) == 0 &&
+        (long)(s.workers / G) * 2 <= (long)a.tiles_n * nkt)
+      s.team = G;
     const int rcf = v3_flags(stream, &s.flags, &s.epoch);
     if (rcf != CLO_OK) return rcf;
   }
   *used_streamk = sk;
-  const size_t smem = (size_t)V3_NST * (V3_BM + V3_BN) * V3_BK * sizeof(float);
   int dev_ = 0;
   {
     const int rcd = check_hip(hipGetDevice(&dev_), "hipGetDevice");
     if (rcd != CLO_OK) return rcd;
   }
-  dim3 grid, block(V3_NTHR);
+  dim3 grid;
   if (sk) {
     a.splitk = 1;
     grid = dim3((unsigned)s.workers, 1);
   } else {
     grid = dim3((unsigned)tiles_mat, (unsigned)(batch * a.splitk));
   }
-#define CLO_V3(AK, BK_, SKV)                                                                                   \
+#define CLO_V3(AK, BK_, SKV, BMV, BNV, WM_, WN_, NSTV)                                                         \
   {                                                                                                            \
-    auto kern = gemm_v3_kernel<AK, BK_, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST, SKV>;                            \
+    auto kern = gemm_v3_kernel<AK, BK_, BMV, BNV, WM_, WN_, NSTV, SKV>;                                        \
+    const size_t smem = (size_t)NSTV * (BMV + BNV) * V3_BK * sizeof(float);                                    \
     static bool attr_done[64] = {};  /* per device: the attribute belongs to the device's copy of the kernel */ \
     bool &attr_set = attr_done[dev_ & 63];                                                                     \
     if (!attr_set) {                                                                                           \
@@ -585,14 +656,20 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
       if (rc_ != CLO_OK) return rc_;                                                                           \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL(kern, grid, block, smem, stream, a, s);                                                 \
+    hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), smem, stream, a, s);                                  \
   }
-#define CLO_V3L(SKV)                                   \
-  if (a_kc && b_kc) CLO_V3(true, true, SKV)            \
-  else if (a_kc) CLO_V3(true, false, SKV)              \
-  else if (b_kc) CLO_V3(false, true, SKV)              \
-  else CLO_V3(false, false, SKV)
-  if (sk) { CLO_V3L(true) } else { CLO_V3L(false) }
+#define CLO_V3L(SKV, BMV, BNV, WM_, WN_, NSTV)                            \
+  if (a_kc && b_kc) CLO_V3(true, true, SKV, BMV, BNV, WM_, WN_, NSTV)     \
+  else if (a_kc) CLO_V3(true, false, SKV, BMV, BNV, WM_, WN_, NSTV)       \
+  else if (b_kc) CLO_V3(false, true, SKV, BMV, BNV, WM_, WN_, NSTV)       \
+  else CLO_V3(false, false, SKV, BMV, BNV, WM_, WN_, NSTV)
+  if (tall) {
+    if (sk) { CLO_V3L(true, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
+    else { CLO_V3L(false, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
+  } else {
+    if (sk) { CLO_V3L(true, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST) }
+    else { CLO_V3L(false, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST) }
+  }
 #undef CLO_V3L
 #undef CLO_V3
   CLO_CHECK_LAUNCH("gemm_v3_kernel");
