@@ -556,7 +556,7 @@ bool gemm_v3_eligible(const GemmArgs &a, int batch) {
 constexpr int V3T_BM = 256, V3T_BN = 128, V3T_WVM = 4, V3T_WVN = 2, V3T_NST = 3;
 static bool v3_use_tall(const GemmArgs &a, int batch) {
   static const int mode = getenv("CLO_GEMM_V3_TALL") ? atoi(getenv("CLO_GEMM_V3_TALL")) : 1;  // 0 never, 2 whenever legal
-  if (!mode || a.sym || a.M < V3T_BM) return false;
+  if (!mode || a.sym || a.M < V3T_BM || a.K < 2048) return false;   // (short k: the longer fill / drain of the tall tile loses, 4608 x 4608 x 512: 226 -> 263 us)
   if (mode == 2) return true;
   const long tall_tiles = cdiv(a.M, V3T_BM) * cdiv(a.N, V3T_BN) * batch;
   // Measured (MI355X): +2-4 % on large squares (4096^3 NT 130.7 -> 135.4, 8192^3 136.4 -> 139.1 TFLOP/s); with stream-K
