@@ -79,7 +79,7 @@ def test_gemm_batched_and_broadcast(hip):
 # ragged M / N / K, every operand layout, batches, alpha / beta
 @pytest.mark.parametrize("M,N,K", [(512, 2304, 1152), (516, 1156, 1000), (132, 128, 4096), (2048, 2048, 68),
                                     (640, 640, 36), (300, 3000, 260), (4608, 512, 772),
-                                    (256, 4608, 1160), (1024, 2304, 580), (4096, 4224, 132)])  # teams of 2 / 8, tall tiles
+                                    (256, 4608, 1160), (1024, 2304, 580), (4096, 4224, 2052)])  # teams of 2 / 8, tall tiles
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("splitk", [None, 1, 3, -1])
 def test_gemm_lds_dma_engine(hip, M, N, K, ta, tb, splitk):
