@@ -503,7 +503,7 @@ def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
     return _eigh_full(A)
 
 
-def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Tensor]]:
+def eigh_many(mats: list[Tensor], num_streams: int | None = None) -> list[tuple[Tensor, Tensor]]:
     """:func:`eigh` of several independent symmetric matrices.  On the GPU the solver (rocSOLVER
     through ``torch.linalg.eigh``) is a long chain of small dependent kernels, so
 
@@ -512,6 +512,8 @@ def eigh_many(mats: list[Tensor], num_streams: int = 4) -> list[tuple[Tensor, Te
       409 -> 258 ms), and
     * the groups are spread, largest first, over a few worker threads that each own a HIP stream
       (the solver synchronises with the host in between)."""
+    if num_streams is None:   # six workers: the three largest factors of a ResNet-18 each get one, three share the rest
+        num_streams = int(os.environ.get("CLO_EIGH_STREAMS", 6))
     out: list = [None] * len(mats)
     for i, A in enumerate(mats):
         if not A.is_cuda:
@@ -546,14 +548,24 @@ def _eigh_many_gpu(mats: list[Tensor], gpu: list[int], out: list, num_streams: i
     for i in gpu:
         groups.setdefault((mats[i].shape[0], mats[i].dtype), []).append(i)
     units: list[list[int]] = []
-    total = sum(float(mats[i].shape[0]) ** 3 for i in gpu)
-    share = total / max(num_streams, 1)  # a group worth more than one worker's share is split
+
+    # Wall-time estimate of one decomposition (ms), fitted to tools/probe_eigh_sizes.py on MI355X (dense full-rank input:
+    # 2.8 / 5.9 / 10.8 / 25.8 / 71.7 / 248 ms at n = 64 / 256 / 576 / 1152 / 2304 / 4608; rank-deficient factors are faster
+    # by a common factor).  n^3 (the flop count) put all four 2304-factors of a ResNet-18 into one unit "worth" half a
+    # 4608-factor, although they take 1.2 x as long.
+    def est(n: int) -> float:
+        return 2.5 + 0.008 * n + 9e-6 * float(n) ** 2
+
+    total = sum(est(mats[i].shape[0]) for i in gpu)
+    largest = max(est(mats[i].shape[0]) for i in gpu)
+    target = max(largest, total / max(num_streams, 1))  # no unit longer than the best possible makespan
     for (n, dtype), idx in groups.items():
         per = 8 * max(n, 1) ** 2 * mats[idx[0]].element_size()  # stacked input + vectors + solver workspace
-        parts = max(1, min(len(idx), round(len(idx) * float(n) ** 3 / max(share, 1.0))))
+        fit = max(1, int(target / max(est(n), 1e-9)))           # matrices of this size one worker can take
+        parts = -(-len(idx) // fit)
         chunk = max(1, min((8 << 30) // per, -(-len(idx) // parts)))
         units.extend(idx[k : k + chunk] for k in range(0, len(idx), chunk))
-    units.sort(key=lambda u: -len(u) * mats[u[0]].shape[0] ** 3)
+    units.sort(key=lambda u: -len(u) * est(mats[u[0]].shape[0]))
 
     def run(unit: list[int]) -> None:
         if len(unit) == 1:
