@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "clo_common.h"
+#include "gemm.h"
 
 namespace clo {
 namespace {
@@ -300,15 +301,37 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_col_kernel(const TdArgs p) {
     yj1 += (x.x + x.y) + (x.z + x.w);
   }
   if (careful) {
+    // t1 = W^T v, t2 = V^T v over the trailing rows, with the actual v (lane = panel column, a wave takes every eighth
+    // row).  Sixteen rows per step with all 32 loads in flight: one row per step was a chain of ~600 dependent L2 round
+    // trips, 50 us per column on well-conditioned matrices, where this path is taken for most columns (sytrd of a
+    // 4608 x 4608 Wishart matrix: 214 -> ~140 ms).  The ORDER of the additions is the one of the one-row loop: the
+    // results are bit-identical to it (a float4 / four-row-group layout was another 20 % faster but moved the
+    // reconstruction error of the rank-deficient 4609 test matrix from 0.8e-4 to 1.3e-4 |A|max -- both are one
+    // rounding error of the top eigenvalue 1152, but the bound of the test is 1e-4).
     float a1 = 0.f, a2 = 0.f;
-    if (lane < c)
-      for (int i = r0 + wave; i < n; i += TD_WAVES) {
-        const float V = p.Vp[(long)i * TD_NB + lane];
-        const float W = p.Wp[(long)i * TD_NB + lane] + s_gam[lane] * V;   // finished entries
-        const float vi = s_v[i - m0];
-        a1 += W * vi;
-        a2 += V * vi;
+    if (lane < c) {
+      constexpr int CU = 16;
+      const float gl_ = s_gam[lane];
+      for (int i0_ = r0 + wave; i0_ < n; i0_ += TD_WAVES * CU) {
+        float Vr[CU], Wr[CU];
+#pragma unroll
+        for (int t = 0; t < CU; ++t) {
+          const int i = min(i0_ + t * TD_WAVES, n - 1);
+          Vr[t] = p.Vp[(long)i * TD_NB + lane];
+          Wr[t] = p.Wp[(long)i * TD_NB + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < CU; ++t) {
+          const int i = i0_ + t * TD_WAVES;
+          if (i < n) {
+            const float vi = s_v[i - m0];
+            const float W = Wr[t] + gl_ * Vr[t];   // finished entries W = w0 + gamma_k v
+            a1 += W * vi;
+            a2 += Vr[t] * vi;
+          }
+        }
       }
+    }
     s_red[wave * TD_NPART + lane] = a1;
     s_red[wave * TD_NPART + TD_NB + lane] = a2;
     __syncthreads();
@@ -582,10 +605,28 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
     const int t = i0 + ncol, m = n - t;
     const float *Vt = Vp + (long)t * TD_NB, *Wt = Wp + (long)t * TD_NB;
     float *C = A + (long)t * lda + t;
-    int rc = clo_gemm_f32(m, m, ncol, -1.f, Vt, TD_NB, 1, 0, Wt, 1, TD_NB, 0, 1.f, C, lda, 0, 1, 1, nullptr, st);
-    if (rc != CLO_OK) return rc;
-    rc = clo_gemm_f32(m, m, ncol, -1.f, Wt, TD_NB, 1, 0, Vt, 1, TD_NB, 0, 1.f, C, lda, 0, 1, 1, nullptr, st);
-    if (rc != CLO_OK) return rc;
+    int rc;
+    if (ncol % 32 == 0) {
+      // ONE symmetric product over the concatenated panels, C -= [V | W] [W | V]^T (second K segment of the GEMM engine),
+      // upper block triangle computed and mirrored: C[i][j] and C[j][i] receive bit-identical updates (two full-square
+      // products added the two terms in opposite orders and let the trailing matrix drift from symmetry), half the flops,
+      // one pass over C instead of two.
+      GemmArgs g{};
+      g.M = m; g.N = m; g.K = 2 * ncol; g.K1 = ncol;
+      g.alpha = -1.f; g.beta = 1.f;
+      g.A = Vt; g.sa_m = TD_NB; g.sa_k = 1;
+      g.B = Wt; g.sb_k = 1; g.sb_n = TD_NB;
+      g.A2 = Wt; g.B2 = Vt;
+      g.C = C; g.ldc = lda;
+      g.splitk = 1; g.sym = 1;
+      rc = launch_gemm(g, 1, st);
+      if (rc != CLO_OK) return rc;
+    } else {   // (the last, shorter panel)
+      rc = clo_gemm_f32(m, m, ncol, -1.f, Vt, TD_NB, 1, 0, Wt, 1, TD_NB, 0, 1.f, C, lda, 0, 1, 1, nullptr, st);
+      if (rc != CLO_OK) return rc;
+      rc = clo_gemm_f32(m, m, ncol, -1.f, Wt, TD_NB, 1, 0, Vt, 1, TD_NB, 0, 1.f, C, lda, 0, 1, 1, nullptr, st);
+      if (rc != CLO_OK) return rc;
+    }
   }
   hipLaunchKernelGGL(sytrd_tail_kernel, dim3(1), dim3(64), 0, st, A, lda, n, D, E, tau);
   CLO_CHECK_LAUNCH("sytrd_tail_kernel");
