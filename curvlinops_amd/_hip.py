@@ -124,6 +124,8 @@ _SIGNATURES = {
     "clo_cg_direction_f32": (c_int, [_PF, _PF, c_long, _PF, _PF, c_void_p]),
     "clo_transpose_f32": (c_int, [_PF, _PF, c_long, c_long, c_void_p]),
     "clo_rowscale_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_int, c_float, c_void_p]),
+    "clo_canonical_pack_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_long, c_void_p]),
+    "clo_canonical_unpack_f32": (c_int, [_PF, _PF, _PF, c_long, c_long, c_long, c_void_p]),
     "clo_pack_probes_f32": (c_int, [_PF, c_long, c_long, c_uint64, c_int, c_void_p]),
     "clo_larft_f32": (c_int, [_PF, _PF, _PF, c_int, c_int, c_void_p]),
     "clo_ormtr_ws_floats": (c_long, [c_int, c_int]),
@@ -703,6 +705,27 @@ def transpose(x: Tensor) -> Tensor:
     out = torch.empty(cols, rows, device=x.device, dtype=torch.float32)
     _check(load().clo_transpose_f32(_pc(out), _pc(x), rows, cols, _stream()), "clo_transpose_f32")
     return out
+
+
+def canonical_pack(w: Tensor, bias: Tensor | None, rows: int, cols_w: int) -> Tensor:
+    """K-trailing parameter tangents ``w [rows * cols_w, K]`` (+ ``bias [rows, K]``) -> K-major canonical
+    ``[K, rows * (cols_w + 1)]`` (bias as the last column of every row) in one pass."""
+    K = w.shape[-1]
+    bc = cols_w + (bias is not None)
+    out = torch.empty(K, rows * bc, device=w.device, dtype=torch.float32)
+    _check(load().clo_canonical_pack_f32(_pc(out), _pc(w), _pc(bias) if bias is not None else None, rows, cols_w, K,
+                                         _stream()), "clo_canonical_pack_f32")
+    return out
+
+
+def canonical_unpack(kmajor: Tensor, rows: int, cols_w: int, with_bias: bool) -> tuple[Tensor, Tensor | None]:
+    """Inverse of :func:`canonical_pack`: ``[K, rows * (cols_w + with_bias)]`` -> ``(w [rows * cols_w, K], bias [rows, K])``."""
+    K = kmajor.shape[0]
+    w = torch.empty(rows * cols_w, K, device=kmajor.device, dtype=torch.float32)
+    b = torch.empty(rows, K, device=kmajor.device, dtype=torch.float32) if with_bias else None
+    _check(load().clo_canonical_unpack_f32(_pc(w), _pc(b) if b is not None else None, _pc(kmajor), rows, cols_w, K,
+                                           _stream()), "clo_canonical_unpack_f32")
+    return w, b
 
 
 def rowscale(x: Tensor, s: Tensor, reciprocal: bool = False, shift: float = 0.0) -> Tensor:

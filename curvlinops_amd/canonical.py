@@ -9,10 +9,20 @@ follow the order of the parameter groups, inputs/outputs the order of the parame
 
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Size, Tensor
 
+from curvlinops_amd import _hip
 from curvlinops_amd.linop import PyTorchLinearOperator
+from curvlinops_amd.utils import is_native_tensor
+
+
+def is_kmajor(t: Tensor) -> bool:
+    """``[n, K]`` tensor whose memory is the contiguous ``[K, n]`` array (K > 1): the layout the batched GEMMs of the
+    Kronecker blocks read; the canonical converters and the blocks hand it to each other without transposes."""
+    return t.ndim == 2 and t.shape[1] > 1 and t.shape[0] > 1 and t.stride(0) == 1 and t.stride(1) == t.shape[0]
 
 ParamGroup = dict[str, str]  # role ("W" / "b") -> full parameter name
 
@@ -63,6 +73,14 @@ class ToCanonicalLinearOperator(_CanonicalBase):
             if "W" in g and "b" in g:
                 w = M[self._position[g["W"]]]
                 b = M[self._position[g["b"]]]
+                if (w.shape[-1] > 1 and is_native_tensor(w) and is_native_tensor(b) and w.is_contiguous()
+                        and b.is_contiguous() and not os.environ.get("CLO_NO_KMAJOR")):
+                    # K columns on the GPU: bias column spliced in AND the K-major layout of the block's GEMMs in one
+                    # pass (clo_canonical_pack_f32) instead of cat + transpose
+                    rows, K = w.shape[0], w.shape[-1]
+                    cols = w.numel() // (rows * K)
+                    out.append(_hip.canonical_pack(w, b, rows, cols).T)
+                    continue
                 joint = torch.cat([w.flatten(start_dim=1, end_dim=-2), b.unsqueeze(1)], dim=1)
                 out.append(joint.flatten(end_dim=-2))
             else:
@@ -87,13 +105,22 @@ class FromCanonicalLinearOperator(_CanonicalBase):
                 w_shape = self._param_shapes[g["W"]]
                 rows = w_shape[0]
                 cols = w_shape.numel() // rows
+                if is_kmajor(M[used]) and is_native_tensor(M[used]):   # K-major from the Kronecker block: one pass
+                    w, b = _hip.canonical_unpack(M[used].T, rows, cols, True)
+                    out[self._position[g["W"]]] = w.view(*w_shape, K)
+                    out[self._position[g["b"]]] = b
+                    used += 1
+                    continue
                 joint = M[used].reshape(rows, cols + 1, K)
                 out[self._position[g["W"]]] = joint[:, :cols].reshape(*w_shape, K)
                 out[self._position[g["b"]]] = joint[:, cols].reshape(rows, K)
                 used += 1
             else:
                 for n in g.values():
-                    out[self._position[n]] = M[used].reshape(*self._param_shapes[n], K)
+                    m = M[used]
+                    if is_kmajor(m) and is_native_tensor(m):
+                        m = _hip.canonical_unpack(m.T, m.shape[0], 1, False)[0]
+                    out[self._position[n]] = m.reshape(*self._param_shapes[n], K)
                     used += 1
         if used != len(M) or any(o is None for o in out):
             raise RuntimeError("Mismatch in number of processed parameters.")

@@ -88,6 +88,62 @@ __global__ void transpose_kernel(float *__restrict__ out, const float *__restric
   }
 }
 
+// Canonical pack / unpack of one (W, b) parameter group fused with the [D, K] <-> [K, D] layout change of the
+// Kronecker matvec (reference kfac_utils.py:280-306 `cat` + 338-385 slicing, each followed by a transpose on this
+// engine): the canonical matrix of the group is [rows][bw + 1] with the bias as its LAST column; its K tangents are
+// stored K-trailing in parameter space (w [rows * bw][K], bias [rows][K]) and K-major in canonical space
+// (kmaj [K][rows][bw + 1]), which is what the batched GEMMs of the block read.  One pass: a tile of TR canonical
+// entries x <= 64 columns goes through LDS, both sides coalesced (parameter side along K then along the entries --
+// the tile is one contiguous run of TR K floats except where a bias entry is spliced in --, canonical side along the
+// entries).  bias == nullptr: a plain transpose of w.  PACK: parameter -> canonical; else the reverse.
+constexpr int CP_TR = 128, CP_KC = 64;
+template <bool PACK>
+__global__ __launch_bounds__(256) void canonical_tr_kernel(float *__restrict__ kmaj, float *__restrict__ w,
+                                                           float *__restrict__ bias, long rows, long bw, long K) {
+  __shared__ float tile[CP_KC][CP_TR + 1];
+  const long bc = bias ? bw + 1 : bw, nv = rows * bc;
+  const long tiles_k = cdiv(K, (long)CP_KC), ntiles = cdiv(nv, (long)CP_TR) * tiles_k;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long e0 = (t / tiles_k) * CP_TR, k0 = (t % tiles_k) * CP_KC;
+    const int kc = (int)min((long)CP_KC, K - k0), ne = (int)min((long)CP_TR, nv - e0);
+    // parameter side: idx -> (entry, k), k fastest
+    // (32-bit index arithmetic inside the tile: the 64-bit divisions happen once per tile)
+    const long r0 = e0 / bc;
+    const unsigned c0 = (unsigned)(e0 - r0 * bc), ubc = (unsigned)min(bc, 0x7fffffffL), ukc = (unsigned)kc;
+    auto param_ptr = [&](int idx) -> float * {
+      const unsigned el = (unsigned)idx / ukc, k = (unsigned)idx - el * ukc;
+      if (!bias) return w + (e0 + el) * K + k0 + k;
+      const unsigned cc = c0 + el, dr = cc / ubc, c = cc - dr * ubc;
+      const long r = r0 + dr;
+      return (c < bw ? w + (r * bw + c) * K : bias + r * K) + k0 + k;
+    };
+    if (PACK) {
+      for (int idx = threadIdx.x; idx < ne * kc; idx += 256) {
+        const unsigned el = (unsigned)idx / ukc, k = (unsigned)idx - el * ukc;
+        tile[k][el] = *param_ptr(idx);
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < kc * CP_TR; idx += 256) {
+        const int k = idx / CP_TR, el = idx - k * CP_TR;
+        if (el < ne) tile[k][el] = kmaj[(k0 + k) * nv + e0 + el];
+      }
+    }
+    __syncthreads();
+    if (PACK) {
+      for (int idx = threadIdx.x; idx < kc * CP_TR; idx += 256) {
+        const int k = idx / CP_TR, el = idx - k * CP_TR;
+        if (el < ne) kmaj[(k0 + k) * nv + e0 + el] = tile[k][el];
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < ne * kc; idx += 256) {
+        const unsigned el = (unsigned)idx / ukc, k = (unsigned)idx - el * ukc;
+        *param_ptr(idx) = tile[k][el];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // y[i][k] = f(s[i]) * x[i][k]; f(s) = s, or 1/(s+shift) when reciprocal.
 __global__ void rowscale_kernel(float *__restrict__ y, const float *__restrict__ x,
                                 const float *__restrict__ s, long rows, long K, int reciprocal,
@@ -289,6 +345,30 @@ extern "C" int clo_transpose_f32(float *out, const float *in, long rows, long co
                      dim3(256), 0, (hipStream_t)stream, out, in, rows, cols);
   CLO_CHECK_LAUNCH("transpose_kernel");
   return CLO_OK;
+}
+
+static int canonical_tr(bool pack, float *kmaj, float *w, float *bias, long rows, long bw, long K, void *stream,
+                        const char *what) {
+  if (rows < 0 || bw < 0 || K < 0) { set_error("%s: negative size", what); return CLO_EINVAL; }
+  const long nv = rows * (bias ? bw + 1 : bw);
+  if (nv == 0 || K == 0) return CLO_OK;
+  if (!kmaj || (bw > 0 && !w)) { set_error("%s: null pointer", what); return CLO_EINVAL; }
+  const long ntiles = cdiv(nv, (long)CP_TR) * cdiv(K, (long)CP_KC);
+  const dim3 grid((unsigned)std::min<long>(ntiles, kNumCU * 8L));
+  if (pack) hipLaunchKernelGGL(canonical_tr_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, kmaj, w, bias, rows, bw, K);
+  else hipLaunchKernelGGL(canonical_tr_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, kmaj, w, bias, rows, bw, K);
+  CLO_CHECK_LAUNCH("canonical_tr_kernel");
+  return CLO_OK;
+}
+extern "C" int clo_canonical_pack_f32(float *out_kmajor, const float *w, const float *bias, long rows, long cols_w,
+                                      long K, void *stream) {
+  return canonical_tr(true, out_kmajor, const_cast<float *>(w), const_cast<float *>(bias), rows, cols_w, K, stream,
+                      "clo_canonical_pack_f32");
+}
+extern "C" int clo_canonical_unpack_f32(float *w, float *bias, const float *in_kmajor, long rows, long cols_w, long K,
+                                        void *stream) {
+  return canonical_tr(false, const_cast<float *>(in_kmajor), w, bias, rows, cols_w, K, stream,
+                      "clo_canonical_unpack_f32");
 }
 
 extern "C" int clo_rowscale_f32(float *y, const float *x, const float *s, long rows, long K,

@@ -27,6 +27,7 @@ from curvlinops_amd.linop import (
     _expect_same_shape,
     _expect_same_spaces,
 )
+from curvlinops_amd.canonical import is_kmajor
 from curvlinops_amd.utils import infer_device, infer_dtype, is_native_tensor, split_list
 
 
@@ -41,6 +42,15 @@ def _kron_apply_native(factors: list[Tensor], x: Tensor, transpose: bool) -> Ten
     K = x.shape[-1]
     ins = [S.shape[0] if transpose else S.shape[1] for S in factors]
     mats = [S.T if transpose else S for S in factors]
+    if len(factors) == 2 and is_kmajor(x):
+        # K-major operand (from ToCanonical's fused pack or from another block): no transposes, and the result stays
+        # K-major for the consumer (FromCanonical's fused unpack, the eigenvalue scaling, the next block)
+        S1, S2 = mats
+        a, b = ins
+        A_, B_ = S1.shape[0], S2.shape[0]
+        T = _hip.gemm(x.T.view(K * a, b), S2.T)          # [(K a), B]
+        Y = _hip.gemm(S1, T.view(K, a, B_))              # [K, A, B]
+        return Y.view(K, A_ * B_).T
     xc = x.contiguous()
     if len(factors) == 1:
         return _hip.gemm(mats[0], xc)
@@ -226,6 +236,8 @@ class EighDecomposedLinearOperator(PyTorchLinearOperator):
 
     def _scale(self, x: Tensor) -> Tensor:
         lam = self._eigenvalues
+        if is_kmajor(x):   # keep the K-major layout of the Kronecker basis products
+            return (x.T * lam.unsqueeze(0)).T
         if is_native_tensor(x) and is_native_tensor(lam) and x.is_contiguous():
             return _hip.rowscale(x, lam.contiguous())
         return lam.unsqueeze(1) * x

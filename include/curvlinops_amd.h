@@ -279,6 +279,14 @@ int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *con
 int clo_axpby_f32(float *y, const float *x, long n, float alpha, float beta, void *stream);
 /* out[r][c] = in[c][r]  ([D,K] <-> [K,D] probe-layout conversion) */
 int clo_transpose_f32(float *out, const float *in, long rows, long cols, void *stream);
+/* Canonical pack / unpack of one joint (W, b) parameter group fused with the K-trailing <-> K-major layout change of
+ * the Kronecker matvec (replaces kfac_utils.py:280-306 `cat` and :338-385 slicing plus one transpose each):
+ * parameter side w [rows * cols_w][K], bias [rows][K] (K trailing, the reference's layout); canonical side
+ * [K][rows][cols_w + 1] with the bias as the last column.  bias == NULL: plain [n][K] <-> [K][n]. */
+int clo_canonical_pack_f32(float *out_kmajor, const float *w, const float *bias, long rows, long cols_w, long K,
+                           void *stream);
+int clo_canonical_unpack_f32(float *w, float *bias, const float *in_kmajor, long rows, long cols_w, long K,
+                             void *stream);
 /* y[i] = s[i] * x[i*K + k] for all k (EighDecomposed scaling, eigh.py:103-105) */
 int clo_rowscale_f32(float *y, const float *x, const float *s, long rows, long K, int reciprocal,
                      float shift, void *stream);

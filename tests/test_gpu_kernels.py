@@ -195,6 +195,63 @@ def test_axpby_transpose_rowscale(hip):
     assert torch.allclose(hip.rowscale(x.cuda(), s.cuda(), True, 0.5).cpu(), x / (s[:, None] + 0.5), atol=1e-6)
 
 
+@pytest.mark.parametrize("rows,cols,K", [(1, 1, 2), (10, 513, 3), (64, 577, 8), (512, 4608, 5), (7, 3, 130), (129, 64, 64),
+                                         (33, 100, 65)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_canonical_pack_unpack(hip, rows, cols, K, bias):
+    """clo_canonical_pack_f32 / _unpack_f32 against the reference's formulation (`kfac_utils.py:280-306` cat of the
+    bias as the last column, `:338-385` slicing) followed by the K-major transpose: exact (pure data movement)."""
+    g = torch.Generator().manual_seed(rows * 131 + cols * 7 + K)
+    w = torch.rand(rows * cols, K, generator=g).cuda()
+    b = torch.rand(rows, K, generator=g).cuda() if bias else None
+    joint = w.view(rows, cols, K) if b is None else torch.cat([w.view(rows, cols, K), b.unsqueeze(1)], dim=1)
+    ref = joint.reshape(-1, K).T.contiguous()                # [K, rows * (cols + 1)]
+    got = hip.canonical_pack(w, b, rows, cols)
+    assert torch.equal(got, ref)
+    w2, b2 = hip.canonical_unpack(got, rows, cols, bias)
+    assert torch.equal(w2, w) and (b is None or torch.equal(b2, b))
+
+
+def test_kmajor_layout_travels_through_the_kfac_chain(hip):
+    """K > 1 columns through P K P^T: the canonical converters hand the blocks a K-major operand (fused pack), the
+    blocks answer K-major (no transposes), the result equals the per-column products and the cat / slice route."""
+    import curvlinops_amd as C
+    from curvlinops_amd.canonical import ToCanonicalLinearOperator, is_kmajor
+
+    torch.manual_seed(0)
+    shapes = {"0.weight": torch.Size((12, 5, 3, 3)), "0.bias": torch.Size((12,)), "1.weight": torch.Size((7, 30)),
+              "2.weight": torch.Size((9, 7)), "2.bias": torch.Size((9,))}
+    groups = [{"W": "0.weight", "b": "0.bias"}, {"W": "1.weight"}, {"W": "2.weight", "b": "2.bias"}]
+    PT = ToCanonicalLinearOperator(shapes, groups, torch.device("cuda:0"), torch.float32)
+    P = PT.adjoint()
+    K = 6
+    M = [torch.rand(*s, K).cuda() for s in shapes.values()]
+    canon = PT._matmat(M)
+    assert is_kmajor(canon[0]) and is_kmajor(canon[2]) and not is_kmajor(canon[1])
+    ref = PT._matmat([m.cpu() for m in M])
+    for a, r in zip(canon, ref):
+        assert torch.equal(a.cpu(), r)
+    back = P._matmat(canon)
+    for a, m in zip(back, M):
+        assert a.is_contiguous() and torch.equal(a, m)
+    # blocks: Kronecker and eigendecomposed, K-major in -> K-major out, equal to the K-trailing route
+    blocks = []
+    for (d_out, d_in) in ((12, 46), (7, 30), (9, 8)):
+        S1, S2 = torch.rand(d_out, d_out).cuda(), torch.rand(d_in, d_in).cuda()
+        blocks.append(C.KroneckerProductLinearOperator(S1 + S1.T, S2 + S2.T))
+    blocks[2] = C.EighDecomposedLinearOperator(torch.rand(72).cuda(), blocks[2])
+    B = C.BlockDiagonalLinearOperator(blocks)
+    y_fused = B._matmat(canon)
+    assert is_kmajor(y_fused[0]) and is_kmajor(y_fused[2])
+    y_plain = B._matmat([c.contiguous() for c in canon])
+    for a, r in zip(y_fused, y_plain):
+        assert rel_err(a.cpu().numpy(), r.cpu().numpy()) < 1e-6
+    out = P._matmat(y_fused)
+    out_ref = P._matmat(y_plain)
+    for a, r in zip(out, out_ref):
+        assert a.shape == r.shape and rel_err(a.cpu().numpy(), r.cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("n", [0, 1, 3, 1000, 4097, 1 << 20, (1 << 22) + 5])
 def test_dot_kernel(hip, n):
     g = torch.Generator().manual_seed(n)
