@@ -96,6 +96,13 @@ _SIGNATURES = {
          c_int, c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
     ),
     "clo_mlp_ggn_matmat_ws_floats": (c_long, [c_int, POINTER(c_int), c_int, c_int]),
+    "clo_mlp_hessian_matmat": (
+        c_int,
+        [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
+         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_long, _PF, c_int,
+         c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
+    ),
+    "clo_mlp_hessian_matmat_ws_floats": (c_long, [c_int, POINTER(c_int), c_int, c_int]),
     "clo_mlp_hessian_matvec": (
         c_int,
         [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
@@ -613,6 +620,32 @@ class MLPPlan:
                                        beta, ws_ptr, stream)
         if rc != 0:
             _check(rc, "clo_mlp_ggn_matmat")
+
+    def hessian_matmat_supported(self, K: int, ldk: int) -> bool:
+        """Shape conditions of ``clo_mlp_hessian_matmat``: those of the GGN columns, one contiguous block of K
+        columns, a linear last layer."""
+        return self.matmat_supported(K, ldk) and ldk == K and int(self.acts[self.L - 1]) == 0
+
+    def hessian_matmat_workspace(self, K: int, device) -> Tensor:
+        key = ("hmm", K, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            n = load().clo_mlp_hessian_matmat_ws_floats(self.L, self.dims, 8, K)
+            ws = torch.empty(n, device=device, dtype=torch.float32)
+            self._ws[key] = ws
+        return ws
+
+    def hessian_matmat_ptrs(self, vw_ptrs, vb_ptrs, ow_ptrs, ob_ptrs, K: int, X_ptr: int, N: int, G_ptr: int,
+                            loss_kind: int, loss_scale: float, alpha: float, beta: float, ws_ptr: int,
+                            stream: int) -> None:
+        """``out[.., k] = beta out + alpha H V[.., k]`` (exact Hessian) for K contiguous columns (``ldk == K``)."""
+        VW, Vb, OW, Ob = self._VW_arr, self._Vb_arr, self._OW_arr, self._Ob_arr
+        for l in range(self.L):
+            VW[l], OW[l], Vb[l], Ob[l] = vw_ptrs[l], ow_ptrs[l], vb_ptrs[l], ob_ptrs[l]
+        rc = load().clo_mlp_hessian_matmat(self.L, self.dims, self.acts, self._W_arr, self._b_arr, VW, Vb, OW, Ob,
+                                           K, X_ptr, N, K, G_ptr, loss_kind, loss_scale, alpha, beta, ws_ptr, stream)
+        if rc != 0:
+            _check(rc, "clo_mlp_hessian_matmat")
 
     def _jac_workspace(self, N: int, device) -> Tensor:
         key = ("jac", N, str(device))

@@ -2070,7 +2070,7 @@ __global__ void pack_at_kernel(const float *__restrict__ a, float *__restrict__ 
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void kouter_stream_kernel(
     float *__restrict__ out, long ldk, float *__restrict__ out_b, const float *__restrict__ aT,
-    const float *__restrict__ delta, int N, int K, int d_in, float beta) {
+    const float *__restrict__ delta, int N, int K, int d_in, float beta, float beta_b) {
   const int j = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = K >> 2, IPW = 64 / G;  // input features per wave instruction
@@ -2085,9 +2085,9 @@ __global__ __launch_bounds__(256) void kouter_stream_kernel(
 #pragma unroll
     for (int n = 0; n < NB; ++n) { sb.x += d[n].x; sb.y += d[n].y; sb.z += d[n].z; sb.w += d[n].w; }
     float *ob = out_b + (long)j * ldk + 4 * kq;
-    if (ACCUM) {
+    if (beta_b != 0.f) {   // (its own beta: the Hessian path accumulates the weights onto a product written before)
       const float4 o = ld4(ob);
-      sb.x += beta * o.x; sb.y += beta * o.y; sb.z += beta * o.z; sb.w += beta * o.w;
+      sb.x += beta_b * o.x; sb.y += beta_b * o.y; sb.z += beta_b * o.z; sb.w += beta_b * o.w;
     }
     *reinterpret_cast<float4 *>(ob) = sb;
   }
@@ -3192,10 +3192,49 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   return CLO_OK;
 }
 
+// K-column exact Hessian (clo_mlp_hessian_matmat): the two elementwise pieces next to the GGN pipeline.
+// daP[n][i][k] = dA[i][n][k]: the tangent activations sample-major, the B operand of d_l^T da_{l-1}.
+__global__ void kcols_perm_kernel(const float *__restrict__ dA, float *__restrict__ daP, int N, int K, int d) {
+  const long total = (long)d * N * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K), n = (int)((e / K) % N);
+    const long i = e / ((long)K * N);
+    daP[((long)n * d + i) * K + k] = dA[e];
+  }
+}
+// Rd_{l-1}[i][n][k] = (phi'' dz)[i][n][k] dsig[n][i] + phi'[n][i] (T[i][n][k] + Xv[n][i][k]) in place on dA = da_{l-1};
+// d_{l-1}[n][i] = phi'[n][i] dsig[n][i].   (T = W_l^T Rd_l, Xv = d_l V_l, dsig = d_l W_l)
+__global__ void kcols_hess_combine_kernel(float *__restrict__ dA, const float *__restrict__ T,
+                                          const float *__restrict__ Xv, const float *__restrict__ dsig,
+                                          const float *__restrict__ a, const float *__restrict__ dphi,
+                                          float *__restrict__ d_out, int N, int K, int d, int act) {
+  const long total = (long)d * N * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K), n = (int)((e / K) % N);
+    const long i = e / ((long)K * N), ni = (long)n * d + i;
+    const float g = dsig[ni], ph = dphi[ni];
+    dA[e] = act_second_times_dz(act, a[ni], dA[e]) * g + ph * (T[e] + Xv[ni * K + k]);
+    if (k == 0) d_out[ni] = ph * g;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K columns at once (see the kfwd / kouter kernels above).
 // ------------------------------------------------------------------------------------------
 static long matmat_gemm_ws(int dmax, int K) { return 16L * dmax * NB * K; }
+
+static long matmat_hessian_extra_ws(int L, const int *dims, int K) {
+  int dmax = 0;
+  long total = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  for (int l = 1; l <= L; ++l) total += (long)NB * dims[l];      // d_l
+  return total + (long)NB * dmax + 3L * dmax * NB * K + 64;        // dsig, T, Xv, daP
+}
+extern "C" long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int K);
+extern "C" long clo_mlp_hessian_matmat_ws_floats(int L, const int *dims, int N, int K) {
+  if (L <= 0 || !dims || K <= 0) return 0;
+  return clo_mlp_ggn_matmat_ws_floats(L, dims, N, K) + matmat_hessian_extra_ws(L, dims, K);
+}
 
 extern "C" long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int K) {
   (void)N;
@@ -3214,12 +3253,17 @@ extern "C" long clo_mlp_ggn_matmat_ws_floats(int L, const int *dims, int N, int 
 // element (0, 0, 0) of the [d_out][d_in][K] blocks (column stride 1, row stride ldk floats), Vb[l]
 // / Ob[l] at [d_out][K] blocks with the same ldk.  Requirements (else CLO_EUNSUP): K % 4 == 0,
 // 4 <= K <= 64, ldk % 4 == 0, dims[0..L-1] % 4 == 0, 16-byte aligned operands.
-extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *const *W,
-                                  const float *const *b, const float *const *VW,
-                                  const float *const *Vb, float *const *OW, float *const *Ob,
-                                  long ldk, const float *X, int N, int K, int loss_kind,
-                                  const float *aux, int aux_rank, float loss_scale, float alpha,
-                                  float beta, float *ws, void *stream) {
+// Gh == nullptr: GGN / EF / MC-GGN columns.  Gh [N][C] (gradient of the reduced mini-batch loss w.r.t. the model output):
+// exact Hessian columns by the R-operator (hessian.py:66 under the vmap of _torch_base.py:946-989) -- the same
+// pipeline plus, per layer, the gradient signal d_l (column independent), the product d_l V_l (the tangent weights
+// stream a second time through the GEMM engine, M = 8 rows), the combine of Rd_{l-1} and d_l^T da_{l-1} added to the result
+// (a rank-8 product over the [d_out][d_in K] block, written before the outer-product stream accumulates onto it).
+static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *acts, const float *const *W,
+                           const float *const *b, const float *const *VW,
+                           const float *const *Vb, float *const *OW, float *const *Ob,
+                           long ldk, const float *X, int N, int K, int loss_kind,
+                           const float *aux, int aux_rank, float loss_scale, float alpha,
+                           float beta, float *ws, void *stream, const float *Gh) {
   CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW, "clo_mlp_ggn_matmat: bad layer table");
   CLO_REQUIRE(N >= 0 && X && ws && K >= 1, "clo_mlp_ggn_matmat: bad batch / workspace / K");
   CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_ggn_matmat: unknown loss kind %d", loss_kind);
@@ -3236,8 +3280,12 @@ extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const
   }
   if (loss_kind == CLO_LOSS_RANK1 && aux_rank > LC_RMAX) ok = false;
   if (!ok) {
-    set_error("clo_mlp_ggn_matmat: needs K %% 4 == 0, 4 <= K <= 64, ldk %% 4 == 0, layer inputs %% 4 == 0 "
-              "and 16-byte aligned operands");
+    set_error("%s: needs K %% 4 == 0, 4 <= K <= 64, ldk %% 4 == 0, layer inputs %% 4 == 0 "
+              "and 16-byte aligned operands", what);
+    return CLO_EUNSUP;
+  }
+  if (Gh && (ldk != K || acts[L - 1] != CLO_ACT_IDENTITY || loss_kind == CLO_LOSS_RANK1)) {
+    set_error("%s: needs ldk == K, a linear last layer and an MSE / CE / BCE loss", what);
     return CLO_EUNSUP;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -3279,6 +3327,15 @@ extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const
   p += part_sz;
   float *gws = p;
   const long gws_sz = matmat_gemm_ws(dmax, K);
+  p += gws_sz + 64;
+  float *dH[65] = {nullptr}, *dsig = nullptr, *Tb = nullptr, *Xv = nullptr, *daP = nullptr;
+  if (Gh) {
+    for (int l = 1; l <= L; ++l) { dH[l] = p; p += (long)NB * dims[l]; }
+    dsig = p; p += ((long)NB * dmax + 3) & ~3L;
+    Tb = p; p += (long)dmax * NB * K;
+    Xv = p; p += (long)dmax * NB * K;
+    daP = p; p += (long)dmax * NB * K;
+  }
   const int G = K / 4, FPT = 16 / G;
   const bool last_linear = acts[L - 1] == CLO_ACT_IDENTITY;
 
@@ -3323,29 +3380,83 @@ extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const
                          loss_scale * alpha);
       CLO_CHECK_LAUNCH("loss_cols_kernel");
     }
+    if (Gh) {  // d_L = alpha G (linear last layer)
+      const long nc = (long)nn * dims[L];
+      hipLaunchKernelGGL(scale_copy_kernel, dim3(ew_grid(nc)), dim3(256), 0, st, dH[L], Gh + (long)n0 * dims[L], nc, alpha);
+      CLO_CHECK_LAUNCH("scale_copy_kernel");
+    }
     // ---- backward: result stream, then the delta GEMM of the next layer down
     for (int l = L; l >= 1; --l) {
       const int di = dims[l - 1], dout = dims[l];
+      float bw = bt;   // beta of the weight block in the outer-product stream
+      if (Gh && l >= 2) {
+        // out_W_l = bt out_W_l + d_l^T da_{l-1} first (da_{l-1} sample-major), the stream then adds Rd_l^T a_{l-1}
+        const long nel = (long)di * nn * K;
+        hipLaunchKernelGGL(kcols_perm_kernel, dim3(ew_grid(nel)), dim3(256), 0, st, dA[l - 1], daP, nn, K, di);
+        CLO_CHECK_LAUNCH("kcols_perm_kernel");
+        GemmArgs g2 = gemm_problem(dout, di * K, nn, dH[l], 1, dout, daP, (long)di * K, 1, bt, OW[l - 1], (long)di * K);
+        int rc = launch_gemm_auto(g2, gws, gws_sz, st);
+        if (rc != CLO_OK) return rc;
+        bw = 1.f;
+      }
       {
-        ProfScope prof(4, 4.0 * di * dout * K * (bt != 0.f ? 2 : 1), st);
+        ProfScope prof(4, 4.0 * di * dout * K * (bw != 0.f ? 2 : 1), st);
         float *ob = Ob ? Ob[l - 1] : nullptr;
-        if (bt != 0.f)
+        if (bw != 0.f)
           hipLaunchKernelGGL(kouter_stream_kernel<true>, dim3(dout), dim3(256), 0, st, OW[l - 1], ldk, ob,
-                             aT[l - 1], dA[l], nn, K, di, bt);
+                             aT[l - 1], dA[l], nn, K, di, bw, bt);
         else
           hipLaunchKernelGGL(kouter_stream_kernel<false>, dim3(dout), dim3(256), 0, st, OW[l - 1], ldk,
-                             ob, aT[l - 1], dA[l], nn, K, di, bt);
+                             ob, aT[l - 1], dA[l], nn, K, di, bw, bt);
         CLO_CHECK_LAUNCH("kouter_stream_kernel");
       }
-      if (l >= 2) {  // delta_{l-1} = phi'_{l-1} * (W_l^T delta_l)   ([di x dout] [dout x NK])
+      if (l >= 2 && !Gh) {  // delta_{l-1} = phi'_{l-1} * (W_l^T delta_l)   ([di x dout] [dout x NK])
         GemmArgs g = gemm_problem(di, NK, dout, W[l - 1], 1, di, dA[l], NK, 1, 0.f, dA[l - 1], NK);
         g.epi = EPI_MUL_T; g.e_mul = dphi[l - 1]; g.ld_mul = di; g.e_div = K;
         int rc = launch_gemm_auto(g, gws, gws_sz, st);
         if (rc != CLO_OK) return rc;
+      } else if (l >= 2) {
+        // T = W_l^T Rd_l ; dsig = d_l W_l ; Xv = d_l V_l ; Rd_{l-1}, d_{l-1} by the combine (in place on da_{l-1})
+        GemmArgs g = gemm_problem(di, NK, dout, W[l - 1], 1, di, dA[l], NK, 1, 0.f, Tb, NK);
+        int rc = launch_gemm_auto(g, gws, gws_sz, st);
+        if (rc != CLO_OK) return rc;
+        GemmArgs gs = gemm_problem(nn, di, dout, dH[l], dout, 1, W[l - 1], di, 1, 0.f, dsig, di);
+        rc = launch_gemm_auto(gs, gws, gws_sz, st);
+        if (rc != CLO_OK) return rc;
+        GemmArgs gv = gemm_problem(nn, di * K, dout, dH[l], dout, 1, VW[l - 1], (long)di * K, 1, 0.f, Xv, (long)di * K);
+        rc = launch_gemm_auto(gv, gws, gws_sz, st);
+        if (rc != CLO_OK) return rc;
+        const long nel = (long)di * nn * K;
+        hipLaunchKernelGGL(kcols_hess_combine_kernel, dim3(ew_grid(nel)), dim3(256), 0, st, dA[l - 1], Tb, Xv, dsig,
+                           a[l - 1], dphi[l - 1], dH[l - 1], nn, K, di, acts[l - 2]);
+        CLO_CHECK_LAUNCH("kcols_hess_combine_kernel");
       }
     }
   }
   return CLO_OK;
+}
+
+extern "C" int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *const *W,
+                                  const float *const *b, const float *const *VW,
+                                  const float *const *Vb, float *const *OW, float *const *Ob,
+                                  long ldk, const float *X, int N, int K, int loss_kind,
+                                  const float *aux, int aux_rank, float loss_scale, float alpha,
+                                  float beta, float *ws, void *stream) {
+  return mlp_matmat_impl("clo_mlp_ggn_matmat", L, dims, acts, W, b, VW, Vb, OW, Ob, ldk, X, N, K, loss_kind, aux, aux_rank,
+                         loss_scale, alpha, beta, ws, stream, nullptr);
+}
+
+// out[.., k] = beta out[.., k] + alpha H V[.., k] (exact Hessian) for K columns in the K-trailing layout; G [N][C] =
+// gradient of the reduced mini-batch loss w.r.t. the model output.  Requirements as clo_mlp_ggn_matmat plus ldk == K, a
+// linear last layer and loss_kind in {MSE, CE, BCE} (else CLO_EUNSUP).  ws: clo_mlp_hessian_matmat_ws_floats floats.
+extern "C" int clo_mlp_hessian_matmat(int L, const int *dims, const int *acts, const float *const *W,
+                                      const float *const *b, const float *const *VW,
+                                      const float *const *Vb, float *const *OW, float *const *Ob,
+                                      long ldk, const float *X, int N, int K, const float *G, int loss_kind,
+                                      float loss_scale, float alpha, float beta, float *ws, void *stream) {
+  CLO_REQUIRE(G, "clo_mlp_hessian_matmat: null output gradient");
+  return mlp_matmat_impl("clo_mlp_hessian_matmat", L, dims, acts, W, b, VW, Vb, OW, Ob, ldk, X, N, K, loss_kind, nullptr, 1,
+                         loss_scale, alpha, beta, ws, stream, G);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -296,8 +296,17 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         shapes / layout do not qualify."""
         nat = self._native
         plan = nat.plan
-        if self._NATIVE_KIND == "hessian" or K < self._NATIVE_COLS_MIN_K or not batches or any(b[0].shape[0] > self._NATIVE_COLS_MAX_ROWS for b in batches):
+        if K < self._NATIVE_COLS_MIN_K or not batches or any(b[0].shape[0] > self._NATIVE_COLS_MAX_ROWS for b in batches):
             return None
+        if self._NATIVE_KIND == "hessian":
+            # exact Hessian columns (clo_mlp_hessian_matmat): one contiguous block of <= 64 columns per call
+            if (K % 4 or not all(m.is_contiguous() and m.data_ptr() % 16 == 0 for m in M)
+                    or not plan.hessian_matmat_supported(min(K, plan.MATMAT_MAX_K), min(K, plan.MATMAT_MAX_K))
+                    or any(a[0] not in (0, 1, 2) or a[2] is None for a in bargs)):
+                return None
+            out = self._alloc_cols_like(M)
+            with torch.cuda.device(self.device):
+                return self._hessian_native_cols_run(M, out, batches, bargs, K)
         # rows of the [D, K] matrix must be float4-complete: K % 4 == 0 (else the column loop runs)
         rank = max([1] + [a[2].shape[1] for a in bargs if a[2] is not None])
         if not all(m.is_contiguous() and m.data_ptr() % 16 == 0 for m in M) or not plan.matmat_supported(4, K, rank):
@@ -323,6 +332,30 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                 plan.ggn_matmat_ptrs(vw, vb, ow, ob, K, kc, Xn.data_ptr(), Xn.shape[0], kind, scale, norm,
                                      0.0 if bi == 0 else 1.0, None if aux is None else aux.data_ptr(),
                                      1 if aux is None else aux.shape[1], ws.data_ptr(), stream)
+        return out
+
+    def _hessian_native_cols_run(self, M, out, batches, bargs, K: int) -> list[Tensor]:
+        nat = self._native
+        plan = nat.plan
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        whole = K <= plan.MATMAT_MAX_K
+        for k0 in range(0, K, plan.MATMAT_MAX_K):
+            kc = min(plan.MATMAT_MAX_K, K - k0)
+            # the kernel wants its K columns contiguous: blocks of a wider matrix travel as copies
+            Mc = M if whole else [m[..., k0:k0 + kc].contiguous() for m in M]
+            Oc = out if whole else [torch.empty_like(m) for m in Mc]
+            ws = plan.hessian_matmat_workspace(kc, self.device)
+            ptr = lambda lst, i: None if i is None else lst[i].data_ptr()  # noqa: E731
+            vw, vb = [ptr(Mc, i) for i in nat.w_idx], [ptr(Mc, i) for i in nat.b_idx]
+            ow, ob = [ptr(Oc, i) for i in nat.w_idx], [ptr(Oc, i) for i in nat.b_idx]
+            for bi, (Xn, y, norm) in enumerate(batches):
+                kind, scale, G = bargs[bi]
+                G = G.contiguous()
+                plan.hessian_matmat_ptrs(vw, vb, ow, ob, kc, Xn.data_ptr(), Xn.shape[0], G.data_ptr(), kind, scale,
+                                         norm, 0.0 if bi == 0 else 1.0, ws.data_ptr(), stream)
+            if not whole:
+                for o, oc in zip(out, Oc):
+                    o[..., k0:k0 + kc] = oc
         return out
 
     @staticmethod

@@ -271,6 +271,16 @@ int clo_mlp_ggn_matmat(int L, const int *dims, const int *acts, const float *con
                        float *const *OW, float *const *Ob, long ldk, const float *X, int N, int K,
                        int loss_kind, const float *aux, int aux_rank, float loss_scale, float alpha,
                        float beta, float *ws, void *stream);
+/* Exact Hessian for K columns (hessian.py:66 under the vmap over the trailing axis, _torch_base.py:946-989): the pipeline
+ * of clo_mlp_ggn_matmat plus the R-operator terms (gradient signal d_l, d_l V_l, d_l^T da_{l-1}).  G [N][C] = gradient of
+ * the reduced mini-batch loss w.r.t. the model output.  Requirements as clo_mlp_ggn_matmat plus ldk == K, a linear last
+ * layer, loss_kind in {MSE, CE, BCE} (else CLO_EUNSUP).  ws: clo_mlp_hessian_matmat_ws_floats(L, dims, N, K) floats. */
+long clo_mlp_hessian_matmat_ws_floats(int L, const int *dims, int N, int K);
+int clo_mlp_hessian_matmat(int L, const int *dims, const int *acts, const float *const *W,
+                           const float *const *b, const float *const *VW, const float *const *Vb,
+                           float *const *OW, float *const *Ob, long ldk, const float *X, int N, int K,
+                           const float *G, int loss_kind, float loss_scale, float alpha, float beta,
+                           float *ws, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Streaming helpers (HBM-bound).

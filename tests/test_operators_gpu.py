@@ -4,6 +4,8 @@ BASELINE.json sizes.  Tolerances: products and factors
 max|y - y_ref| / max|y_ref| <= 1e-4, damped inverses <= 1e-3."""
 
 import numpy as np
+import copy
+
 import pytest
 import torch
 from torch import nn
@@ -69,6 +71,44 @@ def test_native_matches_autograd_path_on_gpu(dev):
         V = torch.rand(nat.shape[1], 3, device=dev)
         a, b = nat @ V, ref @ V
         assert rel_err(a, b.double().cpu().numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("loss_name", ["ce", "mse", "bce"])
+def test_native_hessian_column_kernels_gpu(dev, loss_name):
+    """`H @ M` with K % 4 == 0 columns runs clo_mlp_hessian_matmat (the R-operator on the K-column pipeline; reference
+    `hessian.py:66` under the vmap of `_torch_base.py:946-989`): same result as the torch.func path in float64 and as
+    single-vector products, several mini-batches (one of them two 8-row passes), tanh / sigmoid / ReLU layers, K > 64."""
+    torch.manual_seed(2)
+    model = nn.Sequential(nn.Linear(300, 500), nn.Tanh(), nn.Linear(500, 260), nn.ReLU(), nn.Linear(260, 64),
+                          nn.Sigmoid(), nn.Linear(64, 12)).to(dev)
+    params = dict(model.named_parameters())
+    if loss_name == "ce":
+        loss, tgt = nn.CrossEntropyLoss(), lambda n: torch.randint(0, 12, (n,), device=dev)
+    elif loss_name == "mse":
+        loss, tgt = nn.MSELoss(reduction="sum"), lambda n: torch.rand(n, 12, device=dev)
+    else:
+        loss, tgt = nn.BCEWithLogitsLoss(), lambda n: torch.randint(0, 2, (n, 12), device=dev).float()
+    data = [(torch.rand(8, 300, device=dev), tgt(8)), (torch.rand(5, 300, device=dev), tgt(5)),
+            (torch.rand(13, 300, device=dev), tgt(13))]
+    nat = C.HessianLinearOperator(model, loss, params, data, check_deterministic=False)
+    assert nat.uses_native_kernels
+    model64 = copy.deepcopy(model).double()
+    data64 = [(X.double(), y.double() if y.is_floating_point() else y) for X, y in data]
+    ref = C.HessianLinearOperator(model64, loss, dict(model64.named_parameters()), data64, check_deterministic=False)
+    ref._native = None
+    for K in (8, 72):
+        V = torch.rand(nat.shape[1], K, device=dev) - 0.5
+        calls = []
+        orig = nat._native.plan.hessian_matmat_ptrs
+        nat._native.plan.hessian_matmat_ptrs = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        a = nat @ V
+        nat._native.plan.hessian_matmat_ptrs = orig
+        assert calls, "the Hessian column kernels must have run"
+        Kc = min(K, 8)
+        b = ref @ V[:, :Kc].double()
+        assert rel_err(a[:, :Kc], b.cpu().numpy()) < 2e-4
+        for k in (0, K - 1):   # columns are independent: equal to plain matvecs (the single-vector kernels)
+            assert rel_err(a[:, k], (nat @ V[:, k].contiguous()).double().cpu().numpy()) < 2e-4
 
 
 def test_native_column_kernels_match_autograd_path_on_gpu(dev):
