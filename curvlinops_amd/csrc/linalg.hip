@@ -440,6 +440,9 @@ __global__ void chol_copy_out_kernel(const OutBatch ob, const float *__restrict_
 }
 
 }  // namespace clo
+#include <mutex>
+#include <vector>
+
 #include "gemm.h"
 namespace clo {
 
@@ -506,6 +509,244 @@ static int chol_rec(const CholCtx &c, int o, int m) {
               TRI_KLT_M, 0);
 }
 
+// ---- pipelined variant (round 3): the same arithmetic as a DAG over three streams -----------------------------------
+// chol_rec above is one in-order chain: every product -- also the big trailing updates and the whole triangular inverse --
+// sits between two diagonal nodes although the next node only needs its own 128 x 128 block.  Here the factorisation is
+// right-looking over 128-row block columns with a look-ahead of one:
+//   main:  node k (L_kk, L_kk^-1) -> panel L[k+1:, k] = S[k+1:, k] L_kk^-T -> update of block column k+1 only
+//   side:  the rest of the trailing update S[k+2:, k+2:] -= L[k+2:, k] L[k+2:, k]^T (symmetric product), one step behind
+//   inv:   the triangular inverse by the recursion of chol_rec ((L^-1)21 = -L22^-1 (L21 L11^-1), post-order), every leaf
+//          waiting for "node k done": it runs under the factorisation of the blocks to the right
+// so the critical path is nodes + two skinny products per block column (n = 4608: 36 x ~70 us) instead of everything.
+// Events are recorded before they are waited for in host order (no wait can precede its record in a hardware queue).
+struct CholAsync {
+  hipStream_t side = nullptr, inv = nullptr, inv2 = nullptr;
+  std::vector<hipEvent_t> ev;
+  int err = CLO_OK;
+  hipEvent_t event(size_t i) {
+    while (ev.size() <= i) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = CLO_EHIP; return nullptr; }
+      ev.push_back(e);
+    }
+    return ev[i];
+  }
+};
+// Process-wide pool per device: a call takes a set for its duration and hands it back (the worker threads of
+// linalg_native.concurrent_inverses come and go -- thread-local sets would leak streams).  A set is reused while work of
+// its previous call may still be queued: the helper streams are in order, and every wait below follows its record.
+static std::mutex g_chol_pool_mu;
+static std::vector<CholAsync *> g_chol_pool[64];
+static CholAsync *chol_async_acquire(int *dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  *dev_out = dev & 63;
+  {
+    std::lock_guard<std::mutex> lk(g_chol_pool_mu);
+    auto &pool = g_chol_pool[dev & 63];
+    if (!pool.empty()) {
+      CholAsync *a = pool.back();
+      pool.pop_back();
+      return a;
+    }
+  }
+  CholAsync *a = new CholAsync();
+  // lowest priority: whatever the caller's stream has ready (the nodes and skinny products of the critical path) is
+  // dispatched ahead of the bulk products queued here
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) != hipSuccess ||
+      hipStreamCreateWithPriority(&a->inv, hipStreamNonBlocking, least) != hipSuccess ||
+      hipStreamCreateWithPriority(&a->inv2, hipStreamNonBlocking, least) != hipSuccess) {
+    delete a;
+    return nullptr;
+  }
+  return a;
+}
+static void chol_async_release(CholAsync *a, int dev) {
+  std::lock_guard<std::mutex> lk(g_chol_pool_mu);
+  g_chol_pool[dev].push_back(a);
+}
+
+struct CholPipe {
+  const CholCtx *c;
+  CholAsync *as;
+  std::vector<int> off, bs;   // block columns
+  float *G_side, *G_inv, *G_inv2;
+  int nblk;
+};
+
+static int chol_gemm(const CholCtx &c, hipStream_t st, float *G, int M, int N, int K, float alpha, const float *A,
+                     long sa_m, long sa_k, const float *B, long sb_k, long sb_n, float beta, float *C, long ldc,
+                     int tri, int sym) {
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+  g.A = A; g.sa_m = sa_m; g.sa_k = sa_k; g.sa_b = c.stride;
+  g.B = B; g.sb_k = sb_k; g.sb_n = sb_n; g.sb_b = c.stride;
+  g.C = C; g.ldc = ldc; g.sc_b = c.stride; g.tri = tri; g.sym = sym;
+  return launch_gemm_auto(g, G, c.gws, st, c.batch);
+}
+
+// triangular inverse of the block range [b0, b1) on the `inv` stream (diagonal blocks come from the nodes).  The first
+// product of a node, T = L21 L11^-1, only needs the LEFT half: it is queued before the right half's recursion, so that
+// after the last diagonal node only one product per level of the right spine is left.  T buffers form a stack in c.T
+// (a node's T stays live across its right child: sum over the spine < n^2 / 3).
+// The recursion is first written down as a list of operations in post-order, each with the last diagonal node it needs;
+// the factorisation loop then queues them AS SOON AS that node has been queued (the host submits the helper streams' work
+// interleaved with the main chain -- queued after the loop it would only reach the GPU when the factorisation is over).
+// `second`: the subtree runs on the second inverse stream (the right half of the whole matrix follows the nodes of that half
+// while the first stream is busy with the big T of the top level).
+struct CholInvOp {
+  int kind;   // 0: leaf (wait for node b0); 1: T = L21 L11i of (b0, bm, b1); 2: Li21 = -L22i T (after the right subtree)
+  int b0, bm, b1, need;
+  long toff;
+  bool second, fork;
+};
+static void chol_inv_plan(const CholPipe &P, std::vector<CholInvOp> &ops, int b0, int b1, long toff, bool second, bool top) {
+  if (b1 - b0 == 1) { ops.push_back({0, b0, b0, b1, b0, toff, second, false}); return; }
+  const int bm = (b0 + b1 + 1) / 2;
+  chol_inv_plan(P, ops, b0, bm, toff, second, false);
+  const int a = P.off[b0], b = P.off[bm], m1 = b - a, m2 = P.off[b1 - 1] + P.bs[b1 - 1] - b;
+  const bool fork = top && b1 - bm >= 4;
+  ops.push_back({1, b0, bm, b1, bm, toff, second, fork});
+  chol_inv_plan(P, ops, bm, b1, toff + (long)m2 * m1, second || fork, false);
+  ops.push_back({2, b0, bm, b1, b1 - 1, toff, second, fork});
+}
+static int chol_inv_emit(const CholPipe &P, const CholInvOp &op) {
+  const CholCtx &c = *P.c;
+  const long n = c.n;
+  hipStream_t sv = op.second ? P.as->inv2 : P.as->inv;
+  float *G = op.second ? P.G_inv2 : P.G_inv;
+  if (op.kind == 0) return check_hip(hipStreamWaitEvent(sv, P.as->event(3 * op.b0), 0), "hipStreamWaitEvent");
+  const int a = P.off[op.b0], b = P.off[op.bm], m1 = b - a, m2 = P.off[op.b1 - 1] + P.bs[op.b1 - 1] - b;
+  float *T = c.T + op.toff;
+  if (op.kind == 1) {
+    // T = L21 * L11i: L21 = the rows below of the left half's panels, complete once node bm has been queued
+    int rc = check_hip(hipStreamWaitEvent(sv, P.as->event(3 * op.bm), 0), "hipStreamWaitEvent");
+    if (rc != CLO_OK) return rc;
+    return chol_gemm(c, sv, G, m2, m1, m1, 1.f, c.L + b * n + a, n, 1, c.Li + a * n + a, n, 1, 0.f, T, m1, TRI_KGE_N, 0);
+  }
+  if (op.fork) {
+    hipEvent_t e = P.as->event(3 * (size_t)P.nblk + 3 + P.nblk);   // (behind the group events)
+    if (P.as->err != CLO_OK) { set_error("cholesky inverse: hipEventCreate failed"); return P.as->err; }
+    int rc = check_hip(hipEventRecord(e, P.as->inv2), "hipEventRecord");
+    if (rc != CLO_OK) return rc;
+    rc = check_hip(hipStreamWaitEvent(sv, e, 0), "hipStreamWaitEvent");
+    if (rc != CLO_OK) return rc;
+  }
+  // Li21 = -L22i * T
+  return chol_gemm(c, sv, G, m2, m1, m2, -1.f, c.Li + b * n + b, n, 1, T, m1, 1, 0.f, c.Li + b * n + a, n, TRI_KLT_M, 0);
+}
+
+static int chol_pipe_run(const CholCtx &c, float *G_side, float *G_inv, float *G_inv2, CholAsync *as);
+static int chol_pipe(const CholCtx &c, float *G_side, float *G_inv, float *G_inv2) {
+  int dev = 0;
+  CholAsync *as = chol_async_acquire(&dev);
+  if (!as) { set_error("cholesky inverse: cannot create the side streams"); return CLO_EHIP; }
+  const int rc = chol_pipe_run(c, G_side, G_inv, G_inv2, as);
+  chol_async_release(as, dev);
+  return rc;
+}
+static int chol_pipe_run(const CholCtx &c, float *G_side, float *G_inv, float *G_inv2, CholAsync *as) {
+  CholPipe P;
+  P.c = &c; P.as = as; P.G_side = G_side; P.G_inv = G_inv; P.G_inv2 = G_inv2;
+  const int np = c.n;
+  for (int o = 0; o < np;) {   // 128-row block columns; a short tail is shared with the block before it
+    int m = std::min(QNB, np - o);
+    const int left = np - o - m;
+    if (left > 0 && left < PNB) m = (((np - o) / 2 + 3) & ~3);
+    P.off.push_back(o); P.bs.push_back(m);
+    o += m;
+  }
+  const int nb = P.nblk = (int)P.off.size();
+  const long n = c.n;
+  hipStream_t st = c.st;
+#define CHOL_HIP(call) { int rc_ = check_hip(call, #call); if (rc_ != CLO_OK) return rc_; }
+  // both helper streams start after everything queued on the caller's stream (the initialised S, L, Li)
+  hipEvent_t e0 = as->event(3 * nb);
+  if (as->err != CLO_OK) { set_error("cholesky inverse: hipEventCreate failed"); return as->err; }
+  CHOL_HIP(hipEventRecord(e0, st));
+  CHOL_HIP(hipStreamWaitEvent(as->side, e0, 0));
+  CHOL_HIP(hipStreamWaitEvent(as->inv, e0, 0));
+  CHOL_HIP(hipStreamWaitEvent(as->inv2, e0, 0));
+  // Trailing updates in groups of W block columns: the panels of group g are applied by ONE symmetric product of depth
+  // ~128 W on the side stream to everything from group g + 2 on; the columns of group g + 1 get them just in time from the
+  // main stream's column update (left-looking over the panels of groups g and g + 1 so far: one skinny product of depth
+  // <= 256 W), so the main stream meets the side stream once per group and the bulk runs at a useful depth.
+  static const int W = std::max(1, getenv("CLO_CHOL_GROUP") ? atoi(getenv("CLO_CHOL_GROUP")) : 4);
+  const int ngrp = (nb + W - 1) / W;
+  auto grp_begin = [&](int g) { return g >= ngrp ? np : P.off[g * W]; };
+  const size_t EV_GRP = 3 * (size_t)nb + 3;   // events of the group products
+  std::vector<CholInvOp> inv_ops;
+  chol_inv_plan(P, inv_ops, 0, nb, 0, false, true);
+  size_t inv_pos = 0;
+  for (int k = 0; k < nb; ++k) {
+    const int o = P.off[k], m = P.bs[k], r0 = o + m, rest = np - r0;
+    hipEvent_t ev_node = as->event(3 * k);
+    if (as->err != CLO_OK) { set_error("cholesky inverse: hipEventCreate failed"); return as->err; }
+    int rc;
+    if (m <= PNB) {
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(c.batch), dim3(64), 0, st, c.S + o * n + o, n, c.L + o * n + o, n, m,
+                         c.Li + o * n + o, n, c.status, o, c.stride);
+      CLO_CHECK_LAUNCH("potrf_diag_kernel");
+    } else {
+      rc = potrf_node128_launch(c.S + o * n + o, n, c.L + o * n + o, n, m, c.Li + o * n + o, n, c.status, o, c.stride,
+                                c.batch, st);
+      if (rc != CLO_OK) return rc;
+    }
+    CHOL_HIP(hipEventRecord(ev_node, st));
+    for (; inv_pos < inv_ops.size() && inv_ops[inv_pos].need <= k; ++inv_pos) {
+      rc = chol_inv_emit(P, inv_ops[inv_pos]);
+      if (rc != CLO_OK) return rc;
+    }
+    if (rest == 0) break;
+    // panel: L[r0:, o:o+m] = S[r0:, o:o+m] * Li_kk^T     (B(k,n) = Li_kk[n][k], zero for k > n)
+    rc = chol_gemm(c, st, c.G, rest, m, m, 1.f, c.S + r0 * n + o, n, 1, c.Li + o * n + o, 1, n, 0.f, c.L + r0 * n + o, n,
+                   TRI_KLT_N, 0);
+    if (rc != CLO_OK) return rc;
+    const int g = k / W;
+    if ((k + 1) % W == 0) {
+      // group g complete: its panels go to S[R:, R:], R = first row of group g + 2 (symmetric: half the tiles, mirrored)
+      const int R = grp_begin(g + 2), og = P.off[g * W];
+      if (R < np) {
+        hipEvent_t ev_panel = as->event(3 * k + 1);
+        if (as->err != CLO_OK) { set_error("cholesky inverse: hipEventCreate failed"); return as->err; }
+        CHOL_HIP(hipEventRecord(ev_panel, st));
+        CHOL_HIP(hipStreamWaitEvent(as->side, ev_panel, 0));
+        rc = chol_gemm(c, as->side, P.G_side, np - R, np - R, r0 - og, -1.f, c.L + R * n + og, n, 1, c.L + R * n + og, 1, n,
+                       1.f, c.S + R * n + R, n, 0, 1);
+        if (rc != CLO_OK) return rc;
+        hipEvent_t ev_grp = as->event(EV_GRP + g);
+        if (as->err != CLO_OK) { set_error("cholesky inverse: hipEventCreate failed"); return as->err; }
+        CHOL_HIP(hipEventRecord(ev_grp, as->side));
+      }
+    }
+    // block column k + 1: everything the side stream has not applied to it = the panels of the group before its own and of
+    // its own group so far, in one product.  (A split of this step into "what node k + 1 needs" on this stream and "the
+    // rows below" on a fourth stream was built and measured 3 x SLOWER, 12.9 ms at n = 4608: two streams that wait for each
+    // other once per block column pay the cross-stream hand-over twice per step.)
+    const int cn = k + 1, gc = cn / W, m_next = P.bs[cn];
+    if (cn % W == 0 && gc >= 2) CHOL_HIP(hipStreamWaitEvent(st, as->event(EV_GRP + gc - 2), 0));   // first column of a group
+    const int j0 = gc >= 1 ? (gc - 1) * W : 0, oj = P.off[j0];
+    rc = chol_gemm(c, st, c.G, rest, m_next, r0 - oj, -1.f, c.L + r0 * n + oj, n, 1, c.L + r0 * n + oj, 1, n, 1.f,
+                   c.S + r0 * n + r0, n, 0, 0);
+    if (rc != CLO_OK) return rc;
+  }
+  for (; inv_pos < inv_ops.size(); ++inv_pos) {
+    int rc = chol_inv_emit(P, inv_ops[inv_pos]);
+    if (rc != CLO_OK) return rc;
+  }
+  // join: the caller's stream continues after the inverse (which waited for every node) and the last updates
+  hipEvent_t e1 = as->event(3 * nb + 1), e2 = as->event(3 * nb + 2);
+  if (as->err != CLO_OK) { set_error("cholesky inverse: hipEventCreate failed"); return as->err; }
+  CHOL_HIP(hipEventRecord(e1, as->inv));
+  CHOL_HIP(hipEventRecord(e2, as->side));
+  CHOL_HIP(hipStreamWaitEvent(st, e1, 0));
+  CHOL_HIP(hipStreamWaitEvent(st, e2, 0));
+#undef CHOL_HIP
+  return CLO_OK;
+}
+
 static inline long pad4(long n) { return (n + 3) & ~3L; }
 static const long kCholSlabFloats = 16L * 256 * 256;
 
@@ -517,7 +758,7 @@ using namespace clo;
 extern "C" long clo_cholesky_inverse_batched_ws_floats(int n, int batch) {
   const long np = pad4(n), nn = np * np;
   // per matrix: S, L, Li, T (shares the stride), padded product; plus the split-K slabs
-  return (long)batch * 5 * nn + (long)batch * kCholSlabFloats + 1024;
+  return (long)batch * 5 * nn + 4L * batch * kCholSlabFloats + 1024;   // (a slab region per stream of the pipeline)
 }
 extern "C" long clo_cholesky_inverse_ws_floats(int n) { return clo_cholesky_inverse_batched_ws_floats(n, 1); }
 
@@ -557,7 +798,14 @@ extern "C" int clo_cholesky_inverse_batched_f32(const float *const *A, const lon
                        c.L + (long)b0 * nn, c.Li + (long)b0 * nn, n, np, nn);
     CLO_CHECK_LAUNCH("chol_init_kernel");
   }
-  rc = chol_rec(c, 0, np);
+  static const int pipe = getenv("CLO_CHOL_PIPE") ? atoi(getenv("CLO_CHOL_PIPE")) : 1;
+  // (below ~1500 rows the single chain of chol_rec is as fast or faster: n = 512: 0.34 vs 0.43 ms, 1152: 0.90 vs 0.88 ms,
+  // 2304: 2.11 vs 1.78 ms, 4608: 5.13 vs 3.95 ms)
+  static const int pipe_min = getenv("CLO_CHOL_PIPE_MIN") ? atoi(getenv("CLO_CHOL_PIPE_MIN")) : 1536;
+  if (pipe && np >= pipe_min && np > QNB)
+    rc = chol_pipe(c, c.G + c.gws, c.G + 2 * c.gws, c.G + 3 * c.gws);
+  else
+    rc = chol_rec(c, 0, np);
   if (rc != CLO_OK) return rc;
   // A^-1 = Li^T Li: A(m,k) = Li[k][m] and B(k,n) = Li[k][n] are zero for k < m / k < n.  A single
   // factor with float4-complete rows goes straight to the caller's tensor.
