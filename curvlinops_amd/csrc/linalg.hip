@@ -522,6 +522,7 @@ static int chol_rec(const CholCtx &c, int o, int m) {
 struct CholAsync {
   hipStream_t side = nullptr, inv = nullptr, inv2 = nullptr;
   std::vector<hipEvent_t> ev;
+  hipEvent_t done = nullptr;   // recorded on the caller's stream at the end of the call that used the set last
   int err = CLO_OK;
   hipEvent_t event(size_t i) {
     while (ev.size() <= i) {
@@ -542,22 +543,39 @@ static CholAsync *chol_async_acquire(int *dev_out) {
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   *dev_out = dev & 63;
   {
+    // only a set whose previous call has COMPLETED on the device is taken again: re-recording an event that a queued wait
+    // still refers to, or queueing behind the previous call's helper work, couples successive calls (ResNet-18's 42 factors
+    // back to back: 18.4 instead of 11.7 ms)
     std::lock_guard<std::mutex> lk(g_chol_pool_mu);
     auto &pool = g_chol_pool[dev & 63];
-    if (!pool.empty()) {
-      CholAsync *a = pool.back();
-      pool.pop_back();
-      return a;
+    for (size_t i = 0; i < pool.size(); ++i) {
+      if (!pool[i]->done || hipEventQuery(pool[i]->done) == hipSuccess) {
+        CholAsync *a = pool[i];
+        pool.erase(pool.begin() + i);
+        return a;
+      }
     }
+    (void)hipGetLastError();   // hipEventQuery's "not ready" is not an error
   }
   CholAsync *a = new CholAsync();
   // lowest priority: whatever the caller's stream has ready (the nodes and skinny products of the critical path) is
   // dispatched ahead of the bulk products queued here
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) != hipSuccess ||
-      hipStreamCreateWithPriority(&a->inv, hipStreamNonBlocking, least) != hipSuccess ||
-      hipStreamCreateWithPriority(&a->inv2, hipStreamNonBlocking, least) != hipSuccess) {
+  // ONE helper stream for the trailing updates and the inverse (three were measured first: HIP streams share a handful of
+  // hardware queues, and when two helpers land on the same queue the trailing update the main stream is about to need waits
+  // behind an inverse product that waits for a later node -- 4 x 2305: 2.5 ms alone, 5.2 ms after another call had shifted
+  // the stream-to-queue assignment).  In one in-order stream every operation is queued when the node / panel it needs has
+  // been queued, so nothing ever waits behind a later dependency.
+  static const int nhelp = getenv("CLO_CHOL_HELPERS") ? atoi(getenv("CLO_CHOL_HELPERS")) : 1;
+  bool ok = hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
+  if (ok && nhelp >= 3) {
+    ok = hipStreamCreateWithPriority(&a->inv, hipStreamNonBlocking, least) == hipSuccess &&
+         hipStreamCreateWithPriority(&a->inv2, hipStreamNonBlocking, least) == hipSuccess;
+  } else {
+    a->inv = a->inv2 = a->side;
+  }
+  if (!ok) {
     delete a;
     return nullptr;
   }
@@ -584,7 +602,9 @@ static int chol_gemm(const CholCtx &c, hipStream_t st, float *G, int M, int N, i
   g.A = A; g.sa_m = sa_m; g.sa_k = sa_k; g.sa_b = c.stride;
   g.B = B; g.sb_k = sb_k; g.sb_n = sb_n; g.sb_b = c.stride;
   g.C = C; g.ldc = ldc; g.sc_b = c.stride; g.tri = tri; g.sym = sym;
-  return launch_gemm_auto(g, G, c.gws, st, c.batch);
+  // (no stream-K here: its workgroups wait for each other inside the kernel, and the products of the pipeline run side by
+  // side on several streams -- 4 x 2305: 5.2 ms with it, 2.5 without)
+  return launch_gemm_auto(g, G, std::min(c.gws, gemm_streamk_ws_floats_square() - 1), st, c.batch);
 }
 
 // triangular inverse of the block range [b0, b1) on the `inv` stream (diagonal blocks come from the nodes).  The first
@@ -643,7 +663,9 @@ static int chol_pipe(const CholCtx &c, float *G_side, float *G_inv, float *G_inv
   int dev = 0;
   CholAsync *as = chol_async_acquire(&dev);
   if (!as) { set_error("cholesky inverse: cannot create the side streams"); return CLO_EHIP; }
-  const int rc = chol_pipe_run(c, G_side, G_inv, G_inv2, as);
+  int rc = chol_pipe_run(c, G_side, G_inv, G_inv2, as);
+  if (!as->done && hipEventCreateWithFlags(&as->done, hipEventDisableTiming) != hipSuccess) as->done = nullptr;
+  if (as->done && rc == CLO_OK) rc = check_hip(hipEventRecord(as->done, c.st), "hipEventRecord");
   chol_async_release(as, dev);
   return rc;
 }

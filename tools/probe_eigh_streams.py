@@ -16,7 +16,7 @@ K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], fisher_
                          separate_weight_and_bias=False, check_deterministic=False, num_data=512)
 facs = [S for blk in K[1] for S in blk]
 print("sizes:", sorted(int(S.shape[0]) for S in facs))
-for ns in (4, 5, 6, 7, 8, 10, 6, 8):
+for ns in [int(a) for a in sys.argv[1:]] or (4, 5, 6, 7, 8, 10, 6, 8):
     L.eigh_many(facs, num_streams=ns); torch.cuda.synchronize()
     best = 1e9
     for _ in range(4):
