@@ -750,8 +750,9 @@ static int chol_pipe_run(const CholCtx &c, float *G_side, float *G_inv, float *G
     const int cn = k + 1, gc = cn / W, m_next = P.bs[cn];
     if (cn % W == 0 && gc >= 2) CHOL_HIP(hipStreamWaitEvent(st, as->event(EV_GRP + gc - 2), 0));   // first column of a group
     const int j0 = gc >= 1 ? (gc - 1) * W : 0, oj = P.off[j0];
-    rc = chol_gemm(c, st, c.G, rest, m_next, r0 - oj, -1.f, c.L + r0 * n + oj, n, 1, c.L + r0 * n + oj, 1, n, 1.f,
-                   c.S + r0 * n + r0, n, 0, 0);
+    static const int col_split = getenv("CLO_CHOL_COL_SPLIT") ? atoi(getenv("CLO_CHOL_COL_SPLIT")) : 1;
+    rc = chol_gemm(c, st, col_split ? c.G : nullptr, rest, m_next, r0 - oj, -1.f, c.L + r0 * n + oj, n, 1, c.L + r0 * n + oj,
+                   1, n, 1.f, c.S + r0 * n + r0, n, 0, 0);
     if (rc != CLO_OK) return rc;
   }
   for (; inv_pos < inv_ops.size(); ++inv_pos) {
