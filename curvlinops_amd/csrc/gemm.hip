@@ -872,7 +872,10 @@ struct V2Config { int bm, bn, bk; };
 static V2Config v2_config(int M, int N, int K, long batch, int sym, bool allow_small = true) {
   // (few-row problems keep their 32- / 64-row tiles unless they are tiny)
   static const long small_max = getenv("CLO_GEMM_SMALL_MAX") ? atol(getenv("CLO_GEMM_SMALL_MAX")) : 1024L * 1024L;
-  const long area = (long)M * N * batch;
+  // (a batch of skinny products -- the panels and column updates of the batched Cholesky chain, N <= 128 -- is judged by
+  // ONE matrix: 3 x (4480 x 128) on 128 x 128 x 32 tiles is 105 workgroups with k loops of up to 32 steps, 50-110 us per
+  // product on the critical path; on 64 x 64 x 64 tiles 8-15 us)
+  const long area = (long)M * N * (N <= 128 ? 1 : batch);
   if (allow_small && ((area <= 256L * 256L && K <= 1024) || (area <= small_max && (M > 64 || sym))))
     return {64, 64, 64};
   if (!sym && M <= 32) return {32, 256, 16};
