@@ -684,6 +684,47 @@ def test_cholesky_inverse(hip, n):
         assert torch.equal(got, got.T)
 
 
+def test_cholesky_pipeline_orders_and_repeatability(hip):
+    """Orders >= 1536 run the pipelined factorisation + inverse (look-ahead on the caller's stream, trailing updates and
+    the triangular inverse on a helper stream; reference `kronecker.py:328-373`): block-aligned and ragged orders, single,
+    batched and operator-level (worker threads) -- residual against float64 and run-to-run bit equality (a race between
+    the streams would show up as differing results)."""
+    from curvlinops_amd import linalg_native
+
+    g = torch.Generator().manual_seed(11)
+
+    def spd(n):
+        X = torch.randn(n + 64, n, generator=g).cuda()
+        return X.T @ X / (n + 64)
+
+    def residual(A, X, d):
+        R = (A.double() + d * torch.eye(A.shape[0], dtype=torch.float64, device=A.device)) @ X.double()
+        R.diagonal().sub_(1.0)
+        return float(R.abs().max())
+
+    for n in (1536, 1537, 2052):
+        A = spd(n)
+        X1, X2 = hip.cholesky_inverse(A, 1e-3), hip.cholesky_inverse(A, 1e-3)
+        assert torch.equal(X1, X2) and residual(A, X1, 1e-3) < 5e-4
+    mats = [spd(1664) for _ in range(3)]
+    outs, outs2 = [torch.empty_like(m) for m in mats], [torch.empty_like(m) for m in mats]
+    status = torch.zeros(3, device="cuda", dtype=torch.int32)
+    damps = [1e-3, 2e-3, 5e-4]
+    hip.cholesky_inverse_batched_into(mats, damps, outs, status)
+    hip.cholesky_inverse_batched_into(mats, damps, outs2, status)
+    assert int(status.abs().sum()) == 0
+    for A, X, X2, d in zip(mats, outs, outs2, damps):
+        assert torch.equal(X, X2) and residual(A, X, d) < 5e-4
+    mix = [spd(n) for n in (1600, 1600, 1153, 577, 2305, 64, 129)]
+    res = []
+    for _ in range(2):
+        with linalg_native.concurrent_inverses():
+            res.append([linalg_native.damped_cholesky_inverse(A, 1e-3) for A in mix])
+    torch.cuda.synchronize()
+    for A, X, X2 in zip(mix, *res):
+        assert torch.equal(X, X2) and residual(A, X, 1e-3) < 5e-4
+
+
 def test_cholesky_inverse_not_pd_raises(hip):
     A = torch.eye(70)
     A[40, 40] = -1.0
