@@ -562,6 +562,7 @@ static CholAsync *chol_async_acquire(int *dev_out) {
   // dispatched ahead of the bulk products queued here
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (getenv("CLO_CHOL_HELPER_PRIO")) least = atoi(getenv("CLO_CHOL_HELPER_PRIO"));
   // ONE helper stream for the trailing updates and the inverse (three were measured first: HIP streams share a handful of
   // hardware queues, and when two helpers land on the same queue the trailing update the main stream is about to need waits
   // behind an inverse product that waits for a later node -- 4 x 2305: 2.5 ms alone, 5.2 ms after another call had shifted
