@@ -28,3 +28,18 @@ def test_argument_validation_without_gpu():
     assert lib.clo_gemm_suggest_splitk(128, 128, 64, 1) == 1
     assert lib.clo_gemm_suggest_splitk(27, 27, 500000, 1) > 1
     assert lib.clo_mlp_bwd_ws_floats(8, 2688, 2688) > 0
+
+
+def test_kmajor_layout_predicate():
+    """`canonical.is_kmajor`: the stride signature by which the canonical converters and the Kronecker blocks recognise a
+    `[n, K]` view of a contiguous `[K, n]` array (host logic of the fused pack / unpack, no GPU needed)."""
+    import torch
+
+    from curvlinops_amd.canonical import is_kmajor
+
+    assert is_kmajor(torch.empty(5, 12).T)                    # [12, 5] view of [5, 12]
+    assert not is_kmajor(torch.empty(12, 5))                  # plain K-trailing
+    assert not is_kmajor(torch.empty(12, 1))                  # single vectors are never K-major
+    assert not is_kmajor(torch.empty(1, 12).T[:, :1])
+    assert not is_kmajor(torch.empty(5, 24).T[::2])           # strided rows
+    assert not is_kmajor(torch.empty(3, 4, 5))
