@@ -107,37 +107,44 @@ __global__ __launch_bounds__(256) void canonical_tr_kernel(float *__restrict__ k
     const long e0 = (t / tiles_k) * CP_TR, k0 = (t % tiles_k) * CP_KC;
     const int kc = (int)min((long)CP_KC, K - k0), ne = (int)min((long)CP_TR, nv - e0);
     // parameter side: idx -> (entry, k), k fastest
-    // (32-bit index arithmetic inside the tile: the 64-bit divisions happen once per tile)
+    // (32-bit index arithmetic inside the tile: the 64-bit divisions happen once per tile; a power-of-two column count
+    // splits by shift, and with >= 128 canonical columns a tile crosses at most one row boundary)
     const long r0 = e0 / bc;
     const unsigned c0 = (unsigned)(e0 - r0 * bc), ubc = (unsigned)min(bc, 0x7fffffffL), ukc = (unsigned)kc;
-    auto param_ptr = [&](int idx) -> float * {
-      const unsigned el = (unsigned)idx / ukc, k = (unsigned)idx - el * ukc;
+    const int kshift = (ukc & (ukc - 1)) == 0 ? __builtin_ctz(ukc) : -1;
+    auto split = [&](int idx, unsigned &el, unsigned &k) {
+      if (kshift >= 0) { el = (unsigned)idx >> kshift; k = (unsigned)idx & (ukc - 1); }
+      else { el = (unsigned)idx / ukc; k = (unsigned)idx - el * ukc; }
+    };
+    auto param_ptr = [&](unsigned el, unsigned k) -> float * {
       if (!bias) return w + (e0 + el) * K + k0 + k;
-      const unsigned cc = c0 + el, dr = cc / ubc, c = cc - dr * ubc;
+      const unsigned cc = c0 + el, dr = ubc >= CP_TR ? (cc >= ubc ? 1u : 0u) : cc / ubc, c = cc - dr * ubc;
       const long r = r0 + dr;
       return (c < bw ? w + (r * bw + c) * K : bias + r * K) + k0 + k;
     };
     if (PACK) {
-      for (int idx = threadIdx.x; idx < ne * kc; idx += 256) {
-        const unsigned el = (unsigned)idx / ukc, k = (unsigned)idx - el * ukc;
-        tile[k][el] = *param_ptr(idx);
+      _Pragma("unroll 8") for (int idx = threadIdx.x; idx < ne * kc; idx += 256) {
+        unsigned el, k;
+        split(idx, el, k);
+        tile[k][el] = *param_ptr(el, k);
       }
     } else {
-      for (int idx = threadIdx.x; idx < kc * CP_TR; idx += 256) {
+      _Pragma("unroll 8") for (int idx = threadIdx.x; idx < kc * CP_TR; idx += 256) {
         const int k = idx / CP_TR, el = idx - k * CP_TR;
         if (el < ne) tile[k][el] = kmaj[(k0 + k) * nv + e0 + el];
       }
     }
     __syncthreads();
     if (PACK) {
-      for (int idx = threadIdx.x; idx < kc * CP_TR; idx += 256) {
+      _Pragma("unroll 8") for (int idx = threadIdx.x; idx < kc * CP_TR; idx += 256) {
         const int k = idx / CP_TR, el = idx - k * CP_TR;
         if (el < ne) kmaj[(k0 + k) * nv + e0 + el] = tile[k][el];
       }
     } else {
-      for (int idx = threadIdx.x; idx < ne * kc; idx += 256) {
-        const unsigned el = (unsigned)idx / ukc, k = (unsigned)idx - el * ukc;
-        *param_ptr(idx) = tile[k][el];
+      _Pragma("unroll 8") for (int idx = threadIdx.x; idx < ne * kc; idx += 256) {
+        unsigned el, k;
+        split(idx, el, k);
+        *param_ptr(el, k) = tile[k][el];
       }
     }
     __syncthreads();
