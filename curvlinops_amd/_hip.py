@@ -85,7 +85,7 @@ _SIGNATURES = {
         c_int,
         [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
          POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _PF, c_int,
-         c_int, _PF, c_int, c_float, c_float, c_float, _PF, c_void_p],
+         c_int, _PF, c_int, c_float, c_float, c_float, c_int, _PF, c_void_p],
     ),
     "clo_mlp_ggn_ws_floats": (c_long, [c_int, POINTER(c_int), c_int]),
     "clo_mlp_ggn_ws_init": (c_int, [c_int, POINTER(c_int), c_int, _PF, c_void_p]),
@@ -528,10 +528,17 @@ def mlp_bwd_layer(W, delta, a_prev, dphi_prev, out_W, out_b, alpha: float, beta:
     return dprev
 
 
+MLP_DEFAULT, MLP_NO_PERSISTENT = 0, 1  # CLO_MLP_* flags of clo_mlp_ggn_matvec
+
+
 class MLPPlan:
-    """Pre-marshalled argument tables for ``clo_mlp_ggn_matvec`` (one per operator)."""
+    """Pre-marshalled argument tables for ``clo_mlp_ggn_matvec`` (one per operator).
+
+    ``flags`` (``MLP_*``) is the kernel choice handed to every single-vector product of this plan: an
+    argument of the C call, owned by the operator that owns the plan -- not process state."""
 
     def __init__(self, dims: list[int], acts: list[int]):
+        self.flags = MLP_DEFAULT
         self.L = len(acts)
         self.dims = (c_int * (self.L + 1))(*dims)
         self.acts = (c_int * self.L)(*acts)
@@ -585,7 +592,7 @@ class MLPPlan:
                 Vb[l] = v_base + b_off[l]
                 Ob[l] = o_base + b_off[l]
         rc = self._fn(self.L, self.dims, self.acts, self._W_arr, self._b_arr, VW, Vb, OW, Ob, X_ptr, N,
-                      loss_kind, aux_ptr, aux_rank, loss_scale, alpha, beta, ws_ptr, stream)
+                      loss_kind, aux_ptr, aux_rank, loss_scale, alpha, beta, self.flags, ws_ptr, stream)
         if rc != 0:
             _check(rc, "clo_mlp_ggn_matvec")
 
@@ -706,7 +713,7 @@ class MLPPlan:
         rc = lib.clo_mlp_ggn_matvec(
             self.L, self.dims, self.acts, self._ptr_array(W), self._ptr_array(b),
             self._ptr_array(VW), self._ptr_array(Vb), self._ptr_array(OW), self._ptr_array(Ob),
-            _pc(X), N, loss_kind, _pc(aux), rank, loss_scale, alpha, beta,
+            _pc(X), N, loss_kind, _pc(aux), rank, loss_scale, alpha, beta, self.flags,
             _pc(self.workspace(N, X.device)), _stream(),
         )
         _check(rc, "clo_mlp_ggn_matvec")

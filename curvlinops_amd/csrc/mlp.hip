@@ -2545,17 +2545,13 @@ static int launch_loss(int kind, const float *f, const float *aux, int aux_rank,
 }
 
 // mlp_mega.hip: the <= 8-row matvec of a three-layer net in one persistent launch
-#ifndef CLO_MEGA_DEFAULT_MODE
-#define CLO_MEGA_DEFAULT_MODE 1
-#endif
 bool mega_shape_ok(int L, const int *dims, int N);
 bool mega_ok(int L, const int *dims, const float *const *W, const float *const *VW, float *const *OW,
-             const float *X, int N);
+             const float *X, int N, int loss_kind, int aux_rank);
 int mega_launch(const int *dims, const int *acts, const float *const *W, const float *const *b,
                 const float *const *VW, const float *const *Vb, float *const *OW, float *const *Ob,
                 const float *X, int N, int loss_kind, const float *aux, int aux_rank, float scale,
-                float beta, float *xch, unsigned *sync, hipStream_t st, const float *a1g = nullptr,
-                const float *da1g = nullptr, const float *dphi1g = nullptr);
+                float beta, float *xch, unsigned *sync, hipStream_t st);
 long mega_xch_floats(int d1, int d2);
 long mega_sync_words();
 long mega_debug_floats();
@@ -2919,10 +2915,11 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
                                   const float *const *b, const float *const *VW,
                                   const float *const *Vb, float *const *OW, float *const *Ob,
                                   const float *X, int N, int loss_kind, const float *aux,
-                                  int aux_rank, float loss_scale, float alpha, float beta,
+                                  int aux_rank, float loss_scale, float alpha, float beta, int flags,
                                   float *ws, void *stream) {
   CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW,
               "clo_mlp_ggn_matvec: bad layer table");
+  CLO_REQUIRE((flags & ~1) == 0, "clo_mlp_ggn_matvec: unknown flags 0x%x", flags);
   CLO_REQUIRE(N >= 0 && X && ws, "clo_mlp_ggn_matvec: bad batch / workspace");
   CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_ggn_matvec: unknown loss kind %d",
               loss_kind);
@@ -2980,19 +2977,9 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
   const int Lf = narrow ? L - 1 : L;  // layers run by the generic forward loop
   float *hp = nullptr;
   int head_nblk = 0;
-  if (head && mega_ok(L, dims, W, VW, OW, X, N)) {
+  if (head && !(flags & CLO_MLP_NO_PERSISTENT) && mega_ok(L, dims, W, VW, OW, X, N, loss_kind, aux_rank)) {
     float *xch = ws + ggn_ws_mega_offset(L, dims, N);
     unsigned *sync = reinterpret_cast<unsigned *>(xch + cdiv(mega_xch_floats(dims[1], dims[2]), 64) * 64);
-    // CLO_MLP_MEGA=2: layer 1 as its own launch (no first seam inside the persistent kernel); 1: everything fused
-    const char *em = getenv("CLO_MLP_MEGA");
-    const int mode = em ? atoi(em) : CLO_MEGA_DEFAULT_MODE;
-    if (mode == 2 && vec_ok(dims[0], {W[0], VW[0], X})) {
-      rc = fwd_pass(W[0], b ? b[0] : nullptr, VW[0], Vb ? Vb[0] : nullptr, X, nullptr, a[1], da[1], dphi[1], N,
-                    dims[0], dims[1], acts[0], part, false, nullptr, st);
-      if (rc != CLO_OK) return rc;
-      return mega_launch(dims, acts, W, b, VW, Vb, OW, Ob, X, N, loss_kind, aux, aux_rank, loss_scale * alpha, beta,
-                         xch, sync, st, a[1], da[1], dphi[1]);
-    }
     return mega_launch(dims, acts, W, b, VW, Vb, OW, Ob, X, N, loss_kind, aux, aux_rank, loss_scale * alpha, beta,
                        xch, sync, st);
   }

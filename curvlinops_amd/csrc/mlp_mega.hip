@@ -48,12 +48,19 @@ constexpr int MG_P1S = 8;                // k16 steps per wave in layer 1 (d0 <=
 #ifndef CLO_MG_PRE
 #define CLO_MG_PRE 2
 #endif
-#ifndef CLO_MG_SPLIT
-#define CLO_MG_SPLIT 4
+#ifndef CLO_MG_PACE
+#define CLO_MG_PACE 3
+#endif
+#ifndef CLO_MG_XCD
+#define CLO_MG_XCD 1
 #endif
 constexpr int MG_PRE = CLO_MG_PRE;       // tile steps issued right behind the layer-1 loads
-constexpr int MG_SPLIT = CLO_MG_SPLIT;   // tile steps issued before the first seam (the rest follows it)
+// round 4: the compute waves keep requesting the layer-2 tile WHILE wave 7 runs the first seam, never
+// more than MG_PACE steps (3 KB per wave and step) ahead of what has landed: the vector-memory pipe of the CU stays busy
+// through the seam, and the seam's gather queues behind <= MG_PACE x 21 KB instead of behind the whole tile.
+constexpr int MG_PACE = CLO_MG_PACE;
 constexpr int MG_NB = 8, MG_CMAX = 16;
+constexpr int MG_MAXDEV = 64;            // device ordinals with per-device launch state
 constexpr unsigned MG_SPIN = 1u << 22;   // bound of every spin (each poll is a fabric round trip + s_sleep)
 
 // ---- LDS carve (floats)
@@ -71,8 +78,14 @@ constexpr int MG_M_U = 1280;     // [8][16] J v
 constexpr int MG_M_DL = 1408;    // [8][16] delta_3
 constexpr int MG_M_D1 = 1536;    // [16][8] delta_1 of the layer-1 slice
 constexpr int MG_M_FLAG = 1664;  // [4]
+constexpr int MG_M_B1 = 1696;    // [2][16] b1 / Vb1 of the layer-1 slice (requested before any weight)
+constexpr int MG_M_B2 = 1728;    // [2][16] b2 / Vb2 of the finished slice
+constexpr int MG_M_B3 = 1760;    // [2][16] b3 / Vb3
 constexpr int MG_M_TRASH = 1792;  // [64][4]
-constexpr int MG_LDS_FLOATS = MG_OFF_M + 2048;
+constexpr int MG_M_AUX = 2048;   // [N][aux_rank][C] backpropagated vectors of the rank-M curvature (<= MG_AUX_MAX floats)
+constexpr int MG_AUX_MAX = 1024;
+constexpr int MG_LDS_FLOATS = MG_OFF_M + 2048 + MG_AUX_MAX;
+static_assert(MG_LDS_FLOATS * 4 <= 160 * 1024, "LDS carve exceeds the CU");
 // phase-1 aliases inside the W2 tile area
 constexpr int MG_OFF_RED = MG_OFF_W;                     // [8 waves][2][4][64]
 constexpr int MG_OFF_XW = MG_OFF_W + 4096;               // [8 waves][8][16 MG_P1S + 4]  x slices
@@ -86,7 +99,6 @@ struct MegaArgs {
   const float *aux;
   int aux_rank;
   float scale, beta;
-  const float *a1g, *da1g, *dphi1g;   // L1 = false: outputs of the separate layer-1 launch
   float *xch;       // exchange area, see mega_xch_floats
   unsigned *sync;   // counters, see mega_sync_words
 };
@@ -104,11 +116,14 @@ long mega_xch_floats(int d1, int d2) { return mg_off_slab2(d1, d2) + 16L * MG_NB
 constexpr int MG_SET_LINES = 65;
 long mega_sync_words() { return 32L * (1 + 2 * MG_SET_LINES); }
 // -DCLO_MEGA_TIMING builds stamp wall_clock64() at 16 points per workgroup into the 8192 floats behind the counters
-long mega_debug_floats() { return 8192; }
+long mega_debug_floats() { return 16384; }
 #ifdef CLO_MEGA_TIMING
-#define MG_STAMP(i) do { if (tid == 0) reinterpret_cast<unsigned long long *>(sy + 32 * (1 + 2 * MG_SET_LINES))[w * 16 + (i)] = wall_clock64(); } while (0)
+#define MG_STAMP(i) do { if (tid == 0) reinterpret_cast<unsigned long long *>(sy + 32 * (1 + 2 * MG_SET_LINES))[w * 32 + (i)] = wall_clock64(); } while (0)
+// stamps 16..31: lane 0 of the exchange wave (wave 7)
+#define MG_STAMP7(i) do { if (lane == 0) reinterpret_cast<unsigned long long *>(sy + 32 * (1 + 2 * MG_SET_LINES))[w * 32 + (i)] = wall_clock64(); } while (0)
 #else
 #define MG_STAMP(i) do { } while (0)
+#define MG_STAMP7(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -143,9 +158,7 @@ __device__ __forceinline__ void mg_st4nt(float *p, const float4 &v) {
 }
 __device__ __forceinline__ float mg_and(float x, unsigned m) { return __uint_as_float(__float_as_uint(x) & m); }
 
-// L1 = false: layer 1 ran as its own launch before (fwd_mfma_first_kernel of mlp.hip); a1 / da1 / phi'1 are read from
-// p.a1g / p.da1g / p.dphi1g ([N][d1]) -- no first seam, and the whole layer-2 tile is requested at once.
-template <bool ACCUM, bool L1>
+template <bool ACCUM>
 __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_w = smem + MG_OFF_W, *s_b = smem + MG_OFF_B, *s_sl = smem + MG_OFF_SL, *s_d2 = smem + MG_OFF_D2;
@@ -155,12 +168,31 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int idx = lane & 15, s4 = (lane >> 4) * 4;
-  const int w = blockIdx.x, fb = w >> 4, kb = w & 15;
+  const int w = blockIdx.x;
   const int N = p.N, C = p.C, d0 = p.d0, d1 = p.d1, d2 = p.d2;
 
   // ---- geometry (all splits are balanced integer splits; see mega_ok for the bounds)
   const int S1 = d1 >> 4;
+#if CLO_MG_XCD
+  // Workgroup w runs on XCD w % 8 (observed, used for speed only): an XCD holds the two K ranges 2x, 2x + 1 for every
+  // feature block, so a column group (the 16 workgroups that exchange a1 / delta_1) shares one L2, and the K ranges
+  // are cut in PAIRS on 128-byte lines (a step = 64 B): only the cut inside a pair can fall in the middle of a
+  // line, and both halves of that line are fetched by the same XCD.
+  const int fb = w >> 4, kb = 2 * (w & 7) + ((w >> 3) & 1);
+  int ks0, ns;
+  if ((S1 & 1) == 0) {
+    const int P2 = S1 >> 1, pr = kb >> 1;
+    const int l0 = pr * P2 / 8, l1 = (pr + 1) * P2 / 8;               // 128-byte lines of the pair
+    ns = l1 - l0;                                                     // each half: (2 (l1 - l0)) / 2 steps
+    ks0 = 2 * l0 + (kb & 1) * ns;
+  } else {
+    ks0 = kb * S1 / 16;
+    ns = (kb + 1) * S1 / 16 - ks0;
+  }
+#else
+  const int fb = w >> 4, kb = w & 15;
   const int ks0 = kb * S1 / 16, ns = (kb + 1) * S1 / 16 - ks0;          // k16 steps of the K range
+#endif
   const int k0 = ks0 * 16, kr = ns * 16;
   const int G2 = d2 >> 3;
   const int g0 = fb * G2 / 16, ng = (fb + 1) * G2 / 16 - g0;            // feature groups of the block
@@ -191,9 +223,11 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   const long o_slab2 = mg_off_slab2(d1, d2);
 
   // =====================================================================================
-  // issue phase.  A CU's vector-memory pipe delivers in ISSUE order at ~22 GB/s, so whatever must arrive
-  // early is issued early: x fragments and layer-1 weights first, then only the first MG_SPLIT steps of the
-  // layer-2 tile -- the rest follows behind the first seam, whose gather loads must not queue behind 226 KB.
+  // issue phase.  A CU's vector-memory pipe delivers in ISSUE order (~22-28 GB/s), so whatever must arrive early is
+  // issued early: the small operands of the later phases (wave 7), x fragments and layer-1 weights, then only MG_PRE
+  // steps of the layer-2 tile; the rest of the tile is requested at a bounded depth while the first seam runs.
+  // Every load that sits on a dependency chain is UNCONDITIONAL (clamped address + select): a predicated load makes
+  // hipcc branch and wait for vmcnt(0) right behind it, which serialises the round trips.
   // =====================================================================================
   const int kpw = (int)(((d0 + 7) / 8 + 15) / 16) * 16;       // K range of a wave in layer 1
   const int kb0 = min(wave * kpw, d0);
@@ -203,15 +237,39 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   float *s_xw = smem + MG_OFF_XW + wave * (MG_NB * (16 * MG_P1S + 4));
   const int xq = kpw >> 2;  // float4 per row
   float4 xv[MG_P1S / 2], a1v[MG_P1S][2];
-  if constexpr (L1) {
+  // wave 7: b1 / Vb1 / b2 / Vb2 of the two slices, b3 / Vb3, W3 / V3 columns of the finished slice (2.3 KB, in flight
+  // before any weight of this CU; parked in registers until the layer-1 MFMAs are done)
+  float bpre[3] = {0.f, 0.f, 0.f}, w3pre[8];
+  if (wave == MG_CWAVES) {
+    const int f = lane & 15;
+    const float *bsrc[3] = {lane < 16 ? p.b1 : p.Vb1, lane < 16 ? p.b2 : p.Vb2, lane < 16 ? p.b3 : p.Vb3};
+    const int bidx[3] = {jA + f, jF + f, f};
+    const bool bok[3] = {f < nf1, f < nf2, f < C};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bool ok = bsrc[i] != nullptr && bok[i] && lane < 32;
+      const float *src = ok ? bsrc[i] + bidx[i] : p.W3;
+      const float v = *src;
+      bpre[i] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = i * 64 + lane, c = (e >> 4) & 15;
+      const bool ok = c < C && f < nf2;
+      const float *src = (e >> 8) ? p.V3 : p.W3;
+      const float v = src[ok ? (long)c * d2 + jF + f : 0];
+      w3pre[i] = ok ? v : 0.f;
+    }
+  }
+  {
     const float *pA1[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int row = max(0, min(jA + g * 8 + (idx & 7), jlast1));   // an empty slice (nf1 == 0) loads valid dummies
       pA1[g] = ((idx >= 8) ? p.V1 : p.W1) + (long)row * d0 + kbs + s4;
     }
-    // B of layer 1 = x[:, K range of the wave]: loaded once per wave with linear 16-byte loads (issued FIRST), kept
-    // in a private LDS slice [8][kpw + 4] (rows >= N and columns beyond the range zero)
+    // B of layer 1 = x[:, K range of the wave]: loaded once per wave with linear 16-byte loads, kept in a private
+    // LDS slice [8][kpw + 4] (rows >= N and columns beyond the range zero)
 #pragma unroll
     for (int i = 0; i < MG_P1S / 2; ++i) {
       const int e = i * 64 + lane, n = e / xq, c4 = (e - n * xq) * 4;
@@ -225,16 +283,8 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       for (int g = 0; g < 2; ++g) a1v[s][g] = mg_ld4(pA1[g] + (ok ? s * 16 : 0));
     }
   }
-  if (wave == MG_CWAVES) {  // W3 / V3 columns of the finished slice -> LDS (needed in phase 3)
-    for (int e = lane; e < 2 * MG_CMAX * 16; e += 64) {
-      const int which = e >> 8, c = (e >> 4) & 15, f = e & 15;
-      float v = 0.f;
-      if (c < C && f < nf2) v = (which ? p.V3 : p.W3)[(long)c * d2 + jF + f];
-      s_m[MG_M_W3 + e] = v;
-    }
-  }
   // layer-2 tile: fragments [W rows ; V rows] of this wave's feature groups, step-major issue order; only
-  // MG_PRE steps now (they cover the latency gap behind layer 1), the next ones behind the layer-1 MFMAs
+  // MG_PRE steps now (they cover the latency gap behind layer 1)
   float4 tv[MG_MAXS][MG_MAXG];
   const float *pA2[MG_MAXG];
 #pragma unroll
@@ -243,44 +293,27 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     const int row = j0 + gl * 8 + (idx & 7);
     pA2[g] = ((idx >= 8) ? p.V2 : p.W2) + (long)row * d1 + k0 + s4;
   }
-  if (!L1 && wave == MG_CWAVES) {
-    // [a1 ; da1] of the K range and phi'1 of the layer-1 slice from the separate launch (requested BEFORE the tile)
-    const int q4 = kr >> 2;
-    for (int e = lane; e < 16 * q4; e += 64) {
-      const int c = e / q4, kk = (e - c * q4) * 4, n = c & 7;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N) v = mg_ld4((c < 8 ? p.a1g : p.da1g) + (long)n * d1 + k0 + kk);
-      *reinterpret_cast<float4 *>(&s_b[c * MG_LDB + kk]) = v;
-    }
-    for (int e = lane; e < MG_NB * 16; e += 64) {
-      const int n = e >> 4, f = e & 15;
-      s_m[MG_M_PHI1 + e] = (n < N && f < nf1) ? p.dphi1g[(long)n * d1 + jA + f] : 0.f;
-    }
-  }
   if (wave < MG_CWAVES) {
 #pragma unroll
-    for (int s = 0; s < (L1 ? MG_PRE : MG_MAXS); ++s) {
+    for (int s = 0; s < MG_PRE; ++s) {
       if (s < ns) {
 #pragma unroll
         for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
       }
     }
   }
-  if constexpr (L1) {
 #pragma unroll
-    for (int i = 0; i < MG_P1S / 2; ++i) {
-      const int e = i * 64 + lane, n = e / xq, c4 = (e - n * xq) * 4;
-      if (n < MG_NB) {
-        const bool ok = n < N && c4 < klen;
-        *reinterpret_cast<float4 *>(&s_xw[n * (16 * MG_P1S + 4) + c4]) = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+  for (int i = 0; i < MG_P1S / 2; ++i) {
+    const int e = i * 64 + lane, n = e / xq, c4 = (e - n * xq) * 4;
+    if (n < MG_NB) {
+      const bool ok = n < N && c4 < klen;
+      *reinterpret_cast<float4 *>(&s_xw[n * (16 * MG_P1S + 4) + c4]) = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
   MG_STAMP(1);
 
-  if constexpr (L1) {
   // =====================================================================================
   // phase 1: layer 1 for features [jA, jA + nf1): in-block split-K over the 8 waves
   // =====================================================================================
@@ -302,69 +335,98 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[s][g].w, bw, acc[g], 0, 0, 0);
       }
     }
-    // layer-1 data has landed: the next tile steps go out now (they drain while the first seam runs)
-    if (wave < MG_CWAVES) {
 #pragma unroll
-      for (int s = MG_PRE; s < MG_SPLIT; ++s) {
-        if (s < ns) {
-#pragma unroll
-          for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
-        }
+    for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4 *>(&s_red[((wave * 2 + g) * 64 + lane) * 4]) = acc[g];
+    if (wave == MG_CWAVES) {  // park the small operands (their loads were the wave's first: they have landed)
+      if (lane < 32) {
+        s_m[MG_M_B1 + lane] = bpre[0];
+        s_m[MG_M_B2 + lane] = bpre[1];
+        s_m[MG_M_B3 + lane] = bpre[2];
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s_m[MG_M_W3 + i * 64 + lane] = w3pre[i];
     }
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_red[((wave * 2 + g) * 4 + r) * 64 + lane] = acc[g][r];
   }
   wg_barrier();
   MG_STAMP(2);
-  if (wave < 2) {
-    const int g = wave, q = lane >> 4, col = lane & 15;
+  // ---- waves 0..6: paced requests of the rest of the tile (never more than MG_PACE steps beyond what has landed);
+  //      wave 7: merge of the eight K parts, epilogue of layer 1 and column-group seam A
+  if (wave < MG_CWAVES) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = 0.f;
+    for (int s = MG_PRE; s < MG_MAXS; ++s) {
+      if (s < ns) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (MG_PACE - 1)) : "memory");
 #pragma unroll
-      for (int wv = 0; wv < 8; ++wv) v += s_red[((wv * 2 + g) * 4 + r) * 64 + lane];
-      const float up = __shfl(v, (lane + 24) & 63, 64);    // D[8+i][n] = V1 x
-      const float zsrc = __shfl(v, (lane + 56) & 63, 64);  // D[i][n]   = W1 x
-      if (q < 2 && col >= 8) {
-        const int n = col - 8, f = g * 8 + q * 4 + r, j = jA + f;
-        float aval = 0.f, daval = 0.f, dphi = 0.f;
-        if (f < nf1) {
-          aval = act_apply(p.act1, zsrc + (p.b1 ? p.b1[j] : 0.f), dphi);
-          daval = dphi * (up + (p.Vb1 ? p.Vb1[j] : 0.f));
-        }
-        s_m[MG_M_PUB + n * 16 + f] = aval;
-        s_m[MG_M_PUB + 128 + n * 16 + f] = daval;
-        s_m[MG_M_PHI1 + n * 16 + f] = dphi;
+        for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
       }
     }
-  }
-  wg_barrier();
-  MG_STAMP(3);
-  // ---- column-group seam A (wave 7): publish the slice, gather [a1 ; da1] of the K range into s_b
-  if (wave == MG_CWAVES) {
+    MG_STAMP(3);
+  } else {
+    __builtin_amdgcn_s_setprio(3);
+    MG_STAMP7(16);
+    const int q = lane >> 4, col = lane & 15;
+    f32x4 mv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      mv[g] = *reinterpret_cast<const f32x4 *>(&s_red[(g * 64 + lane) * 4]);
+#pragma unroll
+      for (int wv = 1; wv < 8; ++wv) mv[g] += *reinterpret_cast<const f32x4 *>(&s_red[((wv * 2 + g) * 64 + lane) * 4]);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = mv[g][r];
+        const float up = __shfl(v, (lane + 24) & 63, 64);    // D[8+i][n] = V1 x
+        const float zsrc = __shfl(v, (lane + 56) & 63, 64);  // D[i][n]   = W1 x
+        if (q < 2 && col >= 8) {
+          const int n = col - 8, f = g * 8 + q * 4 + r;
+          float aval = 0.f, daval = 0.f, dphi = 0.f;
+          if (f < nf1) {
+            aval = act_apply(p.act1, zsrc + s_m[MG_M_B1 + f], dphi);
+            daval = dphi * (up + s_m[MG_M_B1 + 16 + f]);
+          }
+          s_m[MG_M_PUB + n * 16 + f] = aval;
+          s_m[MG_M_PUB + 128 + n * 16 + f] = daval;
+          s_m[MG_M_PHI1 + n * 16 + f] = dphi;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    MG_STAMP7(17);
     const int nq = nf1 >> 2;
     for (int e = lane; e < 2 * MG_NB * nq; e += 64) {
-      const int which = e / (MG_NB * nq), n = (e / nq) % MG_NB, q = e % nq;
-      const float *src = &s_m[MG_M_PUB + which * 128 + n * 16 + q * 4];
-      st_x(rs, (which ? o_da1 : o_a1) + (long)n * d1 + jA + q * 4, f32x4{src[0], src[1], src[2], src[3]});
+      const int which = e / (MG_NB * nq), n = (e / nq) % MG_NB, q2 = e % nq;
+      const float *src = &s_m[MG_M_PUB + which * 128 + n * 16 + q2 * 4];
+      st_x(rs, (which ? o_da1 : o_a1) + (long)n * d1 + jA + q2 * 4, f32x4{src[0], src[1], src[2], src[3]});
     }
     drain_vm();
+    MG_STAMP7(18);
     if (lane == 0) {
       mg_arrive(c_colA);
       mg_wait(c_colA, 16u, c_err);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    const int q4 = kr >> 2;
-    for (int e = lane; e < 16 * q4; e += 64) {
-      const int c = e / q4, kk = (e - c * q4) * 4;
-      const f32x4 v = ld_x(rs, (c < 8 ? o_a1 : o_da1) + (long)(c & 7) * d1 + k0 + kk);
-      *reinterpret_cast<f32x4 *>(&s_b[c * MG_LDB + kk]) = v;
+    MG_STAMP7(19);
+    // gather [a1 ; da1] of the K range: all (<= 11) loads of a lane in flight at once
+    {
+      const int q4 = kr >> 2, tot = 16 * q4;
+      f32x4 gv[MG_MAXS];
+      int gdst[MG_MAXS];
+#pragma unroll
+      for (int i = 0; i < MG_MAXS; ++i) {
+        const int e = min(i * 64 + lane, tot - 1);
+        const int c = e / q4, kk = (e - c * q4) * 4;
+        gv[i] = ld_x(rs, (c < 8 ? o_a1 : o_da1) + (long)(c & 7) * d1 + k0 + kk);
+        gdst[i] = c * MG_LDB + kk;
+      }
+#pragma unroll
+      for (int i = 0; i < MG_MAXS; ++i) *reinterpret_cast<f32x4 *>(&s_b[gdst[i]]) = gv[i];  // clamped duplicates rewrite equal data
     }
-  }
+    MG_STAMP7(20);
+    __builtin_amdgcn_s_setprio(0);
   }
   wg_barrier();
   MG_STAMP(4);
@@ -373,16 +435,6 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   // phase 2: partial z2 / dz2 of the tile; W fragments go to LDS for the backward pass
   // =====================================================================================
   if (wave < MG_CWAVES) {
-    // the rest of the tile (its loads queue behind nothing but the first part now)
-    if constexpr (L1) {
-#pragma unroll
-      for (int s = MG_SPLIT; s < MG_MAXS; ++s) {
-        if (s < ns) {
-#pragma unroll
-          for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
-        }
-      }
-    }
     f32x4 acc[MG_MAXG];
 #pragma unroll
     for (int g = 0; g < MG_MAXG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -432,7 +484,16 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       const float *src = &s_sl[wn * MG_NJ + q * 4];
       st_x(rs, o_slab + ((long)kb * 16 + wn) * d2 + j0 + q * 4, f32x4{src[0], src[1], src[2], src[3]});
     }
+    // rank-M curvature: the backpropagated vectors (<= 4 KB) travel to LDS while the slabs are acknowledged
+    const int naux = p.kind == CLO_LOSS_RANK1 ? N * p.aux_rank * C : 0;   // <= MG_AUX_MAX (mega_ok)
+    const float *abase = naux ? p.aux : p.W3;
+    float auxv[MG_AUX_MAX / MG_T];
+#pragma unroll
+    for (int i = 0; i < MG_AUX_MAX / MG_T; ++i) auxv[i] = abase[i * MG_T + tid < naux ? i * MG_T + tid : 0];
     drain_vm();
+#pragma unroll
+    for (int i = 0; i < MG_AUX_MAX / MG_T; ++i)
+      if (i * MG_T + tid < naux) s_m[MG_M_AUX + i * MG_T + tid] = auxv[i];
     wg_barrier();
     if (tid == 0) {
       mg_arrive(c_rowA);
@@ -464,9 +525,8 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       const int n = tid >> 4, f = tid & 15;
       float aval = 0.f, daval = 0.f, dphi = 0.f;
       if (f < nf2) {
-        const int j = jF + f;
-        aval = act_apply(p.act2, s_sl[n * 16 + f] + (p.b2 ? p.b2[j] : 0.f), dphi);
-        daval = dphi * (s_sl[(MG_NB + n) * 16 + f] + (p.Vb2 ? p.Vb2[j] : 0.f));
+        aval = act_apply(p.act2, s_sl[n * 16 + f] + s_m[MG_M_B2 + f], dphi);
+        daval = dphi * (s_sl[(MG_NB + n) * 16 + f] + s_m[MG_M_B2 + 16 + f]);
       }
       s_m[MG_M_FIN + n * 16 + f] = aval;
       s_m[MG_M_FIN + 128 + n * 16 + f] = daval;
@@ -544,10 +604,10 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
 #pragma unroll
       for (int k = 1; k < 16; ++k) sacc += t[k];
       const int which = tid >> 5, n = (tid >> 2) & 7, c4 = (tid & 3) * 4;
-      const float *bias = which ? p.Vb3 : p.b3;
+      const float *bias = &s_m[MG_M_B3 + which * 16 + c4];   // zero beyond C and for absent biases
       float *dst = &s_m[(which ? MG_M_U : MG_M_F) + n * 16 + c4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i] = sacc[i] + ((bias && c4 + i < C) ? bias[c4 + i] : 0.f);
+      for (int i = 0; i < 4; ++i) dst[i] = sacc[i] + bias[i];
     }
     wg_barrier();
     if (tid < MG_NB) {  // loss Hessian per sample (as head_bwd_kernel of mlp.hip)
@@ -576,7 +636,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
           for (int c = 0; c < C; ++c) dl[c] = p.scale * (__expf(fn[c] - mx) * inv) * (un[c] - pu);
         } else {
           for (int m = 0; m < p.aux_rank; ++m) {
-            const float *g = p.aux + ((long)n * p.aux_rank + m) * C;
+            const float *g = &s_m[MG_M_AUX + (n * p.aux_rank + m) * C];
             float sdot = 0.f;
             for (int c = 0; c < C; ++c) sdot += g[c] * un[c];
             for (int c = 0; c < C; ++c) dl[c] += p.scale * g[c] * sdot;
@@ -775,29 +835,31 @@ bool mega_shape_ok(int L, const int *dims, int N) {
 }
 
 bool mega_ok(int L, const int *dims, const float *const *W, const float *const *VW, float *const *OW,
-             const float *X, int N) {
-  // CLO_MLP_MEGA: 0 = off, 1 (default) = on where the shapes qualify; read per call (A/B runs, tests)
-  const char *e = getenv("CLO_MLP_MEGA");
-  if (e && atoi(e) == 0) return false;
+             const float *X, int N, int loss_kind, int aux_rank) {
   if (!mega_shape_ok(L, dims, N)) return false;
+  if (loss_kind == CLO_LOSS_RANK1 && (long)N * aux_rank * dims[3] > MG_AUX_MAX) return false;  // staged in LDS
   for (int l = 0; l < 3; ++l)
     if (!aligned16(W[l]) || !aligned16(VW[l]) || !aligned16(OW[l])) return false;
   if (!aligned16(X)) return false;
-  static int ncu = -1;
-  if (ncu < 0) {
-    int dev = 0;
+  static int ncu[MG_MAXDEV];  // per device (a process may drive several GPUs)
+  static std::once_flag once;
+  std::call_once(once, [] { for (int &c : ncu) c = -1; });
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAXDEV) return false;
+  int c = __atomic_load_n(&ncu[dev], __ATOMIC_RELAXED);
+  if (c < 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-    ncu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    c = prop.multiProcessorCount;
+    __atomic_store_n(&ncu[dev], c, __ATOMIC_RELAXED);
   }
-  return ncu == MG_G;  // one workgroup per CU, all of them resident: the group counters rely on it
+  return c == MG_G;  // one workgroup per CU, all of them resident: the group counters rely on it
 }
 
 int mega_launch(const int *dims, const int *acts, const float *const *W, const float *const *b,
                 const float *const *VW, const float *const *Vb, float *const *OW, float *const *Ob,
                 const float *X, int N, int loss_kind, const float *aux, int aux_rank, float scale,
-                float beta, float *xch, unsigned *sync, hipStream_t st, const float *a1g, const float *da1g,
-                const float *dphi1g) {
+                float beta, float *xch, unsigned *sync, hipStream_t st) {
   MegaArgs a{};
   a.W1 = W[0]; a.V1 = VW[0]; a.W2 = W[1]; a.V2 = VW[1]; a.W3 = W[2]; a.V3 = VW[2];
   a.b1 = b ? b[0] : nullptr; a.b2 = b ? b[1] : nullptr; a.b3 = b ? b[2] : nullptr;
@@ -808,29 +870,29 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
   a.act1 = acts[0]; a.act2 = acts[1];
   a.kind = loss_kind; a.aux = aux; a.aux_rank = aux_rank; a.scale = scale; a.beta = beta;
   a.xch = xch; a.sync = sync;
-  a.a1g = a1g; a.da1g = da1g; a.dphi1g = dphi1g;
   const size_t smem = (size_t)MG_LDS_FLOATS * sizeof(float);
-  static bool attr_done[4] = {false, false, false, false};
-  const int v = (beta != 0.f ? 1 : 0) + (a1g ? 2 : 0);
-  const void *fns[4] = {reinterpret_cast<const void *>(mlp_mega_kernel<false, true>),
-                        reinterpret_cast<const void *>(mlp_mega_kernel<true, true>),
-                        reinterpret_cast<const void *>(mlp_mega_kernel<false, false>),
-                        reinterpret_cast<const void *>(mlp_mega_kernel<true, false>)};
-  if (!attr_done[v]) {
-    int rc = check_hip(hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
-                       "hipFuncSetAttribute(mlp_mega_kernel)");
-    if (rc != CLO_OK) return rc;
-    attr_done[v] = true;
-  }
+  static bool attr_done[MG_MAXDEV][2];  // hipFuncSetAttribute is per device; guarded by `mu` below
+  const int v = beta != 0.f ? 1 : 0;
+  const void *fns[2] = {reinterpret_cast<const void *>(mlp_mega_kernel<false>),
+                        reinterpret_cast<const void *>(mlp_mega_kernel<true>)};
   // Two of these grids must never share the chip (each needs every CU: half-resident grids would wait for
   // each other).  One stream orders its launches by itself; as soon as a second stream shows up on a device,
   // every launch waits for the previous one's event and records its own.
   struct Chain { hipStream_t last = nullptr; bool multi = false, any = false; hipEvent_t ev = nullptr; };
   static std::mutex mu;
-  static Chain chains[16];
+  static Chain chains[MG_MAXDEV];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAXDEV) {
+    set_error("mlp_mega_kernel: device ordinal %d out of range", dev);
+    return CLO_EINVAL;
+  }
   std::lock_guard<std::mutex> lock(mu);
+  if (!attr_done[dev][v]) {
+    int rc = check_hip(hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
+                       "hipFuncSetAttribute(mlp_mega_kernel)");
+    if (rc != CLO_OK) return rc;
+    attr_done[dev][v] = true;
+  }
   Chain &c = chains[dev];
   if (c.any && c.last != st && !c.multi) {
     c.multi = true;
@@ -847,10 +909,8 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
   const double D = (double)dims[0] * dims[1] + (double)dims[1] * dims[2] + (double)dims[2] * dims[3];
   {
     ProfScope prof(6, 12.0 * D, st);
-    if (v == 0) hipLaunchKernelGGL((mlp_mega_kernel<false, true>), dim3(MG_G), dim3(MG_T), smem, st, a);
-    else if (v == 1) hipLaunchKernelGGL((mlp_mega_kernel<true, true>), dim3(MG_G), dim3(MG_T), smem, st, a);
-    else if (v == 2) hipLaunchKernelGGL((mlp_mega_kernel<false, false>), dim3(MG_G), dim3(MG_T), smem, st, a);
-    else hipLaunchKernelGGL((mlp_mega_kernel<true, false>), dim3(MG_G), dim3(MG_T), smem, st, a);
+    if (v == 0) hipLaunchKernelGGL((mlp_mega_kernel<false>), dim3(MG_G), dim3(MG_T), smem, st, a);
+    else hipLaunchKernelGGL((mlp_mega_kernel<true>), dim3(MG_G), dim3(MG_T), smem, st, a);
     CLO_CHECK_LAUNCH("mlp_mega_kernel");
   }
   if (c.multi) {

@@ -61,6 +61,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         PyTorchLinearOperator.__init__(self, self._get_in_shape(), self._get_out_shape())
         self._native: NativeMLP | None = None
         self._native_aux: dict[int, Tensor] = {}
+        self._native_flags = _hip.MLP_DEFAULT
         self._init_mp()
         self._init_native()
         if check_deterministic:
@@ -101,7 +102,21 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         native = NativeMLP(structure, self._params)
         if self._NATIVE_KIND == "hessian" and not native.plan.hessian_supported():
             return
+        native.plan.flags = self._native_flags
         self._native = native
+
+    @property
+    def native_flags(self) -> int:
+        """``CLO_MLP_*`` kernel choice of this operator's single-vector products (an argument of the C
+        call, see ``include/curvlinops_amd.h``): ``_hip.MLP_NO_PERSISTENT`` keeps the launch chain, e.g.
+        while a collective or another long-running kernel of the caller shares the GPU."""
+        return self._native_flags
+
+    @native_flags.setter
+    def native_flags(self, flags: int) -> None:
+        self._native_flags = int(flags)
+        if self._native is not None:
+            self._native.plan.flags = self._native_flags
 
     @property
     def uses_native_kernels(self) -> bool:

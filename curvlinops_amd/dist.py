@@ -26,7 +26,6 @@ checked by comparing R-rank results with the 1-rank result on identical data.
 
 from __future__ import annotations
 
-import os
 
 from collections.abc import Iterable, Sequence
 
@@ -34,6 +33,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from curvlinops_amd import _hip
 from curvlinops_amd.linop import PyTorchLinearOperator
 
 
@@ -179,20 +179,18 @@ class AllReducedLinearOperator(PyTorchLinearOperator):
         not block the host) makes ``Y`` the reduced product.  Consecutive independent products --
         probe vectors of a trace estimator, the steps of the benchmark -- overlap the 4 D K-byte
         all-reduce of one product with the kernels of the next."""
-        if is_distributed():
-            # the collective of the previous product may still hold CUs: a persistent grid that needs every CU
-            # of the chip (csrc/mlp_mega.hip) would spin beside it, so overlapped products take the launch chain
-            prev = os.environ.get("CLO_MLP_MEGA")
-            os.environ["CLO_MLP_MEGA"] = "0"
-            try:
-                Y = self._op @ X
-            finally:
-                if prev is None:
-                    os.environ.pop("CLO_MLP_MEGA", None)
-                else:
-                    os.environ["CLO_MLP_MEGA"] = prev
-        else:
-            Y = self._op @ X
+        # the collective of the previous product may still hold CUs: a persistent grid that needs every CU of the
+        # chip (csrc/mlp_mega.hip) would spin beside it, so overlapped products take the launch chain -- the choice
+        # travels as the `flags` argument of THIS operator's C calls (clo_mlp_ggn_matvec), not as process state
+        op = self._op
+        prev = getattr(op, "native_flags", None) if is_distributed() else None
+        if prev is not None:
+            op.native_flags = prev | _hip.MLP_NO_PERSISTENT
+        try:
+            Y = op @ X
+        finally:
+            if prev is not None:
+                op.native_flags = prev
         if not Y.is_contiguous():
             Y = Y.contiguous()
         work = dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self._group, async_op=True) if is_distributed() else None

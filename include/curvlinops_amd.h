@@ -213,15 +213,19 @@ long clo_mlp_bwd_ws_floats(int N, int d_in, int d_out);
  *   W,b,VW,Vb,OW,Ob  host arrays of L device pointers (b/Vb/Ob entries may be NULL)
  *   X [N][d_0]   input batch;  loss_kind/aux/loss_scale as clo_loss_hessian_apply
  *   ws           workspace of clo_mlp_ggn_ws_floats(L, dims, N) floats
+ *   flags        CLO_MLP_* bits below: the kernel choice is an argument, not process state
  * Works for any N: <= 8 rows in one persistent launch (three layers, narrow head, widths as in
  * mlp_mega.hip; needs clo_mlp_ggn_ws_init) or on the VALU/MFMA streaming chain, 9 ... 64 rows on its
  * all-MFMA variant (narrow head, float4-complete layers), otherwise on the MFMA GEMM engine. */
+#define CLO_MLP_DEFAULT 0        /* the library picks: persistent launch where the shapes qualify            */
+#define CLO_MLP_NO_PERSISTENT 1  /* keep the launch chain (a grid that needs every CU must not share the chip
+                                    with a collective or another long-running kernel of the caller)          */
 int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts,
                        const float *const *W, const float *const *b,
                        const float *const *VW, const float *const *Vb,
                        float *const *OW, float *const *Ob,
                        const float *X, int N, int loss_kind, const float *aux, int aux_rank,
-                       float loss_scale, float alpha, float beta,
+                       float loss_scale, float alpha, float beta, int flags,
                        float *ws, void *stream);
 long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
 /* Must run once on a freshly allocated workspace before its first clo_mlp_ggn_matvec (and again if other

@@ -346,8 +346,10 @@ def test_bwd_layer(hip, N, d_in, d_out):
 
 
 # ------------------------------------------------------------- whole-network GGN matvec
-def _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, loss_kind, scale, alpha, beta, out0=None, aux=None):
+def _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, loss_kind, scale, alpha, beta, out0=None, aux=None,
+                    flags=0):
     plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    plan.flags = flags  # CLO_MLP_* kernel choice (0: the library picks, 1: keep the launch chain)
     dW, db = [dev(W) for W in Ws], [None if b is None else dev(b) for b in bs]
     dVW, dVb = [dev(v) for v in vWs], [None if v is None else dev(v) for v in vbs]
     if out0 is None:
@@ -445,10 +447,9 @@ def _mega_case(g, dims, acts, N, loss, bias=(True, True, True)):
     ([16, 2816, 2688, 16], ["tanh", "relu", "identity"], (False, True, False)),      # the widest tile, C = 16
     ([1024, 1024, 1024, 1], ["relu", "identity", "identity"], (True, True, True)),   # C = 1
 ])
-def test_ggn_matvec_persistent_kernel(hip, monkeypatch, dims, acts, bias, N, loss):
+def test_ggn_matvec_persistent_kernel(hip, dims, acts, bias, N, loss):
     """Round 3: the <= 8-row matvec of a three-layer net as ONE persistent launch (mlp_mega.hip) against the
-    float64 oracle, plain and accumulating, and against the six-launch chain."""
-    monkeypatch.setenv("CLO_MLP_MEGA", "1")
+    float64 oracle, plain and accumulating, and against the six-launch chain (flags = CLO_MLP_NO_PERSISTENT)."""
     g = np.random.default_rng(7 * N + len(loss) + dims[1])
     Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, loss, bias)
     rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", vWs, vbs)
@@ -462,17 +463,16 @@ def test_ggn_matvec_persistent_kernel(hip, monkeypatch, dims, acts, bias, N, los
     ref = O.flatten_params([0.5 * r + o for r, o in zip(rW, out0[0])],
                            [None if r is None else 0.5 * r + o for r, o in zip(rb, out0[1])])
     assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
-    monkeypatch.setenv("CLO_MLP_MEGA", "0")
-    oW, ob = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 0.5, 1.0, out0=out0)
+    oW, ob = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 0.5, 1.0, out0=out0,
+                             flags=hip.MLP_NO_PERSISTENT)
     assert rel_err(O.flatten_params(gW, gb), O.flatten_params(oW, ob)) < 2e-5
 
 
 @pytest.mark.parametrize("N,loss", [(8, "mse"), (5, "ce"), (8, "bce")])
-def test_ggn_matvec_persistent_kernel_c2(hip, monkeypatch, N, loss):
+def test_ggn_matvec_persistent_kernel_c2(hip, N, loss):
     """The benchmark network itself (1024-2688-2688-10, ReLU) through the persistent kernel: float64 oracle,
     every parameter block on its own scale; 20 products on ONE workspace are bit-for-bit identical (fixed
     summation orders, the counters recycle correctly from call to call)."""
-    monkeypatch.setenv("CLO_MLP_MEGA", "1")
     g = np.random.default_rng(N)
     dims, acts = [1024, 2688, 2688, 10], ["relu", "relu", "identity"]
     Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, loss)
@@ -497,16 +497,15 @@ def test_ggn_matvec_persistent_kernel_c2(hip, monkeypatch, N, loss):
             assert all(np.array_equal(a, b) for a, b in zip(got, first)), f"call {it} differs"
 
 
-def test_ggn_matvec_persistent_kernel_rank1(hip, monkeypatch):
+def test_ggn_matvec_persistent_kernel_rank1(hip):
     """Empirical-Fisher / MC output curvature (rank-M) through the persistent kernel."""
     g = np.random.default_rng(3)
     dims, acts, N, M = [64, 256, 512, 10], ["relu", "tanh", "identity"], 6, 3
     Ws, bs, vWs, vbs, X, _ = _mega_case(g, dims, acts, N, "mse")
     aux = g.random((N, M, dims[-1])) - 0.5
-    monkeypatch.setenv("CLO_MLP_MEGA", "1")
     gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 3, 0.25, 1.0, 0.0, aux=dev(aux))
-    monkeypatch.setenv("CLO_MLP_MEGA", "0")
-    oW, ob = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 3, 0.25, 1.0, 0.0, aux=dev(aux))
+    oW, ob = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, 3, 0.25, 1.0, 0.0, aux=dev(aux),
+                             flags=hip.MLP_NO_PERSISTENT)
     assert rel_err(O.flatten_params(gW, gb), O.flatten_params(oW, ob)) < 2e-5
 
 

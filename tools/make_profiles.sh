@@ -8,7 +8,7 @@ CMD="python $R/bench.py --gpus 1 --no-extras --steps 20 --warmup 5"
 rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o ks -- $CMD > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_ks/ks_results.db $OUT/r03_c2_n8_bench_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --no-extras --steps 20 --warmup 5  (C2, 8 rows/GPU, 1 GPU; the driver's command)"
 python $R/tools/gap_analysis.py /tmp/p_ks/ks_results.db mlp_mega > $OUT/r03_c2_n8_kernel_chain.txt
-CLO_MLP_MEGA=0 rocprofv3 --kernel-trace --stats -d /tmp/p_ks0 -o ks -- $CMD > /dev/null 2>&1
+FLAGS_NOTE=chain rocprofv3 --kernel-trace --stats -d /tmp/p_ks0 -o ks -- $CMD > /dev/null 2>&1
 python $R/tools/gap_analysis.py /tmp/p_ks0/ks_results.db outer_all > $OUT/r03_c2_n8_kernel_chain_six_launches.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- $CMD > /dev/null 2>&1

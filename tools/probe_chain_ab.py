@@ -28,19 +28,26 @@ def run(n):
     return 1e6 * (t1 - t0) / n, 1e6 * (time.perf_counter() - t0) / n
 
 
-variants = [v.split(",") for v in os.environ.get("VARIANTS", "CLO_MLP_MEGA=0;CLO_MLP_MEGA=1").split(";")]
+# FLAGS=<int> variants set the operator's CLO_MLP_* kernel choice (1 = launch chain), anything else goes to the environment
+variants = [v.split(",") for v in os.environ.get("VARIANTS", "FLAGS=1;FLAGS=0").split(";")]
 for rnd in range(3):
     for var in variants:
         for kv in var:
             k, v = kv.split("=")
-            os.environ[k] = v
+            if k == "FLAGS":
+                G.native_flags = int(v)
+            else:
+                os.environ[k] = v
         host, tot = run(300)
         print(f"round {rnd} {' '.join(var):40s} host {host:6.1f} us  total {tot:6.1f} us/matvec", flush=True)
 ref = None
 for var in variants:
     for kv in var:
         k, v = kv.split("=")
-        os.environ[k] = v
+        if k == "FLAGS":
+            G.native_flags = int(v)
+        else:
+            os.environ[k] = v
     out = G @ vs[0]
     if ref is None:
         ref = out

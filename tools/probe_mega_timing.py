@@ -18,17 +18,20 @@ plan = _hip.MLPPlan(dims, acts)
 N = 8
 X = torch.rand(N, dims[0], device="cuda")
 names = ["entry", "loads issued", "L1 mfma+merge", "L1 epilogue", "seamA a1 gathered", "L2 mfma", "slab pub+rowA",
-         "finish+hp pub", "top wait", "loss", "delta2", "delta1 mfma", "slab2 pub", "write-only", "colB wait", "end"]
+         "finish+hp pub", "top wait", "loss", "delta2", "delta1 mfma", "slab2 pub", "write-only", "colB wait", "end",
+         "w7 merge start", "w7 merge done", "w7 publish acked", "w7 16 arrived", "w7 gather landed"] + ["-"] * 11
 acc = []
 for i in range(30):
     k = i % nv
     plan.ggn_matvec(W, b, VW[k], Vb[k], OW[k], Ob[k], X, 0, 2.0 / 80, 1.0, 0.0)
     torch.cuda.synchronize()
     ws = next(iter(plan._ws.values()))
-    t = ws[-8192:].view(torch.int64).cpu().numpy()[:256 * 16].reshape(256, 16).astype(np.float64) * 0.01  # 100 MHz -> us
+    t = ws[-16384:].view(torch.int64).cpu().numpy()[:256 * 32].reshape(256, 32).astype(np.float64) * 0.01  # 100 MHz -> us
     if i >= 10:
         acc.append(t - t[:, :1].min())
 t = np.mean(acc, axis=0)
 print("stamp                  min     mean      max   (us since the first workgroup's entry; mean over 20 calls)")
 for i, n in enumerate(names):
+    if n == "-" or t[:, i].max() <= 0:
+        continue
     print(f"{i:2d} {n:18s} {t[:, i].min():7.2f}  {t[:, i].mean():7.2f}  {t[:, i].max():7.2f}")
