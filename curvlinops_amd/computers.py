@@ -182,19 +182,14 @@ def _affine_eval_batchnorm(module: Module, params: dict[str, Tensor]) -> list[Mo
         if any(id(p) in tracked for p in mod.parameters(recurse=False)) or "forward" in mod.__dict__:
             continue
 
-        # scale / shift once per state of the module (kept on it, keyed by the tensors' versions): a build is bound
-        # by the host's op dispatch, so the patched forward is ONE launch like the kernel it replaces
-        srcs = (mod.running_mean, mod.running_var, mod.weight, mod.bias)
-        state = tuple((id(t), t._version) if t is not None else None for t in srcs)
-        cached = mod.__dict__.get("_clo_affine")
-        if cached is None or cached[0] != state:
-            with torch.no_grad():
-                inv = torch.rsqrt(mod.running_var + mod.eps)
-                scale = inv if mod.weight is None else mod.weight * inv
-                shift = -mod.running_mean * scale if mod.bias is None else mod.bias - mod.running_mean * scale
-            cached = mod.__dict__["_clo_affine"] = (state, scale, shift)
+        # scale / shift are recomputed on every entry (once per compute(), four tiny launches per layer): a cache
+        # across calls keyed by tensor identity / version went stale under `.data` updates, which bump neither
+        with torch.no_grad():
+            inv = torch.rsqrt(mod.running_var + mod.eps)
+            scale = inv if mod.weight is None else mod.weight * inv
+            shift = -mod.running_mean * scale if mod.bias is None else mod.bias - mod.running_mean * scale
 
-        def forward(x, scale=cached[1], shift=cached[2]):
+        def forward(x, scale=scale, shift=shift):
             shape = (1, -1) + (1,) * (x.dim() - 2)
             return torch.addcmul(shift.view(shape), x, scale.view(shape))
 

@@ -479,18 +479,30 @@ def _embed_deflated(n: int, idx: Tensor, lam_s: Tensor, Q_s: Tensor) -> tuple[Te
     return lam[order], Q[:, order]
 
 
+def _eigh_2x2(A: Tensor) -> tuple[Tensor, Tensor]:
+    """Closed form for a symmetric 2 x 2 matrix (the G factors of two-class heads): the Jacobi rotation that
+    annihilates the off-diagonal entry, evaluated in float64 with device-side elementwise ops (no host
+    synchronisation, no iteration that could fail to converge); ascending eigenvalues, orthonormal columns."""
+    a, b, c = A[0, 0].double(), 0.5 * (A[0, 1].double() + A[1, 0].double()), A[1, 1].double()
+    theta = 0.5 * torch.atan2(2.0 * b, a - c)
+    cs, sn = torch.cos(theta), torch.sin(theta)
+    lam1 = a * cs * cs + 2.0 * b * cs * sn + c * sn * sn
+    lam2 = a * sn * sn - 2.0 * b * cs * sn + c * cs * cs
+    Q = torch.stack([torch.stack([cs, -sn]), torch.stack([sn, cs])])          # columns: (cs, sn), (-sn, cs)
+    swap = lam1 > lam2
+    lam = torch.where(swap, torch.stack([lam2, lam1]), torch.stack([lam1, lam2]))
+    Q = torch.where(swap, Q.flip(1), Q)
+    return lam.to(A.dtype), Q.to(A.dtype)
+
+
 def _eigh_full(A: Tensor) -> tuple[Tensor, Tensor]:
     """One matrix without zero rows (or a CPU / non-float32 one): solver selection as documented at _EIGH_MODE."""
     if _EIGH_MODE != "rocsolver" and A.is_cuda and A.dtype == torch.float32 and A.dim() == 2:
         n = A.shape[0]
         if 3 <= n <= _SYTRD_MAX_N and (_EIGH_MODE == "native" or 256 <= n <= 2400):
             return eigh_sytrd(A)
-        if _EIGH_MODE == "native" and n == 2:   # already tridiagonal: the leaf solver alone
-            from . import eigh_native
-
-            An, scale = _unit_scale(A)
-            lam, Q = eigh_native.stedc_native(An.diagonal().contiguous(), An[1, :1].contiguous(), 2)
-            return lam * scale.reshape(()), Q
+        if _EIGH_MODE == "native" and n == 2:   # one Jacobi rotation in float64: exact, nothing to verify
+            return _eigh_2x2(A)
     return _torch_eigh_scaled(A)
 
 

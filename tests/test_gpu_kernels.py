@@ -497,6 +497,55 @@ def test_ggn_matvec_persistent_kernel_c2(hip, N, loss):
             assert all(np.array_equal(a, b) for a, b in zip(got, first)), f"call {it} differs"
 
 
+@pytest.mark.parametrize("side_gemm", [False, True])
+def test_ggn_matvec_persistent_kernel_concurrent_streams(hip, side_gemm):
+    """Round 4: the persistent kernel next to other work.  Two HIP streams each issue 50 products of the benchmark
+    network (one plan = one workspace per stream; the library chains persistent launches of different streams by
+    events), optionally with 4096^3 GEMMs looping on a third stream so that the 256-workgroup grid has
+    to become resident while other kernels hold CUs.  Every product must equal the serial run bit for bit, and
+    nothing may trap or hang."""
+    g = np.random.default_rng(11)
+    dims, acts, N = [1024, 2688, 2688, 10], ["relu", "relu", "identity"], 8
+    Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, "mse")
+    scale = 2.0 * O.reduction_factor("mse", "mean", N, dims[-1])
+    dW, db, dX = [dev(W) for W in Ws], [dev(b) for b in bs], dev(X)
+    nvec = 4
+    dV = [([dev(g.random(W.shape) - 0.5) for W in Ws], [dev(g.random(b.shape) - 0.5) for b in bs]) for _ in range(nvec)]
+    plans = [hip.MLPPlan(dims, [ACT_CODE[a] for a in acts]) for _ in range(2)]
+
+    def outputs():
+        return [torch.full_like(w, float("nan")) for w in dW], [torch.full_like(b, float("nan")) for b in db]
+
+    serial = []
+    for k in range(nvec):
+        oW, ob = outputs()
+        plans[0].ggn_matvec(dW, db, dV[k][0], dV[k][1], oW, ob, dX, 0, scale, 1.0, 0.0)
+        torch.cuda.synchronize()
+        serial.append([t.clone() for t in oW + ob])
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for p_, s_ in zip(plans, streams):  # workspaces (and their counters) are created on the stream that uses them
+        with torch.cuda.stream(s_):
+            p_.workspace(N, dX.device)
+    torch.cuda.synchronize()
+    A = torch.randn(4096, 4096, device="cuda") if side_gemm else None
+    results = [[], []]
+    for it in range(50):
+        if side_gemm and it % 5 == 0:
+            with torch.cuda.stream(streams[2]):
+                for _ in range(4):
+                    hip.gemm(A, A)
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                oW, ob = outputs()
+                k = (it + i) % nvec
+                plans[i].ggn_matvec(dW, db, dV[k][0], dV[k][1], oW, ob, dX, 0, scale, 1.0, 0.0)
+                results[i].append((k, oW + ob))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for it, (k, got) in enumerate(results[i]):
+            assert all(torch.equal(a, b) for a, b in zip(got, serial[k])), f"stream {i}, product {it} differs"
+
+
 def test_ggn_matvec_persistent_kernel_rank1(hip):
     """Empirical-Fisher / MC output curvature (rank-M) through the persistent kernel."""
     g = np.random.default_rng(3)

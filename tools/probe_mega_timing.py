@@ -19,7 +19,7 @@ N = 8
 X = torch.rand(N, dims[0], device="cuda")
 names = ["entry", "loads issued", "L1 mfma+merge", "L1 epilogue", "seamA a1 gathered", "L2 mfma", "slab pub+rowA",
          "finish+hp pub", "top wait", "loss", "delta2", "delta1 mfma", "slab2 pub", "write-only", "colB wait", "end",
-         "w7 merge start", "w7 merge done", "w7 publish acked", "w7 16 arrived", "w7 gather landed"] + ["-"] * 11
+         "w7 merge start", "w7 merge done", "w7 publish issued", "w7 gather complete", "w7 a1 in LDS"] + ["-"] * 11
 acc = []
 for i in range(30):
     k = i % nv
@@ -35,3 +35,7 @@ for i, n in enumerate(names):
     if n == "-" or t[:, i].max() <= 0:
         continue
     print(f"{i:2d} {n:18s} {t[:, i].min():7.2f}  {t[:, i].mean():7.2f}  {t[:, i].max():7.2f}")
+
+out = os.environ.get("STAMPS_OUT")
+if out:
+    np.save(out, t)   # [256 workgroups][32 stamps], mean over the measured calls
