@@ -64,22 +64,51 @@ def build_problem(device, batch: int, seed: int):
     return model, X, y
 
 
+def latest_profile(suffix: str):
+    """Path of the newest committed ``profiles/rNN_<suffix>`` (highest round), or None."""
+    import glob
+
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return hits[-1] if hits else None
+
+
+def csrc_sha16() -> str:
+    """Fingerprint of the kernel sources: committed profile summaries carry the one they were collected with, so a
+    figure read from ``profiles/`` can be flagged when the kernels have changed since."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "curvlinops_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_per_launch(kernel: str):
     """Mean HBM bytes per launch of `kernel` from the committed PMC summary (collected by separate
     rocprofv3 --pmc passes of this same command; see tools/pmc_summary.py); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r03_c2_n8_pmc_traffic.json")
+    path = latest_profile("c2_n8_pmc_traffic.json")
     try:
         rows = [k for k in json.load(open(path))["kernels"] if kernel in k["kernel"]]
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         return None
     if not rows:
         return None
     return sum(k["hbm_bytes"] for k in rows) / len(rows)
 
 
+def pmc_traffic_meta():
+    path = latest_profile("c2_n8_pmc_traffic.json")
+    try:
+        sha = json.load(open(path)).get("csrc_sha16")
+    except (OSError, ValueError, TypeError):
+        return None, None
+    return os.path.relpath(path, ROOT), (None if sha is None else sha != csrc_sha16())
+
+
 def rocprof_avg_us(kernels):
     """Launch-weighted mean duration of `kernels` in the committed rocprofv3 --stats summary."""
-    path = os.path.join(ROOT, "profiles", "r03_c2_n8_bench_kernel_stats.txt")
+    path = latest_profile("c2_n8_bench_kernel_stats.txt") or ""
     tot = cnt = 0.0
     try:
         for line in open(path):
@@ -263,7 +292,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 def kfac_clo_kernel_us():
     """Sum of the clo:: kernel durations of one warm factor build in the committed rocprofv3 summary."""
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r03_kfac_resnet18_build_kernels.txt")):
+        for line in open(latest_profile("kfac_resnet18_build_kernels.txt") or ""):
             if line.startswith("clo_kernel_us"):
                 return float(line.split()[1])
     except (OSError, ValueError):
@@ -575,14 +604,16 @@ def main() -> None:
             "alg_bytes_per_matvec": 12 * D,
             "definition": "12 D algorithmic bytes (theta, v, result once; SURVEY 8d) / step time of the timed region",
             "traffic": traffic,
-            "traffic_source": "profiles/r03_c2_n8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                              "passes, FETCH doubled per the gfx950 note), summed over the kernels of one matvec" if traffic else None,
+            "traffic_source": (str(pmc_traffic_meta()[0]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                               "passes of this command, FETCH doubled per the gfx950 note), summed over the kernels of one "
+                               "matvec; NOT measured in this run") if traffic else None,
+            "traffic_stale": pmc_traffic_meta()[1] if traffic else None,
             "dominant_kernel": dom,
             "dominant_kernel_frac": kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS,
             "kernels": kernels,
             "kernels_note": "avg_launch_us_hip_events = HIP-event interval around each launch on the launch stream "
                             "(includes ~2.5 us dispatch latency that rocprofv3 durations exclude); "
-                            "rocprof_avg_kernel_us from profiles/r03_c2_n8_bench_kernel_stats.txt (same command)",
+                            "rocprof_avg_kernel_us from the newest profiles/rNN_c2_n8_bench_kernel_stats.txt (same command)",
             "kernel_us_per_matvec_hip_events": sum(k["us_per_matvec"] for k in kernels.values()),
         }
         try:  # the headline line must be printed whatever happens in the untimed legs

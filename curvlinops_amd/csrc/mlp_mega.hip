@@ -505,7 +505,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   // =====================================================================================
   // phase 3: finish features [jF, jF + nf2) of block fb; head partials
   // =====================================================================================
-  f32x4 d2_ph;
+  f32x4 d2_ph[4];
   float4 d2_w[MG_CMAX];
   {
     const int nq = nf2 >> 2;
@@ -586,12 +586,15 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     }
     wg_barrier();
     MG_STAMP(8);
-    // operands of delta_2 for (n, feature quad) = tid: in flight together with the group sums below
+    // operands of delta_2 for thread = (half of the rows, feature quad): the W3 columns of a quad are loaded ONCE
+    // for four rows (one thread per (row, quad) moved 54 KB of W3 per workgroup and delta_2 waited for it);
+    // in flight together with the group sums below
     {
       const int nq2 = nj >> 2;
-      const bool has = tid < MG_NB * nq2;
-      const int e2 = has ? tid : 0, n2 = e2 / nq2, q2 = e2 - n2 * nq2;
-      d2_ph = ld_x(rs, o_dphi2 + (long)n2 * d2 + j0 + q2 * 4);
+      const bool has = tid < 2 * nq2;
+      const int e2 = has ? tid : 0, h2 = e2 / nq2, q2 = e2 - h2 * nq2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d2_ph[i] = ld_x(rs, o_dphi2 + (long)(h2 * 4 + i) * d2 + j0 + q2 * 4);
 #pragma unroll
       for (int c = 0; c < MG_CMAX; ++c)
         if (c < C) d2_w[c] = mg_ld4(p.W3 + (long)c * d2 + j0 + q2 * 4);
@@ -652,46 +655,72 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   // =====================================================================================
   {
     const int nq = nj >> 2;
-    if (tid < MG_NB * nq) {  // (n, quad): phi'2 (exchanged) x (delta_3 W3), operands prefetched above
-      const int n = tid / nq, q = tid - n * nq;
-      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 2 * nq) {  // (row half, quad): phi'2 (exchanged) x (delta_3 W3), operands prefetched above
+      const int h = tid / nq, q = tid - h * nq;
+      f32x4 sacc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < MG_CMAX; ++c) {
         if (c < C) {
-          const float dl = s_m[MG_M_DL + n * 16 + c];
-          sacc.x = fmaf(dl, d2_w[c].x, sacc.x); sacc.y = fmaf(dl, d2_w[c].y, sacc.y);
-          sacc.z = fmaf(dl, d2_w[c].z, sacc.z); sacc.w = fmaf(dl, d2_w[c].w, sacc.w);
-        }
-      }
-      s_d2[(q * 4 + 0) * MG_NB + n] = sacc.x * d2_ph.x;
-      s_d2[(q * 4 + 1) * MG_NB + n] = sacc.y * d2_ph.y;
-      s_d2[(q * 4 + 2) * MG_NB + n] = sacc.z * d2_ph.z;
-      s_d2[(q * 4 + 3) * MG_NB + n] = sacc.w * d2_ph.w;
-    }
-    wg_barrier();
-    MG_STAMP(10);
-    // partial delta_1[n][k] = sum_{j in block} delta_2[n][j] W2[j][k] on the VALU: thread = (row lane jl, column
-    // quad cq) walks rows jl, jl + rpp, ... of the LDS tile (one ds_read_b128 of W and two broadcast reads of
-    // delta_2 per 32 FMAs); the row lanes are merged through the tile area once every wave is done with it
-    const int ncq = kr >> 2, rpp = min(MG_T / ncq, 16);   // <= 16 row lanes: their partials fit the tile area
-    const int rl = tid / ncq, cq = tid - rl * ncq;
-    {
-      float4 pacc[MG_NB];
 #pragma unroll
-      for (int n = 0; n < MG_NB; ++n) pacc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rl < rpp) {
-        for (int j = rl; j < nj; j += rpp) {
-          const float4 wv = mg_ld4(&s_w[j * MG_LDW + cq * 4]);
-          const float4 da = mg_ld4(&s_d2[j * MG_NB]), db = mg_ld4(&s_d2[j * MG_NB + 4]);
-          const float dn[MG_NB] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
-#pragma unroll
-          for (int n = 0; n < MG_NB; ++n) {
-            pacc[n].x = fmaf(dn[n], wv.x, pacc[n].x); pacc[n].y = fmaf(dn[n], wv.y, pacc[n].y);
-            pacc[n].z = fmaf(dn[n], wv.z, pacc[n].z); pacc[n].w = fmaf(dn[n], wv.w, pacc[n].w);
+          for (int i = 0; i < 4; ++i) {
+            const float dl = s_m[MG_M_DL + (h * 4 + i) * 16 + c];
+            sacc[i].x = fmaf(dl, d2_w[c].x, sacc[i].x); sacc[i].y = fmaf(dl, d2_w[c].y, sacc[i].y);
+            sacc[i].z = fmaf(dl, d2_w[c].z, sacc[i].z); sacc[i].w = fmaf(dl, d2_w[c].w, sacc[i].w);
           }
         }
       }
+      // delta_2 is kept [feature][row]: one float4 = the four rows of this half
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        *reinterpret_cast<f32x4 *>(&s_d2[(q * 4 + f) * MG_NB + h * 4]) =
+            f32x4{sacc[0][f] * d2_ph[0][f], sacc[1][f] * d2_ph[1][f], sacc[2][f] * d2_ph[2][f], sacc[3][f] * d2_ph[3][f]};
+    }
+    wg_barrier();
+    MG_STAMP(10);
+    // partial delta_1[n][k] = sum_{j in block} delta_2[n][j] W2[j][k] on the VALU: thread = (row lane rl, column quad
+    // cq) walks rows rl, rl + rpp, ... of the LDS tile with PACKED FMAs (the sweep is VALU-bound: 512 plain FMAs per
+    // thread took 2 us, and everything that writes results waits for it), four rows per trip with their LDS reads in
+    // flight together; the row lanes are merged through the tile area once every wave is done with it
+    const int ncq = kr >> 2, rpp = min(MG_T / ncq, 16);   // <= 16 row lanes: their partials fit the tile area
+    const int rl = tid / ncq, cq = tid - rl * ncq;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    {
+      f32x2 pa[MG_NB][2];
+#pragma unroll
+      for (int n = 0; n < MG_NB; ++n) pa[n][0] = pa[n][1] = f32x2{0.f, 0.f};
+      if (rl < rpp) {
+        for (int jb = rl; jb < nj; jb += 4 * rpp) {
+          float4 wv[4], da[4], db[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {   // rows beyond the block repeat the last one; they are skipped below
+            const int j = min(jb + u * rpp, nj - 1);
+            wv[u] = mg_ld4(&s_w[j * MG_LDW + cq * 4]);
+            da[u] = mg_ld4(&s_d2[j * MG_NB]);
+            db[u] = mg_ld4(&s_d2[j * MG_NB + 4]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (jb + u * rpp < nj) {
+              const float dn[MG_NB] = {da[u].x, da[u].y, da[u].z, da[u].w, db[u].x, db[u].y, db[u].z, db[u].w};
+              const f32x2 w01 = {wv[u].x, wv[u].y}, w23 = {wv[u].z, wv[u].w};
+#pragma unroll
+              for (int n = 0; n < MG_NB; ++n) {
+                const f32x2 dd = {dn[n], dn[n]};
+                pa[n][0] = __builtin_elementwise_fma(dd, w01, pa[n][0]);
+                pa[n][1] = __builtin_elementwise_fma(dd, w23, pa[n][1]);
+              }
+            }
+          }
+        }
+      }
+      float4 pacc[MG_NB];
+#pragma unroll
+      for (int n = 0; n < MG_NB; ++n) pacc[n] = make_float4(pa[n][0].x, pa[n][0].y, pa[n][1].x, pa[n][1].y);
+      MG_STAMP(21);
       wg_barrier();  // nobody reads the W2 tile any more: its area takes the partials [rl][n][kr]
+      MG_STAMP(22);
       if (rl < rpp) {
 #pragma unroll
         for (int n = 0; n < MG_NB; ++n)
@@ -717,19 +746,25 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     }
     // ---- write-only work: out_W2 tile, out_b2 / out_W3 of the finished slice, out_b3
     {
-      if (rl < rpp) {
-        float4 av[MG_NB];
+      if (rl < rpp) {   // out_W2[j][k] = sum_n delta_2[n][j] a1[n][k]: contiguous 16-byte stores along a row, packed FMAs
+        f32x2 av[MG_NB][2];
 #pragma unroll
-        for (int n = 0; n < MG_NB; ++n) av[n] = mg_ld4(&s_b[n * MG_LDB + cq * 4]);
+        for (int n = 0; n < MG_NB; ++n) {
+          const float4 t = mg_ld4(&s_b[n * MG_LDB + cq * 4]);
+          av[n][0] = f32x2{t.x, t.y};
+          av[n][1] = f32x2{t.z, t.w};
+        }
         for (int j = rl; j < nj; j += rpp) {
           const float4 da = mg_ld4(&s_d2[j * MG_NB]), db = mg_ld4(&s_d2[j * MG_NB + 4]);
           const float dn[MG_NB] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
-          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
 #pragma unroll
           for (int n = 0; n < MG_NB; ++n) {
-            o.x = fmaf(dn[n], av[n].x, o.x); o.y = fmaf(dn[n], av[n].y, o.y);
-            o.z = fmaf(dn[n], av[n].z, o.z); o.w = fmaf(dn[n], av[n].w, o.w);
+            const f32x2 dd = {dn[n], dn[n]};
+            o01 = __builtin_elementwise_fma(dd, av[n][0], o01);
+            o23 = __builtin_elementwise_fma(dd, av[n][1], o23);
           }
+          float4 o = make_float4(o01.x, o01.y, o23.x, o23.y);
           float *po = p.O2 + (long)(j0 + j) * d1 + k0 + cq * 4;
           if (ACCUM) {
             const float4 od = mg_ld4(po);
@@ -769,6 +804,12 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   // =====================================================================================
   {
     MG_STAMP(13);
+    // x rows for the out_W1 products: requested before the wait (L2 hits that would otherwise follow the slab loads)
+    const int ncq = d0 >> 2, lanes_r = MG_T / ncq;   // d0 <= 1024: at least two row lanes
+    const int rl = tid / ncq, cq = tid - rl * ncq;
+    float4 xv[MG_NB];
+#pragma unroll
+    for (int n = 0; n < MG_NB; ++n) xv[n] = mg_ld4(p.X + (long)min(n, N - 1) * d0 + (rl < lanes_r ? cq * 4 : 0));
     if (tid == 0) mg_wait(c_colB, 16u, c_err);
     wg_barrier();
     MG_STAMP(14);
@@ -792,13 +833,8 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       for (int n = 0; n < MG_NB; ++n) sb += s_m[MG_M_D1 + tid * MG_NB + n];
       p.Ob1[jA + tid] = (ACCUM ? p.beta * p.Ob1[jA + tid] : 0.f) + sb;
     }
-    const int ncq = d0 >> 2, lanes_r = MG_T / ncq;   // d0 <= 1024: at least two row lanes
-    const int rl = tid / ncq, cq = tid - rl * ncq;
     if (rl < lanes_r) {
-      float4 xv[MG_NB];
-#pragma unroll
-      for (int n = 0; n < MG_NB; ++n)
-        xv[n] = n < N ? mg_ld4(p.X + (long)n * d0 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // (rows n >= N carry delta_1 = 0 below: their clamped x rows drop out)
       for (int f = rl; f < nf1; f += lanes_r) {
         const float4 da = mg_ld4(&s_m[MG_M_D1 + f * MG_NB]), db = mg_ld4(&s_m[MG_M_D1 + f * MG_NB + 4]);
         const float dn[MG_NB] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};

@@ -21,7 +21,12 @@ def main(fetch_db, write_db, out_json, out_txt, header):
         rows.append({"kernel": key[0], "grid": [key[1], key[2]], "launches": fk[0] or wk[0],
                      "fetch_bytes": 2 * fk[1] * 1024, "write_bytes": wk[1] * 1024,
                      "hbm_bytes": 2 * fk[1] * 1024 + wk[1] * 1024})
-    json.dump({"note": header, "kernels": rows}, open(out_json, "w"), indent=1)
+    import glob, hashlib, os
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "curvlinops_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    json.dump({"note": header, "csrc_sha16": h.hexdigest()[:16], "kernels": rows}, open(out_json, "w"), indent=1)
     with open(out_txt, "w") as t:
         t.write(f"# {header}\n# fetch = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; bytes per launch\n")
         t.write("# launches   fetch_MB   write_MB   total_MB  kernel [grid]\n")

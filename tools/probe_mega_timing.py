@@ -19,7 +19,7 @@ N = 8
 X = torch.rand(N, dims[0], device="cuda")
 names = ["entry", "loads issued", "L1 mfma+merge", "L1 epilogue", "seamA a1 gathered", "L2 mfma", "slab pub+rowA",
          "finish+hp pub", "top wait", "loss", "delta2", "delta1 mfma", "slab2 pub", "write-only", "colB wait", "end",
-         "w7 merge start", "w7 merge done", "w7 publish issued", "w7 gather complete", "w7 a1 in LDS"] + ["-"] * 11
+         "w7 merge start", "w7 merge done", "w7 publish issued", "w7 gather complete", "w7 a1 in LDS", "sweep done (wave 0)", "sweep barrier"] + ["-"] * 9
 acc = []
 for i in range(30):
     k = i % nv
