@@ -62,6 +62,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         self._native: NativeMLP | None = None
         self._native_aux: dict[int, Tensor] = {}
         self._native_flags = _hip.MLP_DEFAULT
+        self.native_column_products = 0   # products that ran on the K-column kernels (clo_mlp_*_matmat); for tests
         self._init_mp()
         self._init_native()
         if check_deterministic:
@@ -320,6 +321,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                     or any(a[0] not in (0, 1, 2) or a[2] is None for a in bargs)):
                 return None
             out = self._alloc_cols_like(M)
+            self.native_column_products += 1
             with torch.cuda.device(self.device):
                 return self._hessian_native_cols_run(M, out, batches, bargs, K)
         # rows of the [D, K] matrix must be float4-complete: K % 4 == 0 (else the column loop runs)
@@ -327,6 +329,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if not all(m.is_contiguous() and m.data_ptr() % 16 == 0 for m in M) or not plan.matmat_supported(4, K, rank):
             return None
         out = self._alloc_cols_like(M)
+        self.native_column_products += 1
         with torch.cuda.device(self.device):  # kernels launch on the operands' device, whatever is current
             return self._matmat_native_cols_run(M, out, batches, bargs, K)
 

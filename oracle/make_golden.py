@@ -244,15 +244,61 @@ def gen_linops(curvlinops):
     print("linops.npz:", len(out), "arrays")
 
 
+# K-column products on shapes the native column kernels accept (layer inputs % 4 == 0, K % 4 == 0, <= 32 rows per
+# mini-batch, linear last layer): `clo_mlp_ggn_matmat` / `clo_mlp_hessian_matmat` against the reference's vmap
+# (_torch_base.py:946-989 over ggn.py:41-72, hessian.py:66, gradient_moments.py:48-87) with K = 8 columns.
+COLUMN_CASES = [
+    # name, dims, acts, bias, loss, reduction, batch sizes
+    ("cols_tanh_mse_mean", [16, 24, 20, 5], ["tanh", "sigmoid", "identity"], [True] * 3, "mse", "mean", [8, 5]),
+    ("cols_relu_ce_mean", [12, 16, 8, 7], ["relu", "tanh", "identity"], [True, False, True], "ce", "mean", [6, 11]),
+    ("cols_sigm_bce_sum", [8, 12, 3], ["sigmoid", "identity"], [True, True], "bce", "sum", [9]),
+]
+
+
+def gen_columns(curvlinops):
+    out = {}
+    for idx, (name, dims, acts, bias, loss, red, bsz) in enumerate(COLUMN_CASES):
+        gen = torch.Generator().manual_seed(4000 + idx)
+        torch.manual_seed(4000 + idx)
+        model = build_mlp(dims, acts, bias)
+        for p in model.parameters():
+            p.data += 0.01 * torch.rand(p.shape, generator=gen)
+        data = make_data(gen, bsz, dims[0], dims[-1], loss)
+        params = dict(model.named_parameters())
+        D = sum(p.numel() for p in params.values())
+        V = torch.rand(D, 8, generator=gen) - 0.5
+        loss_func = LOSS[loss](reduction=red)
+        rec = {
+            "dims": np.array(dims), "acts": np.array(acts), "bias": np.array(bias),
+            "loss": np.array(loss), "reduction": np.array(red), "V": V.numpy(),
+            "num_batches": np.array(len(data)),
+        }
+        for i, (X, y) in enumerate(data):
+            rec[f"X{i}"] = X.numpy()
+            rec[f"y{i}"] = y.numpy()
+        for k, p in params.items():
+            rec[f"param:{k}"] = p.detach().numpy()
+        for opname, cls in (("ggn", curvlinops.GGNLinearOperator),
+                            ("hessian", curvlinops.HessianLinearOperator),
+                            ("ef", curvlinops.EFLinearOperator)):
+            rec[f"{opname}_V"] = (cls(model, loss_func, params, data) @ V).detach().numpy()
+        for k, val in rec.items():
+            out[f"{name}/{k}"] = val
+    np.savez_compressed(OUT / "mlp_columns.npz", **out)
+    print("mlp_columns.npz:", len(out), "arrays")
+
+
 def main():
     if not Path("/root/reference/curvlinops").exists():
         sys.exit("reference not present: golden vectors can only be regenerated in the build container")
     import curvlinops
 
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["mlp", "jacobian", "ggn_diagonal", "linops", "kfac", "trace", "kfoc", "nets"]
+    which = sys.argv[1:] or ["mlp", "columns", "jacobian", "ggn_diagonal", "linops", "kfac", "trace", "kfoc", "nets", "kfac_mc"]
     if "mlp" in which:
         gen_mlp(curvlinops)
+    if "columns" in which:
+        gen_columns(curvlinops)
     if "jacobian" in which:
         gen_jacobian(curvlinops)
     if "ggn_diagonal" in which:
@@ -271,6 +317,10 @@ def main():
         from make_golden_kfac import gen_kfoc
 
         gen_kfoc(curvlinops, OUT)
+    if "kfac_mc" in which:
+        from make_golden_nets import gen_kfac_mc
+
+        gen_kfac_mc(curvlinops, OUT)
     if "nets" in which:
         from make_golden_nets import gen_nets
 

@@ -163,3 +163,81 @@ def gen_nets(curvlinops, OUT):
         out[f"encoder_toy/{k}"] = val
     np.savez_compressed(OUT / "nets.npz", **out)
     print("nets.npz:", len(out), "arrays,", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
+def gen_kfac_mc(curvlinops, OUT):
+    """``fisher_type="mc"`` on the two convolutional benchmark families (LeNet-5 = BASELINE config C3 at B = 6 + 4;
+    the ResNet toy of `gen_nets`) with the reference's SAMPLED backprop vectors captured: torch's CPU and GPU random
+    streams differ, so the test replays the captured ``[M, B, C]`` tensors and compares the factors, the
+    product and the damped inverse of the exact MC code path -- V = mc_samples vectors per datum scaled by 1/sqrt(M),
+    the mean-reduction correction -- with the reference's own numbers instead of "equal in expectation"."""
+    from benchmarks.models import kfac_params, lenet5
+    from curvlinops.computers import _base
+
+    captured = []
+    original = _base._BaseKFACComputer._set_up_grad_outputs_computer
+
+    def capturing(loss_func, fisher_type, mc_samples):
+        fn = original(loss_func, fisher_type, mc_samples)
+
+        def wrapped(output, y, generator):
+            g = fn(output, y, generator)
+            captured.append(g.detach().clone())
+            return g
+
+        return wrapped
+
+    out = {}
+    cases = []
+    gen = torch.Generator().manual_seed(7100)
+    torch.manual_seed(7100)
+    net = lenet5()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.rand(p.shape, generator=gen))
+    data = [(torch.rand(B, 1, 32, 32, generator=gen), torch.randint(0, 10, (B,), generator=gen)) for B in (6, 4)]
+    cases.append(("lenet5", net, dict(net.named_parameters()), data))
+    gen = torch.Generator().manual_seed(7200)
+    torch.manual_seed(7200)
+    net = resnet_toy()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.rand(p.shape, generator=gen))
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(0.2 * torch.rand(m.running_mean.shape, generator=gen) - 0.1)
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=gen))
+    net.eval()
+    data = [(torch.rand(B, 3, 8, 8, generator=gen), torch.randint(0, 5, (B,), generator=gen)) for B in (5, 3)]
+    cases.append(("resnet_toy", net, kfac_params(net), data))
+
+    _base._BaseKFACComputer._set_up_grad_outputs_computer = staticmethod(capturing)
+    try:
+        for name, model, params, data in cases:
+            D = sum(p.numel() for p in params.values())
+            V = torch.rand(D, 2, generator=gen)
+            rec = {"V": V.numpy(), "num_batches": np.array(len(data)), **_state(model)}
+            for i, (X, y) in enumerate(data):
+                rec[f"X{i}"], rec[f"y{i}"] = X.numpy(), y.numpy()
+            lf = nn.CrossEntropyLoss()
+            for M in (1, 3):
+                # (LeNet-5's factors are large for a fixture: joint weight + bias only, as BASELINE config C3 runs it)
+                for sep in ((False,) if name == "lenet5" else (True, False)):
+                    tag = f"mc{M}|{'sep' if sep else 'joint'}"
+                    captured.clear()
+                    K = curvlinops.KFACLinearOperator(model, lf, params, data, fisher_type="mc", mc_samples=M,
+                                                      separate_weight_and_bias=sep, check_deterministic=False)
+                    assert len(captured) == len(data), (len(captured), len(data))
+                    for i, g in enumerate(captured):
+                        rec[f"{tag}/grad_outputs{i}"] = g.numpy()      # [M, B, C], before the 1/B of the mean
+                    rec[f"{tag}/KV"] = (K @ V).detach().numpy()
+                    for b, block in enumerate(K[1]):
+                        for f, fac in enumerate(block):
+                            rec[f"{tag}/block{b}_factor{f}"] = fac.detach().numpy()
+                    rec[f"{tag}/inv_plain"] = (K.inverse(damping=1e-2) @ V).detach().numpy()
+            for k, val in rec.items():   # large arrays in float32 (the GPU comparison is at 1e-4)
+                out[f"{name}/{k}"] = val.astype(np.float32) if val.dtype == np.float64 and val.size > 20000 else val
+    finally:
+        _base._BaseKFACComputer._set_up_grad_outputs_computer = staticmethod(original)
+    np.savez_compressed(OUT / "kfac_mc.npz", **out)
+    print("kfac_mc.npz:", len(out), "arrays")

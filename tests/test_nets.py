@@ -104,6 +104,52 @@ def check_encoder_toy(dtype, device, tol, tol_inv, tol_ekfac_inv):
 
 
 # ------------------------------------------------------------------------------------------ CPU, float64
+def check_kfac_mc_replayed(name, dtype, device, tol, tol_inv, monkeypatch):
+    """``fisher_type="mc"`` with the reference's SAMPLED backprop vectors replayed (tests/golden/kfac_mc.npz,
+    oracle/make_golden_nets.py::gen_kfac_mc): the MC code path itself -- M vectors per datum, the 1/sqrt(M) scale, the
+    mean-reduction correction -- against the reference's factors, product and damped inverse, not "in expectation"."""
+    from curvlinops_amd import computers
+
+    rec = load_golden("kfac_mc")[name]
+    model = _load(lenet5() if name == "lenet5" else ResNetToy(), rec, dtype, device)
+    params = dict(model.named_parameters()) if name == "lenet5" else kfac_params(model)
+    data = _data(rec, dtype, device)
+    V = _t(rec["V"], dtype, device)
+    queue = []
+
+    def replaying_vmap(fn, **kwargs):   # stands in for vmap(make_grad_output_fn(...)): [M, B, C] per mini-batch
+        def replay(output, y, generator):
+            g = queue.pop(0)
+            assert g.shape[1:] == output.shape
+            return g.clone()
+        return replay
+
+    monkeypatch.setattr(computers, "vmap", replaying_vmap)
+    for M in (1, 3):
+        for sep in ((False,) if name == "lenet5" else (True, False)):
+            tag = f"mc{M}|{'sep' if sep else 'joint'}"
+            queue[:] = [_t(rec[f"{tag}/grad_outputs{i}"], dtype, device) for i in range(len(data))]
+            K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, data, fisher_type="mc", mc_samples=M,
+                                     separate_weight_and_bias=sep, check_deterministic=False)
+            assert not queue, "the sampled vectors were not consumed"
+            for b, block in enumerate(K[1]):
+                for f, fac in enumerate(block):
+                    assert rel_err(fac, rec[f"{tag}/block{b}_factor{f}"]) < tol, (tag, b, f)
+            assert rel_err(K @ V, rec[f"{tag}/KV"]) < tol, tag
+            assert rel_err(K.inverse(damping=1e-2) @ V, rec[f"{tag}/inv_plain"]) < tol_inv, tag
+
+
+@pytest.mark.parametrize("name", ["lenet5", "resnet_toy"])
+def test_kfac_mc_replayed_vectors_cpu(name, monkeypatch):
+    check_kfac_mc_replayed(name, F64, torch.device("cpu"), 2e-6, 2e-6, monkeypatch)   # (large arrays stored in float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lenet5", "resnet_toy"])
+def test_kfac_mc_replayed_vectors_gpu(name, monkeypatch):
+    check_kfac_mc_replayed(name, F32, torch.device("cuda:0"), 1e-4, 1e-3, monkeypatch)
+
+
 def test_resnet_toy_cpu():
     check_resnet_toy(F64, torch.device("cpu"), 1e-7, 1e-7, 1e-6)
 

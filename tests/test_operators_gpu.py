@@ -55,6 +55,28 @@ def test_curvature_operators_gpu(dev, golden_mlp, case, name, cls, native):
     assert rel_err(op.to_scipy() @ rec["v"], rec[f"{name}_v"]) < TOL
 
 
+@pytest.mark.parametrize("case", sorted(load_golden("mlp_columns")))
+@pytest.mark.parametrize("name,cls", [("ggn", C.GGNLinearOperator), ("ef", C.EFLinearOperator),
+                                      ("hessian", C.HessianLinearOperator)])
+def test_native_column_kernels_vs_reference_golden(dev, case, name, cls):
+    """Round 4: K = 8 GGN / EF / exact-Hessian columns through ``clo_mlp_ggn_matmat`` / ``clo_mlp_hessian_matmat``
+    (asserted: the column kernels ran) against goldens generated from the REFERENCE's vmap
+    (_torch_base.py:946-989 over ggn.py:41-72, gradient_moments.py:48-87, hessian.py:66); fp32 vs float64, 1e-4."""
+    rec = load_golden("mlp_columns")[case]
+    dims, acts, bias, loss, red, *_ = mlp_case_tensors(rec)
+    model = build_mlp(dims, acts, bias)
+    params = load_into(model, rec, F32, dev)
+    data = golden_data(rec, F32, dev, loss)
+    op = cls(model, LOSS[loss](reduction=red), params, data)
+    assert op.uses_native_kernels
+    V = g32(rec["V"], dev)
+    got = op @ V
+    assert op.native_column_products >= 1, "the K-column kernels did not run"
+    assert rel_err(got, rec[f"{name}_V"]) < TOL
+    for k in (0, 7):   # and column by column through the single-vector kernels
+        assert rel_err(op @ V[:, k].contiguous(), rec[f"{name}_V"][:, k]) < TOL
+
+
 def test_native_matches_autograd_path_on_gpu(dev):
     """Same operator, both execution paths, same device and dtype."""
     torch.manual_seed(0)
