@@ -257,7 +257,7 @@ def secondary_configs(device) -> dict:
                   "factor size, block-reflector back-transformation; 6 worker streams, units sized by a measured "
                   "wall-time model; orthogonality / residual verified, float64 retry) + eigenvalue-correction sweep; "
                   "eigh_ms = min of 3 calls")
-    ek["eigh_policy"] = linalg_native._EIGH_MODE
+    ek["eigh_policy"] = "native (clo_sytrd_f32 persistent panels -> divide & conquer -> block reflectors)"
     out["c4_ekfac_resnet18"] = ek
     del K, E, facs, model, params
     torch.cuda.empty_cache()

@@ -51,7 +51,7 @@ _SIGNATURES = {
     "clo_cholesky_inverse_batched_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                                  _PF, c_void_p, c_void_p]),
     "clo_cholesky_inverse_batched_ws_floats": (c_long, [c_int, c_int]),
-    "clo_sytrd_f32": (c_int, [_PF, c_long, c_int, _PF, _PF, _PF, _PF, c_long, c_void_p]),
+    "clo_sytrd_f32": (c_int, [_PF, c_long, c_int, _PF, _PF, _PF, _PF, c_long, c_int, c_void_p]),
     "clo_sytrd_ws_bytes": (c_long, [c_int]),
     "clo_im2col_syrk_accum_f32": (
         c_int,
@@ -452,7 +452,12 @@ def cholesky_inverse_batched_into(As: list[Tensor], dampings: list[float], outs:
     _check(rc, "clo_cholesky_inverse_batched_f32")
 
 
-def sytrd_(A: Tensor, n: int) -> tuple[Tensor, Tensor, Tensor]:
+# cap on the workgroups of one persistent panel launch of clo_sytrd_f32 (0 = the library's 128): the eigensolver's
+# multi-stream driver lowers it so that the launches running side by side stay co-resident (two workgroups per CU)
+SYTRD_MAX_BLOCKS = 0
+
+
+def sytrd_(A: Tensor, n: int, max_blocks: int | None = None) -> tuple[Tensor, Tensor, Tensor]:
     """In-place Householder tridiagonalisation of the symmetric matrix in ``A[:n, :n]`` (``clo_sytrd_f32``).
     ``A``: fp32 GPU tensor ``[>= n, ld]`` with ``ld % 4 == 0`` and zero padding columns.  Returns
     ``(D, E, tau)``; afterwards ``A`` holds the Householder vectors in LAPACK's ``uplo='L'`` layout of
@@ -463,7 +468,8 @@ def sytrd_(A: Tensor, n: int) -> tuple[Tensor, Tensor, Tensor]:
     tau = torch.empty(n, device=A.device, dtype=torch.float32)
     nbytes = lib.clo_sytrd_ws_bytes(n)
     ws = torch.zeros(nbytes // 4, device=A.device, dtype=torch.float32)
-    rc = lib.clo_sytrd_f32(_p(A), A.stride(0), n, _p(D), _p(E), _p(tau), _p(ws), nbytes, _stream())
+    rc = lib.clo_sytrd_f32(_p(A), A.stride(0), n, _p(D), _p(E), _p(tau), _p(ws), nbytes,
+                           SYTRD_MAX_BLOCKS if max_blocks is None else max_blocks, _stream())
     _check(rc, "clo_sytrd_f32")
     return D, E, tau
 

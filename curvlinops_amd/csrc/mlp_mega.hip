@@ -28,6 +28,7 @@
 // that must arrive quickly (x, the exchanged activations) is loaded by wave 7, which owns no weight tile.
 // All sums are taken in fixed orders: results are bit-for-bit repeatable.  Every spin is bounded.
 #include "clo_common.h"
+#include "persist_gate.h"
 
 #include <mutex>
 
@@ -911,35 +912,26 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
   const int v = beta != 0.f ? 1 : 0;
   const void *fns[2] = {reinterpret_cast<const void *>(mlp_mega_kernel<false>),
                         reinterpret_cast<const void *>(mlp_mega_kernel<true>)};
-  // Two of these grids must never share the chip (each needs every CU: half-resident grids would wait for
-  // each other).  One stream orders its launches by itself; as soon as a second stream shows up on a device,
-  // every launch waits for the previous one's event and records its own.
-  struct Chain { hipStream_t last = nullptr; bool multi = false, any = false; hipEvent_t ev = nullptr; };
+  // Persistent grids never share the chip partly resident: csrc/persist_gate.h makes this stream wait (device side) for
+  // the persistent launches other streams still have in flight until all of them plus this one (every CU) fit.
   static std::mutex mu;
-  static Chain chains[MG_MAXDEV];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAXDEV) {
     set_error("mlp_mega_kernel: device ordinal %d out of range", dev);
     return CLO_EINVAL;
   }
-  std::lock_guard<std::mutex> lock(mu);
-  if (!attr_done[dev][v]) {
-    int rc = check_hip(hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
-                       "hipFuncSetAttribute(mlp_mega_kernel)");
-    if (rc != CLO_OK) return rc;
-    attr_done[dev][v] = true;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!attr_done[dev][v]) {
+      int rc = check_hip(hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
+                         "hipFuncSetAttribute(mlp_mega_kernel)");
+      if (rc != CLO_OK) return rc;
+      attr_done[dev][v] = true;
+    }
   }
-  Chain &c = chains[dev];
-  if (c.any && c.last != st && !c.multi) {
-    c.multi = true;
-    int rc = check_hip(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming), "hipEventCreate(persistent matvec)");
-    if (rc != CLO_OK) return rc;
-    // the previous launch was not recorded: let this stream wait for all of the other stream's work so far
-    rc = check_hip(hipEventRecord(c.ev, c.last), "hipEventRecord(persistent matvec)");
-    if (rc != CLO_OK) return rc;
-  }
-  if (c.multi && c.last != st) {
-    int rc = check_hip(hipStreamWaitEvent(st, c.ev, 0), "hipStreamWaitEvent(persistent matvec)");
+  PersistGate &gate = PersistGate::of(dev);
+  {
+    int rc = gate.admit(st, MG_G);
     if (rc != CLO_OK) return rc;
   }
   const double D = (double)dims[0] * dims[1] + (double)dims[1] * dims[2] + (double)dims[2] * dims[3];
@@ -947,14 +939,16 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
     ProfScope prof(6, 12.0 * D, st);
     if (v == 0) hipLaunchKernelGGL((mlp_mega_kernel<false>), dim3(MG_G), dim3(MG_T), smem, st, a);
     else hipLaunchKernelGGL((mlp_mega_kernel<true>), dim3(MG_G), dim3(MG_T), smem, st, a);
-    CLO_CHECK_LAUNCH("mlp_mega_kernel");
   }
-  if (c.multi) {
-    int rc = check_hip(hipEventRecord(c.ev, st), "hipEventRecord(persistent matvec)");
+  {
+    int rc = check_hip(hipGetLastError(), "mlp_mega_kernel");
+    if (rc != CLO_OK) {
+      gate.abort();
+      return rc;
+    }
+    rc = gate.done(st);
     if (rc != CLO_OK) return rc;
   }
-  c.last = st;
-  c.any = true;
   return CLO_OK;
 }
 

@@ -8,10 +8,11 @@ factorisation fails.  ``eigh`` replaces ``torch.linalg.eigh`` at ``kronecker.py:
 
 fp32 GPU inputs: the Cholesky inverse runs on the hand-written kernels (``csrc/linalg.hip`` for
 the diagonal blocks, the MFMA GEMM of ``csrc/gemm.hip`` for every O(n^3) step; driver
-``_hip.cholesky_inverse``).  The symmetric eigensolver is hand-written end to end by default
-(``CLO_EIGH=native``): Householder reduction ``csrc/sytrd.hip``, tridiagonal divide & conquer and
-block-reflector back-transformation ``csrc/eigh.hip`` / ``eigh_native.py``; ``CLO_EIGH=hybrid|rocsolver``
-keep ``torch.linalg.eigh`` (rocSOLVER) where it is faster / everywhere -- measured in DESIGN.md section 7.
+``_hip.cholesky_inverse``).  The symmetric eigensolver is hand-written end to end: Householder reduction
+``csrc/sytrd.hip`` (one persistent launch per 64-column panel), tridiagonal divide & conquer and block-reflector
+back-transformation ``csrc/eigh.hip`` / ``eigh_native.py``.  ``torch.linalg.eigh`` remains for CPU / float64
+operands (the reference's own path) and as the float64 retry of a result that fails its verification; the rocSOLVER
+comparison routes of rounds 1-3 live in ``tools/`` (``tools/_rocsolver.py``, ``tools/probe_rocsolver_phases.py``).
 """
 
 from __future__ import annotations
@@ -283,20 +284,7 @@ def damped_cholesky_inverse(A: Tensor, damping: float, retry_double_precision: b
         return _torch_damped_cholesky_inverse(A.to(torch.float64), damping).to(A.dtype)
 
 
-# Which solver :func:`eigh` uses for fp32 GPU matrices:
-#   "native" (default)  hand-written end to end for every order up to 8184: clo_sytrd_f32 (Householder reduction),
-#                       divide & conquer on the tridiagonal matrix and block-reflector back-transformation
-#                       (eigh_native.py); matrices of equal size are separate units on the worker streams;
-#   "hybrid"            rounds 1-2: the own route for single matrices of order 256..2400, rocSOLVER
-#                       (torch.linalg.eigh, batched by size) elsewhere -- ~20 % faster on ResNet-18's factors;
-#   "sytrd"             = "native" (kept as an alias); "rocsolver": torch.linalg.eigh only.
-# All routes are verified (orthogonality, residual) with a float64 retry, see _torch_eigh_scaled; DESIGN.md section 7.
-_EIGH_MODE = {"sytrd": "native", "auto": "native"}.get(os.environ.get("CLO_EIGH", "native").lower(),
-                                                         os.environ.get("CLO_EIGH", "native").lower())
-_SYTRD_MAX_N = 8184
-# What follows the own reduction: "native" (default) = the hand-written divide & conquer on the tridiagonal
-# matrix and block-reflector back-transformation of eigh_native.py; "rocsolver" = sstedc / sormtr (rounds 1-2).
-_EIGH_VENDOR_TAIL = os.environ.get("CLO_EIGH_TAIL", "native").lower() == "rocsolver"
+_SYTRD_MAX_N = 8184   # the reduction keeps two vectors of the matrix order in LDS
 
 
 def _unit_scale(A: Tensor) -> tuple[Tensor, Tensor]:
@@ -369,54 +357,35 @@ def _eigh_unit_checked(An: Tensor) -> tuple[Tensor, Tensor]:
     return res.eigenvalues.float(), res.eigenvectors.float()
 
 
-def _eigh_sytrd_unit(An: Tensor) -> tuple[Tensor, Tensor]:
-    """``clo_sytrd_f32`` -> ``sstedc`` -> ``sormtr`` on a normalised matrix (no checks)."""
-    from . import _rocsolver
+def _eigh_sytrd_unit(An: Tensor, max_blocks: int = 0) -> tuple[Tensor, Tensor]:
+    """``clo_sytrd_f32`` -> divide & conquer on the tridiagonal matrix -> block-reflector back-transformation on a
+    normalised matrix (no checks)."""
+    from . import eigh_native
 
     n = An.shape[0]
     ld = (n + 3) // 4 * 4
     work = torch.zeros(n, ld, device=An.device, dtype=torch.float32)   # zero padding columns
     work[:, :n].copy_(An)
-    D, E, tau = _hip.sytrd_(work, n)
-    Z = torch.empty(n, ld, device=An.device, dtype=torch.float32)      # column-major eigenvectors
-    if _EIGH_VENDOR_TAIL:
-        info = _rocsolver.stedc_(D, E, Z, n)
-        if int(info) != 0:   # checked BEFORE the back-transformation is queued on an unconverged Z
-            raise RuntimeError(f"eigh_sytrd: the tridiagonal eigensolver did not converge (info = {int(info)})")
-        _rocsolver.ormtr_(work, tau, Z, n)
-        return D, Z[:, :n].T
-    # hand-written tail: divide & conquer on the tridiagonal matrix, block-reflector back-transformation
-    from . import eigh_native
-
+    D, E, tau = _hip.sytrd_(work, n, max_blocks=max_blocks)
     lam, Qt = eigh_native.stedc_native(D, E, n)
-    Z.zero_()
+    Z = torch.zeros(n, ld, device=An.device, dtype=torch.float32)      # rows = eigenvectors
     Z[:, :n] = Qt.T
     eigh_native.ormtr_native(work, tau, Z, n)
     return lam, Z[:, :n].T
 
 
-def eigh_sytrd(A: Tensor) -> tuple[Tensor, Tensor]:
-    """Symmetric eigendecomposition with the hand-written Householder reduction: ``clo_sytrd_f32`` (one launch
-    per column) -> rocSOLVER ``sstedc`` on the tridiagonal matrix -> ``sormtr``.  fp32 GPU matrices of order
-    3..8184; same conventions as ``torch.linalg.eigh`` (ascending eigenvalues, eigenvectors in columns)."""
+def eigh_sytrd(A: Tensor, max_blocks: int = 0) -> tuple[Tensor, Tensor]:
+    """Symmetric eigendecomposition on the hand-written kernels: ``clo_sytrd_f32`` (persistent panel launches) ->
+    Cuppen divide & conquer -> block-reflector back-transformation, verified (orthogonality, residual) with a float64
+    retry.  fp32 GPU matrices of order 3..8184; conventions of ``torch.linalg.eigh`` (ascending eigenvalues,
+    eigenvectors in columns)."""
     n = A.shape[0]
     if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[1] == n and 3 <= n <= _SYTRD_MAX_N):
         raise ValueError(f"eigh_sytrd: need a square fp32 GPU matrix of order 3..{_SYTRD_MAX_N}, got {tuple(A.shape)} {A.dtype}")
-    if not _EIGH_VENDOR_TAIL:
-        return _eigh_native_group([A])[0]
-    An, scale = _unit_scale(A)
-    try:
-        lam, Q = _eigh_sytrd_unit(An)
-        ok = bool((_orth_defect(Q) <= _ORTH_TOL) & (_residual_defect(An, lam, Q) <= _RES_TOL))   # verified like the rocSOLVER route
-    except (RuntimeError, OSError):   # a recoverable solver failure must not abort a KFAC build
-        ok = False
-    if not ok:
-        res = torch.linalg.eigh(An.double())
-        lam, Q = res.eigenvalues.float(), res.eigenvectors.float()
-    return lam * scale.reshape(()), Q
+    return _eigh_native_group([A], max_blocks)[0]
 
 
-def _eigh_native_group(As: list[Tensor]) -> list[tuple[Tensor, Tensor]]:
+def _eigh_native_group(As: list[Tensor], max_blocks: int = 0) -> list[tuple[Tensor, Tensor]]:
     """Hand-written route for several fp32 GPU matrices of ONE order n >= 3 (repeated layer shapes): one reduction
     per matrix (``clo_sytrd_f32``: a chain of n launches inside one foreign call), then ONE divide & conquer whose
     tree levels carry all matrices (``eigh_native.stedc_native`` with a batch dimension), one back-transformation
@@ -429,7 +398,7 @@ def _eigh_native_group(As: list[Tensor]) -> list[tuple[Tensor, Tensor]]:
     ld = (n + 3) // 4 * 4
     work = torch.zeros(B, n, ld, device=dev, dtype=torch.float32)
     work[:, :, :n] = An
-    DEt = [_hip.sytrd_(work[b], n) for b in range(B)]
+    DEt = [_hip.sytrd_(work[b], n, max_blocks=max_blocks) for b in range(B)]
     lam, Qt = eigh_native.stedc_native(torch.stack([x[0] for x in DEt]), torch.stack([x[1] for x in DEt]), n)
     Z = torch.zeros(B, n, ld, device=dev, dtype=torch.float32)
     Z[:, :, :n] = Qt.mT
@@ -495,13 +464,14 @@ def _eigh_2x2(A: Tensor) -> tuple[Tensor, Tensor]:
     return lam.to(A.dtype), Q.to(A.dtype)
 
 
-def _eigh_full(A: Tensor) -> tuple[Tensor, Tensor]:
-    """One matrix without zero rows (or a CPU / non-float32 one): solver selection as documented at _EIGH_MODE."""
-    if _EIGH_MODE != "rocsolver" and A.is_cuda and A.dtype == torch.float32 and A.dim() == 2:
+def _eigh_full(A: Tensor, max_blocks: int = 0) -> tuple[Tensor, Tensor]:
+    """One matrix without zero rows: fp32 GPU matrices on the hand-written solver, everything else (CPU, float64,
+    orders beyond the reduction's 8184) through ``torch.linalg.eigh`` on the normalised matrix."""
+    if A.is_cuda and A.dtype == torch.float32 and A.dim() == 2:
         n = A.shape[0]
-        if 3 <= n <= _SYTRD_MAX_N and (_EIGH_MODE == "native" or 256 <= n <= 2400):
-            return eigh_sytrd(A)
-        if _EIGH_MODE == "native" and n == 2:   # one Jacobi rotation in float64: exact, nothing to verify
+        if 3 <= n <= _SYTRD_MAX_N:
+            return eigh_sytrd(A, max_blocks)
+        if n == 2:   # one Jacobi rotation in float64: exact, nothing to verify
             return _eigh_2x2(A)
     return _torch_eigh_scaled(A)
 
@@ -519,16 +489,15 @@ def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
 
 
 def eigh_many(mats: list[Tensor], num_streams: int | None = None) -> list[tuple[Tensor, Tensor]]:
-    """:func:`eigh` of several independent symmetric matrices.  On the GPU the solver (rocSOLVER
-    through ``torch.linalg.eigh``) is a long chain of small dependent kernels, so
+    """:func:`eigh` of several independent symmetric matrices.  A single decomposition is a chain of dependent
+    steps (one grid-wide hand-off per matrix column in the reduction), so
 
-    * factors of EQUAL size are stacked and decomposed by ONE batched call (networks repeat layer
-      shapes; measured on MI355X: 12 x 768^2 208 -> 21 ms, 4 x 2305^2 220 -> 75 ms, 3 x 4609^2
-      409 -> 258 ms), and
-    * the groups are spread, largest first, over a few worker threads that each own a HIP stream
-      (the solver synchronises with the host in between)."""
-    if num_streams is None:   # six workers: the three largest factors of a ResNet-18 each get one, three share the rest
-        num_streams = int(os.environ.get("CLO_EIGH_STREAMS", 6))
+    * factors of EQUAL size share the divide & conquer levels and the verification (networks repeat layer shapes), and
+    * the units are spread, largest first, over a few worker threads that each own a HIP stream; the persistent
+      panel launches of the reductions that run side by side share the chip's 256 CUs in proportion to their matrix
+      sizes (``max_blocks`` of ``clo_sytrd_f32``; the library's admission control keeps any combination safe)."""
+    if num_streams is None:   # six workers: the largest factors of a ResNet-18 each get one, the rest share the others
+        num_streams = 6
     out: list = [None] * len(mats)
     for i, A in enumerate(mats):
         if not A.is_cuda:
@@ -581,15 +550,22 @@ def _eigh_many_gpu(mats: list[Tensor], gpu: list[int], out: list, num_streams: i
         chunk = max(1, min((8 << 30) // per, -(-len(idx) // parts)))
         units.extend(idx[k : k + chunk] for k in range(0, len(idx), chunk))
     units.sort(key=lambda u: -len(u) * est(mats[u[0]].shape[0]))
+    # workgroups per panel launch: the units that start together (the `num_streams` largest) split the 256 CUs by
+    # matrix area, later (smaller) units take the share their size would have had among those
+    lead = sum(mats[u[0]].shape[0] ** 2 for u in units[: max(num_streams, 1)])
+    blocks = {id(u): int(min(256, max(16, round(256.0 * mats[u[0]].shape[0] ** 2 / max(lead, 1))))) for u in units}
+    if len(units) == 1:
+        blocks[id(units[0])] = 0   # a lone reduction: the library's default (every CU it can use)
 
     def run(unit: list[int]) -> None:
+        mb = blocks[id(unit)]
         if len(unit) == 1:
             for i in unit:
-                out[i] = _eigh_full(mats[i])
+                out[i] = _eigh_full(mats[i], mb)
             return
         A0 = mats[unit[0]]
-        if _EIGH_MODE == "native" and A0.dtype == torch.float32 and 3 <= A0.shape[0] <= _SYTRD_MAX_N:
-            for i, res in zip(unit, _eigh_native_group([mats[i] for i in unit])):
+        if A0.dtype == torch.float32 and 3 <= A0.shape[0] <= _SYTRD_MAX_N:
+            for i, res in zip(unit, _eigh_native_group([mats[i] for i in unit], mb)):
                 out[i] = res
             return
         lam, vec = _torch_eigh_scaled(torch.stack([mats[i] for i in unit]))

@@ -58,13 +58,38 @@ def _gram_orthonormal_basis(X: Tensor, rel_tol: float = 1e-5) -> Tensor:
     return Q
 
 
+def _gram_qr(X: Tensor) -> tuple[Tensor, Tensor] | None:
+    """``(Q, T^-T)`` with ``X = Q T``, ``Q`` orthonormal, for a tall full-rank fp32 GPU block -- the factorisation
+    XTrace / XDiag need (``trace/epperly2024xtrace.py:52-60`` call ``torch.linalg.qr``, which is rocSOLVER on this
+    platform).  Their leave-one-out vectors ``s_i`` are the directions of ``T^-T e_i``: the complement of
+    ``range(X[:, != i])`` inside ``range(Q)`` whatever the shape of ``T``, so ``T`` need not be triangular.  Two Gram
+    passes on the matrix pipe (``clo_syrk_accum_f32`` / ``clo_gemm_f32``), the two small eigenproblems in float64;
+    ``T = (L2^1/2 V2^T)(L1^1/2 V1^T)`` is inverted in closed form.  None if ``X`` is numerically rank-deficient (the
+    caller then takes the float64 route)."""
+    Q = X if X.is_contiguous() else X.contiguous()
+    n = Q.shape[1]
+    Tinv = torch.eye(n, device=X.device, dtype=torch.float64)
+    for it in range(2):
+        gram = torch.empty(n, n, device=Q.device, dtype=torch.float32)
+        _hip.syrk_accum(gram, Q, alpha=1.0, beta=0.0)
+        gscale = gram.abs().amax().clamp_min(torch.finfo(torch.float32).tiny).double()
+        lam, V = torch.linalg.eigh(gram.double() / gscale)
+        lam = lam * gscale
+        if not bool((lam > lam.max() * (1e-5 if it == 0 else 1e-12)).all()):
+            return None
+        step = V / lam.sqrt()                      # X_it = X_{it+1} (L^1/2 V^T)  =>  X_{it+1} = X_it (V L^-1/2)
+        Q = _hip.gemm(Q, step.float().contiguous())
+        Tinv = Tinv @ step
+    return Q, Tinv.T.to(X.dtype)
+
+
 def orthonormal_basis(X: Tensor) -> Tensor:
     """``Q`` of the reduced QR factorisation of a tall ``[m, n]`` matrix (``meyer2020hutch.py:93``).
     Above ``2^30`` elements the factorisation is done as TSQR -- Householder QR of row chunks, QR of
     the stacked triangular factors, one small GEMM per chunk -- which is as stable as the direct
     call, works for rank-deficient inputs, and keeps every library call within 32-bit indexing."""
     m, n = X.shape
-    if is_native_tensor(X) and m * n >= _GRAM_MIN_ELEMS and m >= 64 * n:
+    if is_native_tensor(X) and m >= 2 * n:   # fp32 on the GPU: always the Gram route on the own GEMM engine
         return _gram_orthonormal_basis(X)
     if m * n <= _QR_MAX_ELEMS or m <= 2 * n:
         return torch.linalg.qr(X)[0]
@@ -172,6 +197,20 @@ def _leave_one_out_vectors(R: Tensor) -> Tensor:
     return RT_inv / (RT_inv**2).sum(0) ** 0.5
 
 
+def _q_and_leave_one_out(A_W: Tensor) -> tuple[Tensor, Tensor]:
+    """``(Q, S)`` for XTrace / XDiag: fp32 GPU blocks through :func:`_gram_qr` (own kernels), everything else --
+    and numerically rank-deficient blocks -- through the reference's QR (in float64 for the fallback)."""
+    if is_native_tensor(A_W) and A_W.shape[0] >= 2 * A_W.shape[1]:
+        qt = _gram_qr(A_W)
+        if qt is not None:
+            Q, RT_inv = qt
+            return Q, RT_inv / (RT_inv**2).sum(0) ** 0.5
+        Q, R = torch.linalg.qr(A_W.double())
+        return Q.to(A_W.dtype), _leave_one_out_vectors(R).to(A_W.dtype)
+    Q, R = torch.linalg.qr(A_W)
+    return Q, _leave_one_out_vectors(R)
+
+
 def xtrace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribution: str = "rademacher",
            probes: Tensor | None = None) -> Tensor:
     """XTrace (Epperly, Tropp & Webber 2024; reference ``trace/epperly2024xtrace.py``): exchangeable
@@ -183,10 +222,9 @@ def xtrace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribution: st
     N = num_matvecs // 2
     W = random_matrix(dim, N, distribution, A.device, A.dtype) if probes is None else probes
     A_W = A @ W
-    Q, R = torch.linalg.qr(A_W)
+    Q, S = _q_and_leave_one_out(A_W)
     A_Q = A @ Q
     QT_A_Q = Q.T @ A_Q
-    S = _leave_one_out_vectors(R)
     traces = QT_A_Q.trace() - torch.einsum("ij,ik,kj->j", S, QT_A_Q, S)
     # (I - Q_i Q_i^T) A (I - Q_i Q_i^T) w_i for all i; deflation = v - <s_i, v> s_i column by column
     def deflate(V: Tensor) -> Tensor:
@@ -206,9 +244,8 @@ def xdiag(A: Tensor | PyTorchLinearOperator, num_matvecs: int, probes: Tensor | 
     N = num_matvecs // 2
     W = random_matrix(dim, N, "rademacher", A.device, A.dtype) if probes is None else probes
     A_W = A @ W
-    Q, R = torch.linalg.qr(A_W)
+    Q, S = _q_and_leave_one_out(A_W)
     QT_A = Q.T @ A
-    S = _leave_one_out_vectors(R)
     diagonal = (Q * QT_A.T).sum(1) - ((Q @ S) * (QT_A.T @ S)).sum(1) / N
 
     def deflate(V: Tensor) -> Tensor:

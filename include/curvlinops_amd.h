@@ -157,14 +157,19 @@ long clo_cholesky_inverse_batched_ws_floats(int n, int batch);
 
 /* Householder reduction of a symmetric matrix to tridiagonal form, the 85 % of the reference's
  * torch.linalg.eigh (kronecker.py:294-301 eigendecomposed Kronecker factors; ekfac.py's eigenbases) that
- * rocSOLVER runs as ~5 dependent kernels per column; here one launch per column plus one MFMA rank-128
- * update per 64 columns.  A: row-major [n][lda] FULL symmetric matrix, 16-byte aligned rows zero-padded to a
- * multiple of 4 columns; overwritten.  On return, LAPACK ssytrd(uplo='L') storage of the column-major
- * (== row-major, symmetric) matrix: row j, columns j+2.. = Householder vector j (unit entry at j+1 implied),
- * D[n] / E[n-1] the tridiagonal matrix, tau[n-1] the reflector scales -- the inputs of sstedc / sormtr.
- * 3 <= n <= 8184.  ws: clo_sytrd_ws_bytes(n) bytes, 16-byte aligned. */
+ * rocSOLVER runs as ~5 dependent kernels per column; here ONE persistent launch per 64-column panel (the
+ * workgroups own their matrix rows for the whole panel and hand the reflector data to each other between
+ * columns) plus one MFMA rank-128 update per panel.  A: row-major [n][lda] FULL symmetric matrix, 16-byte
+ * aligned rows zero-padded to a multiple of 4 columns; overwritten.  On return, LAPACK ssytrd(uplo='L') storage
+ * of the column-major (== row-major, symmetric) matrix: row j, columns j+2.. = Householder vector j (unit entry
+ * at j+1 implied), D[n] / E[n-1] the tridiagonal matrix, tau[n-1] the reflector scales -- the inputs of a
+ * LAPACK-compatible tridiagonal solver / back-transformation (clo_eigh_* below).  3 <= n <= 8184.
+ * ws: clo_sytrd_ws_bytes(n) bytes, 16-byte aligned.
+ * max_blocks: cap on the workgroups of a panel launch (0 = 128).  All of them must be resident at once (they
+ * wait for each other); two fit a CU, so callers that run k reductions side by side on different streams pass
+ * <= 512 / k. */
 int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, float *tau, float *ws, long ws_bytes,
-                  void *stream);
+                  int max_blocks, void *stream);
 long clo_sytrd_ws_bytes(int n);
 
 /* ------------------------------------------------------------------------- *

@@ -969,13 +969,9 @@ def test_eigh_sytrd(hip, kind, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [24, 200, 1500])
 def test_sytrd_is_a_similarity_transform(hip, n):
-    """The tridiagonal matrix (d, e) of clo_sytrd_f32 has the spectrum of the input (the entries themselves
-    are not forward-stable for later columns, only the first ones are compared with rocSOLVER's ssytrd,
-    which follows the same LAPACK sign convention)."""
-    import ctypes
-
-    from curvlinops_amd import _rocsolver
-
+    """The tridiagonal matrix (d, e) of clo_sytrd_f32 has the spectrum of the input, and its first entries follow
+    LAPACK's ssytrd sign convention (the first reflector recomputed in float64 here; later entries are not
+    forward-stable, only the spectrum is).  The rocSOLVER comparison of rounds 2-3 lives in tools/probe_sytrd.py."""
     dev = torch.device("cuda:0")
     A64 = _sym_case("indefinite", n, dev)
     ld = (n + 3) // 4 * 4
@@ -991,49 +987,42 @@ def test_sytrd_is_a_similarity_transform(hip, n):
     ref = torch.linalg.eigvalsh(A64)
     assert float((torch.linalg.eigvalsh(T) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     assert float(tau[: n - 2].min()) >= 0.0 and float(tau[: n - 2].max()) <= 2.0   # reflector scales
-    _, rs = _rocsolver._load()
-    rs.rocsolver_ssytrd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
-                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    Ar = padded()
-    Dr, Er, taur = (torch.empty(n, device=dev) for _ in range(3))
-    assert rs.rocsolver_ssytrd(_rocsolver._handle(dev), 122, n, Ar.data_ptr(), ld, Dr.data_ptr(), Er.data_ptr(),
-                               taur.data_ptr()) == 0
-    torch.cuda.synchronize()
+    # column 0 in float64: d_0 = a_00, e_0 = -sign(a_10) |a[1:, 0]|, tau_0 = (e_0 - a_10) / e_0
+    a = A64[:, 0].double().cpu()
+    e0 = -torch.sign(a[1]) * a[1:].norm()
     sc = float(A64.abs().max())
-    k = 8
-    assert float((D[:k] - Dr[:k]).abs().max()) <= 1e-4 * sc
-    assert float((E[:k] - Er[:k]).abs().max()) <= 1e-4 * sc
-    assert float((tau[:k] - taur[:k]).abs().max()) <= 1e-4
+    assert abs(float(D[0]) - float(a[0])) <= 1e-6 * sc
+    assert abs(float(E[0]) - float(e0)) <= 1e-5 * sc
+    assert abs(float(tau[0]) - float((e0 - a[1]) / e0)) <= 1e-5
 
 
 @pytest.mark.gpu
-def test_eigh_mode_switch(hip, monkeypatch):
-    """The default policy ("native") routes every fp32 GPU eigh through the hand-written solver; "hybrid" /
-    "rocsolver" keep torch.linalg.eigh where it is faster / everywhere.  Same spectrum either way."""
+def test_eigh_takes_the_native_route(hip, monkeypatch):
+    """Every fp32 GPU eigh of order 3..8184 runs on the hand-written solver (one path in the package: no
+    torch.linalg.eigh / rocSOLVER call unless the verification fails)."""
     from curvlinops_amd import linalg_native as L
 
     dev = torch.device("cuda:0")
     A = _sym_case("lowrank", 300, dev).to(dev, torch.float32)
-    monkeypatch.setattr(L, "_EIGH_MODE", "rocsolver")
-    lam0, _ = L.eigh(A)
-    monkeypatch.setattr(L, "_EIGH_MODE", "native")
     calls = []
     real = L.eigh_sytrd
-    monkeypatch.setattr(L, "eigh_sytrd", lambda M: (calls.append(1), real(M))[1])
+    monkeypatch.setattr(L, "eigh_sytrd", lambda M, mb=0: (calls.append(1), real(M, mb))[1])
+    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (_ for _ in ()).throw(AssertionError("vendor eigh called")))
     lam1, Q1 = L.eigh(A)
     assert calls == [1]
-    assert float((lam0 - lam1).abs().max()) <= 1e-5 * float(lam0.abs().max())
+    ref = np.linalg.eigvalsh(A.double().cpu().numpy())
+    assert float(np.abs(lam1.double().cpu().numpy() - ref).max()) <= 1e-5 * float(np.abs(ref).max())
     assert float((A @ Q1 - Q1 * lam1).abs().max()) <= 1e-5 * float(A.abs().max())
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("power", [-8, -6, -3, 0, 4, 7])
-@pytest.mark.parametrize("mode", ["rocsolver", "native", "hybrid", "many"])
+@pytest.mark.parametrize("mode", ["native", "many"])
 def test_eigh_is_scale_invariant(hip, monkeypatch, power, mode):
-    """Factors of tiny norm (gradient covariances of mean-reduced losses) and of huge norm: rocSOLVER's
-    tridiagonal solver applies an absolute tolerance (fp32 matrices of norm 1e-6: 30 % eigenvalue error through
-    plain torch.linalg.eigh), so every GPU entry point normalises first.  Relative accuracy must not depend on
-    the scale."""
+    """Factors of tiny norm (gradient covariances of mean-reduced losses) and of huge norm: every GPU entry point
+    normalises first (rocSOLVER's tridiagonal solver behind plain torch.linalg.eigh applies an absolute tolerance:
+    fp32 matrices of norm 1e-6 come back with 30 % eigenvalue error).  Relative accuracy must not depend on the
+    scale."""
     from curvlinops_amd import linalg_native as L
 
     dev = torch.device("cuda:0")
@@ -1048,7 +1037,6 @@ def test_eigh_is_scale_invariant(hip, monkeypatch, power, mode):
         refb = torch.linalg.eigvalsh(B.double().cpu())
         assert float((lam_b.double().cpu() - refb).abs().max()) <= 1e-5 * float(refb.abs().max())
     else:
-        monkeypatch.setattr(L, "_EIGH_MODE", mode)
         lam, Q = L.eigh(A)
     ref = torch.linalg.eigvalsh(A64)
     scale = float(A64.abs().max())
@@ -1120,7 +1108,12 @@ def test_block_reflector_back_transformation(hip, n):
 @pytest.mark.parametrize("n", [64, 577, 1153, 2305, 4609])
 def test_native_eigh_at_the_factor_sizes_of_the_benchmarks(hip, n):
     """The hand-written solver end to end (no torch.linalg.eigh / rocSOLVER on the way) at the factor orders of
-    ResNet-18 / the encoder: |Q^T Q - I| <= 1e-5 and Q diag(lam) Q^T against the float64 matrix <= 1e-4."""
+    ResNet-18 / the encoder: |Q^T Q - I| <= 1e-5 and Q diag(lam) Q^T against the float64 matrix within 4 eps32 |A|_2
+    (the backward-error scale of an fp32 eigensolver) and, up to n = 1153, within 1e-4 |A|max entrywise.  Beyond, the
+    entrywise error of this rank-one-dominated matrix (n = 4609: |A|_2 = 3500 |A|max, ONE rounding of the top
+    eigenvalue is 2e-4 |A|max) depends on the order of the reduction's sums: round 3's column launches 0.7e-4 at 4609,
+    the persistent panel launches 0.7 ... 2.3e-4 for 32 ... 128 workgroups (tools/cmp_sytrd_recon.py) -- all below half
+    an eps32 |A|_2."""
     from curvlinops_amd import linalg_native as L
 
     dev = torch.device("cuda:0")
@@ -1128,11 +1121,13 @@ def test_native_eigh_at_the_factor_sizes_of_the_benchmarks(hip, n):
     X = torch.rand(max(16, n // 3), n, generator=g, dtype=torch.float64)      # rank-deficient covariance
     A64 = X.T @ X / X.shape[0]
     A = A64.to(dev, torch.float32)
-    assert L._EIGH_MODE == "native" and not L._EIGH_VENDOR_TAIL
     lam, Q = L.eigh(A)
     Qd, ld_ = Q.double().cpu(), lam.double().cpu()
     assert float((Qd.T @ Qd - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-5
-    assert float(((Qd * ld_) @ Qd.T - A.double().cpu()).abs().max()) <= 1e-4 * float(A64.abs().max())
+    rec = float(((Qd * ld_) @ Qd.T - A.double().cpu()).abs().max())
+    assert rec <= 4.0 * 2.0 ** -24 * float(ld_.abs().max())
+    if n <= 1153:
+        assert rec <= 1e-4 * float(A64.abs().max())
 
 
 @pytest.mark.gpu
@@ -1175,8 +1170,10 @@ def test_eigh_orthogonal_on_dead_relu_factor(hip, entry):
         assert float((Q2.T @ Q2 - torch.eye(n, device=dev)).abs().max()) <= 2e-5
     A64, Q64, l64 = A.double().cpu(), Q.double().cpu(), lam.double().cpu()
     assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 2e-5
-    assert float((A64 @ Q64 - Q64 * l64).abs().max()) <= 1e-4 * float(A64.abs().max())
     ref = torch.linalg.eigvalsh(A64)
+    # residual on the backward-error scale of fp32: eps32 |A|_2 = 6e-8 x 256 x |A|max = 1.5e-5 |A|max here; the entrywise residual moves
+    # with the summation order of the reduction (round 3: 2.2e-5 ... 3.0e-5 |A|max, persistent panels 3.2e-5 at most)
+    assert float((A64 @ Q64 - Q64 * l64).abs().max()) <= 8.0 * 2.0 ** -24 * float(ref.abs().max())
     assert float((l64 - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 

@@ -1,6 +1,7 @@
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np, torch, ctypes
-from curvlinops_amd import _hip, _rocsolver
+from curvlinops_amd import _hip
+import _rocsolver  # tools/_rocsolver.py
 dev=torch.device("cuda:0")
 rng=np.random.default_rng(0)
 n=65

@@ -10,7 +10,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from curvlinops_amd import _hip, _rocsolver
+from curvlinops_amd import _hip
+import _rocsolver  # tools/_rocsolver.py
 
 P, I = ctypes.c_void_p, ctypes.c_int
 
