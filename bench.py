@@ -144,10 +144,19 @@ def other_points(model, params, device, D: int) -> dict:
                               "frac_of_f32_mfma_peak": 10.0 * rows * D / us / 1e6 / 157.3}
     X, y = torch.rand(8, DIMS[0], device=device), torch.rand(8, DIMS[3], device=device)
     G = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X, y)], check_deterministic=False)
-    V = torch.rand(D, 32, device=device)
-    us = us_per_call(lambda: G @ V, 4)
-    out["k32_columns_rows8"] = {"us_per_column": us / 32, "columns_per_s": 32e6 / us,
-                                "alg_bytes_per_column": 8 * D, "achieved_GBps": 8 * D * 32 / us / 1e3}
+    for K in (32, 64):
+        Vs = [torch.rand(D, K, device=device) for _ in range(2)]   # two blocks: V and the result stream from / to HBM
+        state = {"i": 0}
+
+        def prod():
+            state["i"] ^= 1
+            return G @ Vs[state["i"]]
+
+        us = us_per_call(prod, 6)
+        out[f"k{K}_columns_rows8"] = {"us_per_column": us / K, "columns_per_s": K * 1e6 / us,
+                                      "alg_bytes_per_column": 8 * D, "achieved_GBps": 8 * D * K / us / 1e3,
+                                      "frac_of_hbm_peak": 8 * D * K / us / 1e3 / HBM_PEAK_GBPS}
+        del Vs
     return out
 
 
@@ -238,7 +247,40 @@ def secondary_configs(device) -> dict:
             best = min(best, time.perf_counter() - t0)
         return 1e3 * best, out
 
+    def median_of(fn, repeats):
+        """(median ms, [min, max] ms, last result) after one warm-up: the protocol of the noisy multi-thread legs."""
+        fn()
+        torch.cuda.synchronize()
+        ts, out = [], None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        ts.sort()
+        return ts[len(ts) // 2], [ts[0], ts[-1]], out
+
     out = {}
+    # ---- C3: LeNet-5 on 32 x 32 inputs, B = 1024, KFAC factor build + damped inverse + matvec (BASELINE configs[2])
+    from benchmarks.models import lenet5
+
+    torch.manual_seed(0)
+    net3 = lenet5().to(device)
+    p3 = dict(net3.named_parameters())
+    X3, y3 = torch.rand(1024, 1, 32, 32, device=device), torch.randint(0, 10, (1024,), device=device)
+    kw3 = dict(separate_weight_and_bias=False, check_deterministic=False, num_data=1024)
+    c3 = {"rows": 1024}
+    for ft in ("mc", "type-2"):
+        ms, sp, K3 = median_of(lambda: C.KFACLinearOperator(net3, nn.CrossEntropyLoss(), p3, [(X3, y3)], fisher_type=ft, **kw3), 5)
+        c3[f"factor_build_ms_{ft}"] = ms
+        c3[f"factor_build_ms_{ft}_min_max"] = sp
+    c3["inverse_ms"], c3["inverse_ms_min_max"], K3inv = median_of(lambda: K3.inverse(damping=1e-3), 5)
+    v3 = torch.rand(K3.shape[1], device=device)
+    c3["matvec_ms"], _, _ = median_of(lambda: K3 @ v3, 5)
+    c3["inverse_matvec_ms"], _, _ = median_of(lambda: K3inv @ v3, 5)
+    c3["note"] = "LeNet-5, joint W+b, CE mean; medians of 5 after one warm-up; type-2 = ten backpropagated vectors in one batched pass"
+    out["c3_kfac_lenet5"] = c3
+    del net3, p3, K3, K3inv
     torch.manual_seed(0)
     model = ResNet18().to(device).eval()
     params = kfac_params(model)
@@ -248,15 +290,16 @@ def secondary_configs(device) -> dict:
     K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw)
     facs = [S for blk in K[1] for S in blk]
     ek = {"rows": B}
-    ek["eigh_ms"], _ = timed(lambda: linalg_native.eigh_many(facs), 3)   # min of 3: six host threads, noisy
-    ek["ekfac_total_ms"], E = timed(lambda: C.EKFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw), 1)
+    ek["eigh_ms"], ek["eigh_ms_min_max"], _ = median_of(lambda: linalg_native.eigh_many(facs), 5)   # six host threads: noisy
+    ek["ekfac_total_ms"], ek["ekfac_total_ms_min_max"], E = median_of(
+        lambda: C.EKFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw), 5)
     v = torch.rand(E.shape[1], device=device)
     ek["ekfac_matvec_ms"], _ = timed(lambda: E @ v, 3)
     ek["note"] = ("EKFAC = factors + eigendecompositions of the 42 factors (dead-feature rows deflated, normalised, "
                   "hand-written solver end to end: Householder reduction, tridiagonal divide & conquer batched per "
                   "factor size, block-reflector back-transformation; 6 worker streams, units sized by a measured "
                   "wall-time model; orthogonality / residual verified, float64 retry) + eigenvalue-correction sweep; "
-                  "eigh_ms = min of 3 calls")
+                  "eigh_ms / ekfac_total_ms = MEDIAN of 5 calls after one warm-up, [min, max] beside them")
     ek["eigh_policy"] = "native (clo_sytrd_f32 persistent panels -> divide & conquer -> block reflectors)"
     out["c4_ekfac_resnet18"] = ek
     del K, E, facs, model, params
@@ -269,7 +312,7 @@ def secondary_configs(device) -> dict:
     D5 = EF.shape[1]
     v5 = torch.rand(D5, device=device)
     c5 = {"D": D5, "rows": 8, "seq_len": 128}
-    c5["ef_matvec_ms"], _ = timed(lambda: EF @ v5, 2)
+    c5["ef_matvec_ms"], c5["ef_matvec_ms_min_max"], _ = median_of(lambda: EF @ v5, 5)
     t0 = time.perf_counter()
     C.hutchpp_trace(EF, num_matvecs=96)
     torch.cuda.synchronize()
@@ -624,6 +667,16 @@ def main() -> None:
             result["other_points"] = other_points(model, params, device, D)
         except Exception as e:  # noqa: BLE001
             result["other_points"] = {"error": repr(e)}
+        kc = result["other_points"].get("k32_columns_rows8") if isinstance(result.get("other_points"), dict) else None
+        if kc:
+            result["roofline_kcols"] = {
+                "bound": "hbm", "kernel": "K = 32 probe columns (clo_mlp_ggn_matmat: kfwd_stream / kouter_stream + GEMM chain)",
+                "achieved": kc["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kc["frac_of_hbm_peak"],
+                "alg_bytes_per_column": 8 * D,
+                "definition": "8 D algorithmic bytes per column (V read, result written; W shared; SURVEY 8d) x 32 columns / "
+                              "time of one G @ [D, 32] product; K = 64 beside it in other_points",
+                "profile": "profiles/r04_c2_k32_kernel_stats.txt, profiles/r04_c2_k32_pmc_traffic.txt",
+            }
         try:
             result["other_points"].update(secondary_configs(device))
         except Exception as e:  # noqa: BLE001

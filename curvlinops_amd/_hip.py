@@ -52,6 +52,12 @@ _SIGNATURES = {
                                                  _PF, c_void_p, c_void_p]),
     "clo_cholesky_inverse_batched_ws_floats": (c_long, [c_int, c_int]),
     "clo_sytrd_f32": (c_int, [_PF, c_long, c_int, _PF, _PF, _PF, _PF, c_long, c_int, c_void_p]),
+    "clo_eigh_ws_bytes": (c_long, [c_int, c_int]),
+    "clo_eigh_f32": (c_int, [_PF, c_long, c_int, _PF, _PF, c_long, c_void_p, c_long, c_int, c_void_p]),
+    "clo_eigh_batched_f32": (c_int, [_PF, c_long, c_long, c_int, c_int, _PF, c_long, _PF, c_long, c_long, c_void_p, c_long,
+                                     c_int, c_void_p]),
+    "clo_stedc_ws_bytes": (c_long, [c_int, c_int]),
+    "clo_stedc_f32": (c_int, [_PF, _PF, c_long, c_int, c_int, _PF, c_long, _PF, c_long, c_long, c_void_p, c_long, c_void_p]),
     "clo_sytrd_ws_bytes": (c_long, [c_int]),
     "clo_im2col_syrk_accum_f32": (
         c_int,
@@ -723,6 +729,43 @@ class MLPPlan:
             _pc(self.workspace(N, X.device)), _stream(),
         )
         _check(rc, "clo_mlp_ggn_matvec")
+
+
+def eigh_batched_(work: Tensor, n: int, max_blocks: int = 0) -> tuple[Tensor, Tensor]:
+    """``clo_eigh_batched_f32``: eigendecomposition of the symmetric matrices in ``work[b, :n, :n]`` (fp32 GPU tensor
+    ``[B, n, ld]``, ``ld % 4 == 0``, zero padding columns, contiguous; OVERWRITTEN) in one foreign call.  Returns
+    ``(lam [B, n] ascending, Z [B, n, ld])`` with the eigenvectors in the ROWS of ``Z[b, :, :n]``."""
+    lib = load()
+    B, ld = work.shape[0], work.shape[2]
+    lam = torch.empty(B, n, device=work.device, dtype=torch.float32)
+    Z = torch.empty(B, n, ld, device=work.device, dtype=torch.float32)
+    nbytes = lib.clo_eigh_ws_bytes(n, B)
+    ws = torch.empty((nbytes + 3) // 4, device=work.device, dtype=torch.float32)
+    with torch.cuda.device(work.device):
+        rc = lib.clo_eigh_batched_f32(_p(work), ld, work.stride(0), n, B, _p(lam), n, _p(Z), ld, Z.stride(0), ws.data_ptr(),
+                                      nbytes, max_blocks, torch.cuda.current_stream(work.device).cuda_stream)
+    _check(rc, "clo_eigh_batched_f32")
+    return lam, Z
+
+
+def stedc_(d: Tensor, e: Tensor, n: int) -> tuple[Tensor, Tensor]:
+    """``clo_stedc_f32``: ``d``, ``e`` fp32 GPU ``[B, >= n]`` (same row stride) -> ``(lam [B, n], Z [B, n, n])`` with the
+    eigenvectors of the tridiagonal matrices in the ROWS of ``Z``."""
+    lib = load()
+    B = d.shape[0]
+    if d.stride(0) != e.stride(0) or d.stride(1) != 1 or e.stride(1) != 1:
+        d, e = d.contiguous(), e.contiguous()
+        if d.shape != e.shape:
+            e = torch.nn.functional.pad(e, (0, d.shape[1] - e.shape[1]))
+    lam = torch.empty(B, n, device=d.device, dtype=torch.float32)
+    Z = torch.empty(B, n, n, device=d.device, dtype=torch.float32)
+    nbytes = lib.clo_stedc_ws_bytes(n, B)
+    ws = torch.empty((nbytes + 3) // 4, device=d.device, dtype=torch.float32)
+    with torch.cuda.device(d.device):
+        rc = lib.clo_stedc_f32(_p(d), _p(e), d.stride(0), n, B, _p(lam), n, _p(Z), n, Z.stride(0), ws.data_ptr(), nbytes,
+                               torch.cuda.current_stream(d.device).cuda_stream)
+    _check(rc, "clo_stedc_f32")
+    return lam, Z
 
 
 # --------------------------------------------------------------------------------------

@@ -21,7 +21,11 @@ class PersistGate {
     mu_.lock();
     int total = cus;
     for (Slot &s : slots_) {
-      if (s.st == st || !s.busy) continue;
+      if (!s.busy) continue;
+      if (s.st == st) {   // own slot: forget the sizes of launches that have drained
+        if (s.recorded && hipEventQuery(s.ev) == hipSuccess) s.busy = false;
+        continue;
+      }
       if (!s.recorded) {   // that stream was alone so far and skipped its records: an event NOW covers all it has queued
         if (hipEventRecord(s.ev, s.st) != hipSuccess) { mu_.unlock(); set_error("persistent launch: hipEventRecord failed"); return CLO_EHIP; }
         s.recorded = true;
@@ -62,7 +66,9 @@ class PersistGate {
       if (hipEventRecord(mine->ev, st) != hipSuccess) { rc = CLO_EHIP; set_error("persistent launch: hipEventRecord failed"); }
       mine->recorded = true;
     }
-    mine->cus = std::max(pending_, mine->busy && !mine->recorded ? mine->cus : 0);
+    // the event covers EVERY launch queued on the stream so far: the slot carries the largest of those that may
+    // still be in flight (busy is cleared only once an event of the stream has been seen complete)
+    mine->cus = mine->busy ? std::max(pending_, mine->cus) : pending_;
     mine->busy = true;
     mu_.unlock();
     return rc;

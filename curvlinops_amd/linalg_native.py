@@ -358,20 +358,13 @@ def _eigh_unit_checked(An: Tensor) -> tuple[Tensor, Tensor]:
 
 
 def _eigh_sytrd_unit(An: Tensor, max_blocks: int = 0) -> tuple[Tensor, Tensor]:
-    """``clo_sytrd_f32`` -> divide & conquer on the tridiagonal matrix -> block-reflector back-transformation on a
-    normalised matrix (no checks)."""
-    from . import eigh_native
-
+    """``clo_eigh_f32`` on a normalised matrix (no checks)."""
     n = An.shape[0]
     ld = (n + 3) // 4 * 4
-    work = torch.zeros(n, ld, device=An.device, dtype=torch.float32)   # zero padding columns
-    work[:, :n].copy_(An)
-    D, E, tau = _hip.sytrd_(work, n, max_blocks=max_blocks)
-    lam, Qt = eigh_native.stedc_native(D, E, n)
-    Z = torch.zeros(n, ld, device=An.device, dtype=torch.float32)      # rows = eigenvectors
-    Z[:, :n] = Qt.T
-    eigh_native.ormtr_native(work, tau, Z, n)
-    return lam, Z[:, :n].T
+    work = torch.zeros(1, n, ld, device=An.device, dtype=torch.float32)   # zero padding columns
+    work[0, :, :n].copy_(An)
+    lam, Z = _hip.eigh_batched_(work, n, max_blocks)
+    return lam[0], Z[0, :, :n].T
 
 
 def eigh_sytrd(A: Tensor, max_blocks: int = 0) -> tuple[Tensor, Tensor]:
@@ -386,27 +379,20 @@ def eigh_sytrd(A: Tensor, max_blocks: int = 0) -> tuple[Tensor, Tensor]:
 
 
 def _eigh_native_group(As: list[Tensor], max_blocks: int = 0) -> list[tuple[Tensor, Tensor]]:
-    """Hand-written route for several fp32 GPU matrices of ONE order n >= 3 (repeated layer shapes): one reduction
-    per matrix (``clo_sytrd_f32``: a chain of n launches inside one foreign call), then ONE divide & conquer whose
-    tree levels carry all matrices (``eigh_native.stedc_native`` with a batch dimension), one back-transformation
-    call per matrix, and a batched verification (own GEMMs) with the float64 retry of the other routes."""
-    from . import eigh_native
-
+    """Hand-written route for several fp32 GPU matrices of ONE order n >= 3 (repeated layer shapes): ONE foreign call
+    (``clo_eigh_batched_f32``: one reduction per matrix, a divide & conquer whose tree levels carry all matrices, one
+    back-transformation per matrix -- no Python between the stages), then a batched verification (own GEMMs) with the
+    float64 retry of the reference's Cholesky path as a model."""
     n, B = As[0].shape[0], len(As)
     dev = As[0].device
     An, scale = _unit_scale(torch.stack(As))
     ld = (n + 3) // 4 * 4
     work = torch.zeros(B, n, ld, device=dev, dtype=torch.float32)
     work[:, :, :n] = An
-    DEt = [_hip.sytrd_(work[b], n, max_blocks=max_blocks) for b in range(B)]
-    lam, Qt = eigh_native.stedc_native(torch.stack([x[0] for x in DEt]), torch.stack([x[1] for x in DEt]), n)
-    Z = torch.zeros(B, n, ld, device=dev, dtype=torch.float32)
-    Z[:, :, :n] = Qt.mT
-    for b in range(B):
-        eigh_native.ormtr_native(work[b], DEt[b][2], Z[b], n)
-    Q = Z[:, :, :n].mT
-    # verification on the engine: |Q^T Q - I| and |A Q - Q diag(lam)| per matrix, one host read for the group
+    lam, Z = _hip.eigh_batched_(work, n, max_blocks)
     Zc = Z[:, :, :n]
+    Q = Zc.mT
+    # verification on the engine: |Q^T Q - I| and |A Q - Q diag(lam)| per matrix, one host read for the group
     G = _hip.gemm(Zc, Zc.mT)                                  # rows of Z are the eigenvectors
     G.diagonal(dim1=-2, dim2=-1).sub_(1.0)
     R = _hip.gemm(An, Q) - Q * lam.unsqueeze(-2)

@@ -332,8 +332,9 @@ int clo_cg_direction_f32(float *p, const float *z, long n, const float *num, con
                          void *stream);
 
 /* ---- symmetric eigensolver behind clo_sytrd_f32 (csrc/eigh.hip; replaces rocSOLVER sstedc / sormtr behind
- * torch.linalg.eigh at computers/_base.py:355-372, kronecker.py:292-300).  The host side
- * (curvlinops_amd/eigh_native.py) drives them level by level; every O(n^3) product is a clo_gemm_f32.
+ * torch.linalg.eigh at computers/_base.py:355-372, kronecker.py:292-300): the building blocks that clo_eigh_f32
+ * composes (rounds 2-3 drove them level by level from curvlinops_amd/eigh_native.py); every O(n^3) product is a
+ * clo_gemm_f32.
  *   clo_larft_f32       : T factors (nb x nb, upper triangular) of `np` block reflectors from G = V^T V and tau
  *   clo_tql2_batched_f32: eigen-decomposition of `batch` symmetric tridiagonal matrices of order L <= 64
  *                         (implicit QL in float64, one wave each): lam ascending, eigenvectors in columns
@@ -341,6 +342,26 @@ int clo_cg_direction_f32(float *p, const float *z, long n, const float *num, con
  *                         deflation scan (in place on D, z), secular roots (float64 bisection on the shifted
  *                         variable) + Gu-Eisenstat weights, eigenvector matrix MT [nodes][s][s] (transposed),
  *                         Givens rotations of the deflation. */
+/* ---- the symmetric eigensolver in ONE call (csrc/eigh_driver.hip; replaces torch.linalg.eigh = rocSOLVER ssyevd at
+ * computers/_base.py:355-372 and kronecker.py:292-300): clo_sytrd_f32 -> tridiagonal divide & conquer (every level of
+ * the tree walked in C++, device-side sorts and gathers, no host synchronisation) -> block-reflector
+ * back-transformation.  `batch` matrices of ONE order 1 <= n <= 8184:
+ *   A   [batch][n][lda]  full symmetric fp32, 16-byte aligned rows with ZERO padding columns up to lda (>= pad4(n),
+ *                        multiple of 4), batch stride strideA floats; OVERWRITTEN (reflectors of the reduction).
+ *                        Normalise to max |A| = 1 first (the deflation tolerances are relative to the matrix scale).
+ *   lam [batch][ld_lam]  eigenvalues, ascending (NaN if a leaf of the tridiagonal solver did not converge)
+ *   Z   [batch][n][ldz]  eigenvectors in the ROWS (Z^T = torch.linalg.eigh(...).eigenvectors); ldz >= pad4(n),
+ *                        multiple of 4; padding columns zero on return; batch stride strideZ floats
+ *   ws  clo_eigh_ws_bytes(n, batch) bytes, 16-byte aligned;  max_blocks: as clo_sytrd_f32.
+ * clo_stedc_f32: the tridiagonal stage alone (d[b][ldd] diagonal, e[b][ldd] sub-diagonal, n - 1 entries). */
+long clo_eigh_ws_bytes(int n, int batch);
+int clo_eigh_f32(float *A, long lda, int n, float *lam, float *Z, long ldz, void *ws, long ws_bytes,
+                 int max_blocks, void *stream);
+int clo_eigh_batched_f32(float *A, long lda, long strideA, int n, int batch, float *lam, long ld_lam, float *Z,
+                         long ldz, long strideZ, void *ws, long ws_bytes, int max_blocks, void *stream);
+long clo_stedc_ws_bytes(int n, int batch);
+int clo_stedc_f32(const float *d, const float *e, long ldd, int n, int batch, float *lam, long ld_lam, float *Z,
+                  long ldz, long strideZ, void *ws, long ws_bytes, void *stream);
 int clo_larft_f32(const float *G, const float *tau, float *T, int np, int nb, void *stream);
 /* Back-transformation Z <- Z Q^T: every ROW of Z [m][ldz] (ldz >= pad4(n), multiple of 4, 16-byte aligned) is
  * multiplied by Q = H_0 ... H_{n-2}, the reflectors clo_sytrd_f32 left in the rows of `work` [n][ldw] and `tau`

@@ -1131,6 +1131,58 @@ def test_native_eigh_at_the_factor_sizes_of_the_benchmarks(hip, n):
 
 
 @pytest.mark.gpu
+def test_persistent_grids_of_different_streams_are_admitted_safely(hip):
+    """Round 4: panel launches of clo_sytrd_f32 (up to 256 workgroups that wait for each other) on two streams next to
+    persistent GGN products (256 workgroups) on a third.  Partly resident persistent grids would wait for each other
+    forever; the library's admission control (csrc/persist_gate.h) makes a launch wait, device side, until everything
+    in flight plus itself fits the chip.  Results equal the serial ones bit for bit; nothing hangs or traps."""
+    device = torch.device("cuda:0")
+    n = 1100
+    ld = (n + 3) // 4 * 4
+    mats = [_sym_case(kind, n, device).float().to(device) for kind in ("lowrank", "indefinite")]
+
+    def reduce(A):
+        P = torch.zeros(n, ld, device=device)
+        P[:, :n] = A
+        return hip.sytrd_(P, n)
+
+    serial = [reduce(A) for A in mats]
+    g = np.random.default_rng(5)
+    dims, acts, N = [1024, 2688, 2688, 10], ["relu", "relu", "identity"], 8
+    Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, "mse")
+    plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    dW, db, dVW, dVb, dX = [dev(W) for W in Ws], [dev(b) for b in bs], [dev(v) for v in vWs], [dev(v) for v in vbs], dev(X)
+    scale = 2.0 * O.reduction_factor("mse", "mean", N, dims[-1])
+
+    def product():
+        oW, ob = [torch.full_like(w, float("nan")) for w in dW], [torch.full_like(b, float("nan")) for b in db]
+        plan.ggn_matvec(dW, db, dVW, dVb, oW, ob, dX, 0, scale, 1.0, 0.0)
+        return oW + ob
+
+    ref = product()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    with torch.cuda.stream(streams[2]):
+        plan.workspace(N, dX.device)
+    torch.cuda.synchronize()
+    got_red, got_prod = [[], []], []
+    for rep in range(3):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                got_red[i].append(reduce(mats[i]))
+        with torch.cuda.stream(streams[2]):
+            for _ in range(10):
+                got_prod.append(product())
+    torch.cuda.synchronize()
+    for i in range(2):
+        for D, E, tau in got_red[i]:
+            assert torch.equal(D, serial[i][0]) and torch.equal(E[: n - 1], serial[i][1][: n - 1])
+            assert torch.equal(tau[: n - 2], serial[i][2][: n - 2])
+    for out in got_prod:
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
+@pytest.mark.gpu
 def test_sytrd_is_deterministic(hip):
     """Rank-deficient factors take the per-block panel pass in many columns: no block may observe another
     block's updates of the panel (a race here showed up as run-to-run differences of 1e-2)."""
