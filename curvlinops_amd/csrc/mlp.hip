@@ -1947,7 +1947,16 @@ __global__ __launch_bounds__(KW * 64) void kfwd_stream_kernel(
   const int G = K >> 2, FPT = 16 / G;        // features per tile
   const int f = c / G, kq = c - f * G;
   const bool cvalid = f < FPT;
-  const int wb = min(wave * i_per_wave, d_in), we = min(d_in, wb + i_per_wave);
+#ifndef CLO_KF_INTERLEAVE
+#define CLO_KF_INTERLEAVE 1
+#endif
+  // the waves of a block take the 16-row groups of the contraction range round robin (group g -> wave g % KW): the
+  // block then reads ONE moving window of KW x 2 KB per feature instead of KW streams 1 / KW of a row apart
+  constexpr bool IL = CLO_KF_INTERLEAVE != 0;
+  const int wb = IL ? 16 * wave : min(wave * i_per_wave, d_in), we = IL ? d_in : min(d_in, wb + i_per_wave);
+  const int fb = IL ? 0 : wb;                       // a valid row for the masked loads
+  const int gstep = IL ? 16 * KW : 16;              // distance between two groups of this wave
+  const int ngw = wb < we ? (we - wb + gstep - 1) / gstep : 0;   // groups of this wave
   const unsigned bmask = cvalid ? 0xffffffffu : 0u;
   const int n = c;  // A operand row
   const unsigned amask = n < N ? 0xffffffffu : 0u;
@@ -1971,11 +1980,11 @@ __global__ __launch_bounds__(KW * 64) void kfwd_stream_kernel(
 
     auto load = [&](Group &g, int ib) {  // the 16 input features ib .. ib + 15 (clamped: values masked)
       const bool aok = ib + 4 * s + 3 < we;
-      g.av = ld4(pa + (aok ? ib : wb));
+      g.av = ld4(pa + (aok ? ib : fb));
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         const int i = ib + 4 * s + st;
-        const long off = (long)(i < we ? i : wb) * ldk;
+        const long off = (long)(i < we ? i : fb) * ldk;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) g.bv[t][st] = ld4(pV[t] + off);
       }
@@ -2003,13 +2012,14 @@ __global__ __launch_bounds__(KW * 64) void kfwd_stream_kernel(
     };
     // two register buffers: the loads of group g + 1 are in flight while group g feeds the MFMAs
     Group ga, gb;
-    if (wb < we) load(ga, wb);
-    for (int ib = wb; ib < we; ib += 32) {
-      if (ib + 16 < we) load(gb, ib + 16);
+    if (ngw > 0) load(ga, wb);
+    for (int t = 0; t < ngw; t += 2) {
+      const int ib = wb + t * gstep;
+      if (t + 1 < ngw) load(gb, ib + gstep);
       mma(ga, ib);
-      if (ib + 16 < we) {
-        if (ib + 32 < we) load(ga, ib + 32);
-        mma(gb, ib + 16);
+      if (t + 1 < ngw) {
+        if (t + 2 < ngw) load(ga, ib + 2 * gstep);
+        mma(gb, ib + gstep);
       }
     }
 #pragma unroll
@@ -2070,8 +2080,11 @@ __global__ void pack_at_kernel(const float *__restrict__ a, float *__restrict__ 
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void kouter_stream_kernel(
     float *__restrict__ out, long ldk, float *__restrict__ out_b, const float *__restrict__ aT,
-    const float *__restrict__ delta, int N, int K, int d_in, float beta, float beta_b) {
-  const int j = blockIdx.x;
+    const float *__restrict__ delta, int N, int K, int d_in, float beta, float beta_b, int nchunk, int chunk_rows) {
+  // a block writes ONE chunk of `chunk_rows` consecutive input features of output feature j (16 KB per trip): blocks
+  // are dispatched in index order, so the chip writes one moving window instead of a slow stream per output feature
+  const int j = blockIdx.x / nchunk, ch = blockIdx.x - j * nchunk;
+  const int ibeg = ch * chunk_rows, iend = min(d_in, ibeg + chunk_rows);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = K >> 2, IPW = 64 / G;  // input features per wave instruction
   const int io = lane / G, kq = lane - io * G;
@@ -2080,7 +2093,7 @@ __global__ __launch_bounds__(256) void kouter_stream_kernel(
 #pragma unroll
   for (int n = 0; n < NB; ++n)
     d[n] = n < N ? ld4(delta + ((long)j * N + n) * K + 4 * kq) : zero4();
-  if (out_b && wave == 0 && io == 0) {
+  if (out_b && ch == 0 && wave == 0 && io == 0) {
     float4 sb = zero4();
 #pragma unroll
     for (int n = 0; n < NB; ++n) { sb.x += d[n].x; sb.y += d[n].y; sb.z += d[n].z; sb.w += d[n].w; }
@@ -2092,13 +2105,16 @@ __global__ __launch_bounds__(256) void kouter_stream_kernel(
     *reinterpret_cast<float4 *>(ob) = sb;
   }
   float *oj = out + (long)j * d_in * ldk + 4 * kq;
-  constexpr int U = 4;
+#ifndef CLO_KO_U
+#define CLO_KO_U 4
+#endif
+  constexpr int U = CLO_KO_U;
   const int step = 4 * IPW;  // input features per block trip
-  for (int i0 = wave * IPW + io; i0 < d_in; i0 += U * step) {
+  for (int i0 = ibeg + wave * IPW + io; i0 < iend; i0 += U * step) {
     float4 x0[U], x1[U], old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = min(i0 + u * step, d_in - 1);
+      const int i = min(i0 + u * step, iend - 1);
       x0[u] = ld4(aT + (long)i * NB);
       x1[u] = ld4(aT + (long)i * NB + 4);
       if (ACCUM) old[u] = ld4(oj + (long)i * ldk);
@@ -2106,7 +2122,7 @@ __global__ __launch_bounds__(256) void kouter_stream_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * step;
-      if (i >= d_in) break;
+      if (i >= iend) break;
       const float xs[NB] = {x0[u].x, x0[u].y, x0[u].z, x0[u].w, x1[u].x, x1[u].y, x1[u].z, x1[u].w};
       float4 o = ACCUM ? make_float4(beta * old[u].x, beta * old[u].y, beta * old[u].z, beta * old[u].w)
                        : zero4();
@@ -3389,12 +3405,20 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
       {
         ProfScope prof(4, 4.0 * di * dout * K * (bw != 0.f ? 2 : 1), st);
         float *ob = Ob ? Ob[l - 1] : nullptr;
+#ifndef CLO_KO_TRIPS
+#define CLO_KO_TRIPS 1
+#endif
+        // rows of a chunk: CLO_KO_TRIPS trips of 16 wave instructions = 16 KB each (0: the whole input range per block)
+        const int trip_rows = 4 * CLO_KO_U * (64 / (K >> 2));
+        const int chunk_rows = CLO_KO_TRIPS > 0 ? CLO_KO_TRIPS * trip_rows : di;
+        const int nchunk = (int)cdiv(di, chunk_rows);
+        const dim3 kgrid((unsigned)((long)dout * nchunk));
         if (bw != 0.f)
-          hipLaunchKernelGGL(kouter_stream_kernel<true>, dim3(dout), dim3(256), 0, st, OW[l - 1], ldk, ob,
-                             aT[l - 1], dA[l], nn, K, di, bw, bt);
+          hipLaunchKernelGGL(kouter_stream_kernel<true>, kgrid, dim3(256), 0, st, OW[l - 1], ldk, ob,
+                             aT[l - 1], dA[l], nn, K, di, bw, bt, nchunk, chunk_rows);
         else
-          hipLaunchKernelGGL(kouter_stream_kernel<false>, dim3(dout), dim3(256), 0, st, OW[l - 1], ldk,
-                             ob, aT[l - 1], dA[l], nn, K, di, bw, bt);
+          hipLaunchKernelGGL(kouter_stream_kernel<false>, kgrid, dim3(256), 0, st, OW[l - 1], ldk,
+                             ob, aT[l - 1], dA[l], nn, K, di, bw, bt, nchunk, chunk_rows);
         CLO_CHECK_LAUNCH("kouter_stream_kernel");
       }
       if (l >= 2 && !Gh) {  // delta_{l-1} = phi'_{l-1} * (W_l^T delta_l)   ([di x dout] [dout x NK])
