@@ -9,7 +9,6 @@ follow the order of the parameter groups, inputs/outputs the order of the parame
 
 from __future__ import annotations
 
-import os
 
 import torch
 from torch import Size, Tensor
@@ -17,6 +16,9 @@ from torch import Size, Tensor
 from curvlinops_amd import _hip
 from curvlinops_amd.linop import PyTorchLinearOperator
 from curvlinops_amd.utils import is_native_tensor
+
+# K-major column blocks go through the native pack / unpack kernels (tools/probe_canonical.py flips this attribute for A/B runs)
+KMAJOR_BLOCKS = True
 
 
 def is_kmajor(t: Tensor) -> bool:
@@ -74,7 +76,7 @@ class ToCanonicalLinearOperator(_CanonicalBase):
                 w = M[self._position[g["W"]]]
                 b = M[self._position[g["b"]]]
                 if (w.shape[-1] > 1 and is_native_tensor(w) and is_native_tensor(b) and w.is_contiguous()
-                        and b.is_contiguous() and not os.environ.get("CLO_NO_KMAJOR")):
+                        and b.is_contiguous() and KMAJOR_BLOCKS):
                     # K columns on the GPU: bias column spliced in AND the K-major layout of the block's GEMMs in one
                     # pass (clo_canonical_pack_f32) instead of cat + transpose
                     rows, K = w.shape[0], w.shape[-1]

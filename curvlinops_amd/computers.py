@@ -13,7 +13,6 @@ tensors are fp32 on the GPU.
 
 from __future__ import annotations
 
-import os
 
 from collections.abc import Callable, Iterable, MutableMapping
 from contextlib import contextmanager
@@ -157,7 +156,7 @@ def _use_params(module: Module, params: dict[str, Tensor]):
                 p.data = saved[name]
 
 
-_FAST_BN = os.environ.get("CLO_KFAC_FAST_BN", "1") != "0"
+_FAST_BN = True      # (module attributes: the A/B scripts under tools/ set them before building a computer)
 
 
 def _affine_eval_batchnorm(module: Module, params: dict[str, Tensor]) -> list[Module]:
@@ -201,7 +200,7 @@ def _affine_eval_batchnorm(module: Module, params: dict[str, Tensor]) -> list[Mo
 # Factor accumulation (im2col + SYRK) runs on its own HIP stream so that it overlaps the autograd
 # kernels of the layers that follow: the hook only orders it after the producer of its operand.
 _FACTOR_STREAMS: dict = {}
-_OVERLAP = os.environ.get("CLO_KFAC_OVERLAP", "1") != "0"
+_OVERLAP = True
 
 
 class _factor_stream:
@@ -287,8 +286,8 @@ def _gram_accumulate(store: dict, key, X2d: Tensor, alpha: float, ones_col: bool
 
 # Conv2d input covariances: "1" = patches generated inside the SYRK's tile loader wherever that is the
 # faster or the only memory-friendly way (default), "0" = always materialise them, "all" = always fused.
-_FUSED_IM2COL = os.environ.get("CLO_KFAC_FUSED_IM2COL", "1")
-_PATCH_LIMIT_BYTES = int(float(os.environ.get("CLO_KFAC_PATCH_LIMIT_MB", "1024")) * 2**20)
+_FUSED_IM2COL = "1"   # "0": always materialise the patch matrix, "all": never
+_PATCH_LIMIT_BYTES = 1024 * 2**20
 
 
 def _conv_patches_fusable(hyper: dict) -> bool:

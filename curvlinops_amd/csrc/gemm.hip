@@ -871,7 +871,10 @@ static int pick_mode(const float *P, long so, long sk, long sbatch, int batch) {
 struct V2Config { int bm, bn, bk; };
 static V2Config v2_config(int M, int N, int K, long batch, int sym, bool allow_small = true) {
   // (few-row problems keep their 32- / 64-row tiles unless they are tiny)
-  static const long small_max = getenv("CLO_GEMM_SMALL_MAX") ? atol(getenv("CLO_GEMM_SMALL_MAX")) : 1024L * 1024L;
+#ifndef CLO_GEMM_SMALL_MAX
+#define CLO_GEMM_SMALL_MAX (1024L * 1024L)
+#endif
+  static const long small_max = CLO_GEMM_SMALL_MAX;
   // (a batch of skinny products -- the panels and column updates of the batched Cholesky chain, N <= 128 -- is judged by
   // ONE matrix: 3 x (4480 x 128) on 128 x 128 x 32 tiles is 105 workgroups with k loops of up to 32 steps, 50-110 us per
   // product on the critical path; on 64 x 64 x 64 tiles 8-15 us)
@@ -886,7 +889,10 @@ static V2Config v2_config(int M, int N, int K, long batch, int sym, bool allow_s
 // v2 needs float4-complete operands: 16-byte aligned, K % 4 == 0 for k-contiguous operands, the
 // outer extent in memory % 4 == 0 for outer-contiguous ones.
 bool gemm_v2_eligible(const GemmArgs &a, int batch) {
-  static const int v2_off = getenv("CLO_GEMM_V1") ? atoi(getenv("CLO_GEMM_V1")) : 0;
+#ifndef CLO_GEMM_V1
+#define CLO_GEMM_V1 0
+#endif
+  static const int v2_off = CLO_GEMM_V1;
   const int ma = pick_mode(a.A, a.sa_m, a.sa_k, a.sa_b, batch);
   const int mb = pick_mode(a.B, a.sb_n, a.sb_k, a.sb_b, batch);
   const bool a_vec = ma == MODE_OC_VEC || ma == MODE_KC_VEC;

@@ -534,12 +534,17 @@ static long v3_streamk_workers(long tiles, int K) {
   // at least two k tiles per worker: a shorter range is all pipeline fill
   workers = std::max<long>(1, std::min<long>(workers, units / 2));
   if (workers <= tiles && tiles <= kNumCU) return 0;   // nothing to split: one tile per workgroup
-  if (const char *e = getenv("CLO_V3_SK_WORKERS")) workers = std::max<long>(1, std::min<long>(atol(e), std::min<long>(units, kNumCU)));
+#ifdef CLO_V3_SK_WORKERS   // (experiments: a fixed number of stream-K workers)
+  workers = std::max<long>(1, std::min<long>(CLO_V3_SK_WORKERS, std::min<long>(units, kNumCU)));
+#endif
   return workers;
 }
 
 bool gemm_v3_eligible(const GemmArgs &a, int batch) {
-  static const int off = getenv("CLO_GEMM_V3") ? !atoi(getenv("CLO_GEMM_V3")) : 0;
+#ifndef CLO_GEMM_V3
+#define CLO_GEMM_V3 1
+#endif
+  static const int off = !CLO_GEMM_V3;
   if (off || a.patch || a.ones || a.ones_b || a.col_out) return false;
   if (a.A2 && (a.K1 % V3_BK != 0)) return false;
   // 32-bit byte offsets inside one k tile of one output tile
@@ -555,7 +560,10 @@ bool gemm_v3_eligible(const GemmArgs &a, int batch) {
 // enough rows and enough tiles.
 constexpr int V3T_BM = 256, V3T_BN = 128, V3T_WVM = 4, V3T_WVN = 2, V3T_NST = 3;
 static bool v3_use_tall(const GemmArgs &a, int batch) {
-  static const int mode = getenv("CLO_GEMM_V3_TALL") ? atoi(getenv("CLO_GEMM_V3_TALL")) : 1;  // 0 never, 2 whenever legal
+#ifndef CLO_GEMM_V3_TALL
+#define CLO_GEMM_V3_TALL 1
+#endif
+  static const int mode = CLO_GEMM_V3_TALL;  // 0 never, 2 whenever legal
   if (!mode || a.sym || a.M < V3T_BM || a.K < 2048) return false;   // (short k: the longer fill / drain of the tall tile loses, 4608 x 4608 x 512: 226 -> 263 us)
   if (mode == 2) return true;
   const long tall_tiles = cdiv(a.M, V3T_BM) * cdiv(a.N, V3T_BN) * batch;
@@ -595,7 +603,10 @@ bool gemm_v3_would_streamk(int M, int N, int K, long batch) {
 int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk) {
   GemmArgs a = a0;
   V3Sched s{};
-  static const int sk_off = getenv("CLO_GEMM_STREAMK") ? !atoi(getenv("CLO_GEMM_STREAMK")) : 0;
+#ifndef CLO_GEMM_STREAMK
+#define CLO_GEMM_STREAMK 1
+#endif
+  static const int sk_off = !CLO_GEMM_STREAMK;
   const bool sk_ok = a.streamk && a.ws && !a.tri && !sk_off;
   bool tall = false;
   long workers = v3_plan(a, batch, sk_ok ? a.streamk : 0, &tall);
@@ -621,7 +632,10 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
     s.units = tiles * nkt;
     s.slots = a.ws;
     // teams of G = tiles_m members when the row tiles are few (each panel = all row tiles of one block column)
-    static const int team_off = getenv("CLO_GEMM_SK_TEAM") ? !atoi(getenv("CLO_GEMM_SK_TEAM")) : 0;
+#ifndef CLO_GEMM_SK_TEAM
+#define CLO_GEMM_SK_TEAM 1
+#endif
+    static const int team_off = !CLO_GEMM_SK_TEAM;
     s.team = 1;
     const int G = a.tiles_m;
     if (!team_off && !a.sym && batch == 1 && (G == 2 || G == 4 || G == 8) && s.workers % (kNumXCD * G) == 0 &&

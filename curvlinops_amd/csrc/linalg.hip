@@ -468,7 +468,10 @@ static int chol_rec(const CholCtx &c, int o, int m) {
     CLO_CHECK_LAUNCH("potrf_diag_kernel");
     return CLO_OK;
   }
-  static const int node128 = getenv("CLO_CHOL_NODE128") ? atoi(getenv("CLO_CHOL_NODE128")) : 1;
+#ifndef CLO_CHOL_NODE128
+#define CLO_CHOL_NODE128 1
+#endif
+  static const int node128 = CLO_CHOL_NODE128;
   if (m <= QNB && node128) {
     int rcq = potrf_node128_launch(c.S + o * n + o, n, c.L + o * n + o, n, m, c.Li + o * n + o, n, c.status, o,
                                    c.stride, c.batch, c.st);
@@ -562,13 +565,18 @@ static CholAsync *chol_async_acquire(int *dev_out) {
   // dispatched ahead of the bulk products queued here
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (getenv("CLO_CHOL_HELPER_PRIO")) least = atoi(getenv("CLO_CHOL_HELPER_PRIO"));
+#ifdef CLO_CHOL_HELPER_PRIO   // (experiments: a fixed priority for the helper streams)
+  least = CLO_CHOL_HELPER_PRIO;
+#endif
   // ONE helper stream for the trailing updates and the inverse (three were measured first: HIP streams share a handful of
   // hardware queues, and when two helpers land on the same queue the trailing update the main stream is about to need waits
   // behind an inverse product that waits for a later node -- 4 x 2305: 2.5 ms alone, 5.2 ms after another call had shifted
   // the stream-to-queue assignment).  In one in-order stream every operation is queued when the node / panel it needs has
   // been queued, so nothing ever waits behind a later dependency.
-  static const int nhelp = getenv("CLO_CHOL_HELPERS") ? atoi(getenv("CLO_CHOL_HELPERS")) : 1;
+#ifndef CLO_CHOL_HELPERS
+#define CLO_CHOL_HELPERS 1
+#endif
+  static const int nhelp = CLO_CHOL_HELPERS;
   bool ok = hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
   if (ok && nhelp >= 3) {
     ok = hipStreamCreateWithPriority(&a->inv, hipStreamNonBlocking, least) == hipSuccess &&
@@ -696,7 +704,10 @@ static int chol_pipe_run(const CholCtx &c, float *G_side, float *G_inv, float *G
   // ~128 W on the side stream to everything from group g + 2 on; the columns of group g + 1 get them just in time from the
   // main stream's column update (left-looking over the panels of groups g and g + 1 so far: one skinny product of depth
   // <= 256 W), so the main stream meets the side stream once per group and the bulk runs at a useful depth.
-  static const int W = std::max(1, getenv("CLO_CHOL_GROUP") ? atoi(getenv("CLO_CHOL_GROUP")) : 4);
+#ifndef CLO_CHOL_GROUP
+#define CLO_CHOL_GROUP 4
+#endif
+  static const int W = std::max(1, CLO_CHOL_GROUP);
   const int ngrp = (nb + W - 1) / W;
   auto grp_begin = [&](int g) { return g >= ngrp ? np : P.off[g * W]; };
   const size_t EV_GRP = 3 * (size_t)nb + 3;   // events of the group products
@@ -751,7 +762,10 @@ static int chol_pipe_run(const CholCtx &c, float *G_side, float *G_inv, float *G
     const int cn = k + 1, gc = cn / W, m_next = P.bs[cn];
     if (cn % W == 0 && gc >= 2) CHOL_HIP(hipStreamWaitEvent(st, as->event(EV_GRP + gc - 2), 0));   // first column of a group
     const int j0 = gc >= 1 ? (gc - 1) * W : 0, oj = P.off[j0];
-    static const int col_split = getenv("CLO_CHOL_COL_SPLIT") ? atoi(getenv("CLO_CHOL_COL_SPLIT")) : 1;
+#ifndef CLO_CHOL_COL_SPLIT
+#define CLO_CHOL_COL_SPLIT 1
+#endif
+    static const int col_split = CLO_CHOL_COL_SPLIT;
     rc = chol_gemm(c, st, col_split ? c.G : nullptr, rest, m_next, r0 - oj, -1.f, c.L + r0 * n + oj, n, 1, c.L + r0 * n + oj,
                    1, n, 1.f, c.S + r0 * n + r0, n, 0, 0);
     if (rc != CLO_OK) return rc;
@@ -822,10 +836,16 @@ extern "C" int clo_cholesky_inverse_batched_f32(const float *const *A, const lon
                        c.L + (long)b0 * nn, c.Li + (long)b0 * nn, n, np, nn);
     CLO_CHECK_LAUNCH("chol_init_kernel");
   }
-  static const int pipe = getenv("CLO_CHOL_PIPE") ? atoi(getenv("CLO_CHOL_PIPE")) : 1;
+#ifndef CLO_CHOL_PIPE
+#define CLO_CHOL_PIPE 1
+#endif
+  static const int pipe = CLO_CHOL_PIPE;
   // (below ~1500 rows the single chain of chol_rec is as fast or faster: n = 512: 0.34 vs 0.43 ms, 1152: 0.90 vs 0.88 ms,
   // 2304: 2.11 vs 1.78 ms, 4608: 5.13 vs 3.95 ms)
-  static const int pipe_min = getenv("CLO_CHOL_PIPE_MIN") ? atoi(getenv("CLO_CHOL_PIPE_MIN")) : 1536;
+#ifndef CLO_CHOL_PIPE_MIN
+#define CLO_CHOL_PIPE_MIN 1536
+#endif
+  static const int pipe_min = CLO_CHOL_PIPE_MIN;
   if (pipe && np >= pipe_min && np > QNB)
     rc = chol_pipe(c, c.G + c.gws, c.G + 2 * c.gws, c.G + 3 * c.gws);
   else

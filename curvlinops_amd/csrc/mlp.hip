@@ -1925,7 +1925,10 @@ __global__ void small_outer_reduce_kernel(float *__restrict__ out, const float *
 //   dprev    : GEMM delta_{l-1} = phi' * (W_l^T delta_l) with N K columns
 // Tangents / deltas are stored feature-major: [d_l][N][K].  N <= 8 rows per pass, K % 4 == 0, K <= 64.
 // ------------------------------------------------------------------------------------------
-constexpr int KC_WAVES = 8;   // waves of a kfwd block: split the contraction among themselves
+#ifndef CLO_KC_WAVES
+#define CLO_KC_WAVES 8
+#endif
+constexpr int KC_WAVES = CLO_KC_WAVES;   // waves of a kfwd block: split the contraction among themselves
                               // (1 tile x 8 waves measured best among {1,2,3,4} tiles x {1,2,4,8} waves)
 constexpr int KC_TPW = 1;     // MFMA tiles per wave (1 measured best: more, smaller blocks)
 
@@ -1933,8 +1936,11 @@ constexpr int KC_TPW = 1;     // MFMA tiles per wave (1 measured best: more, sma
 // (c, s = lane >> 4) loads ONE float4 V[j + f][i][4 kq ..] per i and feeds four MFMAs (one per
 // column of the quad), all with the A operand a[n][i].  k-slot s takes i = ib + 4 s + t in step t,
 // so the A operand is one float4 of row n per 16 i.
+#ifndef CLO_KC_WPE
+#define CLO_KC_WPE 1
+#endif
 template <bool ACC, int TPW, int KW>
-__global__ __launch_bounds__(KW * 64) void kfwd_stream_kernel(
+__global__ __launch_bounds__(KW * 64, CLO_KC_WPE) void kfwd_stream_kernel(
     const float *__restrict__ V, long ldk, const float *__restrict__ Vb,
     const float *__restrict__ a, const float *__restrict__ dphi, float *__restrict__ dA, int N,
     int K, int d_in, int d_out, int i_per_wave) {
@@ -2655,7 +2661,10 @@ constexpr int MID_MAX_N = 64;
 
 static bool mid_chain_ok(int L, const int *dims, const float *const *W, const float *const *VW,
                          float *const *OW, int N) {
-  static const bool off = getenv("CLO_MLP_NO_MID") != nullptr;
+#ifndef CLO_MLP_NO_MID
+#define CLO_MLP_NO_MID 0
+#endif
+  static const bool off = CLO_MLP_NO_MID != 0;
   if (off || N <= NB || N > MID_MAX_N || L < 2 || L > OUTER_MAXL) return false;
   for (int l = 1; l <= L - 1; ++l)
     if (dims[l - 1] % 4 != 0 || dims[l] % 4 != 0 || dims[l - 1] < 16 || !aligned16(W[l - 1]) ||
@@ -2696,8 +2705,14 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     // 8 waves: no slabs, no finish launch: -2...4 us).  With a tangent the kernel issues twice the B loads per
     // weight load and measured slower than the slab route (C2 layer 2: 24.8 vs 17.9 us at 16 rows, 67 vs 46 us
     // at 64); CLO_MLP_MID_FULL_DA=1 forces it.
-    static const bool no_full = getenv("CLO_MLP_NO_MID_FULL") != nullptr;
-    static const bool full_da = getenv("CLO_MLP_MID_FULL_DA") != nullptr;
+#ifndef CLO_MLP_NO_MID_FULL
+#define CLO_MLP_NO_MID_FULL 0
+#endif
+    static const bool no_full = CLO_MLP_NO_MID_FULL != 0;
+#ifndef CLO_MLP_MID_FULL_DA
+#define CLO_MLP_MID_FULL_DA 0
+#endif
+    static const bool full_da = CLO_MLP_MID_FULL_DA != 0;
     if (!no_full && (!has_da || full_da) && di >= 256 && cdiv(dout, 16) >= kNumCU / 2) {
       const int kpw = (int)cdiv(cdiv(di, 8), 16) * 16;
       const int fpb = (int)std::min<long>(16, std::max<long>(4, cdiv(dout, kNumCU)));
@@ -3003,7 +3018,10 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
 #define CLO_MID_CHAIN(T)                                                                              \
   mid_chain<T>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank, loss_scale * alpha, beta, \
                a, da, dphi, dl, gws, gws_sz, st)
-    static const int mid_max = getenv("CLO_MLP_MID_MAX") ? atoi(getenv("CLO_MLP_MID_MAX")) : MID_MAX_N;
+#ifndef CLO_MLP_MID_MAX
+#define CLO_MLP_MID_MAX MID_MAX_N
+#endif
+    static const int mid_max = CLO_MLP_MID_MAX;
     rc = N > mid_max ? CLO_EUNSUP
          : N <= 16 ? CLO_MID_CHAIN(1) : N <= 32 ? CLO_MID_CHAIN(2) : N <= 48 ? CLO_MID_CHAIN(3) : CLO_MID_CHAIN(4);
 #undef CLO_MID_CHAIN
@@ -3362,7 +3380,10 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
         if (rc != CLO_OK) return rc;
       }
       const int ipw = (int)cdiv(cdiv(di, KC_WAVES), 16) * 16;
-      static const int kc_bpc = getenv("CLO_KC_BPC") ? atoi(getenv("CLO_KC_BPC")) : 4;
+#ifndef CLO_KC_BPC
+#define CLO_KC_BPC 4
+#endif
+      static const int kc_bpc = CLO_KC_BPC;
       dim3 grid((unsigned)std::min<long>(cdiv(dout, FPT * KC_TPW), (long)kc_bpc * kNumCU)), block(KC_WAVES * 64);
       const float *vb = Vb ? Vb[l - 1] : nullptr;
       const float *dp = (l == L && last_linear) ? nullptr : dphi[l];
@@ -3527,7 +3548,10 @@ extern "C" int clo_mlp_hessian_matvec(int L, const int *dims, const int *acts, c
     part_sz = std::max({part_sz, clo_mlp_bwd_ws_floats(N, dims[l - 1], dims[l]),
                         clo_mlp_fwd_ws_floats(N, dims[l - 1], dims[l])});
   part_sz = (part_sz + 3) & ~3L;
-  static const int no_skinny = getenv("CLO_HESSIAN_GEMM") ? atoi(getenv("CLO_HESSIAN_GEMM")) : 0;
+#ifndef CLO_HESSIAN_GEMM
+#define CLO_HESSIAN_GEMM 0
+#endif
+  static const int no_skinny = CLO_HESSIAN_GEMM;
   const bool skinny = N <= SKINNY_MAX_N && !no_skinny && 3 * part_sz + 2 * nd <= gws_sz;
   float *part = gws, *part2 = gws + part_sz, *part3 = gws + 2 * part_sz, *ones = gws + 3 * part_sz, *T2b = ones + nd;
   if (skinny) {

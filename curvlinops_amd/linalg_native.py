@@ -17,7 +17,6 @@ comparison routes of rounds 1-3 live in ``tools/`` (``tools/_rocsolver.py``, ``t
 
 from __future__ import annotations
 
-import os
 from contextlib import contextmanager
 from warnings import warn
 
@@ -243,7 +242,7 @@ def concurrent_inverses(num_streams: int = 2, distributed: bool = False):
         return
     import os
 
-    batch = _ACTIVE_BATCH = _InverseBatch(int(os.environ.get("CLO_INV_STREAMS", num_streams)), distributed)
+    batch = _ACTIVE_BATCH = _InverseBatch(num_streams, distributed)
     try:
         yield
     except BaseException:

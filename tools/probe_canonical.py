@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch import nn
 import curvlinops_amd as C
-from curvlinops_amd import _hip
+from curvlinops_amd import _hip, canonical
 _hip.load()
 dev = torch.device("cuda:0")
 
@@ -40,6 +40,6 @@ for K in (1, 8, 32):
     V = torch.rand(Kop.shape[1], K, device=dev)
     print(f"KFAC @ V, K = {K}: {t_us(lambda: Kop @ V, 10) / 1e3:.3f} ms", flush=True)
     if K > 1:
-        os.environ["CLO_NO_KMAJOR"] = "1"
+        canonical.KMAJOR_BLOCKS = False
         print(f"   (cat / transpose route: {t_us(lambda: Kop @ V, 10) / 1e3:.3f} ms)", flush=True)
-        del os.environ["CLO_NO_KMAJOR"]
+        canonical.KMAJOR_BLOCKS = True
