@@ -14,7 +14,7 @@
 //     N > 8 rows   : GEMM engine of gemm.hip (fused forward gemm_fwd3_kernel, epilogue-fused
 //                    backward GEMMs) + head_rows_* / small_outer_* for narrow layers and biases
 //   clo_mlp_ggn_matmat      K probe columns in the reference's K-trailing layout
-//       kfwd_stream_kernel, kouter_stream_kernel, loss_cols_kernel, pack_at_kernel
+//       kfwd_stream_kernel, kouter_stream_kernel, loss_cols_kernel, pack_at_multi_kernel
 //   clo_mlp_hessian_matvec  exact Hessian by the R-operator (hess_combine_kernel + GEMMs)
 //   clo_mlp_jvp / clo_mlp_vjp  the two halves on their own (Jacobian operators)
 //   clo_mlp_fwd_jvp_layer / clo_mlp_bwd_layer / clo_loss_hessian_apply  per-layer building blocks
@@ -1930,7 +1930,10 @@ __global__ void small_outer_reduce_kernel(float *__restrict__ out, const float *
 #endif
 constexpr int KC_WAVES = CLO_KC_WAVES;   // waves of a kfwd block: split the contraction among themselves
                               // (1 tile x 8 waves measured best among {1,2,3,4} tiles x {1,2,4,8} waves)
-constexpr int KC_TPW = 1;     // MFMA tiles per wave (1 measured best: more, smaller blocks)
+#ifndef CLO_KC_TPW
+#define CLO_KC_TPW 1
+#endif
+constexpr int KC_TPW = CLO_KC_TPW;     // MFMA tiles per wave (1 measured best: more, smaller blocks)
 
 // One MFMA tile = 16 "columns" c = (feature f = c / G, column quad kq = c % G), G = K / 4; lane
 // (c, s = lane >> 4) loads ONE float4 V[j + f][i][4 kq ..] per i and feeds four MFMAs (one per
@@ -1943,9 +1946,14 @@ template <bool ACC, int TPW, int KW>
 __global__ __launch_bounds__(KW * 64, CLO_KC_WPE) void kfwd_stream_kernel(
     const float *__restrict__ V, long ldk, const float *__restrict__ Vb,
     const float *__restrict__ a, const float *__restrict__ dphi, float *__restrict__ dA, int N,
-    int K, int d_in, int d_out, int i_per_wave) {
-  // PERSISTENT: the grid is ~2 blocks per CU (the occupancy at which a read stream peaks on this
-  // part, profiles/r01_ubench_read_stream.txt) and every block walks feature tiles tb, tb + grid, ...
+    int K, int d_in, int d_out) {
+  // PERSISTENT: the grid is a few blocks per CU and every block walks feature tiles tb, tb + grid, ...  The block's waves
+  // take the 16-row groups of the contraction range round robin (group g -> wave g % KW); (tile, group) pairs form ONE
+  // flat sequence of steps per wave, software-pipelined over a ring of register groups: the loads of step s + 2 are
+  // issued -- ALWAYS, from clamped addresses, no branch around them -- before the MFMAs of step s, also across a tile
+  // boundary (the first groups of the next tile are in flight under the LDS merge of this one).  Round 4: with the loads under `if (more)`
+  // hipcc joined the two paths at the MFMAs with `s_waitcnt vmcnt(3)`, i.e. it waited for the loads it had just issued;
+  // a wave then had one group in flight instead of two.
   __shared__ float s_red[KW][TPW][4][4][64];  // [wave][tile][m][r][lane]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1953,81 +1961,64 @@ __global__ __launch_bounds__(KW * 64, CLO_KC_WPE) void kfwd_stream_kernel(
   const int G = K >> 2, FPT = 16 / G;        // features per tile
   const int f = c / G, kq = c - f * G;
   const bool cvalid = f < FPT;
-#ifndef CLO_KF_INTERLEAVE
-#define CLO_KF_INTERLEAVE 1
-#endif
-  // the waves of a block take the 16-row groups of the contraction range round robin (group g -> wave g % KW): the
-  // block then reads ONE moving window of KW x 2 KB per feature instead of KW streams 1 / KW of a row apart
-  constexpr bool IL = CLO_KF_INTERLEAVE != 0;
-  const int wb = IL ? 16 * wave : min(wave * i_per_wave, d_in), we = IL ? d_in : min(d_in, wb + i_per_wave);
-  const int fb = IL ? 0 : wb;                       // a valid row for the masked loads
-  const int gstep = IL ? 16 * KW : 16;              // distance between two groups of this wave
-  const int ngw = wb < we ? (we - wb + gstep - 1) / gstep : 0;   // groups of this wave
+  const int wb = 16 * wave, gstep = 16 * KW;
+  const int NGW = (int)cdiv(cdiv(d_in, 16), KW);   // groups per wave and tile (the same for every wave: surplus ones masked)
   const unsigned bmask = cvalid ? 0xffffffffu : 0u;
   const int n = c;  // A operand row
   const unsigned amask = n < N ? 0xffffffffu : 0u;
-  const float *pa = a + (long)min(n, N - 1) * d_in + 4 * s;
+  const float *arow = a + (long)min(n, N - 1) * d_in;
+  const float *vcol = V + 4 * (cvalid ? kq : 0);
   const int ntb = (int)cdiv(d_out, FPT * TPW);
+  const int ntl = (ntb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block (grid <= ntb)
+  const int nsteps = ntl * NGW;
 
   struct Group { float4 av; float4 bv[TPW][4]; };
-  for (int tb = blockIdx.x; tb < ntb; tb += gridDim.x) {
-    const int j0 = tb * FPT * TPW;
-    const float *pV[TPW];
+  auto load = [&](Group &g, int tl, int gi) {   // group gi of the block's tile tl; rows beyond d_in read row 0 (masked)
+    const int j0 = ((int)blockIdx.x + tl * (int)gridDim.x) * FPT * TPW;
+    const int ib = wb + gi * gstep + 4 * s;
+    g.av = ld4(arow + (ib + 3 < d_in ? ib : 0));
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int j = min(j0 + t * FPT + (cvalid ? f : 0), d_out - 1);
-      pV[t] = V + ((long)j * d_in) * ldk + 4 * (cvalid ? kq : 0);
+    for (int st = 0; st < 4; ++st) {
+      const int i = ib + st;
+      const long off = (long)(i < d_in ? i : 0) * ldk;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int j = min(j0 + t * FPT + (cvalid ? f : 0), d_out - 1);
+        g.bv[t][st] = ld4(vcol + ((long)j * d_in) * ldk + off);
+      }
     }
-    f32x4 acc[TPW][4];
+  };
+  f32x4 acc[TPW][4];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto load = [&](Group &g, int ib) {  // the 16 input features ib .. ib + 15 (clamped: values masked)
-      const bool aok = ib + 4 * s + 3 < we;
-      g.av = ld4(pa + (aok ? ib : fb));
+  };
+  auto mma = [&](const Group &g, int gi, bool live) {
+    const unsigned am = (live && wb + gi * gstep + 4 * s + 3 < d_in) ? amask : 0u;
+    const float avs[4] = {__uint_as_float(__float_as_uint(g.av.x) & am),
+                          __uint_as_float(__float_as_uint(g.av.y) & am),
+                          __uint_as_float(__float_as_uint(g.av.z) & am),
+                          __uint_as_float(__float_as_uint(g.av.w) & am)};
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const int i = ib + 4 * s + st;
-        const long off = (long)(i < we ? i : fb) * ldk;
+    for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) g.bv[t][st] = ld4(pV[t] + off);
+      for (int t = 0; t < TPW; ++t) {
+        const float4 b = g.bv[t][st];
+        const float bx = __uint_as_float(__float_as_uint(b.x) & bmask);
+        const float by = __uint_as_float(__float_as_uint(b.y) & bmask);
+        const float bz = __uint_as_float(__float_as_uint(b.z) & bmask);
+        const float bw = __uint_as_float(__float_as_uint(b.w) & bmask);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bx, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], by, acc[t][1], 0, 0, 0);
+        acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bz, acc[t][2], 0, 0, 0);
+        acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bw, acc[t][3], 0, 0, 0);
       }
-    };
-    auto mma = [&](const Group &g, int ib) {
-      const unsigned am = (ib + 4 * s + 3 < we) ? amask : 0u;
-      const float avs[4] = {__uint_as_float(__float_as_uint(g.av.x) & am),
-                            __uint_as_float(__float_as_uint(g.av.y) & am),
-                            __uint_as_float(__float_as_uint(g.av.z) & am),
-                            __uint_as_float(__float_as_uint(g.av.w) & am)};
-#pragma unroll
-      for (int st = 0; st < 4; ++st)
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          const float4 b = g.bv[t][st];
-          const float bx = __uint_as_float(__float_as_uint(b.x) & bmask);
-          const float by = __uint_as_float(__float_as_uint(b.y) & bmask);
-          const float bz = __uint_as_float(__float_as_uint(b.z) & bmask);
-          const float bw = __uint_as_float(__float_as_uint(b.w) & bmask);
-          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bx, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], by, acc[t][1], 0, 0, 0);
-          acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bz, acc[t][2], 0, 0, 0);
-          acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[st], bw, acc[t][3], 0, 0, 0);
-        }
-    };
-    // two register buffers: the loads of group g + 1 are in flight while group g feeds the MFMAs
-    Group ga, gb;
-    if (ngw > 0) load(ga, wb);
-    for (int t = 0; t < ngw; t += 2) {
-      const int ib = wb + t * gstep;
-      if (t + 1 < ngw) load(gb, ib + gstep);
-      mma(ga, ib);
-      if (t + 1 < ngw) {
-        if (t + 2 < ngw) load(ga, ib + 2 * gstep);
-        mma(gb, ib + gstep);
-      }
-    }
+  };
+  // merge of the waves' K ranges and the tile's epilogue (once per tile)
+  auto finish_tile = [&](int tl) {
+    const int j0 = ((int)blockIdx.x + tl * (int)gridDim.x) * FPT * TPW;
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -2068,16 +2059,70 @@ __global__ __launch_bounds__(KW * 64, CLO_KC_WPE) void kfwd_stream_kernel(
       }
     }
     __syncthreads();  // s_red is reused by the next tile
+  };
+
+  // load cursor (one step ahead of the compute cursor; parked on the last step at the end) and compute cursor
+  int lt = 0, lg = 0, ct = 0, cg = 0;
+  auto next_load = [&]() {
+    const bool wrap = lg + 1 == NGW, last = wrap && lt + 1 == ntl;
+    lg = last ? lg : (wrap ? 0 : lg + 1);
+    lt = last ? lt : (wrap ? lt + 1 : lt);
+  };
+  auto step = [&](const Group &cur, int sidx) {
+    const bool live = sidx < nsteps;
+    mma(cur, cg, live);
+    if (live && cg + 1 == NGW) {
+      finish_tile(ct);
+      zero_acc();
+    }
+    const bool wrap = cg + 1 == NGW;
+    cg = wrap ? 0 : cg + 1;
+    ct = wrap ? ct + 1 : ct;
+  };
+#ifndef CLO_KF_DEPTH
+#define CLO_KF_DEPTH 2
+#endif
+  // register ring of CLO_KF_DEPTH groups: DEPTH - 1 groups of loads are in flight while one feeds the MFMAs.  The
+  // sched_barriers pin "issue the loads, THEN the MFMAs": the machine scheduler otherwise sinks the loads into the
+  // MFMA sequence to save registers, which shortens the prefetch distance to half a step.
+  Group ring[CLO_KF_DEPTH];
+  zero_acc();
+#pragma unroll
+  for (int q = 0; q < CLO_KF_DEPTH - 1; ++q) {
+    load(ring[q], lt, lg);
+    next_load();
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += CLO_KF_DEPTH) {
+#pragma unroll
+    for (int q = 0; q < CLO_KF_DEPTH; ++q) {
+      load(ring[(q + CLO_KF_DEPTH - 1) % CLO_KF_DEPTH], lt, lg);
+      next_load();
+      __builtin_amdgcn_sched_barrier(0);
+      step(ring[q], s0 + q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
 // aT[i][0..7] = a[n][i] (zero beyond N): the outer-product stream reads 8 samples of one input
 // feature as two float4.
-__global__ void pack_at_kernel(const float *__restrict__ a, float *__restrict__ aT, int N, int d) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d * NB) return;
-  const int i = e / NB, n = e % NB;
-  aT[e] = n < N ? a[(long)n * d + i] : 0.f;
+// Up to 8 consecutive layers per launch (their aT blocks are consecutive in the workspace): the K-column product packs
+// every layer input after its forward loop instead of one tiny launch per layer.
+struct PackMulti {
+  const float *a[8];
+  int d[8];
+  long start[9];   // first element of layer q in the concatenated [sum d][NB] block
+  int nl, N;
+};
+__global__ void pack_at_multi_kernel(const PackMulti p, float *__restrict__ aT) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.start[p.nl]) return;
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < 8; ++t) q += (t < p.nl && e >= p.start[t]) ? 1 : 0;
+  const long r = e - p.start[q];
+  const int i = (int)(r / NB), n = (int)(r % NB);
+  aT[e] = n < p.N ? p.a[q][(long)n * p.d[q] + i] : 0.f;
 }
 
 // out[j][i][k] = beta out[j][i][k] + sum_n aT[i][n] delta[j][n][k] ; out_b[j][k] likewise with 1.
@@ -3371,15 +3416,11 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
       int rc = fwd_pass(W[l - 1], b ? b[l - 1] : nullptr, nullptr, nullptr, a[l - 1], nullptr, a[l],
                         nullptr, dphi[l], nn, di, dout, acts[l - 1], part, false, nullptr, st);
       if (rc != CLO_OK) return rc;
-      hipLaunchKernelGGL(pack_at_kernel, dim3((unsigned)cdiv((long)di * NB, 256)), dim3(256), 0, st,
-                         a[l - 1], aT[l - 1], nn, di);
-      CLO_CHECK_LAUNCH("pack_at_kernel");
       if (l >= 2) {  // dA_l = W_l dA_{l-1}   ([dout x di] [di x NK])
         GemmArgs g = gemm_problem(dout, NK, di, W[l - 1], di, 1, dA[l - 1], NK, 1, 0.f, dA[l], NK);
         rc = launch_gemm_auto(g, gws, gws_sz, st);
         if (rc != CLO_OK) return rc;
       }
-      const int ipw = (int)cdiv(cdiv(di, KC_WAVES), 16) * 16;
 #ifndef CLO_KC_BPC
 #define CLO_KC_BPC 4
 #endif
@@ -3390,11 +3431,25 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
       ProfScope prof(0, 4.0 * di * dout * K, st);
       if (l >= 2)
         hipLaunchKernelGGL((kfwd_stream_kernel<true, KC_TPW, KC_WAVES>), grid, block, 0, st, VW[l - 1], ldk, vb,
-                           a[l - 1], dp, dA[l], nn, K, di, dout, ipw);
+                           a[l - 1], dp, dA[l], nn, K, di, dout);
       else
         hipLaunchKernelGGL((kfwd_stream_kernel<false, KC_TPW, KC_WAVES>), grid, block, 0, st, VW[l - 1], ldk, vb,
-                           a[l - 1], dp, dA[l], nn, K, di, dout, ipw);
+                           a[l - 1], dp, dA[l], nn, K, di, dout);
       CLO_CHECK_LAUNCH("kfwd_stream_kernel");
+    }
+    // ---- layer inputs sample-minor for the result streams (needed from here on): 8 layers per launch
+    for (int l0 = 0; l0 < L; l0 += 8) {
+      PackMulti pm{};
+      pm.nl = std::min(8, L - l0);
+      pm.N = nn;
+      for (int q = 0; q < pm.nl; ++q) {
+        pm.a[q] = a[l0 + q];
+        pm.d[q] = dims[l0 + q];
+        pm.start[q] = aT[l0 + q] - aT[l0];
+      }
+      pm.start[pm.nl] = pm.start[pm.nl - 1] + (long)dims[l0 + pm.nl - 1] * NB;
+      hipLaunchKernelGGL(pack_at_multi_kernel, dim3((unsigned)cdiv(pm.start[pm.nl], 256)), dim3(256), 0, st, pm, aT[l0]);
+      CLO_CHECK_LAUNCH("pack_at_multi_kernel");
     }
     // ---- output-space curvature per (n, k), in place: dA_L becomes delta_L
     {

@@ -240,7 +240,6 @@ def concurrent_inverses(num_streams: int = 2, distributed: bool = False):
     if _ACTIVE_BATCH is not None:  # nested: the outermost block owns the batch
         yield
         return
-    import os
 
     batch = _ACTIVE_BATCH = _InverseBatch(num_streams, distributed)
     try:

@@ -385,3 +385,21 @@ def test_eigh_zero_row_deflation_logic_cpu():
     assert float(L._orth_defect(Q)) < 1e-12 and float(L._residual_defect(A, lam, Q)) < 1e-12
     Z, sz = L._unit_scale(torch.zeros(3, 3))
     assert float(sz) == 1.0 and not torch.isnan(Z).any()
+
+
+@pytest.mark.parametrize("entries", [(2.0, 0.5, 1.0), (1.0, 0.0, 3.0), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), (-1.0, 2.0, -1.0),
+                                     (1e-8, 3e-9, 2e-8), (5.0, -4.0, 5.0)])
+def test_eigh_of_order_two_closed_form(entries):
+    """The n == 2 branch of linalg_native.eigh (G factors of two-class heads): one Jacobi rotation in float64.
+    Ascending eigenvalues, orthonormal columns, A = Q diag(lam) Q^T, against torch.linalg.eigh in float64."""
+    from curvlinops_amd.linalg_native import _eigh_2x2
+
+    a, b, c = entries
+    A = torch.tensor([[a, b], [b, c]], dtype=torch.float32)
+    lam, Q = _eigh_2x2(A)
+    assert lam.dtype == A.dtype and Q.dtype == A.dtype and lam[0] <= lam[1]
+    ref = torch.linalg.eigvalsh(A.double())
+    scale = max(float(A.abs().max()), 1e-30)
+    assert float((lam.double() - ref).abs().max()) <= 4e-7 * scale
+    assert float((Q.T @ Q - torch.eye(2)).abs().max()) <= 4e-7
+    assert float((Q @ torch.diag(lam) @ Q.T - A).abs().max()) <= 8e-7 * scale
