@@ -40,6 +40,13 @@ import os
 import sys
 import time
 
+# The multi-stream legs (six eigensolver workers, the pipelined Cholesky inverses, the factor stream of the KFAC build) run
+# on more HIP streams than the runtime's default of 4 hardware queues; streams that share a queue serialise, and WHICH
+# ones share one depends on creation order (tools/run_hwq.sh: eigh 119-121 / 130-136 / 107-108 ms and inverses 13.9 /
+# 12.4 / 12.6 ms at 4 / 8 / 16 queues).  One queue per stream takes the lottery out; the runtime reads this at
+# initialisation, so it is set before torch touches the device.  The headline matvec is single-stream and unaffected.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -603,6 +610,7 @@ def main() -> None:
             "workload": "C2: GGNLinearOperator @ v, MLP 1024-2688-2688-10 (D=10010122), MSE mean, "
                         f"{args.batch} rows per GPU, K=1",
             "rows_per_gpu": args.batch,
+            "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "parallelism": (f"dp{world} (data shards + RCCL all-reduce of the [D] result"
                             + (", overlapped with the next product)" if overlap else ")")) if world > 1 else "single GPU",
         },
