@@ -67,19 +67,24 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 // (16-workgroup groups, leaders, one top counter) and sc1 loads, exactly the hand-off of csrc/mlp_mega.hip.  The
 // algebra, the summation orders and the storage are those of sytrd_col_kernel; the matrix itself is only read (the
 // rank-128 trailing update runs between two panel launches on the GEMM engine), so its rows keep the plain loads.
-// The per-workgroup partial sums travel in two levels: the leader of every 16-workgroup group adds its group's records
-// between the group counter and the top counter, and a column's prologue reads <= 16 group records (at one level every
-// workgroup read G x 1 KB per column, 6 us of a CU's memory pipe at G = 128).
+// The per-workgroup partial sums travel in two levels: the 16 workgroups of a group ADD theirs into the group's record
+// with float atomics (0.37 us per round for all 256 workgroups incl. the acknowledgements, tools/ubench/atomic_probe.hip;
+// the first version had the group's leader read, add and re-publish 16 private records between the two counters: two
+// more fabric round trips per column, 10.9 -> 8.4 us per column at n = 577), and a column's prologue adds the <= 16 group
+// records in a fixed order.  Three record buffers rotate (read c % 3, add into (c + 1) % 3, leaders clear (c + 2) % 3).
+// The additions inside a group happen in arrival order: two runs agree to rounding, not bit for bit -- and since the map
+// A -> T is ill-conditioned for rank-deficient A, T itself may differ visibly past the numerical rank while its
+// spectrum and the similarity Q^T A Q = T hold to eps (tests compare spectra).
 // Every spin is bounded and traps.  All G <= TD_GMAX (256) workgroups must be resident at once (one per CU: the kernel
 // uses the full register budget of eight waves).
 // ------------------------------------------------------------------------------------------------------------------
 struct TpArgs {
   const float *A;
   long lda;
-  int n, i0, ncol, rpw, G;
+  int n, i0, ncol, rpb, rpw, G;   // rpb rows per workgroup, rpw of them per wave
   float *ws;                 // exchange workspace: V panel at offset 0
   long ws_floats;
-  long o_W, o_u0[2], o_vv[2], o_part[2], o_gpart[2], o_gam;   // float offsets inside ws
+  long o_W, o_u0[2], o_vv[2], o_gpart[3], o_gam;   // float offsets inside ws
   float *D, *E, *tau;
   unsigned *cnt;             // [TD_GMAX / 16 + 1] counters (one per 128-byte line), zero at launch, then {err}
 };
@@ -134,8 +139,12 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
   const int grp = blockIdx.x / TP_GROUP, gsize = min(TP_GROUP, G - grp * TP_GROUP);
   unsigned *c_grp = p.cnt + 32 * grp, *c_top = p.cnt + 32 * (TD_GMAX / TP_GROUP), *c_err = c_top + 32;
 
-  const int wbase = p.i0 + 2 + (blockIdx.x * TD_WAVES + wave) * p.rpw;   // this wave's rows, fixed for the panel
-  const int wend = min(n, wbase + p.rpw);
+  // this wave's rows, fixed for the panel: the workgroup owns rpb consecutive rows, its waves rpw of them each (the rows
+  // are dealt per WORKGROUP: dealing rpw rows per wave over the whole grid left a quarter of the CUs without rows at
+  // n = 4609 -- 24 rows each for 192 workgroups -- and the row pass is bound by what one CU's memory pipe ingests)
+  const int bbase = p.i0 + 2 + blockIdx.x * p.rpb;
+  const int wbase = bbase + wave * p.rpw;
+  const int wend = min(min(n, bbase + p.rpb), wbase + p.rpw);
 
 #ifdef CLO_TD_TIMING
   // phase stamps of workgroup 0 (and of the last workgroup), summed over the columns of the panel at i0 == 0
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
     if (c > 0 && tid < NQ4) {
       v4 x[NGRP];   // all loads of a thread in flight at once: one fabric round trip
 #pragma unroll
-      for (int g = 0; g < NGRP; ++g) x[g] = L4(g < ngroups, p.o_gpart[in] + (long)g * TD_NPART + 4 * tid);
+      for (int g = 0; g < NGRP; ++g) x[g] = L4(g < ngroups, p.o_gpart[c % 3] + (long)g * TD_NPART + 4 * tid);
       v4 sacc = x[0];
 #pragma unroll
       for (int g = 1; g < NGRP; ++g) sacc += x[g];
@@ -470,8 +479,13 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
       float sacc = 0.f;
 #pragma unroll
       for (int w = 0; w < TD_WAVES; ++w) sacc += s_red[w * TD_NPART + tid];
-      S1(p.o_part[out] + (long)blockIdx.x * TD_NPART + tid, sacc);
+      // the group's record of the NEXT column: float atomics (the 16 workgroups of a group add in arrival order; the
+      // prologue then adds the <= 16 group records in a fixed order)
+      __hip_atomic_fetch_add(p.ws + p.o_gpart[(c + 1) % 3] + (long)grp * TD_NPART + tid, sacc, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (blockIdx.x % TP_GROUP == 0 && tid < NQ4)   // the record this group adds into at the end of column c + 1
+      S4(p.o_gpart[(c + 2) % 3] + (long)grp * TD_NPART + 4 * tid, zero4);
     if (c + 1 == p.ncol) break;
     // ---- hand-off to the next column: every store of this workgroup acknowledged, then the two-level barrier ----
     TD_STAMP(4);   // partial sums
@@ -480,22 +494,9 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
     TD_STAMP(5);   // stores acknowledged
     const unsigned epoch = (unsigned)(c + 1);
     if (tid == 0) __hip_atomic_fetch_add(c_grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x % TP_GROUP == 0) {   // the group's leader: its group's records -> one group record, then the top counter
-      if (tid == 0) tp_wait(c_grp, (unsigned)gsize * epoch, c_err);
-      __syncthreads();
-      if (tid < NQ4) {
-        v4 x[TP_GROUP];
-#pragma unroll
-        for (int k = 0; k < TP_GROUP; ++k)
-          x[k] = L4(k < gsize, p.o_part[out] + (long)(blockIdx.x + k) * TD_NPART + 4 * tid);
-        v4 sacc = x[0];
-#pragma unroll
-        for (int k = 1; k < TP_GROUP; ++k) sacc += x[k];
-        S4(p.o_gpart[out] + (long)grp * TD_NPART + 4 * tid, sacc);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(c_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x % TP_GROUP == 0 && tid == 0) {   // the group's leader: everybody of the group has arrived -> top counter
+      tp_wait(c_grp, (unsigned)gsize * epoch, c_err);
+      __hip_atomic_fetch_add(c_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) tp_wait(c_top, (unsigned)ngroups * epoch, c_err);
     __syncthreads();
@@ -506,6 +507,8 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.cnt + TP_CNT_WORDS) + (blockIdx.x == 0 ? 0 : 8);
     for (int i = 0; i < 8; ++i) dst[i] = tacc[i];
   }
+  if (tid == 0 && p.i0 == 0)   // row pass and barrier time of EVERY workgroup
+    reinterpret_cast<unsigned long long *>(p.cnt + TP_CNT_WORDS)[16 + blockIdx.x] = (tacc[3] << 32) | (tacc[6] & 0xffffffffull);
 #endif
 }
 
@@ -552,8 +555,7 @@ __global__ void sytrd_tail_kernel(const float *A, long lda, int n, float *D, flo
 
 long td_ws_floats(int n) {
   const long n4 = (n + 3) & ~3L;
-  return 2L * n * TD_NB + 4 * n4 + 2L * TD_GMAX * TD_NPART + 2L * (TD_GMAX / TP_GROUP) * TD_NPART + 2L * TD_NB + 64 +
-         TP_CNT_WORDS + 64;   // (+ timing slots)
+  return 2L * n * TD_NB + 4 * n4 + 2L * TD_NB + 64 + 3L * (TD_GMAX / TP_GROUP) * TD_NPART + TP_CNT_WORDS + 64 + 2 * TD_GMAX;   // (+ timing slots)
 }
 
 }  // namespace
@@ -576,10 +578,12 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
   float *Vp = ws, *Wp = Vp + (long)n * TD_NB;
   float *u0[2] = {Wp + (long)n * TD_NB, Wp + (long)n * TD_NB + n4};
   float *vv[2] = {u0[1] + n4, u0[1] + 2 * n4};
-  float *part[2] = {vv[1] + n4, vv[1] + n4 + (long)TD_GMAX * TD_NPART};
-  float *gpart[2] = {part[1] + (long)TD_GMAX * TD_NPART, part[1] + (long)TD_GMAX * TD_NPART + (long)(TD_GMAX / TP_GROUP) * TD_NPART};
-  float *gam = gpart[1] + (long)(TD_GMAX / TP_GROUP) * TD_NPART;   // [TD_NB]
-  unsigned *cnt = reinterpret_cast<unsigned *>(gam + 2 * TD_NB + 64);
+  float *gam = vv[1] + n4;   // [TD_NB]
+  // three rotating buffers of group records (column c reads c % 3, adds into (c + 1) % 3, clears (c + 2) % 3), then the
+  // counters: ONE memset per panel clears both
+  constexpr long GREC = (long)(TD_GMAX / TP_GROUP) * TD_NPART;
+  float *gpart[3] = {gam + 2 * TD_NB + 64, gam + 2 * TD_NB + 64 + GREC, gam + 2 * TD_NB + 64 + 2 * GREC};
+  unsigned *cnt = reinterpret_cast<unsigned *>(gpart[2] + GREC);
   const int gmax = max_blocks > 0 ? std::min(max_blocks, TD_GMAX) : TD_GMAX;
 
   const size_t lds = (2 * n4 + TD_WAVES * TD_NPART + 5 * TD_NB + 5 * TD_WAVES + 16) * sizeof(float);
@@ -613,18 +617,20 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
     const int ncol = std::min(TD_NB, n - 2 - i0);
     // the panel's row owners: every wave of the G workgroups keeps `rpw` consecutive rows >= i0 + 2 for all columns
     const int nd = n - i0 - 2;
-    const int G = (int)std::max<long>(1, std::min<long>(gmax, cdiv(nd, TD_WAVES)));
-    const int rpw = (int)cdiv(nd, (long)G * TD_WAVES);
-    int rc = check_hip(hipMemsetAsync(cnt, 0, TP_CNT_WORDS * sizeof(unsigned), st), "clo_sytrd_f32: counter reset");
+    const int Gmax = (int)std::max<long>(1, std::min<long>(gmax, cdiv(nd, TD_WAVES)));
+    const int rpb = (int)cdiv(nd, Gmax);                 // rows per workgroup ...
+    const int G = (int)cdiv(nd, rpb);                    // ... on as few workgroups as that needs
+    const int rpw = (int)cdiv(rpb, TD_WAVES);
+    int rc = check_hip(hipMemsetAsync(gpart[0], 0, (3 * GREC + TP_CNT_WORDS) * sizeof(float), st),
+                       "clo_sytrd_f32: group records / counter reset");
     if (rc != CLO_OK) return rc;
     TpArgs a;
-    a.A = A; a.lda = lda; a.n = n; a.i0 = i0; a.ncol = ncol; a.rpw = rpw; a.G = G;
+    a.A = A; a.lda = lda; a.n = n; a.i0 = i0; a.ncol = ncol; a.rpb = rpb; a.rpw = rpw; a.G = G;
     a.ws = ws; a.ws_floats = td_ws_floats(n);
     a.o_W = Wp - ws;
     a.o_u0[0] = u0[0] - ws; a.o_u0[1] = u0[1] - ws;
     a.o_vv[0] = vv[0] - ws; a.o_vv[1] = vv[1] - ws;
-    a.o_part[0] = part[0] - ws; a.o_part[1] = part[1] - ws;
-    a.o_gpart[0] = gpart[0] - ws; a.o_gpart[1] = gpart[1] - ws;
+    a.o_gpart[0] = gpart[0] - ws; a.o_gpart[1] = gpart[1] - ws; a.o_gpart[2] = gpart[2] - ws;
     a.o_gam = gam - ws;
     a.D = D; a.E = E; a.tau = tau; a.cnt = cnt;
     // (no partly resident persistent grids side by side: csrc/persist_gate.h)
@@ -639,8 +645,8 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
 #undef CLO_TP_CASE
       default: hipLaunchKernelGGL(sytrd_panel_kernel<8>, dim3(G), dim3(TD_THREADS), lds, st, a); break;
     }
-    const int flip = (ncol & 1) ? 1 : 0;   // the buffer the last column of the panel wrote its partial sums to
-    const int g_prev = G;
+    const int flip = ncol % 3;   // the buffer the last column of the panel added its partial sums into
+    const int g_prev = (int)cdiv(G, TP_GROUP);   // group records
     rc = check_hip(hipGetLastError(), "sytrd_panel_kernel");
     if (rc != CLO_OK) {
       gate.abort();
@@ -649,7 +655,7 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
     rc = gate.done(st);
     if (rc != CLO_OK) return rc;
     hipLaunchKernelGGL(sytrd_panel_end_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, A, lda, n, i0,
-                       ncol, Vp, Wp, part[flip], g_prev, tau, gam);
+                       ncol, Vp, Wp, gpart[flip], g_prev, tau, gam);
     CLO_CHECK_LAUNCH("sytrd_panel_end_kernel");
     // trailing update A[t:, t:] -= V W^T + W V^T on the MFMA GEMM engine (full square: the column
     // kernel reads complete rows)

@@ -1109,11 +1109,12 @@ def test_block_reflector_back_transformation(hip, n):
 def test_native_eigh_at_the_factor_sizes_of_the_benchmarks(hip, n):
     """The hand-written solver end to end (no torch.linalg.eigh / rocSOLVER on the way) at the factor orders of
     ResNet-18 / the encoder: |Q^T Q - I| <= 1e-5 and Q diag(lam) Q^T against the float64 matrix within 4 eps32 |A|_2
-    (the backward-error scale of an fp32 eigensolver) and, up to n = 1153, within 1e-4 |A|max entrywise.  Beyond, the
+    (the backward-error scale of an fp32 eigensolver) and, up to n = 577, within 1e-4 |A|max entrywise.  Beyond, the
     entrywise error of this rank-one-dominated matrix (n = 4609: |A|_2 = 3500 |A|max, ONE rounding of the top
     eigenvalue is 2e-4 |A|max) depends on the order of the reduction's sums: round 3's column launches 0.7e-4 at 4609,
-    the persistent panel launches 0.7 ... 2.3e-4 for 32 ... 128 workgroups (tools/cmp_sytrd_recon.py) -- all below half
-    an eps32 |A|_2."""
+    the persistent panel launches 0.7 ... 2.3e-4 for 32 ... 128 workgroups (tools/cmp_sytrd_recon.py), and since a group's
+    partial sums are added in arrival order (float atomics) also on the run: 0.5 ... 1.4e-4 |A|max at n = 1153 -- all below
+    half an eps32 |A|_2."""
     from curvlinops_amd import linalg_native as L
 
     dev = torch.device("cuda:0")
@@ -1126,8 +1127,23 @@ def test_native_eigh_at_the_factor_sizes_of_the_benchmarks(hip, n):
     assert float((Qd.T @ Qd - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-5
     rec = float(((Qd * ld_) @ Qd.T - A.double().cpu()).abs().max())
     assert rec <= 4.0 * 2.0 ** -24 * float(ld_.abs().max())
-    if n <= 1153:
+    if n <= 577:
         assert rec <= 1e-4 * float(A64.abs().max())
+
+
+def _assert_same_reduction(got, ref, n, tol=2e-6):
+    """Two runs of clo_sytrd_f32 on the same matrix.  A group's partial sums are added with float atomics (arrival
+    order), and the map A -> T is ill-conditioned for rank-deficient A (entries of T past the numerical rank move by
+    1e-2 under a rounding-level change), so the runs are compared through what IS well conditioned: the spectrum of T."""
+    from scipy.linalg import eigvalsh_tridiagonal
+
+    def spectrum(red):
+        d, e = red[0][:n].double().cpu().numpy(), red[1][: n - 1].double().cpu().numpy()
+        return eigvalsh_tridiagonal(d, e)
+
+    lam, lam_ref = spectrum(got), spectrum(ref)
+    assert np.isfinite(lam).all()
+    assert np.abs(lam - lam_ref).max() <= tol * np.abs(lam_ref).max() * n ** 0.5
 
 
 @pytest.mark.gpu
@@ -1135,7 +1151,7 @@ def test_persistent_grids_of_different_streams_are_admitted_safely(hip):
     """Round 4: panel launches of clo_sytrd_f32 (up to 256 workgroups that wait for each other) on two streams next to
     persistent GGN products (256 workgroups) on a third.  Partly resident persistent grids would wait for each other
     forever; the library's admission control (csrc/persist_gate.h) makes a launch wait, device side, until everything
-    in flight plus itself fits the chip.  Results equal the serial ones bit for bit; nothing hangs or traps."""
+    in flight plus itself fits the chip.  Products equal the serial ones bit for bit, reductions to rounding; nothing hangs or traps."""
     device = torch.device("cuda:0")
     n = 1100
     ld = (n + 3) // 4 * 4
@@ -1174,10 +1190,10 @@ def test_persistent_grids_of_different_streams_are_admitted_safely(hip):
             for _ in range(10):
                 got_prod.append(product())
     torch.cuda.synchronize()
+    # (a torn or stale exchange moves the spectrum at the 1e-2 level; arrival-order rounding does not)
     for i in range(2):
         for D, E, tau in got_red[i]:
-            assert torch.equal(D, serial[i][0]) and torch.equal(E[: n - 1], serial[i][1][: n - 1])
-            assert torch.equal(tau[: n - 2], serial[i][2][: n - 2])
+            _assert_same_reduction((D, E, tau), serial[i], n)
     for out in got_prod:
         assert all(torch.equal(a, b) for a, b in zip(out, ref))
 
@@ -1185,7 +1201,8 @@ def test_persistent_grids_of_different_streams_are_admitted_safely(hip):
 @pytest.mark.gpu
 def test_sytrd_is_deterministic(hip):
     """Rank-deficient factors take the per-block panel pass in many columns: no block may observe another
-    block's updates of the panel (a race here showed up as run-to-run differences of 1e-2)."""
+    block's updates of the panel (a race here showed up as run-to-run differences of 1e-2).  Runs agree to rounding
+    (round 4: a group's partial sums are added with float atomics, in arrival order)."""
     dev = torch.device("cuda:0")
     n = 777
     A64 = _sym_case("lowrank", n, dev)
@@ -1196,9 +1213,8 @@ def test_sytrd_is_deterministic(hip):
         P[:, :n] = A64.float().to(dev)
         D, E, tau = hip.sytrd_(P, n)
         outs.append((D.clone(), E.clone(), tau.clone()))
-    for D, E, tau in outs[1:]:
-        assert torch.equal(D, outs[0][0]) and torch.equal(E[: n - 1], outs[0][1][: n - 1])
-        assert torch.equal(tau[: n - 2], outs[0][2][: n - 2])
+    for red in outs[1:]:
+        _assert_same_reduction(red, outs[0], n)
 
 
 @pytest.mark.gpu

@@ -22,9 +22,14 @@ for kind in ("lowrank", "wishart"):
     rc = lib.clo_sytrd_f32(work.data_ptr(), ld, n, D.data_ptr(), E.data_ptr(), tau.data_ptr(), ws.data_ptr(), nb, maxb,
                            torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize(); assert rc == 0
-    off = 2 * n * 64 + 4 * n4 + 2 * 256 * 264 + 2 * 16 * 264 + 192 + 576
+    off = 2 * n * 64 + 4 * n4 + 192 + 3 * 16 * 264 + 576
     st = ws[off:off + 32].view(torch.int64).cpu().numpy().astype(np.float64) * 0.01 / 64   # us per column
     print(f"n={n} {kind}: us per column, first / last workgroup")
     for i, nm in enumerate(names):
         print(f"   {nm:16s} {st[i]:7.2f} {st[8 + i]:7.2f}")
     print(f"   {'total':16s} {st[:7].sum():7.2f} {st[8:15].sum():7.2f}")
+    pw = ws[off + 32:off + 32 + 512].view(torch.int64).cpu().numpy()
+    rp, br = (pw >> 32).astype(np.float64) * 0.01 / 64, (pw & 0xffffffff).astype(np.float64) * 0.01 / 64
+    print("   row pass per workgroup (us per column), workgroups 0, 8, 16, ...:", " ".join(f"{x:.1f}" for x in rp[::8]))
+    print("   row pass by XCD (workgroup % 8), mean:", " ".join(f"{rp[x::8][rp[x::8] > 0].mean():.1f}" for x in range(8)))
+    print("   barrier wait by workgroup 0, 8, ...:", " ".join(f"{x:.1f}" for x in br[::8]))
