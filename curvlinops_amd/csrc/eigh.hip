@@ -414,10 +414,27 @@ extern "C" int clo_dc_rotate(float *MT, const int *rot_p, const double *rot_c, c
 // ---- back-transformation  Z <- Z Q^T  (every ROW of Z [m][ldz >= pad4(n)] times Q = H_0 ... H_{n-2}, the
 // reflectors clo_sytrd_f32 left in `work` / `tau`): blocks of 64 reflectors as I - V T^T V^T, three GEMMs each.
 static inline long ormtr_pad4(long n) { return (n + 3) & ~3L; }
+// Blocks of OB_Q x 64 = 256 reflectors (round 4; 64 before: 72 x 3 skinny products of ~50 us at n = 4609).  The T factor of
+// a big block is assembled from its panels' 64 x 64 factors with the compact-WY product rule
+//   (I - Va Ta Va^T)(I - Vb Tb Vb^T) = I - [Va Vb] [[Ta, -Ta (Va^T Vb) Tb], [0, Tb]] [Va Vb]^T,
+// panel by panel: column block j of T_big above its diagonal block = -(T_big[0:64j, 0:64j] G_big[0:64j, j]) T_j.
+constexpr int OB_Q = 4, OB_NB = 64 * OB_Q;
+namespace clo {
+// T_big[b] (256 x 256, zeroed by the caller) <- diagonal blocks T[4 b + q]
+__global__ void ormtr_tbig_diag_kernel(const float *__restrict__ T, float *__restrict__ Tbig, int npan) {
+  const int pnl = blockIdx.x, b = pnl / OB_Q, q = pnl - b * OB_Q;
+  if (pnl >= npan) return;
+  for (int e = threadIdx.x; e < 4096; e += blockDim.x) {
+    const int r = e >> 6, c = e & 63;
+    Tbig[(long)b * OB_NB * OB_NB + (long)(64 * q + r) * OB_NB + 64 * q + c] = T[(long)pnl * 4096 + e];
+  }
+}
+}  // namespace clo
 extern "C" long clo_ormtr_ws_floats(int m, int n) {
   if (n < 3 || m < 1) return 64;
-  const long ldv = ormtr_pad4(n), npan = cdiv(n - 1, 64), R = npan * 64;
-  return R * ldv + 2 * npan * 4096 + R + 2L * m * 64 + 8L * std::max<long>(m, 64) * 64 + 256;
+  const long ldv = ormtr_pad4(n), nbig = cdiv(n - 1, OB_NB), R = nbig * OB_NB, npan = nbig * OB_Q;
+  return R * ldv + 2 * npan * 4096 + R + 2 * nbig * OB_NB * OB_NB + nbig * (OB_NB - 64) * 64 + 2L * m * OB_NB +
+         8L * std::max<long>(m, 64) * 64 + 256;
 }
 extern "C" int clo_ormtr_f32(const float *work, long ldw, const float *tau, float *Z, long ldz, int m, int n,
                              float *ws, long ws_floats, void *stream) {
@@ -428,9 +445,12 @@ extern "C" int clo_ormtr_f32(const float *work, long ldw, const float *tau, floa
               "clo_ormtr_f32: Z needs a 16-byte aligned base and a leading dimension >= pad4(n), multiple of 4");
   CLO_REQUIRE(ws_floats >= clo_ormtr_ws_floats(m, n), "clo_ormtr_f32: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int npan = (int)cdiv(n - 1, 64), R = npan * 64;
+  // reflector rows padded to whole big blocks: the surplus rows are zero reflectors (tau = 0 -> T = 0)
+  const int nbig = (int)cdiv(n - 1, OB_NB), R = nbig * OB_NB, npan = nbig * OB_Q;
+  constexpr long TB = (long)OB_NB * OB_NB;
   float *Vt = ws, *G = Vt + (long)R * ldv, *T = G + (long)npan * 4096, *tp = T + (long)npan * 4096;
-  float *W = tp + R, *W2 = W + (long)m * 64, *gws = W2 + (long)m * 64;
+  float *Gbig = tp + R, *Tbig = Gbig + nbig * TB, *Y = Tbig + nbig * TB;
+  float *W = Y + (long)nbig * (OB_NB - 64) * 64, *W2 = W + (long)m * OB_NB, *gws = W2 + (long)m * OB_NB;
   const long gws_floats = ws_floats - (gws - ws);
   hipLaunchKernelGGL(ormtr_vt_kernel, dim3((unsigned)std::min<long>(cdiv((long)R * ldv, 256), 4096)), dim3(256), 0, st,
                      work, ldw, Vt, ldv, n, R);
@@ -446,20 +466,36 @@ extern "C" int clo_ormtr_f32(const float *work, long ldw, const float *tau, floa
     g.C = C; g.ldc = ldc; g.sc_b = sc_b;
     return launch_gemm_auto(g, gws, gws_floats, st, batch);
   };
+  // Gram matrices: per panel (64 x 64, for the panels' own T factors) and per big block (256 x 256, cross terms)
   int rc = gemm(64, 64, (int)ldv, 1.f, Vt, ldv, 1, 64 * ldv, Vt, 1, ldv, 64 * ldv, 0.f, G, 64, 4096, npan);
+  if (rc != CLO_OK) return rc;
+  rc = gemm(OB_NB, OB_NB, (int)ldv, 1.f, Vt, ldv, 1, OB_NB * ldv, Vt, 1, ldv, OB_NB * ldv, 0.f, Gbig, OB_NB, TB, nbig);
   if (rc != CLO_OK) return rc;
   hipLaunchKernelGGL(larft_kernel, dim3(npan), dim3(64), 0, st, G, tp, T, 64);
   CLO_CHECK_LAUNCH("larft_kernel");
-  for (int p = npan - 1; p >= 0; --p) {
-    const long c0 = 64L * p;
+  rc = check_hip(hipMemsetAsync(Tbig, 0, nbig * TB * sizeof(float), st), "clo_ormtr_f32: T reset");
+  if (rc != CLO_OK) return rc;
+  hipLaunchKernelGGL(ormtr_tbig_diag_kernel, dim3(npan), dim3(256), 0, st, T, Tbig, npan);
+  CLO_CHECK_LAUNCH("ormtr_tbig_diag_kernel");
+  for (int j = 1; j < OB_Q; ++j) {   // all big blocks at once
+    const int h = 64 * j;
+    rc = gemm(h, 64, h, 1.f, Tbig, OB_NB, 1, TB, Gbig + h, OB_NB, 1, TB, 0.f, Y, 64, (long)(OB_NB - 64) * 64, nbig);   // Y = T[0:h,0:h] G[0:h, j]
+    if (rc != CLO_OK) return rc;
+    rc = gemm(h, 64, 64, -1.f, Y, 64, 1, (long)(OB_NB - 64) * 64, Tbig + (long)h * OB_NB + h, OB_NB, 1, TB, 0.f,
+              Tbig + h, OB_NB, TB, nbig);                                                                                // T[0:h, j] = -Y T_j
+    if (rc != CLO_OK) return rc;
+  }
+  for (int b = nbig - 1; b >= 0; --b) {
+    const long c0 = (long)OB_NB * b;
     const int w = (int)(ldv - c0);
-    const float *Vp = Vt + c0 * ldv + c0;   // rows 64 p .., columns c0 ..
+    const float *Vp = Vt + c0 * ldv + c0;   // rows c0 .., columns c0 ..
+    const float *Tb = Tbig + b * TB;
     float *Zs = Z + c0;
-    rc = gemm(m, 64, w, 1.f, Zs, ldz, 1, 0, Vp, 1, ldv, 0, 0.f, W, 64, 0, 1);           // W  = Zs Vp^T
+    rc = gemm(m, OB_NB, w, 1.f, Zs, ldz, 1, 0, Vp, 1, ldv, 0, 0.f, W, OB_NB, 0, 1);        // W  = Zs Vp^T
     if (rc != CLO_OK) return rc;
-    rc = gemm(m, 64, 64, 1.f, W, 64, 1, 0, T + (long)p * 4096, 1, 64, 0, 0.f, W2, 64, 0, 1);   // W2 = W T^T
+    rc = gemm(m, OB_NB, OB_NB, 1.f, W, OB_NB, 1, 0, Tb, 1, OB_NB, 0, 0.f, W2, OB_NB, 0, 1);   // W2 = W T^T
     if (rc != CLO_OK) return rc;
-    rc = gemm(m, w, 64, -1.f, W2, 64, 1, 0, Vp, ldv, 1, 0, 1.f, Zs, ldz, 0, 1);         // Zs -= W2 Vp
+    rc = gemm(m, w, OB_NB, -1.f, W2, OB_NB, 1, 0, Vp, ldv, 1, 0, 1.f, Zs, ldz, 0, 1);      // Zs -= W2 Vp
     if (rc != CLO_OK) return rc;
   }
   return CLO_OK;
