@@ -31,7 +31,7 @@ from curvlinops_amd.canonical import ParamGroup
 from curvlinops_amd.enums import FisherType, KFACType
 from curvlinops_amd.loss_sampling import make_grad_output_fn
 from curvlinops_amd.risk import EmpiricalRiskMixin
-from curvlinops_amd.utils import flatten_output_and_labels, is_native_tensor, seed_generator
+from curvlinops_amd.utils import flatten_output_and_labels, is_native_tensor, seed_generator, side_stream
 
 ParamGroupKey = tuple[str, ...]
 
@@ -217,7 +217,7 @@ class _factor_stream:
         dev = self._t.device
         side = _FACTOR_STREAMS.get(dev)
         if side is None:
-            side = _FACTOR_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            side = _FACTOR_STREAMS[dev] = side_stream(dev, 0)   # (first of the package-wide worker streams)
         side.wait_event(torch.cuda.current_stream(dev).record_event())
         self._t.record_stream(side)
         self._ctx = torch.cuda.stream(side)

@@ -28,7 +28,7 @@ from curvlinops_amd.linop import (
     _expect_same_spaces,
 )
 from curvlinops_amd.canonical import is_kmajor
-from curvlinops_amd.utils import infer_device, infer_dtype, is_native_tensor, split_list
+from curvlinops_amd.utils import infer_device, infer_dtype, is_native_tensor, side_stream, split_list
 
 
 def ensure_all_square(*objs) -> None:
@@ -313,7 +313,6 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         return state
 
     _POOL_STREAMS = 4
-    _pool: dict = {}
 
     def _matmat(self, X: list[Tensor]) -> list[Tensor]:
         parts = split_list(X, [len(B._in_shape) for B in self._blocks])
@@ -401,10 +400,7 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         """The blocks are independent and individually too small to fill 256 CUs (a ResNet-18 KFAC
         product is 21 blocks of two GEMMs each): spread them over a few HIP streams and join."""
         dev = parts[0][0].device
-        pool = BlockDiagonalLinearOperator._pool.get(dev)
-        if pool is None:
-            pool = BlockDiagonalLinearOperator._pool[dev] = [torch.cuda.Stream(device=dev)
-                                                             for _ in range(self._POOL_STREAMS)]
+        pool = [side_stream(dev, i) for i in range(self._POOL_STREAMS)]   # the package-wide worker streams
         main = torch.cuda.current_stream(dev)
         ready = main.record_event()
         for side in pool:

@@ -25,19 +25,7 @@ from torch import Tensor
 
 from curvlinops_amd import _hip
 from curvlinops_amd.utils import is_native_tensor
-
-
-_SIDE_STREAMS: dict = {}
-
-
-def _side_stream(device: torch.device, index: int) -> "torch.cuda.Stream":
-    """Persistent worker streams: the caching allocator keeps freed blocks PER STREAM, so workers
-    that made a fresh stream per call could never reuse the (GB-sized) workspaces of the previous
-    call and fell back to hipMalloc / cache flushes (inverse time 15 <-> 58 ms from run to run)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), index)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+from curvlinops_amd.utils import side_stream as _side_stream   # one pool of worker streams per device for the whole package
 
 
 def _torch_damped_cholesky_inverse(A: Tensor, damping: float) -> Tensor:
