@@ -483,7 +483,9 @@ __global__ __launch_bounds__(WAVES * 64) void fwd_mfma_first_kernel(
 #pragma unroll
   for (int g = 0; g < RG; ++g) {
     const int row = min(j0 + g * 8 + (idx & 7), jlast);
-    pA[g] = ((idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
+    // (no tangent weights: rows 8 .. 15 of the tile alias the W rows -- the same addresses inside one load instruction --
+    // and da_out is not written; the forward pass of the K-column products runs layers of <= 8 rows without slabs this way)
+    pA[g] = ((idx >= 8 && VW) ? VW : W) + (long)row * d_in + kb0 + s4;
   }
   // B lanes: columns 0..7 = x rows, columns 8..15 (the absent da) and rows >= N are zero: they
   // load a valid duplicate address and are masked
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(WAVES * 64) void fwd_mfma_first_kernel(
         const float aval = act_apply(act, zsrc + (b ? b[j] : 0.f), dphi);
         a_out[(long)n * d_out + j] = aval;
         if (dphi_out) dphi_out[(long)n * d_out + j] = dphi;
-        da_out[(long)n * d_out + j] = dphi * (up + (Vb ? Vb[j] : 0.f));
+        if (da_out) da_out[(long)n * d_out + j] = dphi * (up + (Vb ? Vb[j] : 0.f));
       }
     }
   }
@@ -1224,7 +1226,9 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
 #pragma unroll
   for (int g = 0; g < RG; ++g) {
     const int row = min(j0 + g * 8 + (idx & 7), d_out - 1);
-    pA[g] = ((idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
+    // (no tangent weights: rows 8 .. 15 of the tile alias the W rows -- the same addresses inside one load instruction --
+    // and da_out is not written; the forward pass of the K-column products runs layers of <= 8 rows without slabs this way)
+    pA[g] = ((idx >= 8 && VW) ? VW : W) + (long)row * d_in + kb0 + s4;
   }
   constexpr int U = 2;
   struct Group { float4 av[U][RG]; };
@@ -1351,7 +1355,9 @@ __global__ __launch_bounds__(512) void mid_full_kernel(
 #pragma unroll
   for (int g = 0; g < RG; ++g) {
     const int row = min(j0 + g * 8 + (idx & 7), jlast);
-    pA[g] = ((idx >= 8) ? VW : W) + (long)row * d_in + kb0 + s4;
+    // (no tangent weights: rows 8 .. 15 of the tile alias the W rows -- the same addresses inside one load instruction --
+    // and da_out is not written; the forward pass of the K-column products runs layers of <= 8 rows without slabs this way)
+    pA[g] = ((idx >= 8 && VW) ? VW : W) + (long)row * d_in + kb0 + s4;
   }
   long offB[NT];
   unsigned bmask[NT];
@@ -2417,21 +2423,24 @@ static int fwd_pass(const float *W, const float *b, const float *VW, const float
                     bool leave_partials, int *ksplit_out, hipStream_t st) {
   const bool has_v = VW != nullptr, has_da = da_in != nullptr;
   const bool vec = vec_ok(d_in, {W, VW, a_in, da_in});
-  if (vec && N >= 1 && has_v && !has_da && d_in >= 256 && cdiv(d_out, MF1_RG * 8) >= kNumCU / 2) {
+  // (without tangent weights only where a wave's K range is one round trip: d_in = 2688 measured 16.3 us against 9.0 + 4.9
+  // for the slab kernel + finish, d_in = 1024 9.6 against 13.9)
+  if (vec && N >= 1 && !has_da && (has_v || (!leave_partials && d_in <= 1024)) && d_in >= 256 &&
+      cdiv(d_out, MF1_RG * 8) >= kNumCU / 2) {
     // ---- first layer: in-block split-K, no slabs, no finish launch
     if (ksplit_out) *ksplit_out = 1;
     const int kpw = (int)cdiv(cdiv(d_in, MF1_WAVES), 16) * 16;
     // features per block: fill the CUs evenly (11 for d_out = 2688), at most one RG x 8 tile group
     const int fpb = (int)std::min<long>(MF1_RG * 8, std::max<long>(4, cdiv(d_out, kNumCU)));
-    ProfScope prof(0, 4.0 * d_in * d_out * 2, st);
+    ProfScope prof(0, 4.0 * d_in * d_out * (has_v ? 2 : 1), st);
     // all of a wave's weight loads in ONE round trip where its K range is 8 steps (d_in = 1024)
     if (kpw == 128 && d_in % 128 == 0)
       hipLaunchKernelGGL((fwd_mfma_first_kernel<MF1_WAVES, MF1_RG, 8>), dim3((unsigned)cdiv(d_out, fpb)),
-                         dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in,
+                         dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, has_v ? da_out : nullptr, dphi_out, N, d_in,
                          d_out, act, kpw, fpb);
     else
       hipLaunchKernelGGL((fwd_mfma_first_kernel<MF1_WAVES, MF1_RG, MF1_U>), dim3((unsigned)cdiv(d_out, fpb)),
-                         dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, da_out, dphi_out, N, d_in,
+                         dim3(MF1_WAVES * 64), 0, st, W, b, VW, Vb, a_in, a_out, has_v ? da_out : nullptr, dphi_out, N, d_in,
                          d_out, act, kpw, fpb);
     CLO_CHECK_LAUNCH("fwd_mfma_first_kernel");
     return CLO_OK;
