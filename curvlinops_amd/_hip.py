@@ -148,6 +148,15 @@ _SIGNATURES = {
     "clo_dc_secular": (c_int, [_PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, c_int, c_void_p]),
     "clo_dc_build": (c_int, [_PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, c_int, c_void_p]),
     "clo_dc_rotate": (c_int, [_PF, _PF, _PF, _PF, c_int, c_int, c_void_p]),
+    "clo_kron_ws_floats": (c_long, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "clo_kron_matmat": (c_int, [_PF, _PF, c_long, _PF, c_long, _PF, c_int, c_int, c_int, c_int, c_int, c_int, _PF, c_long, c_void_p]),
+    "clo_eigh_apply": (c_int, [_PF, _PF, c_long, _PF, c_long, _PF, _PF, c_int, c_int, c_int, c_int, _PF, c_long, c_void_p]),
+    "clo_kron_matmat_blocks": (
+        c_int,
+        [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_long), POINTER(c_void_p), POINTER(c_long), POINTER(c_void_p),
+         POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int, _PF, c_long,
+         c_void_p],
+    ),
 }
 
 
@@ -833,3 +842,82 @@ def pack_probes(D: int, K: int, seed: int, distribution: str, device) -> Tensor:
     _check(load().clo_pack_probes_f32(_pc(out), D, K, seed & (2**64 - 1), dist, _stream()),
            "clo_pack_probes_f32")
     return out
+
+
+_KRON_WS: dict = {}
+
+
+def _kron_ws(device, floats: int) -> Tensor:
+    """One growing workspace per (device, stream) for the Kronecker block calls (temporaries + split-K slabs)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _KRON_WS.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = _KRON_WS[key] = torch.empty(floats, device=device, dtype=torch.float32)
+    return ws
+
+
+def _rm(S: Tensor) -> None:
+    if S.dim() != 2 or (S.shape[1] > 1 and S.stride(1) != 1) or (S.shape[0] > 1 and S.stride(0) < S.shape[1]):
+        raise ValueError("expected a row-major factor (unit column stride)")
+
+
+def kron_blocks(blocks: list[tuple[Tensor, Tensor, Tensor | None, int]], xs: list[Tensor], K: int) -> list[Tensor]:
+    """Every block of a block-diagonal Kronecker operator in ONE foreign call (``clo_kron_matmat_blocks``).
+
+    ``blocks[i] = (S1 [A, a], S2 [B, b], lam | None, flags)`` (row-major fp32, any leading dimension; ``lam [A*B]`` marks
+    an eigen-decomposed block ``(S1 (x) S2) diag(lam) (S1 (x) S2)^T``; bit 0 / 1 of ``flags``: array 1 / 2 holds the
+    transposed factor resp. its eigenvectors in the rows), ``xs[i]`` the K-major operand, a contiguous ``[K, .]`` array.
+    Returns the K-major results."""
+    lib = load()
+    n = len(blocks)
+    dev = xs[0].device
+    for S1, S2, _, _ in blocks:
+        _rm(S1)
+        _rm(S2)
+    A = (c_int * n)(*[b[0].shape[0] for b in blocks])
+    a = (c_int * n)(*[b[0].shape[1] for b in blocks])
+    B = (c_int * n)(*[b[1].shape[0] for b in blocks])
+    b_ = (c_int * n)(*[b[1].shape[1] for b in blocks])
+    fl = (c_int * n)(*[int(b[3]) for b in blocks])
+    ld1 = (c_long * n)(*[max(b[0].stride(0), b[0].shape[1]) for b in blocks])
+    ld2 = (c_long * n)(*[max(b[1].stride(0), b[1].shape[1]) for b in blocks])
+    ys, floats = [], 0
+    for i, (S1, S2, lam, f) in enumerate(blocks):
+        r1 = a[i] if (f & 1) and lam is None else A[i]
+        r2 = b_[i] if (f & 2) and lam is None else B[i]
+        ys.append(torch.empty(K, r1 * r2, device=dev, dtype=torch.float32))
+        floats = max(floats, lib.clo_kron_ws_floats(A[i], a[i], B[i], b_[i], K, int(lam is not None)))
+    ws = _kron_ws(dev, floats)
+    ptrs = lambda ts: (c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])   # noqa: E731
+    _check(lib.clo_kron_matmat_blocks(n, ptrs(ys), ptrs([b[0] for b in blocks]), ld1, ptrs([b[1] for b in blocks]), ld2,
+                                      ptrs([b[2] for b in blocks]), ptrs(xs), A, a, B, b_, fl, K, _pc(ws),
+                                      ws.numel(), _stream()), "clo_kron_matmat_blocks")
+    return ys
+
+
+def kron_matmat(S1: Tensor, S2: Tensor, x: Tensor, K: int, trans: int = 0) -> Tensor:
+    """``Y_k = E1 X_k E2^T`` for the K-major operand ``x``, ``E_i = S_i`` or ``S_i^T`` (bit i-1 of ``trans``):
+    ``clo_kron_matmat``."""
+    lib = load()
+    _rm(S1)
+    _rm(S2)
+    A, a, B, b = S1.shape[0], S1.shape[1], S2.shape[0], S2.shape[1]
+    y = torch.empty(K, (a if trans & 1 else A) * (b if trans & 2 else B), device=x.device, dtype=torch.float32)
+    ws = _kron_ws(x.device, lib.clo_kron_ws_floats(A, a, B, b, K, 0))
+    _check(lib.clo_kron_matmat(_pc(y), _p(S1), max(S1.stride(0), a), _p(S2), max(S2.stride(0), b), _pc(x), A, a, B, b, K,
+                               int(trans), _pc(ws), ws.numel(), _stream()), "clo_kron_matmat")
+    return y
+
+
+def eigh_apply(Q1: Tensor, Q2: Tensor, lam: Tensor, x: Tensor, K: int, rows: int = 0) -> Tensor:
+    """``Y_k = Q1 (lam .* (Q1^T X_k Q2)) Q2^T`` for the K-major operand ``x [K, n1*n2]``: ``clo_eigh_apply``
+    (bit i-1 of ``rows``: array i holds its eigenvectors in the rows, i.e. ``Q_i^T``)."""
+    lib = load()
+    _rm(Q1)
+    _rm(Q2)
+    n1, n2 = Q1.shape[0], Q2.shape[0]
+    y = torch.empty(K, n1 * n2, device=x.device, dtype=torch.float32)
+    ws = _kron_ws(x.device, lib.clo_kron_ws_floats(n1, n1, n2, n2, K, 1))
+    _check(lib.clo_eigh_apply(_pc(y), _p(Q1), max(Q1.stride(0), n1), _p(Q2), max(Q2.stride(0), n2), _pc(lam), _pc(x), n1, n2,
+                              K, int(rows), _pc(ws), ws.numel(), _stream()), "clo_eigh_apply")
+    return y

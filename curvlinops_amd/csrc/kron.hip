@@ -1,0 +1,122 @@
+// Kronecker-factored blocks behind ONE foreign call (SURVEY 8b export list; round 4):
+//   clo_kron_matmat        Y_k = S1 X_k S2^T  (per factor: or its transpose)       reference kronecker.py:141-171 (einsum over the factors)
+//   clo_eigh_apply         Y_k = Q1 (lam .* (Q1^T X_k Q2)) Q2^T      reference eigh.py:84-105 with a Kronecker eigenbasis
+//   clo_kron_matmat_blocks every block of a block-diagonal KFAC / EKFAC operator in one call (reference
+//                          block_diagonal.py: loop over blocks; kfac.py / ekfac.py build one such block per layer)
+// The operand is K-major: X [K][a*b], column k a row-major [a, b] matrix, and so is the result -- the layout the canonical
+// converters (clo_canonical_pack_f32) produce and consume, for K == 1 simply the vector.  Per block two products on the MFMA
+// GEMM engine: T = [X_0; ...; X_{K-1}] S2^T as ONE product with K a rows, then Y_k = S1 T_k batched over k.  Everything is
+// queued on the caller's stream; the rounds 1-3 composition of these products in Python (kronecker.py, one ctypes call and
+// one torch allocation per product) stays as the path for operands in other layouts.
+#include <algorithm>
+
+#include "clo_common.h"
+#include "gemm.h"
+
+namespace clo {
+namespace {
+
+struct Fac {   // a factor as the effective matrix E [rows][cols] with element strides
+  const float *p;
+  int rows, cols;
+  long sr, sc;
+};
+inline Fac fac(const float *S, int R, int C, long ld, bool trans) {
+  return trans ? Fac{S, C, R, 1, ld} : Fac{S, R, C, ld, 1};   // S is row-major [R][C] with leading dimension ld >= C
+}
+
+__global__ void kron_scale_kernel(float *__restrict__ Z, const float *__restrict__ lam, long n, int K) {
+  const long total = n * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) Z[e] *= lam[e % n];
+}
+
+// Y_k [R1, R2] = E1 X_k E2^T for k < K;  X [K][C1*C2], Y [K][R1*R2], T: K*C1*R2 floats
+int kron_apply(float *Y, const Fac &E1, const Fac &E2, const float *X, int K, float *T, float *gws, long gws_floats,
+               hipStream_t st) {
+  const int C1 = E1.cols, C2 = E2.cols, R1 = E1.rows, R2 = E2.rows;
+  {
+    GemmArgs g{};
+    g.M = K * C1; g.N = R2; g.K = C2; g.alpha = 1.f; g.beta = 0.f;
+    g.A = X; g.sa_m = C2; g.sa_k = 1;
+    g.B = E2.p; g.sb_k = E2.sc; g.sb_n = E2.sr;       // B(k = c2, n = r2) = E2[r2][c2]
+    g.C = T; g.ldc = R2;
+    int rc = launch_gemm_auto(g, gws, gws_floats, st, 1);
+    if (rc != CLO_OK) return rc;
+  }
+  GemmArgs g{};
+  g.M = R1; g.N = R2; g.K = C1; g.alpha = 1.f; g.beta = 0.f;
+  g.A = E1.p; g.sa_m = E1.sr; g.sa_k = E1.sc; g.sa_b = 0;
+  g.B = T; g.sb_k = R2; g.sb_n = 1; g.sb_b = (long)C1 * R2;
+  g.C = Y; g.ldc = R2; g.sc_b = (long)R1 * R2;
+  return launch_gemm_auto(g, gws, gws_floats, st, K);
+}
+
+constexpr long KR_GWS = 4L << 20;   // floats of split-K workspace behind the temporaries
+
+long block_ws(int A, int a, int B, int b, int K, bool eig) {
+  // T of the (larger) first product, and for eigen-decomposed blocks the coefficient block Z
+  const long t = (long)K * std::max<long>((long)std::max(A, a) * std::max(B, b), 1);
+  return (eig ? 2 : 1) * ((t + 3) & ~3L);
+}
+
+int one_block(float *Y, const float *S1, long ld1, const float *S2, long ld2, const float *lam, const float *X, int A, int a,
+              int B, int b, int K, int trans, float *ws, long ws_floats, hipStream_t st) {
+  CLO_REQUIRE(ld1 >= a && ld2 >= b, "clo_kron: leading dimensions %ld / %ld below the factor widths %d / %d", ld1, ld2, a, b);
+  const long need = block_ws(A, a, B, b, K, lam != nullptr);
+  CLO_REQUIRE(ws_floats >= need + 1024, "clo_kron: workspace too small (%ld < %ld floats)", ws_floats, need + 1024);
+  float *T = ws, *gws = ws + need;
+  const long gws_floats = ws_floats - need;
+  const bool t1 = (trans & 1) != 0, t2 = (trans & 2) != 0;   // per factor: the array holds the transposed factor
+  if (!lam) return kron_apply(Y, fac(S1, A, a, ld1, t1), fac(S2, B, b, ld2, t2), X, K, T, gws, gws_floats, st);
+  // eigen-decomposed block: S1 = Q1 [A, A], S2 = Q2 [B, B] (a == A, b == B), eigenvectors in the COLUMNS; a factor's trans bit:
+  // in the ROWS (what clo_eigh_f32 returns), i.e. the array holds Q^T
+  float *Z = ws + need / 2;
+  int rc = kron_apply(Z, fac(S1, A, A, ld1, !t1), fac(S2, B, B, ld2, !t2), X, K, T, gws, gws_floats, st);   // Z = Q1^T X Q2
+  if (rc != CLO_OK) return rc;
+  const long n = (long)A * B;
+  hipLaunchKernelGGL(kron_scale_kernel, dim3((unsigned)std::min<long>(cdiv(n * K, 256), 2048)), dim3(256), 0, st, Z, lam, n, K);
+  CLO_CHECK_LAUNCH("kron_scale_kernel");
+  return kron_apply(Y, fac(S1, A, A, ld1, t1), fac(S2, B, B, ld2, t2), Z, K, T, gws, gws_floats, st);      // Y = Q1 Z Q2^T
+}
+
+}  // namespace
+}  // namespace clo
+
+using namespace clo;
+
+extern "C" long clo_kron_ws_floats(int A, int a, int B, int b, int K, int eig) {
+  if (A < 1 || a < 1 || B < 1 || b < 1 || K < 1) return 0;
+  return block_ws(A, a, B, b, K, eig != 0) + KR_GWS;
+}
+
+extern "C" int clo_kron_matmat(float *Y, const float *S1, long ld1, const float *S2, long ld2, const float *X, int A, int a,
+                               int B, int b, int K, int trans, float *ws, long ws_floats, void *stream) {
+  CLO_REQUIRE(Y && S1 && S2 && X && ws, "clo_kron_matmat: null operand");
+  CLO_REQUIRE(A >= 1 && a >= 1 && B >= 1 && b >= 1 && K >= 1 && (trans & ~3) == 0, "clo_kron_matmat: bad extents / flags");
+  return one_block(Y, S1, ld1, S2, ld2, nullptr, X, A, a, B, b, K, trans, ws, ws_floats, (hipStream_t)stream);
+}
+
+extern "C" int clo_eigh_apply(float *Y, const float *Q1, long ld1, const float *Q2, long ld2, const float *lam, const float *X,
+                              int n1, int n2, int K, int rows, float *ws, long ws_floats, void *stream) {
+  CLO_REQUIRE(Y && Q1 && Q2 && lam && X && ws, "clo_eigh_apply: null operand");
+  CLO_REQUIRE(n1 >= 1 && n2 >= 1 && K >= 1, "clo_eigh_apply: bad extents");
+  return one_block(Y, Q1, ld1, Q2, ld2, lam, X, n1, n1, n2, n2, K, rows, ws, ws_floats, (hipStream_t)stream);
+}
+
+extern "C" int clo_kron_matmat_blocks(int nblocks, float *const *Y, const float *const *S1, const long *ld1,
+                                      const float *const *S2, const long *ld2, const float *const *lam,
+                                      const float *const *X, const int *A, const int *a, const int *B, const int *b,
+                                      const int *trans, int K, float *ws, long ws_floats, void *stream) {
+  CLO_REQUIRE(nblocks >= 0 && K >= 1, "clo_kron_matmat_blocks: bad extents");
+  CLO_REQUIRE(nblocks == 0 || (Y && S1 && ld1 && S2 && ld2 && X && A && a && B && b && ws), "clo_kron_matmat_blocks: null operand");
+  for (int i = 0; i < nblocks; ++i) {
+    CLO_REQUIRE(Y[i] && S1[i] && S2[i] && X[i] && A[i] >= 1 && a[i] >= 1 && B[i] >= 1 && b[i] >= 1,
+                "clo_kron_matmat_blocks: block %d has a null operand or an empty extent", i);
+    const float *l = lam ? lam[i] : nullptr;
+    CLO_REQUIRE(!l || (A[i] == a[i] && B[i] == b[i]), "clo_kron_matmat_blocks: eigen-decomposed block %d is not square", i);
+    int rc = one_block(Y[i], S1[i], ld1[i], S2[i], ld2[i], l, X[i], A[i], a[i], B[i], b[i], K, trans ? trans[i] : 0, ws, ws_floats,
+                       (hipStream_t)stream);
+    if (rc != CLO_OK) return rc;
+  }
+  return CLO_OK;
+}

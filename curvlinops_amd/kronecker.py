@@ -37,14 +37,42 @@ def ensure_all_square(*objs) -> None:
             raise RuntimeError(f"{type(o)} is not square: {o.shape}.")
 
 
+def _row_major(S: Tensor) -> bool:
+    return S.dim() == 2 and (S.shape[1] == 1 or S.stride(1) == 1) and (S.shape[0] == 1 or S.stride(0) >= S.shape[1])
+
+
+def _contiguous_pair(factors, transpose: bool):
+    """``(S1, S2, flags)`` with row-major arrays (any leading dimension) for ``clo_kron_matmat``: bit i-1 of ``flags`` says
+    that array i holds the TRANSPOSE of the factor the product needs -- adjoint operators and the eigensolver's
+    row-eigenvector arrays arrive as ``.T`` views of row-major arrays; None if a factor is neither."""
+    arrays, flags = [], 0
+    for i, S in enumerate(factors):
+        if _row_major(S):
+            arrays.append(S)
+            flags |= (1 << i) if transpose else 0
+        elif _row_major(S.T):
+            arrays.append(S.T)
+            flags |= 0 if transpose else (1 << i)
+        else:
+            return None
+    return arrays[0], arrays[1], flags
+
+
 def _kron_apply_native(factors: list[Tensor], x: Tensor, transpose: bool) -> Tensor:
     """``(S_1 (x) ... (x) S_n) x`` for ``x [prod(in dims), K]`` on the HIP GEMM."""
     K = x.shape[-1]
     ins = [S.shape[0] if transpose else S.shape[1] for S in factors]
     mats = [S.T if transpose else S for S in factors]
+    if len(factors) == 2 and (K == 1 or is_kmajor(x)):
+        # the vector, or a K-major operand (from ToCanonical's fused pack or from another block): ONE foreign call, no
+        # transposes, and the result stays K-major for the consumer
+        fc = _contiguous_pair(factors, transpose)
+        if fc is not None:
+            xk = x.T if K > 1 else x.reshape(1, -1)
+            if xk.is_contiguous():
+                y = _hip.kron_matmat(fc[0], fc[1], xk, K, trans=fc[2])
+                return y.T if K > 1 else y.reshape(-1, 1)
     if len(factors) == 2 and is_kmajor(x):
-        # K-major operand (from ToCanonical's fused pack or from another block): no transposes, and the result stays
-        # K-major for the consumer (FromCanonical's fused unpack, the eigenvalue scaling, the next block)
         S1, S2 = mats
         a, b = ins
         A_, B_ = S1.shape[0], S2.shape[0]
@@ -250,6 +278,14 @@ class EighDecomposedLinearOperator(PyTorchLinearOperator):
                 QTx = _hip.gemm(Q.T, x.contiguous())
                 return [_hip.gemm(Q, self._scale(QTx))]
             return [Q @ (self._eigenvalues.unsqueeze(1) * (Q.mH @ x))]
+        K = x.shape[-1]
+        if (type(Q) is KroneckerProductLinearOperator and len(Q) == 2 and is_native_tensor(x) and (K == 1 or is_kmajor(x))
+                and all(is_native_tensor(f) and f.shape[0] == f.shape[1] for f in Q) and is_native_tensor(self._eigenvalues)):
+            fc = _contiguous_pair(list(Q), False)   # (the eigensolver hands back row-eigenvector arrays: .T views)
+            xk = x.T if K > 1 else x.reshape(1, -1)
+            if fc is not None and xk.is_contiguous():   # Q1 (lam .* (Q1^T X Q2)) Q2^T in ONE foreign call
+                y = _hip.eigh_apply(fc[0], fc[1], self._eigenvalues.contiguous(), xk, K, rows=fc[2])
+                return [y.T if K > 1 else y.reshape(-1, 1)]
         (QTx,) = Q._adjoint_matmat([x])
         (res,) = Q._matmat([self._scale(QTx)])
         return [res]
@@ -316,16 +352,52 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
 
     def _matmat(self, X: list[Tensor]) -> list[Tensor]:
         parts = split_list(X, [len(B._in_shape) for B in self._blocks])
-        if len(self._blocks) >= 4 and all(is_native_tensor(x) for x in X):
-            if X[0].shape[-1] == 1:
+        if len(self._blocks) >= 2 and all(is_native_tensor(x) for x in X):
+            # single vectors of nets with repeated layer shapes: the equal blocks as ONE batched product pair fill the
+            # chip better than one product per block (ResNet-18, tools/probe_kron_blocks.py: KFAC 1.32 vs 1.38 ms, EKFAC
+            # 2.44 vs 2.78 ms); everything else that is a vector or K-major goes through ONE foreign call
+            if len(self._blocks) >= 4 and X[0].shape[-1] == 1 and self.GROUP_FIRST:
                 out = self._matmat_grouped(parts)
                 if out is not None:
                     return out
+            out = self._matmat_single_call(parts)
+            if out is not None:
+                return out
+        if len(self._blocks) >= 4 and all(is_native_tensor(x) for x in X):
             return self._matmat_concurrent(parts)
         out: list[Tensor] = []
         for B, xs in zip(self._blocks, parts):
             out.extend(B._matmat(xs))
         return out
+
+    SINGLE_CALL = True   # (tools/probe_kron_blocks.py flips these for A/B runs)
+    GROUP_FIRST = True
+
+    def _matmat_single_call(self, parts: list[list[Tensor]]) -> list[Tensor] | None:
+        """All blocks ``S1 (x) S2`` / ``(Q1 (x) Q2) diag(lam) (Q1 (x) Q2)^T`` of a KFAC / EKFAC operator in ONE foreign
+        call (``clo_kron_matmat_blocks``) when the operands are vectors or K-major blocks; None: take the other routes."""
+        if not self.SINGLE_CALL or any(len(xs) != 1 for xs in parts):
+            return None
+        K = parts[0][0].shape[-1]
+        pairs = [self._kron_pair(B) for B in self._blocks]
+        if any(p is None for p in pairs):
+            return None
+        blocks, xs = [], []
+        for (kp, lam), (x,) in zip(pairs, parts):
+            if x.shape[-1] != K or not (K == 1 or is_kmajor(x)):
+                return None
+            xk = x.T if K > 1 else x.reshape(1, -1)
+            fc = _contiguous_pair(list(kp), False)
+            if fc is None or not xk.is_contiguous():
+                return None
+            if lam is not None:
+                if fc[0].shape[0] != fc[0].shape[1] or fc[1].shape[0] != fc[1].shape[1]:
+                    return None
+                lam = lam.contiguous()
+            blocks.append((fc[0], fc[1], lam, fc[2]))
+            xs.append(xk)
+        ys = _hip.kron_blocks(blocks, xs, K)
+        return [y.T if K > 1 else y.reshape(-1, 1) for y in ys]
 
     @staticmethod
     def _kron_pair(B) -> tuple[KroneckerProductLinearOperator, Tensor | None] | None:

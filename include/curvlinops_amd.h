@@ -363,6 +363,29 @@ long clo_stedc_ws_bytes(int n, int batch);
 int clo_stedc_f32(const float *d, const float *e, long ldd, int n, int batch, float *lam, long ld_lam, float *Z,
                   long ldz, long strideZ, void *ws, long ws_bytes, void *stream);
 int clo_larft_f32(const float *G, const float *tau, float *T, int np, int nb, void *stream);
+/* ---- Kronecker-factored blocks in one call (csrc/kron.hip).  Replace the einsum over the factors at
+ * kronecker.py:141-171 (KroneckerProductLinearOperator._matmat / _adjoint_matmat), the eigen-decomposed product at
+ * eigh.py:84-105 with a Kronecker eigenbasis (EKFAC blocks, ekfac.py), and the loop over the blocks of a block-diagonal
+ * KFAC / EKFAC operator (block_diagonal.py; kfac.py / ekfac.py build one block per layer).
+ * Operands are K-major: X [K][a*b] -- column k is a row-major [a, b] matrix (for K == 1 the flat vector) --, Y [K][A*B]
+ * likewise; factors are row-major S1 [A][ld1 >= a], S2 [B][ld2 >= b].
+ *   clo_kron_matmat        : Y_k = E1 X_k E2^T with E_i = S_i, or S_i^T where bit i-1 of `trans` is set (trans = 3:
+ *                            Y_k = S1^T X_k S2, X [K][A*B], Y [K][a*b]) -- adjoint operators hold transposed arrays
+ *   clo_eigh_apply         : Y_k = Q1 (lam .* (Q1^T X_k Q2)) Q2^T with Q1 [n1][n1], Q2 [n2][n2], lam [n1*n2]; bit i-1 of
+ *                            `rows`: array i holds its eigenvectors in the ROWS (as clo_eigh_f32 returns them)
+ *   clo_kron_matmat_blocks : `nblocks` independent blocks (HOST arrays of device pointers / extents); lam may be NULL,
+ *                            lam[i] != NULL marks block i as eigen-decomposed (S1 = Q1, S2 = Q2 square); trans[i] (may be
+ *                            NULL = 0) are block i's flags as above
+ *   ws: the largest clo_kron_ws_floats(A, a, B, b, K, eig) over the blocks, 16-byte aligned. */
+long clo_kron_ws_floats(int A, int a, int B, int b, int K, int eig);
+int clo_kron_matmat(float *Y, const float *S1, long ld1, const float *S2, long ld2, const float *X, int A, int a, int B,
+                    int b, int K, int trans, float *ws, long ws_floats, void *stream);
+int clo_eigh_apply(float *Y, const float *Q1, long ld1, const float *Q2, long ld2, const float *lam, const float *X, int n1,
+                   int n2, int K, int rows, float *ws, long ws_floats, void *stream);
+int clo_kron_matmat_blocks(int nblocks, float *const *Y, const float *const *S1, const long *ld1, const float *const *S2,
+                           const long *ld2, const float *const *lam, const float *const *X, const int *A, const int *a,
+                           const int *B, const int *b, const int *trans, int K, float *ws, long ws_floats, void *stream);
+
 /* Back-transformation Z <- Z Q^T: every ROW of Z [m][ldz] (ldz >= pad4(n), multiple of 4, 16-byte aligned) is
  * multiplied by Q = H_0 ... H_{n-2}, the reflectors clo_sytrd_f32 left in the rows of `work` [n][ldw] and `tau`
  * (LAPACK sormtr, side = left on the column-major eigenvector matrix).  ws: clo_ormtr_ws_floats(m, n) floats. */

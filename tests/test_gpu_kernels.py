@@ -1293,3 +1293,44 @@ def test_eigh_deflates_zero_rows(hip, n, dead, entry):
     assert float((A32 @ Q64 - Q64 * l64).abs().max()) <= 2e-5 * scale
     assert float((Q64.T @ Q64 - torch.eye(n, dtype=torch.float64)).abs().max()) <= 2e-5
     assert int((l64 == 0).sum()) >= int(kill.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 5, 32])
+@pytest.mark.parametrize("shape", [(64, 65, 10, 11), (7, 7, 3, 3), (130, 128, 577, 577), (1, 4, 9, 1), (512, 512, 129, 129)])
+def test_kron_single_call_entries(hip, shape, K):
+    """clo_kron_matmat / clo_eigh_apply / clo_kron_matmat_blocks (csrc/kron.hip; reference kronecker.py:141-171,
+    eigh.py:84-105) on K-major operands against the float64 einsum the reference evaluates."""
+    A, a, B, b = shape
+    g = torch.Generator().manual_seed(A * 7 + a + K)
+    S1, S2 = torch.rand(A, a, generator=g, dtype=torch.float64) - 0.5, torch.rand(B, b, generator=g, dtype=torch.float64) - 0.5
+    X = torch.rand(K, a, b, generator=g, dtype=torch.float64) - 0.5
+    ref = torch.einsum("Aa,kab,Bb->kAB", S1, X, S2).reshape(K, A * B)
+    d = lambda t: t.float().cuda().contiguous()   # noqa: E731
+    y = hip.kron_matmat(d(S1), d(S2), d(X).reshape(K, a * b), K)
+    assert rel_err(y.cpu(), ref) < TOL
+    Xt = torch.rand(K, A, B, generator=g, dtype=torch.float64) - 0.5
+    ref_t = torch.einsum("Aa,kAB,Bb->kab", S1, Xt, S2).reshape(K, a * b)
+    yt = hip.kron_matmat(d(S1), d(S2), d(Xt).reshape(K, A * B), K, trans=3)
+    assert rel_err(yt.cpu(), ref_t) < TOL
+    # eigen-decomposed block with a Kronecker eigenbasis
+    Q1, Q2 = torch.linalg.qr(torch.rand(A, A, generator=g, dtype=torch.float64))[0], torch.linalg.qr(torch.rand(B, B, generator=g, dtype=torch.float64))[0]
+    lam = torch.rand(A * B, generator=g, dtype=torch.float64) + 0.1
+    Xe = torch.rand(K, A, B, generator=g, dtype=torch.float64) - 0.5
+    Z = torch.einsum("Aa,kAB,Bb->kab", Q1, Xe, Q2) * lam.reshape(1, A, B)
+    ref_e = torch.einsum("Aa,kab,Bb->kAB", Q1, Z, Q2).reshape(K, A * B)
+    ye = hip.eigh_apply(d(Q1), d(Q2), d(lam), d(Xe).reshape(K, A * B), K)
+    assert rel_err(ye.cpu(), ref_e) < TOL
+    for rows in (1, 2, 3):   # eigenvectors of factor 1 / 2 / both in the rows of the arrays passed
+        yr = hip.eigh_apply(d(Q1.T if rows & 1 else Q1), d(Q2.T if rows & 2 else Q2), d(lam), d(Xe).reshape(K, A * B), K, rows=rows)
+        assert rel_err(yr.cpu(), ref_e) < TOL
+    # mixed orientation, padded leading dimension
+    S1p = torch.zeros(A, a + 3, dtype=torch.float64); S1p[:, :a] = S1
+    ym = hip.kron_matmat(d(S1p)[:, :a], d(S2.T), d(X).reshape(K, a * b), K, trans=2)
+    assert rel_err(ym.cpu(), ref) < TOL
+    # the three of them as blocks of one call (a plain block twice, then eigen-decomposed ones in their own call)
+    ys = hip.kron_blocks([(d(S1), d(S2), None, 0), (d(S2), d(S1), None, 0)], [d(X).reshape(K, a * b), d(X.transpose(1, 2)).reshape(K, a * b)], K)
+    assert rel_err(ys[0].cpu(), ref) < TOL
+    assert rel_err(ys[1].cpu(), torch.einsum("Bb,kba,Aa->kBA", S2, X.transpose(1, 2), S1).reshape(K, A * B)) < TOL
+    (yb,) = hip.kron_blocks([(d(Q1), d(Q2), d(lam), 0)], [d(Xe).reshape(K, A * B)], K)
+    assert torch.equal(yb, ye)
