@@ -149,6 +149,9 @@ _SIGNATURES = {
     "clo_dc_build": (c_int, [_PF, _PF, _PF, _PF, _PF, _PF, _PF, c_int, c_int, c_int, c_void_p]),
     "clo_dc_rotate": (c_int, [_PF, _PF, _PF, _PF, c_int, c_int, c_void_p]),
     "clo_kron_ws_floats": (c_long, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "clo_ekfac_correction_ws_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "clo_ekfac_correction_f32": (c_int, [_PF, c_long, _PF, c_long, _PF, c_long, c_int, _PF, _PF, c_int, c_int, c_int, c_int,
+                                         c_int, c_float, c_float, _PF, c_long, c_void_p]),
     "clo_kron_matmat": (c_int, [_PF, _PF, c_long, _PF, c_long, _PF, c_int, c_int, c_int, c_int, c_int, c_int, _PF, c_long, c_void_p]),
     "clo_eigh_apply": (c_int, [_PF, _PF, c_long, _PF, c_long, _PF, _PF, c_int, c_int, c_int, c_int, _PF, c_long, c_void_p]),
     "clo_kron_matmat_blocks": (
@@ -921,3 +924,21 @@ def eigh_apply(Q1: Tensor, Q2: Tensor, lam: Tensor, x: Tensor, K: int, rows: int
     _check(lib.clo_eigh_apply(_pc(y), _p(Q1), max(Q1.stride(0), n1), _p(Q2), max(Q2.stride(0), n2), _pc(lam), _pc(x), n1, n2,
                               K, int(rows), _pc(ws), ws.numel(), _stream()), "clo_eigh_apply")
     return y
+
+
+def ekfac_correction(g: Tensor, Qg: Tensor, a: Tensor, Qa: Tensor, rows: int = 0) -> Tensor:
+    """``sum_{v,n} (Qg^T (sum_s g_vns a_ns^T) Qa)^2`` as ``[d_out, d_in]`` in ONE foreign call (``clo_ekfac_correction_f32``):
+    ``g [V, B, S, d_out]``, ``a [B, S, d_in]`` contiguous; row-major eigenvector arrays, bit 0 / 1 of ``rows``: the array of
+    ``Qg`` / ``Qa`` holds the eigenvectors in its rows."""
+    lib = load()
+    _rm(Qg)
+    _rm(Qa)
+    V, B, S, d1 = g.shape
+    d2 = a.shape[-1]
+    out = torch.empty(d1, d2, device=g.device, dtype=torch.float32)
+    nws = lib.clo_ekfac_correction_ws_floats(V, B, S, d1, d2)
+    ws = torch.empty(nws, device=g.device, dtype=torch.float32)
+    _check(lib.clo_ekfac_correction_f32(_pc(out), d2, _p(Qg), max(Qg.stride(0), d1), _p(Qa), max(Qa.stride(0), d2), int(rows),
+                                        _pc(g), _pc(a), V, B, S, d1, d2, 1.0, 0.0, _pc(ws), nws, _stream()),
+           "clo_ekfac_correction_f32")
+    return out

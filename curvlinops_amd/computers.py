@@ -648,6 +648,13 @@ def compute_eigenvalue_correction(g: Tensor, Qg: Tensor, a: Tensor | None, Qa: T
         rot = gs if identity else (_hip.gemm(gs.contiguous(), Qg) if native else gs @ Qg)
         return rot.square().sum(dim=0)
     d2 = a.shape[-1]
+    if native and not identity and is_native_tensor(a) and is_native_tensor(Qa) and V * B * S < 2**31:
+        # both rotations and the squared-product reduction in ONE foreign call
+        from curvlinops_amd.kronecker import _contiguous_pair
+
+        fc = _contiguous_pair([Qg, Qa], False)
+        if fc is not None:
+            return _hip.ekfac_correction(g.contiguous(), fc[0], a.contiguous(), fc[1], rows=fc[2])
     if native:
         if identity:
             g_rot, a_rot = g.contiguous(), a.contiguous()

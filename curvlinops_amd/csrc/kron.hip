@@ -3,6 +3,9 @@
 //   clo_eigh_apply         Y_k = Q1 (lam .* (Q1^T X_k Q2)) Q2^T      reference eigh.py:84-105 with a Kronecker eigenbasis
 //   clo_kron_matmat_blocks every block of a block-diagonal KFAC / EKFAC operator in one call (reference
 //                          block_diagonal.py: loop over blocks; kfac.py / ekfac.py build one such block per layer)
+//   clo_ekfac_correction_f32  a layer's eigenvalue correction lam += alpha sum_{v,n} (Qg^T (sum_s g_vns a_ns^T) Qa)^2 from
+//                          its layer inputs and output gradients: both rotations + the fused squared-product kernel
+//                          (reference computers/ekfac_hooks.py:25-238)
 // The operand is K-major: X [K][a*b], column k a row-major [a, b] matrix, and so is the result -- the layout the canonical
 // converters (clo_canonical_pack_f32) produce and consume, for K == 1 simply the vector.  Per block two products on the MFMA
 // GEMM engine: T = [X_0; ...; X_{K-1}] S2^T as ONE product with K a rows, then Y_k = S1 T_k batched over k.  Everything is
@@ -10,6 +13,7 @@
 // one torch allocation per product) stays as the path for operands in other layouts.
 #include <algorithm>
 
+#include "../../include/curvlinops_amd.h"
 #include "clo_common.h"
 #include "gemm.h"
 
@@ -116,6 +120,91 @@ extern "C" int clo_kron_matmat_blocks(int nblocks, float *const *Y, const float 
     CLO_REQUIRE(!l || (A[i] == a[i] && B[i] == b[i]), "clo_kron_matmat_blocks: eigen-decomposed block %d is not square", i);
     int rc = one_block(Y[i], S1[i], ld1[i], S2[i], ld2[i], l, X[i], A[i], a[i], B[i], b[i], K, trans ? trans[i] : 0, ws, ws_floats,
                        (hipStream_t)stream);
+    if (rc != CLO_OK) return rc;
+  }
+  return CLO_OK;
+}
+
+// ---- EKFAC eigenvalue correction of one layer in one call ------------------------------------------------------------
+namespace clo {
+namespace {
+// g2[n][i] = sum_v g[v][n][i]^2 ; a2 = a^2 (S == 1: the squared per-example gradient is the outer product of the squares)
+__global__ void ekfac_square_kernel(const float *__restrict__ g, float *__restrict__ g2, long nb_d1, int V,
+                                    const float *__restrict__ a, float *__restrict__ a2, long nb_d2) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nb_d1) {
+    float sacc = 0.f;
+    for (int v = 0; v < V; ++v) {
+      const float x = g[(long)v * nb_d1 + e];
+      sacc += x * x;
+    }
+    g2[e] = sacc;
+  }
+  if (e < nb_d2) a2[e] = a[e] * a[e];
+}
+inline long pad4l(long x) { return (x + 3) & ~3L; }
+}  // namespace
+}  // namespace clo
+
+extern "C" long clo_ekfac_correction_ws_floats(int V, int B, int S, int d_out, int d_in) {
+  if (V < 1 || B < 1 || S < 1 || d_out < 1 || d_in < 1) return 0;
+  const long rot = pad4l((long)V * B * S * d_out) + pad4l((long)B * S * d_in);
+  const long sq = S == 1 ? pad4l((long)B * d_out) + pad4l((long)B * d_in) : 0;
+  const long splits = S == 1 ? 0 : (long)clo_gemm_sqsum_suggest_splits(d_out, d_in, B) * d_out * d_in;
+  return rot + sq + pad4l(splits) + KR_GWS;
+}
+
+extern "C" int clo_ekfac_correction_f32(float *lam, long ld_lam, const float *Qg, long ldg, const float *Qa, long lda,
+                                        int rows, const float *g, const float *a, int V, int B, int S, int d_out,
+                                        int d_in, float alpha, float beta, float *ws, long ws_floats, void *stream) {
+  CLO_REQUIRE(lam && Qg && Qa && g && a && ws, "clo_ekfac_correction_f32: null operand");
+  CLO_REQUIRE(V >= 1 && B >= 1 && S >= 1 && d_out >= 1 && d_in >= 1 && ld_lam >= d_in && ldg >= d_out && lda >= d_in &&
+                  (rows & ~3) == 0,
+              "clo_ekfac_correction_f32: bad extents / flags");
+  CLO_REQUIRE(ws_floats >= clo_ekfac_correction_ws_floats(V, B, S, d_out, d_in), "clo_ekfac_correction_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long ng = (long)V * B * S * d_out, na = (long)B * S * d_in;
+  float *g_rot = ws, *a_rot = g_rot + pad4l(ng), *p = a_rot + pad4l(na);
+  float *g2 = nullptr, *a2 = nullptr, *sws = nullptr;
+  int splits = 1;
+  if (S == 1) {
+    g2 = p; p += pad4l((long)B * d_out);
+    a2 = p; p += pad4l((long)B * d_in);
+  } else {
+    splits = clo_gemm_sqsum_suggest_splits(d_out, d_in, B);
+    sws = p; p += pad4l((long)splits * d_out * d_in);
+  }
+  float *gws = p;
+  const long gws_floats = ws_floats - (gws - ws);
+  // rotations into the eigenbases: g_rot = g Qg, a_rot = a Qa (arrays that hold the eigenvectors in their rows: Q = array^T)
+  auto rotate = [&](const float *X, long nrows, int d, const float *Q, long ldq, bool qrows, float *out) {
+    GemmArgs m{};
+    m.M = (int)nrows; m.N = d; m.K = d; m.alpha = 1.f; m.beta = 0.f;
+    m.A = X; m.sa_m = d; m.sa_k = 1;
+    m.B = Q; m.sb_k = qrows ? 1 : ldq; m.sb_n = qrows ? ldq : 1;
+    m.C = out; m.ldc = d;
+    return launch_gemm_auto(m, gws, gws_floats, st, 1);
+  };
+  CLO_REQUIRE((long)V * B * S <= 2147483647L, "clo_ekfac_correction_f32: more than 2^31 - 1 gradient rows");
+  int rc = rotate(g, (long)V * B * S, d_out, Qg, ldg, (rows & 1) != 0, g_rot);
+  if (rc != CLO_OK) return rc;
+  rc = rotate(a, (long)B * S, d_in, Qa, lda, (rows & 2) != 0, a_rot);
+  if (rc != CLO_OK) return rc;
+  if (S == 1) {   // sum_{v,n} (g_vn a_n^T)^2 = (sum_v g_vn^2)^T (a_n^2): ONE product with K = B
+    const long n1 = (long)B * d_out, n2 = (long)B * d_in;
+    hipLaunchKernelGGL(ekfac_square_kernel, dim3((unsigned)cdiv(std::max(n1, n2), 256)), dim3(256), 0, st, g_rot, g2, n1, V,
+                       a_rot, a2, n2);
+    CLO_CHECK_LAUNCH("ekfac_square_kernel");
+    GemmArgs m{};
+    m.M = d_out; m.N = d_in; m.K = B; m.alpha = alpha; m.beta = beta;
+    m.A = g2; m.sa_m = 1; m.sa_k = d_out;
+    m.B = a2; m.sb_k = d_in; m.sb_n = 1;
+    m.C = lam; m.ldc = ld_lam;
+    return launch_gemm_auto(m, gws, gws_floats, st, 1);
+  }
+  for (int v = 0; v < V; ++v) {   // per-example products P_n = g_rot_n^T a_rot_n [d_out, d_in], squared and summed over n, fused
+    rc = clo_gemm_sqsum_f32(d_out, d_in, S, alpha, g_rot + (long)v * B * S * d_out, 1, d_out, (long)S * d_out, a_rot, d_in, 1,
+                            (long)S * d_in, v == 0 ? beta : 1.f, lam, ld_lam, B, splits, splits > 1 ? sws : nullptr, stream);
     if (rc != CLO_OK) return rc;
   }
   return CLO_OK;

@@ -377,6 +377,15 @@ int clo_larft_f32(const float *G, const float *tau, float *T, int np, int nb, vo
  *                            lam[i] != NULL marks block i as eigen-decomposed (S1 = Q1, S2 = Q2 square); trans[i] (may be
  *                            NULL = 0) are block i's flags as above
  *   ws: the largest clo_kron_ws_floats(A, a, B, b, K, eig) over the blocks, 16-byte aligned. */
+/* EKFAC eigenvalue correction of ONE layer in one call (replaces computers/ekfac_hooks.py:25-238, both strategies):
+ *   lam[i][j] = beta lam[i][j] + alpha sum_{v < V, n < B} ( Qg^T ( sum_{s < S} g[v][n][s][:] a[n][s][:]^T ) Qa )[i][j]^2
+ * g [V][B][S][d_out] (V backpropagated vectors), a [B][S][d_in] (S weight-sharing positions), both contiguous;
+ * Qg [d_out][ldg], Qa [d_in][lda] eigenvector arrays, bit 0 / 1 of `rows`: Qg / Qa hold their eigenvectors in the ROWS;
+ * lam [d_out][ld_lam].  ws: clo_ekfac_correction_ws_floats(...) floats, 16-byte aligned. */
+long clo_ekfac_correction_ws_floats(int V, int B, int S, int d_out, int d_in);
+int clo_ekfac_correction_f32(float *lam, long ld_lam, const float *Qg, long ldg, const float *Qa, long lda, int rows,
+                             const float *g, const float *a, int V, int B, int S, int d_out, int d_in, float alpha,
+                             float beta, float *ws, long ws_floats, void *stream);
 long clo_kron_ws_floats(int A, int a, int B, int b, int K, int eig);
 int clo_kron_matmat(float *Y, const float *S1, long ld1, const float *S2, long ld2, const float *X, int A, int a, int B,
                     int b, int K, int trans, float *ws, long ws_floats, void *stream);

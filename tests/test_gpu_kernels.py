@@ -1334,3 +1334,21 @@ def test_kron_single_call_entries(hip, shape, K):
     assert rel_err(ys[1].cpu(), torch.einsum("Bb,kba,Aa->kBA", S2, X.transpose(1, 2), S1).reshape(K, A * B)) < TOL
     (yb,) = hip.kron_blocks([(d(Q1), d(Q2), d(lam), 0)], [d(Xe).reshape(K, A * B)], K)
     assert torch.equal(yb, ye)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,B,S,d1,d2", [(1, 16, 1, 10, 33), (2, 8, 5, 12, 27), (3, 4, 49, 64, 148), (1, 64, 1, 512, 129)])
+@pytest.mark.parametrize("rows", [0, 1, 2, 3])
+def test_ekfac_correction_single_call(hip, V, B, S, d1, d2, rows):
+    """clo_ekfac_correction_f32 (reference computers/ekfac_hooks.py:25-238): sum_{v,n} (Qg^T (sum_s g a^T) Qa)^2 against the
+    float64 einsum over materialised per-example gradients; eigenvector arrays in either orientation."""
+    gen = torch.Generator().manual_seed(V * 100 + S)
+    g = torch.rand(V, B, S, d1, generator=gen, dtype=torch.float64) - 0.5
+    a = torch.rand(B, S, d2, generator=gen, dtype=torch.float64) - 0.5
+    Qg = torch.linalg.qr(torch.rand(d1, d1, generator=gen, dtype=torch.float64))[0]
+    Qa = torch.linalg.qr(torch.rand(d2, d2, generator=gen, dtype=torch.float64))[0]
+    per = torch.einsum("vnsi,nsj->vnij", g @ Qg, a @ Qa)
+    ref = per.square().sum(dim=(0, 1))
+    d = lambda t: t.float().cuda().contiguous()   # noqa: E731
+    out = hip.ekfac_correction(d(g), d(Qg.T if rows & 1 else Qg), d(a), d(Qa.T if rows & 2 else Qa), rows=rows)
+    assert rel_err(out.cpu(), ref) < 5 * TOL
