@@ -412,7 +412,7 @@ extern "C" int clo_dc_rotate(float *MT, const int *rot_p, const double *rot_c, c
 }
 
 // ---- back-transformation  Z <- Z Q^T  (every ROW of Z [m][ldz >= pad4(n)] times Q = H_0 ... H_{n-2}, the
-// reflectors clo_sytrd_f32 left in `work` / `tau`): blocks of 64 reflectors as I - V T^T V^T, three GEMMs each.
+// reflectors clo_sytrd_f32 left in `work` / `tau`): blocks of 256 reflectors as I - V T^T V^T, three GEMMs each.
 static inline long ormtr_pad4(long n) { return (n + 3) & ~3L; }
 // Blocks of OB_Q x 64 = 256 reflectors (round 4; 64 before: 72 x 3 skinny products of ~50 us at n = 4609).  The T factor of
 // a big block is assembled from its panels' 64 x 64 factors with the compact-WY product rule

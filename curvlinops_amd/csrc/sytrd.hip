@@ -1,24 +1,23 @@
-// Householder tridiagonalisation of a dense symmetric matrix, one persistent launch per 64-column panel
-// (rounds 2-3: one launch per column).
+// Householder tridiagonalisation of a dense symmetric matrix: ONE persistent launch per 64-column panel (round 4; rounds
+// 2-3 ran one launch per column).
 //
-// The eigendecompositions of the Kronecker factors (reference kronecker.py:294 / ekfac.py: torch.linalg.eigh,
-// i.e. rocSOLVER ssyevd on this platform) spend 85 % of their time in the reduction to tridiagonal form:
-// rocSOLVER's latrd runs ~5 small dependent kernels per column (n = 4609: 107 of 126 ms,
-// tools/probe_rocsolver_phases.py).  This file is that reduction with ONE kernel per column:
+// The eigendecompositions of the Kronecker factors (reference kronecker.py:294 / ekfac.py: torch.linalg.eigh, i.e.
+// rocSOLVER ssyevd on this platform) spend 85 % of their time in the reduction to tridiagonal form: rocSOLVER's latrd runs
+// ~5 small dependent kernels per column (n = 4609: 107 of 126 ms, tools/probe_rocsolver_phases.py).  This file is that
+// reduction (LAPACK latrd algebra, deferred reductions):
 //
-//   * the trailing matrix is kept as a full symmetric array, so a block owns complete rows of the
-//     matrix-vector product y = A22 v (no cross-block accumulation);
-//   * the scalar that finishes column j of W (gamma_j = -tau/2 w^T v) and the norm / panel dot products that
-//     start column j+1 are global reductions; instead of a launch each, every block leaves per-block
-//     partial sums and the NEXT launch's prologue adds them up (redundantly per block, in a fixed order):
-//     the next column is u = u0 - 2 gamma v with u0 computable before gamma is known, and all panel dot
-//     products with v' = s (u0 - 2 gamma v) are linear in quantities summed one launch earlier;
-//   * the rank-2nb trailing update runs on the MFMA GEMM engine once per 64-column panel.
+//   * the trailing matrix is kept as a full symmetric array, so a workgroup owns complete rows of the matrix-vector
+//     product y = A22 v (no cross-workgroup accumulation of y);
+//   * the scalar that finishes column j of W (gamma_j = -tau/2 w^T v) and the norm / panel dot products that start column
+//     j+1 are global reductions taken ONE synchronisation late: the next column is u = u0 - 2 gamma v with u0 computable
+//     before gamma is known, and all panel dot products with v' = s (u0 - 2 gamma v) are linear in quantities summed one
+//     column earlier -- so a column needs exactly one grid-wide hand-off (see sytrd_panel_kernel below);
+//   * the rank-2nb trailing update runs on the MFMA GEMM engine once per 64-column panel, between two panel launches.
 //
-// Storage is LAPACK's (ssytrd, uplo = 'L' of the column-major matrix == the rows of the row-major
-// array): on return row j holds the Householder vector of column j in columns j+2.. (unit entry at
-// column j+1 implied), D/E the tridiagonal matrix and tau the reflector scales, so rocSOLVER's
-// sstedc / sormtr (or any LAPACK-compatible back-transformation) take over from there.
+// Storage is LAPACK's (ssytrd, uplo = 'L' of the column-major matrix == the rows of the row-major array): on return row j
+// holds the Householder vector of column j in columns j+2.. (unit entry at column j+1 implied), D/E the tridiagonal
+// matrix and tau the reflector scales, so any LAPACK-compatible divide & conquer / back-transformation can take over
+// (csrc/eigh.hip does; tools/_rocsolver.py drives rocSOLVER's for comparisons).
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -59,13 +58,13 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Round 4: ONE persistent launch per 64-column panel (the column kernel above paid ~3.5 us of dependent dispatch plus a
+// Round 4: ONE persistent launch per 64-column panel (the column kernel of rounds 2-3 paid ~3.5 us of dependent dispatch plus a
 // cold prologue per column: 25 us x 4609 columns = 117 of the 144 ms of a 4609 x 4609 eigh).  The G workgroups of the
 // launch own the same matrix rows for the whole panel and walk its columns in lock step; between two columns they
 // exchange what the next reflector needs -- the per-block partial sums, the next column u0, the current reflector v
 // and one more column of the panels V / W -- through write-through (sc1) stores, a two-level counter barrier
 // (16-workgroup groups, leaders, one top counter) and sc1 loads, exactly the hand-off of csrc/mlp_mega.hip.  The
-// algebra, the summation orders and the storage are those of sytrd_col_kernel; the matrix itself is only read (the
+// algebra and the storage are those of the column kernel; the matrix itself is only read (the
 // rank-128 trailing update runs between two panel launches on the GEMM engine), so its rows keep the plain loads.
 // The per-workgroup partial sums travel in two levels: the 16 workgroups of a group ADD theirs into the group's record
 // with float atomics (0.37 us per round for all 256 workgroups incl. the acknowledgements, tools/ubench/atomic_probe.hip;
@@ -270,7 +269,10 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
       alpha += x[1];   // one thread holds it, the rest added 0
       su0_tot += x[2];
     }
-    const bool careful = c > 0 && su0_tot > 16.f * (alpha * alpha + sigma);   // see sytrd_col_kernel
+    // cancellation guard: the deferred formulas below take W^T v', V^T v' from sums over u0 and v_prev taken one column
+    // earlier; when u = u0 - 2 gamma v_prev cancels (|u0|^2 >> |u|^2: rank-deficient factors once the numerical rank is
+    // exhausted) those sums carry the rounding error of the LARGE terms, so the products are then formed from the actual v
+    const bool careful = c > 0 && su0_tot > 16.f * (alpha * alpha + sigma);
     float beta, tau, s;
     if (sigma == 0.f) {
       beta = alpha;
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
       const v4 x = *reinterpret_cast<const v4 *>(s_slotB + w);
       yj1 += (x[0] + x[1]) + (x[2] + x[3]);
     }
-    if (careful) {   // t1, t2 over the trailing rows with the actual v (every block, redundantly; see sytrd_col_kernel)
+    if (careful) {   // t1, t2 over the trailing rows with the actual v (every workgroup, redundantly)
       float a1 = 0.f, a2 = 0.f;
       if (lane < c) {
         constexpr int CU = 16;
