@@ -450,7 +450,8 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
                 "kernel_ms_rocprof": clo_us / 1e3, "executed_gflop": executed / 1e9,
                 "achieved_tflops_executed": executed / clo_us / 1e6,
                 "frac_of_f32_mfma_peak": executed / clo_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                "source": "profiles/r03_kfac_resnet18_build_kernels.txt (rocprofv3 --kernel-trace of one warm build: "
+                "source": "profiles/" + os.path.basename(latest_profile("kfac_resnet18_build_kernels.txt") or "")
+                          + " (rocprofv3 --kernel-trace of one warm build: "
                           "im2col, SYRK / Gram, split-K reduce kernels; they run on a side stream under the autograd "
                           "kernels, and the build itself is bound by the host's dispatch of ~440 launches)"}
         v = torch.rand(K.shape[1], device=device)
