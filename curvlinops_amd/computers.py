@@ -217,6 +217,7 @@ def _affine_eval_batchnorm(module: Module, params: dict[str, Tensor]) -> list[Mo
 # Factor accumulation (im2col + SYRK) runs on its own HIP stream so that it overlaps the autograd
 # kernels of the layers that follow: the hook only orders it after the producer of its operand.
 _FACTOR_STREAMS: dict = {}
+_FACTOR_EVENTS: dict = {}
 _OVERLAP = True
 
 
@@ -235,7 +236,11 @@ class _factor_stream:
         side = _FACTOR_STREAMS.get(dev)
         if side is None:
             side = _FACTOR_STREAMS[dev] = side_stream(dev, 0)   # (first of the package-wide worker streams)
-        side.wait_event(torch.cuda.current_stream(dev).record_event())
+        ev = _FACTOR_EVENTS.get(dev)
+        if ev is None:   # one reusable event per device (a wait captures the record that precedes it)
+            ev = _FACTOR_EVENTS[dev] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        side.wait_event(ev)
         self._t.record_stream(side)
         self._ctx = torch.cuda.stream(side)
         self._ctx.__enter__()
