@@ -3434,7 +3434,11 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
 #define CLO_KC_BPC 4
 #endif
       static const int kc_bpc = CLO_KC_BPC;
-      dim3 grid((unsigned)std::min<long>(cdiv(dout, FPT * KC_TPW), (long)kc_bpc * kNumCU)), block(KC_WAVES * 64);
+      // equal tile counts per block: with `slots` blocks in flight ceil(tiles / slots) rounds of tiles are needed anyway, so
+      // the tiles are dealt to tiles / rounds blocks (d_out = 2688, K = 32: 1344 tiles on 672 blocks x 2 instead of 1024
+      // blocks with 1 or 2; 96.8 -> 92.6 us per launch)
+      const long kc_tiles = cdiv(dout, FPT * KC_TPW);
+      dim3 grid((unsigned)cdiv(kc_tiles, cdiv(kc_tiles, (long)kc_bpc * kNumCU))), block(KC_WAVES * 64);
       const float *vb = Vb ? Vb[l - 1] : nullptr;
       const float *dp = (l == L && last_linear) ? nullptr : dphi[l];
       ProfScope prof(0, 4.0 * di * dout * K, st);
