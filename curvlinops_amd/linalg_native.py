@@ -460,6 +460,9 @@ def eigh(A: Tensor) -> tuple[Tensor, Tensor]:
     return _eigh_full(A)
 
 
+EIGH_WORKERS = 12   # default number of worker streams of eigh_many (module attribute: tools/run_workers.sh sweeps it)
+
+
 def eigh_many(mats: list[Tensor], num_streams: int | None = None) -> list[tuple[Tensor, Tensor]]:
     """:func:`eigh` of several independent symmetric matrices.  A single decomposition is a chain of dependent
     steps (one grid-wide hand-off per matrix column in the reduction), so
@@ -468,8 +471,12 @@ def eigh_many(mats: list[Tensor], num_streams: int | None = None) -> list[tuple[
     * the units are spread, largest first, over a few worker threads that each own a HIP stream; the persistent
       panel launches of the reductions that run side by side share the chip's 256 CUs in proportion to their matrix
       sizes (``max_blocks`` of ``clo_sytrd_f32``; the library's admission control keeps any combination safe)."""
-    if num_streams is None:   # six workers: the largest factors of a ResNet-18 each get one, the rest share the others
-        num_streams = 6
+    if num_streams is None:
+        # twelve workers (six until round 4): the reduction is latency-bound per column, so more factors in flight -- each on a
+        # share of the CUs -- shorten the set (tools/probe_eigh_streams.py, ResNet-18's 42 factors, 6 / 8 / 12 / 16 / 20
+        # workers: 92 / 83 / 76 / 71 / 73 ms with one hardware queue per stream, 119 / 98 / 96 / 100 / 105 ms with the
+        # runtime's default of four)
+        num_streams = EIGH_WORKERS
     out: list = [None] * len(mats)
     for i, A in enumerate(mats):
         if not A.is_cuda:

@@ -1,6 +1,6 @@
 # does the number of HIP hardware queues (GPU_MAX_HW_QUEUES, default 4) move the multi-stream legs of the bench line?
-out=gpurun_out/hwq2; mkdir -p $out
-for q in 4 8 16; do
+out=gpurun_out/hwq3; mkdir -p $out
+for q in 16 24 32; do
   for rep in 1 2; do
     GPU_MAX_HW_QUEUES=$q python bench.py > $out/bench_q${q}_$rep.json 2> /dev/null
     python - $out/bench_q${q}_$rep.json $q $rep <<'PY'
