@@ -214,8 +214,14 @@ class _InverseBatch:
 _ACTIVE_BATCH: _InverseBatch | None = None
 
 
+# default number of worker streams of concurrent_inverses: ONE since round 4 -- every big factor's call is already a pipeline
+# over a helper stream of its own; in the bench process 1 / 2 / 4 workers take 11.8 - 12.1 / 14.1 - 15.0 / 14.2 ms for ResNet-18's
+# 42 factors (tools/run_inv_workers.sh; round 3, with four hardware queues, had two ahead)
+INVERSE_WORKERS = 1
+
+
 @contextmanager
-def concurrent_inverses(num_streams: int = 2, distributed: bool = False):
+def concurrent_inverses(num_streams: int | None = None, distributed: bool = False):
     """Inside the block, fp32 GPU calls of :func:`damped_cholesky_inverse` are collected and return
     their (still empty) output tensors immediately; on exit the factors are inverted concurrently
     (worker threads with their own streams -- two by default: the big factors' calls are pipelines over a helper stream
@@ -229,7 +235,7 @@ def concurrent_inverses(num_streams: int = 2, distributed: bool = False):
         yield
         return
 
-    batch = _ACTIVE_BATCH = _InverseBatch(num_streams, distributed)
+    batch = _ACTIVE_BATCH = _InverseBatch(INVERSE_WORKERS if num_streams is None else num_streams, distributed)
     try:
         yield
     except BaseException:

@@ -5,4 +5,6 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 w = int(sys.argv[1]); sys.argv = ["bench.py"] + sys.argv[2:]
 from curvlinops_amd import linalg_native
 linalg_native.EIGH_WORKERS = w
+if os.environ.get('INV_WORKERS'):
+    linalg_native.INVERSE_WORKERS = int(os.environ['INV_WORKERS'])
 runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
