@@ -85,9 +85,16 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             return tuple(out[k] for k in keys)
 
         self._mp = vmap(one_column, in_dims=(None, None, -1), out_dims=-1, randomness="same")
+        self._one_column = one_column
 
     def _matmat_batch(self, X, y: Tensor, M: list[Tensor]) -> list[Tensor]:
+        if self.SINGLE_COLUMN_DIRECT and M and M[0].shape[-1] == 1:
+            # one column: the product itself, without the vmap over a trailing axis of length one (same functions, same
+            # result; the batching rules of every op in three passes through the network are host time)
+            return [o.unsqueeze(-1) for o in self._one_column(X, y, tuple(m[..., 0] for m in M))]
         return list(self._mp(X, y, tuple(M)))
+
+    SINGLE_COLUMN_DIRECT = True
 
     def _matvec_batch(self, X, y: Tensor, v: dict[str, Tensor]) -> dict[str, Tensor]:
         raise NotImplementedError
