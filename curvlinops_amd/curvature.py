@@ -513,6 +513,8 @@ def make_ggn_vector_product(f: Callable, c: Callable) -> Callable:
         def net(p):
             return f(p, X)
 
+        if FUSED_SINGLE_COLUMN and not any(_is_transformed(t) for t in v.values()):
+            return _ggn_vp_one_pass(net, c, params, loss_args, v)
         pred, Jv = jvp(net, (params,), (v,))
         _, HJv = jvp(jacrev(lambda out: c(out, loss_args)), (pred,), (Jv,))
         _, pull = vjp(net, params)
@@ -520,6 +522,41 @@ def make_ggn_vector_product(f: Callable, c: Callable) -> Callable:
         return JtHJv
 
     return ggn_vp
+
+
+FUSED_SINGLE_COLUMN = True   # (tools/probe_general_direct.py flips it for A/B runs)
+
+
+def _is_transformed(t: Tensor) -> bool:
+    """True inside vmap / jvp / grad of torch.func (the tensor is a functorch wrapper)."""
+    try:
+        return torch._C._functorch.is_functorch_wrapped_tensor(t)
+    except AttributeError:   # pragma: no cover - very old torch
+        return False
+
+
+def _ggn_vp_one_pass(net: Callable, c: Callable, params: dict[str, Tensor], loss_args: tuple,
+                     v: dict[str, Tensor]) -> dict[str, Tensor]:
+    """``J^T (nabla_f^2 c) J v`` for ONE vector with ONE forward pass: the network runs once on dual numbers (forward-mode
+    tangent ``J v``) while the reverse graph of its primal part is recorded, the pull-back then runs on that graph --
+    ``jvp`` followed by ``vjp`` (the composition of ``ggn.py:41-72``) evaluates the network twice.  Same arithmetic for the
+    prediction, the tangent and the pull-back; only used outside ``vmap`` (single columns)."""
+    import torch.autograd.forward_ad as fwAD
+
+    keys = list(params.keys())
+    with torch.enable_grad():
+        leaves = {k: params[k].detach().requires_grad_(True) for k in keys}
+        with fwAD.dual_level():
+            out = net({k: fwAD.make_dual(leaves[k], v[k]) for k in keys})
+            pred, Jv = fwAD.unpack_dual(out)
+        if Jv is None:
+            Jv = torch.zeros_like(pred)
+        with torch.no_grad():
+            _, HJv = jvp(jacrev(lambda o: c(o, loss_args)), (pred.detach(),), (Jv.detach(),))
+        if not pred.requires_grad:   # the prediction does not depend on the parameters
+            return {k: torch.zeros_like(params[k]) for k in keys}
+        grads = torch.autograd.grad(pred, [leaves[k] for k in keys], grad_outputs=HJv, allow_unused=True)
+    return {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(keys, grads)}
 
 
 def make_batch_hessian_vector_product(f: Callable, loss_func: Module) -> Callable:

@@ -23,8 +23,9 @@ for name, model, X, y in cases:
         op = cls(model, nn.CrossEntropyLoss(), params, [(X, y)], check_deterministic=False)
         v = torch.rand(op.shape[1], device=dev)
         res = {}
-        for flag in (True, False):
-            curvature.CurvatureLinearOperator.SINGLE_COLUMN_DIRECT = flag
-            res[flag] = (t(lambda: op @ v), op @ v)
-        err = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
-        print(f"{name} {cls.__name__}: direct {res[True][0]:.1f} ms | vmap {res[False][0]:.1f} ms | rel diff {err:.1e}", flush=True)
+        for mode in ("one pass", "direct", "vmap"):
+            curvature.CurvatureLinearOperator.SINGLE_COLUMN_DIRECT = mode != "vmap"
+            curvature.FUSED_SINGLE_COLUMN = mode == "one pass"
+            res[mode] = (t(lambda: op @ v), op @ v)
+        err = max(float((res[m][1] - res["vmap"][1]).abs().max() / res["vmap"][1].abs().max()) for m in res)
+        print(f"{name} {cls.__name__}: one forward pass {res['one pass'][0]:.1f} ms | direct {res['direct'][0]:.1f} ms | vmap {res['vmap'][0]:.1f} ms | max rel diff {err:.1e}", flush=True)
