@@ -43,8 +43,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     obj_dir = LIB_DIR / "obj"
     obj_dir.mkdir(exist_ok=True)
 
+    hdr_time = max((CSRC / h).stat().st_mtime for h in HEADERS)
+
     def compile_one(src: Path) -> Path:
         obj = obj_dir / (src.stem + ".o")
+        # objects are kept between builds (git- and gpurun-ignored): only translation units older than their source
+        # or any header are recompiled
+        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_time):
+            return obj
         cmd = [_hipcc(), *flags, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
@@ -64,7 +70,6 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
-    shutil.rmtree(obj_dir, ignore_errors=True)
     return LIB_PATH
 
 

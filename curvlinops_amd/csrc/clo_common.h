@@ -57,6 +57,19 @@ constexpr int kWave = 64;
 constexpr int kNumCU = 256;   // MI355X
 constexpr int kNumXCD = 8;
 
+// Compute units of device `dev` as the runtime reports them (a partitioned or CU-masked part has fewer than kNumCU):
+// what a persistent grid -- one workgroup per CU, all of them resident -- may count on.  Queried once per device.
+inline int device_cu_count(int dev) {
+  static int cached[64] = {0};
+  const int slot = dev & 63;
+  if (cached[slot] <= 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = kNumCU;
+    cached[slot] = n;
+  }
+  return cached[slot];
+}
+
 // Sum over the 64 lanes of a wave; every lane gets the result.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

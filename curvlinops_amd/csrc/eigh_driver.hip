@@ -124,7 +124,10 @@ __global__ void ed_z_kernel(const float *__restrict__ Qc, const double *__restri
 }
 
 // Stable ascending rank sort of every row of keys [nodes][s]: perm[rank] = index, optionally the sorted keys and one
-// companion array gathered along.  rank_i = #{k_j < k_i} + #{j < i : k_j == k_i}: s comparisons per element.
+// companion array gathered along.  rank_i = #{k_j < k_i} + #{j < i : k_j == k_i}: s comparisons per element.  The
+// comparison is a TOTAL order (NaN keys sort last, among themselves by index), so the ranks are a permutation of 0..s-1
+// whatever the keys hold: a non-finite factor yields NaN eigenpairs (caught by the caller's verification), never an
+// unwritten perm slot that a later gather would use as an index.
 template <typename KT>
 __global__ __launch_bounds__(256) void ed_rank_sort_kernel(const KT *__restrict__ keys, int *__restrict__ perm,
                                                            int *__restrict__ rank_out, double *__restrict__ keys_sorted,
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256) void ed_rank_sort_kernel(const KT *__restrict_
   const int node = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   const KT *kr = keys + (long)node * s;
   const KT ki = i < s ? kr[i] : KT(0);
+  const bool ni = ki != ki;
   int rank = 0;
   for (int j0 = 0; j0 < s; j0 += 256) {
     __syncthreads();
@@ -142,7 +146,10 @@ __global__ __launch_bounds__(256) void ed_rank_sort_kernel(const KT *__restrict_
     const int cnt = min(256, s - j0);
     for (int t = 0; t < cnt; ++t) {
       const KT kj = tile[t];
-      rank += (kj < ki || (kj == ki && j0 + t < i)) ? 1 : 0;
+      const bool nj = kj != kj;
+      const bool lt = ni ? !nj : (!nj && kj < ki);
+      const bool eq = ni ? nj : (kj == ki);
+      rank += (lt || (eq && j0 + t < i)) ? 1 : 0;
     }
   }
   if (i < s) {

@@ -34,7 +34,7 @@ class PersistGate {
       total += s.cus;
     }
     // make room: wait for the largest launches of other streams first
-    while (total > kNumCU) {
+    while (total > cus_avail_) {
       Slot *big = nullptr;
       for (Slot &s : slots_)
         if (s.st != st && s.busy && !s.waited && (!big || s.cus > big->cus)) big = &s;
@@ -76,14 +76,18 @@ class PersistGate {
   void abort() { mu_.unlock(); }   // admit() succeeded but the launch did not happen
   static PersistGate &of(int dev) {
     static PersistGate gates[64];
-    return gates[dev & 63];
+    PersistGate &g = gates[dev & 63];
+    if (g.cus_avail_ <= 0) g.cus_avail_ = device_cu_count(dev);   // (benign race: every writer stores the same value)
+    return g;
   }
+  int cus_available() const { return cus_avail_; }
 
  private:
   struct Slot { hipStream_t st = nullptr; hipEvent_t ev = nullptr; int cus = 0; bool busy = false, waited = false, recorded = false; };
   std::mutex mu_;
   std::vector<Slot> slots_;
   int pending_ = 0;
+  int cus_avail_ = 0;   // compute units of the device (queried, not assumed)
 };
 
 }  // namespace clo

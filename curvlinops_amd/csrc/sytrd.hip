@@ -586,15 +586,17 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
   constexpr long GREC = (long)(TD_GMAX / TP_GROUP) * TD_NPART;
   float *gpart[3] = {gam + 2 * TD_NB + 64, gam + 2 * TD_NB + 64 + GREC, gam + 2 * TD_NB + 64 + 2 * GREC};
   unsigned *cnt = reinterpret_cast<unsigned *>(gpart[2] + GREC);
-  const int gmax = max_blocks > 0 ? std::min(max_blocks, TD_GMAX) : TD_GMAX;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  // a panel grid spins on its own workgroups: never more of them than can be resident at once (one per CU of THIS
+  // device -- a partition or a CU-masked queue has fewer than 256), whatever the caller asked for
+  const int gmax = std::min(max_blocks > 0 ? std::min(max_blocks, TD_GMAX) : TD_GMAX, device_cu_count(dev));
 
   const size_t lds = (2 * n4 + TD_WAVES * TD_NPART + 5 * TD_NB + 5 * TD_WAVES + 16) * sizeof(float);
   // several host threads may run reductions at once (linalg_native.eigh_many): the attribute must be in
   // place for every instantiation before any of them launches with the larger size
   static std::mutex lds_mutex;
   static size_t lds_set_dev[64] = {0};   // per device: function attributes are per device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   {
   std::lock_guard<std::mutex> lds_lock(lds_mutex);
   size_t &lds_set = lds_set_dev[dev];

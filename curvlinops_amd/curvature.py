@@ -131,36 +131,61 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         return self._native is not None
 
     # The reference recomputes everything per product and holds params / data by reference
-    # (`_torch_base.py:832-905`, `gradient_moments.py:48-87`, `hessian.py:66`).  The native path keeps
-    # two derived quantities between products -- the per-batch output gradients of the EF / Hessian
-    # kernels and the merged input batches of the flat fast path -- and validates them on every
-    # product: same parameter tensors at the same autograd version, same batch tensor OBJECTS (held
-    # by the cache entry, so an address cannot be recycled) at the same version.  A `DataLoader`
-    # yields new tensors every sweep, so nothing is ever reused for it.
-    def _params_state(self) -> tuple:
-        return tuple((id(p), p._version) for p in self._params.values())
+    # (`_torch_base.py:923-944`, `gradient_moments.py:48-87`, `hessian.py:66`).  So does the native path: on every
+    # product the kernels' pointer tables are checked against the live storage of `params` (`NativeMLP.is_current`),
+    # the per-batch output gradients of the EF / Hessian kernels are recomputed (one forward pass of the mini-batch)
+    # and copies of the data (merged or re-laid-out mini-batches) are re-made.  Nothing derived from parameter or data
+    # VALUES is kept between products: autograd version counters do not see `p.data.add_()`, `p.data.copy_()` or
+    # `vector_to_parameters`, so they cannot validate such a cache.  A caller that knows better opts in:
+    # `op.assume_frozen = True` keeps the derived quantities until `op.refresh()` / `assume_frozen = False`.
+    @property
+    def assume_frozen(self) -> bool:
+        """Opt-in promise that neither the parameters nor the data change between products: the native path then keeps
+        the per-batch output gradients (EF, Hessian) and its merged mini-batch copies.  Default False = the reference's
+        semantics (everything re-read per product).  :meth:`refresh` drops what has been kept."""
+        return getattr(self, "_assume_frozen", False)
+
+    @assume_frozen.setter
+    def assume_frozen(self, value: bool) -> None:
+        self._assume_frozen = bool(value)
+        self.refresh()
+
+    def refresh(self) -> None:
+        """Forget every quantity derived from parameter / data values (only kept under ``assume_frozen``)."""
+        self._native_aux.clear()
+        self._native_flat = None
 
     def _aux_lookup(self, idx: int, X: Tensor, y: Tensor) -> Tensor | None:
+        if not self.assume_frozen:
+            return None
         hit = self._native_aux.get(idx)
         if hit is None:
             return None
-        Xr, yr, xv, yv, pstate, value = hit
-        if Xr is X and yr is y and xv == X._version and yv == y._version and pstate == self._params_state():
-            return value
-        return None
+        Xr, yr, value = hit
+        return value if Xr is X and yr is y else None
 
     def _aux_store(self, idx: int, X: Tensor, y: Tensor, value: Tensor) -> Tensor:
-        self._native_aux[idx] = (X, y, X._version, y._version, self._params_state(), value)
+        if self.assume_frozen:
+            self._native_aux[idx] = (X, y, value)
         return value
 
     def _native_rebind_if_replaced(self) -> None:
-        """Entries of the ``params`` dict replaced by other tensors: bind the kernels to the new ones."""
+        """Storage of ``params`` replaced (entries of the dict swapped for other tensors, ``p.data = t``,
+        ``vector_to_parameters``, ``module.to(...)``): bind the kernels to what is there now, or leave the
+        native path if the new tensors do not qualify (dtype, device, layout)."""
         nat = self._native
-        if nat is not None and any(p is not q for p, q in zip(self._params.values(), nat.bound)):
+        if nat is not None:
+            if nat.is_current(self._params):
+                return
             self._native = None
-            self._native_aux.clear()
-            self._native_flat = False
-            self._init_native()
+            self.refresh()
+        elif getattr(self, "_native_lost", None) is None:
+            return   # this operator never ran natively: nothing to follow
+        sig = tuple((id(p), p.data_ptr(), p.dtype) for p in self._params.values())
+        if nat is None and sig == self._native_lost:
+            return   # still the tensors that did not qualify
+        self._init_native()
+        self._native_lost = None if self._native is not None else sig
 
     def _native_batch_args(self, idx: int, X: Tensor, y: Tensor, X_user: Tensor | None = None):
         """(loss_kind, scale, aux) of batch ``idx`` for the native kernel; ``X`` is the prepared
@@ -190,8 +215,8 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             c = {"mean": float(N), "sum": 1.0}[self._loss_func.reduction]
             return _hip.LOSS_RANK1, 1.0 / c, g.reshape(N, g.shape[1], C).contiguous()
         # empirical Fisher: H_n = (1/c) g_n g_n^T with g_n the UNREDUCED per-sample gradient
-        # of the loss w.r.t. the prediction (gradient_moments.py:48-87); kept per batch for as long
-        # as neither the parameters nor the batch tensors change (`_aux_lookup`).
+        # of the loss w.r.t. the prediction (gradient_moments.py:48-87), recomputed on every product like
+        # the reference does (kept only under `assume_frozen`, `_aux_lookup`).
         aux = self._aux_lookup(idx, X_user, y)
         if aux is None:
             with torch.no_grad():
@@ -274,7 +299,6 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
     def _matmat_native(self, M: list[Tensor]) -> list[Tensor] | None:
         """All columns of ``M`` through the HIP kernels; None if some batch does not qualify
         (then nothing has been written and the caller uses the autograd path)."""
-        self._native_rebind_if_replaced()
         nat = self._native
         if nat is None:
             return None
@@ -397,56 +421,61 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         return out
 
     # ------------------------------------------------------------------ flat fast path
-    def _native_flat_state(self) -> tuple | None:
-        """What the kept flat-path constants were derived from: the batch tensor objects and their
-        versions, plus the parameter versions where per-batch output gradients are cached (EF)."""
+    def _native_flat_key(self) -> tuple | None:
+        """What the kept flat-path ARGUMENT TABLES (addresses, row counts, loss constants) were derived from: the batch
+        tensor objects, their storage addresses and shapes.  Values are not part of it -- nothing value-derived is kept
+        unless ``assume_frozen``."""
         if not isinstance(self._data, (list, tuple)):
             return None
         try:
-            data = tuple((X, X._version, y, y._version) for X, y in self._data)
+            return tuple((X, X.data_ptr(), X.shape, y, y.data_ptr(), y.shape) for X, y in self._data)
         except (AttributeError, TypeError, ValueError):
             return None
-        return data, (self._params_state() if self._NATIVE_KIND == "ef" else None)
 
     @staticmethod
-    def _same_flat_state(a: tuple | None, b: tuple | None) -> bool:
-        if a is None or b is None or len(a[0]) != len(b[0]) or a[1] != b[1]:
+    def _same_flat_key(a: tuple | None, b: tuple | None) -> bool:
+        if a is None or b is None or len(a) != len(b):
             return False
-        return all(p[0] is q[0] and p[1] == q[1] and p[2] is q[2] and p[3] == q[3] for p, q in zip(a[0], b[0]))
+        return all(p[0] is q[0] and p[3] is q[3] and p[1] == q[1] and p[4] == q[4] and p[2] == q[2] and p[5] == q[5]
+                   for p, q in zip(a, b))
 
     def _native_flat_setup(self):
-        """Per-batch constants of the native path when ``data`` is a list of device-resident
-        fp32 batches (references only, nothing is copied unless mini-batches are merged); None
-        otherwise.  Re-derived whenever a batch tensor or (for the EF) a parameter was replaced or
-        modified in place since they were computed."""
+        """Per-batch argument tables of the native path when ``data`` is a list of device-resident fp32 batches; None
+        otherwise.  They are kept between products only while they hold nothing but ADDRESSES of the caller's live
+        tensors (the GGN on contiguous batches: the kernels then read parameters and data in place, like the
+        reference); tables that contain value-derived tensors -- the EF's per-sample output gradients, merged or
+        re-laid-out copies of mini-batches -- are rebuilt on every product unless ``assume_frozen``."""
         self._native_rebind_if_replaced()
         if (self._native is None or self._NATIVE_KIND not in ("ggn", "ef")
                 or not isinstance(self._data, (list, tuple))):
             return None  # the flat path is the whole-network GGN-type kernel only
-        state = self._native_flat_state()
-        cached = getattr(self, "_native_flat", False)
-        if cached is not False and cached is not None and self._same_flat_state(cached[0], state):
+        key = self._native_flat_key()
+        cached = getattr(self, "_native_flat", None)
+        if cached is not None and (cached[2] or self.assume_frozen) and self._same_flat_key(cached[0], key):
             return cached[1]
         self._native_flat = None
-        if state is None:
+        if key is None:
             return None
-        entries = []
+        entries, live = [], True
         for bi, (X, y) in enumerate(self._data):
             if not (isinstance(X, Tensor) and X.device == self.device and y.device == self.device):
                 return None
             Xn = self._native.prepare_input(X)
             if Xn is None or y.shape[0] != Xn.shape[0] or Xn.shape[0] == 0:
                 return None
+            live = live and Xn.data_ptr() == X.data_ptr()
             entries.append((Xn, *self._native_batch_args(bi, Xn, y, X), self._get_normalization_factor(X, y)))
         if not entries:
             return None
-        # consecutive mini-batches as one larger batch where that pays off (concatenated copies, kept)
+        # consecutive mini-batches as one larger batch where that pays off (concatenated copies)
+        merged = self._merge_native_batches(entries)
+        live = live and len(merged) == len(entries) and all(e[3] is None for e in merged)
         batches = [(Xn, Xn.data_ptr(), Xn.shape[0], kind, scale, None if aux is None else aux.data_ptr(),
                     1 if aux is None else aux.shape[1], aux, norm)
-                   for Xn, kind, scale, aux, norm in self._merge_native_batches(entries)]
+                   for Xn, kind, scale, aux, norm in merged]
         nmax = max(b[2] for b in batches)
         ws = self._native.plan.workspace(nmax, self.device)
-        self._native_flat = (state, (batches, ws, ws.data_ptr()))
+        self._native_flat = (key, (batches, ws, ws.data_ptr()), live)
         return self._native_flat[1]
 
     def __matmul__(self, X):
@@ -489,6 +518,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
 
     # ------------------------------------------------------------------ product
     def _matmat(self, M: list[Tensor]) -> list[Tensor]:
+        self._native_rebind_if_replaced()
         if self._native is not None and all(m.is_cuda and m.dtype == torch.float32 for m in M):
             out = self._matmat_native(M)
             if out is not None:

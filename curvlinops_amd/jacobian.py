@@ -100,6 +100,7 @@ class JacobianLinearOperator(_JacobianBase):
         return self._output_space()
 
     def _matmat(self, M: list[Tensor]) -> list[Tensor]:
+        self._native_rebind_if_replaced()   # params are held by reference: follow swapped storage
         if self._native is not None and all(m.is_cuda and m.dtype == torch.float32 for m in M):
             out = self._matmat_native(M)
             if out is not None:
@@ -142,6 +143,7 @@ class TransposedJacobianLinearOperator(_JacobianBase):
         return self._output_space()
 
     def _matmat(self, M: list[Tensor]) -> list[Tensor]:
+        self._native_rebind_if_replaced()   # params are held by reference: follow swapped storage
         if self._native is not None and all(m.is_cuda and m.dtype == torch.float32 for m in M):
             out = self._matmat_native(M)
             if out is not None:

@@ -356,7 +356,7 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
             # single vectors of nets with repeated layer shapes: the equal blocks as ONE batched product pair fill the
             # chip better than one product per block (ResNet-18, tools/probe_kron_blocks.py: KFAC 1.32 vs 1.38 ms, EKFAC
             # 2.44 vs 2.78 ms); everything else that is a vector or K-major goes through ONE foreign call
-            if len(self._blocks) >= 4 and X[0].shape[-1] == 1 and self.GROUP_FIRST:
+            if len(self._blocks) >= 4 and X[0].shape[-1] == 1 and self.GROUP_FIRST and self.assume_frozen:
                 out = self._matmat_grouped(parts)
                 if out is not None:
                     return out
@@ -372,6 +372,19 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
 
     SINGLE_CALL = True   # (tools/probe_kron_blocks.py flips these for A/B runs)
     GROUP_FIRST = True
+
+    @property
+    def assume_frozen(self) -> bool:
+        """Opt-in promise that the blocks' factors are not modified any more.  Only then may equal-shape blocks run as
+        one batched product on STACKED COPIES of their factors (`_matmat_grouped`); by default every product reads
+        the live factor tensors through `clo_kron_matmat_blocks`, like the reference's loop over blocks
+        (`block_diagonal.py`), so `factor.data.mul_()`, `.copy_()` or an EMA update are seen."""
+        return getattr(self, "_assume_frozen", False)
+
+    @assume_frozen.setter
+    def assume_frozen(self, value: bool) -> None:
+        self._assume_frozen = bool(value)
+        self._group_cache = None
 
     def _matmat_single_call(self, parts: list[list[Tensor]]) -> list[Tensor] | None:
         """All blocks ``S1 (x) S2`` / ``(Q1 (x) Q2) diag(lam) (Q1 (x) Q2)^T`` of a KFAC / EKFAC operator in ONE foreign
@@ -414,8 +427,9 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         identical factor shapes (repeated layer shapes), their factors stacked ONCE:
         ``[(block indices, S1 [n, A, a], S2 [n, B, b], lambda [n, A, B] | None), ...]``."""
         pairs = [self._kron_pair(B) for B in self._blocks]
-        # identity AND autograd version: an in-place update of a factor (e.g. an EMA) must refresh the stacks
-        key = tuple((id(t), getattr(t, "_version", 0)) for p in pairs if p is not None for t in (*p[0], p[1]))
+        # the stacks are COPIES of the factors: only kept under `assume_frozen` (version counters do not see
+        # `factor.data.mul_()`), and even then re-made when a factor object or its storage address changed
+        key = tuple((id(t), t.data_ptr()) for p in pairs if p is not None for t in (*p[0], p[1]) if t is not None)
         cached = getattr(self, "_group_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]

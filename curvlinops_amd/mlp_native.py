@@ -122,7 +122,21 @@ class NativeMLP:
         self.w_off = [offs[n] for n in structure.weight_names]
         self.b_off = [None if n is None else offs[n] for n in structure.bias_names]
         self.bound = [params[n] for n in self.names]  # the tensor objects the plan's pointers refer to
+        self.bound_ptrs = [p.data_ptr() for p in self.bound]
+        self.bound_shapes = [p.shape for p in self.bound]
         self.plan.bind_params(self.W, self.b)
+
+    def is_current(self, params: dict[str, Tensor]) -> bool:
+        """True if the plan's pointer tables still describe ``params``: same tensor objects AND same storage
+        addresses, dtype and shape.  ``p.data = t``, ``vector_to_parameters``, ``module.to(...)`` keep the
+        ``Parameter`` object and swap its storage, so object identity alone says nothing (the reference reads
+        ``params`` afresh on every product, ``_torch_base.py:923-944``)."""
+        if len(params) != len(self.bound):
+            return False
+        for p, q, ptr, shape in zip(params.values(), self.bound, self.bound_ptrs, self.bound_shapes):
+            if p is not q or p.data_ptr() != ptr or p.dtype is not torch.float32 or p.shape != shape:
+                return False
+        return True
 
     def prepare_input(self, X: Tensor) -> Tensor | None:
         if not isinstance(X, Tensor) or not X.is_cuda or X.dtype != torch.float32:

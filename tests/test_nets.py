@@ -146,8 +146,8 @@ def test_kfac_mc_replayed_vectors_cpu(name, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["lenet5", "resnet_toy"])
-def test_kfac_mc_replayed_vectors_gpu(name, monkeypatch):
-    check_kfac_mc_replayed(name, F32, torch.device("cuda:0"), 1e-4, 1e-3, monkeypatch)
+def test_kfac_mc_replayed_vectors_gpu(name, monkeypatch, dev):
+    check_kfac_mc_replayed(name, F32, dev, 1e-4, 1e-3, monkeypatch)
 
 
 def test_resnet_toy_cpu():

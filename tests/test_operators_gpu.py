@@ -521,6 +521,8 @@ def test_equal_shape_blocks_run_batched(dev, cls_name, sep):
     assert isinstance(K, BlockDiagonalLinearOperator) and K._kron_groups(), "equal-shape blocks must be grouped"
     v = torch.rand(op.shape[1], dtype=torch.float64)
     V = torch.rand(op.shape[1], 3, dtype=torch.float64)
+    assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4   # live factors, one foreign call
+    K.assume_frozen = True                                                        # stacked copies, batched products
     assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4
     assert rel_err((op @ V.float().to(dev)).cpu(), (ref @ V).numpy()) < 1e-4
     assert rel_err((op.inverse(damping=1e-1) @ v.float().to(dev)).cpu(), (ref.inverse(damping=1e-1) @ v).numpy()) < 1e-3
@@ -646,9 +648,114 @@ def test_inplace_updates_of_params_and_data_are_seen(dev, cls, loss):
     assert rel_err(op @ v, (fresh() @ v).cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("cls", [C.GGNLinearOperator, C.EFLinearOperator, C.HessianLinearOperator])
+@pytest.mark.parametrize("loss", ["mse", "ce"])
+def test_data_style_updates_of_params_and_data_are_seen(dev, cls, loss):
+    """Updates that neither replace the ``Parameter`` object nor bump its autograd version -- ``p.data.add_()``,
+    ``p.data.copy_()``, ``p.data = t``, ``vector_to_parameters``, ``model.to(dtype).to(float32)``, ``X.data.mul_()`` --
+    are what hand-written SGD loops and older optimizers do.  The reference re-reads parameters and data on every
+    product (``_torch_base.py:923-944``, ``gradient_moments.py:48-87``, ``hessian.py:66``); an existing operator must
+    therefore equal a freshly built one after each of them, in the flat, K-column and list formats."""
+    from torch.nn.utils import parameters_to_vector, vector_to_parameters
+
+    torch.manual_seed(2)
+    model = build_mlp([16, 24, 12, 4], ["tanh", "relu", "identity"], [True, True, True]).to(dev)
+    params = dict(model.named_parameters())
+    mk = lambda n: (torch.rand(n, 16, device=dev),  # noqa: E731
+                    torch.randint(0, 4, (n,), device=dev) if loss == "ce" else torch.rand(n, 4, device=dev))
+    data = [mk(5), mk(5), mk(7)]
+    lf = LOSS[loss]()
+    op = cls(model, lf, params, data)
+    assert op.uses_native_kernels
+    v = torch.rand(op.shape[1], device=dev)
+    V = torch.rand(op.shape[1], 8, device=dev)
+    vl = [torch.rand_like(p) for p in params.values()]
+
+    def check(what):
+        new = cls(model, lf, params, data)
+        assert op.uses_native_kernels and new.uses_native_kernels, what
+        assert rel_err(op @ v, (new @ v).cpu().numpy()) < 1e-6, what          # flat fast path
+        assert rel_err(op @ V, (new @ V).cpu().numpy()) < 1e-6, what          # K = 8 columns
+        for a, b in zip(op @ vl, new @ vl):                                   # tensor-list format
+            assert rel_err(a, b.cpu().numpy()) < 1e-6, what
+
+    first = op @ v
+    versions = [p._version for p in params.values()]
+    for p in params.values():
+        p.data.add_(0.05 * torch.randn_like(p))
+    assert [p._version for p in params.values()] == versions          # invisible to the version counters ...
+    assert rel_err(first, (cls(model, lf, params, data) @ v).cpu().numpy()) > 1e-3  # ... but it matters
+    check("p.data.add_")
+    for p in params.values():
+        p.data.copy_(p.data * 0.9 + 0.01)
+    check("p.data.copy_")
+    for p in params.values():
+        p.data = (p.data * 1.1).clone()                               # same Parameter object, other storage
+    check("p.data = t")
+    vector_to_parameters(parameters_to_vector(params.values()) * 0.8, params.values())
+    check("vector_to_parameters")
+    model.to(torch.float64).to(torch.float32)                        # storage swapped twice, objects kept
+    check("model.to(dtype).to(float32)")
+    data[0][0].data.mul_(1.3)
+    if loss != "ce":
+        data[1][1].data.add_(0.2)
+    check("X.data.mul_ / y.data.add_")
+    data[2][0].data = torch.rand(7, 16, device=dev)
+    check("X.data = t")
+    # opt-in caching keeps what it derived until refresh()
+    op.assume_frozen = True
+    kept = op @ v
+    for p in params.values():
+        p.data.mul_(1.05)
+    if cls is not C.GGNLinearOperator:   # EF / Hessian keep per-batch output gradients of the OLD parameters
+        assert rel_err(op @ v, (cls(model, lf, params, data) @ v).cpu().numpy()) > 1e-6
+    op.refresh()
+    assert rel_err(op @ v, (cls(model, lf, params, data) @ v).cpu().numpy()) < 1e-6
+    assert rel_err(kept, (cls(model, lf, params, data) @ v).cpu().numpy()) > 1e-4
+    op.assume_frozen = False
+    check("after assume_frozen = False")
+
+
+def test_native_path_is_left_when_params_stop_qualifying(dev):
+    """``model.double()`` swaps the parameters' storage for float64 tensors: the kernels' pointer tables must not be
+    used any more (the products run on the torch.func path in float64 like the reference's)."""
+    torch.manual_seed(0)
+    model = build_mlp([16, 24, 4], ["tanh", "identity"], [True, True]).to(dev)
+    params = dict(model.named_parameters())
+    X, y = torch.rand(6, 16, device=dev), torch.rand(6, 4, device=dev)
+    op = C.GGNLinearOperator(model, nn.MSELoss(), params, [(X, y)])
+    v = torch.rand(op.shape[1], device=dev)
+    before = op @ v
+    assert op.uses_native_kernels
+    model.double()
+    X.data, y.data = X.data.double(), y.data.double()
+    out = op @ v.double()
+    assert not op.uses_native_kernels and out.dtype == torch.float64
+    assert rel_err(out, before.cpu().numpy()) < 1e-5
+    model.float()
+    X.data, y.data = X.data.float(), y.data.float()
+    assert rel_err(op @ v, before.cpu().numpy()) < 1e-6 and op.uses_native_kernels
+
+
+def test_jacobian_operators_follow_swapped_parameter_storage(dev):
+    """``JacobianLinearOperator`` / its transpose on the native kernels after ``p.data = t`` and a replaced dict entry."""
+    torch.manual_seed(0)
+    model = build_mlp([16, 24, 4], ["tanh", "identity"], [True, True]).to(dev)
+    params = dict(model.named_parameters())
+    data = [(torch.rand(6, 16, device=dev), torch.rand(6, 4, device=dev))]
+    J = C.JacobianLinearOperator(model, params, data)
+    JT = C.TransposedJacobianLinearOperator(model, params, data)
+    v, u = torch.rand(J.shape[1], device=dev), torch.rand(J.shape[0], device=dev)
+    for p in params.values():
+        p.data = (p.data * 0.7 + 0.05).clone()
+    assert rel_err(J @ v, (C.JacobianLinearOperator(model, params, data) @ v).cpu().numpy()) < 1e-6
+    assert rel_err(JT @ u, (C.TransposedJacobianLinearOperator(model, params, data) @ u).cpu().numpy()) < 1e-6
+
+
 def test_grouped_kronecker_blocks_see_inplace_factor_updates(dev):
-    """Equal-shape blocks run as one batched product on stacked factor copies; an in-place update of
-    a factor (EMA) must refresh them (K = 1 grouped path == K > 1 path)."""
+    """A block-diagonal operator reads its blocks' LIVE factors on every product (reference ``block_diagonal.py`` loops
+    over the blocks): in-place updates of a factor -- also ``.data`` ones, which no version counter sees -- show up.
+    Stacked factor copies (equal-shape blocks as one batched product) exist only under ``assume_frozen``."""
     torch.manual_seed(0)
     blocks = []
     for _ in range(4):
@@ -656,11 +763,20 @@ def test_grouped_kronecker_blocks_see_inplace_factor_updates(dev):
         blocks.append(C.KroneckerProductLinearOperator(A + A.T, B + B.T))
     bd = C.BlockDiagonalLinearOperator(blocks)
     x = torch.rand(bd.shape[1], device=dev)
+    dense = lambda: torch.block_diag(*[torch.kron(b[0], b[1]) for b in blocks])  # noqa: E731
     _ = bd @ x
     with torch.no_grad():
         blocks[2][0].mul_(0.5).add_(torch.eye(6, device=dev))
-    dense = torch.block_diag(*[torch.kron(b[0], b[1]) for b in blocks])
-    assert rel_err(bd @ x, (dense @ x).cpu().numpy()) < TOL
+    assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL
+    blocks[1][1].data.mul_(1.7)
+    blocks[3][0].data.copy_(blocks[0][0].data * 0.3)
+    assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL
+    bd.assume_frozen = True
+    assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL     # grouped path on fresh stacks
+    assert bd._group_cache is not None
+    bd.assume_frozen = False
+    blocks[0][0].data.mul_(2.0)
+    assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL
 
 
 def test_fuzz_kfac_operators_gpu():

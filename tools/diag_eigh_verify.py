@@ -5,8 +5,8 @@ import torch
 from curvlinops_amd import _hip, eigh_native, linalg_native as L
 dev = torch.device("cuda:0"); g = torch.Generator().manual_seed(0)
 for n in [int(a) for a in sys.argv[1:]] or [577, 1153, 2305]:
-    for kind in ("lowrank", "wishart"):
-        r = max(16, n // 3) if kind == "lowrank" else 2 * n
+    for kind in ("lowrank", "verylow", "wishart"):
+        r = max(16, n // 3) if kind == "lowrank" else (8 if kind == "verylow" else 2 * n)
         X = torch.rand(r, n, generator=g).to(dev); A = X.T @ X / r
         An, scale = L._unit_scale(A)
         ld = (n + 3) // 4 * 4
@@ -19,4 +19,5 @@ for n in [int(a) for a in sys.argv[1:]] or [577, 1153, 2305]:
         eigh_native.ormtr_native(work, tau, Z, n); torch.cuda.synchronize(); t3 = time.perf_counter()
         Q = Z[:, :n].T
         orth = float(L._orth_defect(Q)); res = float(L._residual_defect(An, lam, Q))
-        print(f"n={n:5d} {kind:8s} sytrd {1e3*(t1-t0):7.1f} stedc {1e3*(t2-t1):7.1f} ormtr {1e3*(t3-t2):6.1f} ms | tridiag: res {rt:.1e} orth {ot:.1e} | full: orth {orth:.1e} (tol {L._ORTH_TOL}) res {res:.1e} (tol {L._RES_TOL})", flush=True)
+        nf = float(torch.linalg.matrix_norm(An)); n2 = float(lam.abs().max()); tol = float(L._residual_tol(An))
+        print(f"n={n:5d} {kind:8s} sytrd {1e3*(t1-t0):7.1f} stedc {1e3*(t2-t1):7.1f} ormtr {1e3*(t3-t2):6.1f} ms | tridiag: res {rt:.1e} orth {ot:.1e} | full: orth {orth:.1e} (tol {L._ORTH_TOL}) res {res:.1e} = {res/(L._EPS32*nf):.1f} eps|A|_F = {res/(L._EPS32*n2):.1f} eps|A|_2 (|A|_F {nf:.3g}, |A|_2 {n2:.3g}; tol {tol:.1e})", flush=True)
