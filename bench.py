@@ -602,6 +602,13 @@ def main() -> None:
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        # weak scaling: one step = ONE product of the GGN of the whole (N x rows_per_gpu)-row data set with a vector,
+        # computed as N shard products + one all-reduce.  `value` counts the shard products all ranks finished (the
+        # contract's "units all ranks processed"); the number of full-data products per second is beside it.
+        "full_data_matvecs_per_s": args.steps / elapsed,
+        "shard_products_per_s": world * args.steps / elapsed,
+        "value_definition": "shard products/s = n_gpus x full-data matvecs/s (weak scaling: rows_per_gpu fixed, the "
+                            "data set grows with n_gpus); at n_gpus = 1 both are BASELINE's matvecs/s",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

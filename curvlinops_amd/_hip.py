@@ -64,6 +64,12 @@ _SIGNATURES = {
         [_PF, c_long, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
          c_int, c_int, c_int, c_float, c_float, c_int, _PF, c_void_p],
     ),
+    "clo_patch_fold_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "clo_patch_fold_f32": (
+        c_int,
+        [_PF, c_long, _PF, c_long, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_int, c_int, c_float, c_float, c_void_p],
+    ),
     "clo_im2col_f32": (
         c_int,
         [_PF, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -391,6 +397,31 @@ def im2col(x: Tensor, kernel_size, stride, padding, dilation) -> Tensor:
                                OH, OW, _stream())
     _check(rc, "clo_im2col_f32")
     return out
+
+
+def pixel_gram_accum(C: Tensor, x: Tensor, kernel_size, stride, padding, dilation, alpha: float = 1.0,
+                      beta: float = 1.0, ones_col: bool = False) -> Tensor:
+    """``C = beta C + alpha [P | 1]^T [P | 1]`` with ``P = unfold(x)^T`` WITHOUT forming patches: the pixel Gram
+    ``Gam = X^T X`` of ``X = x.view(B, C*H*W)`` (one dense SYRK with K = B) folded into the patch covariance by
+    ``clo_patch_fold_f32`` (see ``csrc/conv.hip``).  For feature maps with ``(H W)^2 < OH OW (KH KW)^2``."""
+    lib = load()
+    B, C_, H, W = x.shape
+    (KH, KW), (SH, SW), (PH, PW), (DH, DW) = kernel_size, stride, padding, dilation
+    OH = (H + 2 * PH - DH * (KH - 1) - 1) // SH + 1
+    OW = (W + 2 * PW - DW * (KW - 1) - 1) // SW + 1
+    dd = C_ * KH * KW + (1 if ones_col else 0)
+    if C.shape != (dd, dd) or C.stride(1) != 1:
+        raise ValueError(f"C must be a row-major [{dd}, {dd}] matrix, got {tuple(C.shape)}")
+    n = C_ * H * W
+    ld = (n + 3) // 4 * 4
+    X2 = x.contiguous().view(B, n)
+    gam = torch.empty(n, ld, device=x.device, dtype=torch.float32)
+    syrk_accum(gam[:, :n], X2, alpha=1.0, beta=0.0)
+    colsum = X2.sum(dim=0) if ones_col else None
+    rc = lib.clo_patch_fold_f32(_p(C), C.stride(0), _p(gam), ld, _pc(colsum), B, C_, H, W, KH, KW, SH, SW, PH, PW, DH, DW,
+                                OH, OW, int(ones_col), alpha, beta, _stream())
+    _check(rc, "clo_patch_fold_f32")
+    return C
 
 
 def im2col_syrk_accum(C: Tensor, x: Tensor, kernel_size, stride, padding, dilation, alpha: float = 1.0,

@@ -351,6 +351,53 @@ def _use_fused_patches(hyper: dict, x: Tensor, ones_col: bool) -> bool:
     return not _hip.load().clo_gram_tall_supported(rows, Q, int(ones_col))  # tall-skinny: the streaming Gram kernel wins
 
 
+# Conv2d input covariances of SMALL feature maps: pixel Gram + fold instead of a product over patches (csrc/conv.hip,
+# `clo_patch_fold_f32`) wherever that is fewer flops -- (H W)^2 < OH OW (KH KW)^2 -- and the Gram fits `_PIXEL_GRAM_LIMIT`.
+_PIXEL_GRAM = True
+_PIXEL_GRAM_LIMIT_BYTES = 512 * 2**20
+
+
+def _conv_geometry(hyper: dict, x: Tensor):
+    ks, st, dl = _pair(hyper["kernel_size"]), _pair(hyper["stride"]), _pair(hyper["dilation"])
+    pad = hyper["padding"]
+    if isinstance(pad, str):
+        pad = tuple(_string_padding(k, pad, d)[0] for k, d in zip(ks, dl))
+    pad = _pair(pad)
+    B, C_, H, W = x.shape
+    C_ //= hyper["groups"]
+    OH = (H + 2 * pad[0] - dl[0] * (ks[0] - 1) - 1) // st[0] + 1
+    OW = (W + 2 * pad[1] - dl[1] * (ks[1] - 1) - 1) // st[1] + 1
+    return ks, st, pad, dl, (B, C_, H, W), (OH, OW)
+
+
+def _use_pixel_gram(hyper: dict, x: Tensor) -> bool:
+    if not _PIXEL_GRAM or not _conv_patches_fusable(hyper):
+        return False
+    ks, st, pad, dl, (B, C_, H, W), (OH, OW) = _conv_geometry(hyper, x)
+    if B == 0 or OH <= 0 or OW <= 0:
+        return False
+    hw, taps, pos = H * W, ks[0] * ks[1], OH * OW
+    if hw * hw >= pos * taps * taps or 4 * (C_ * hw) ** 2 > _PIXEL_GRAM_LIMIT_BYTES:
+        return False
+    return bool(_hip.load().clo_patch_fold_supported(C_, H, W, ks[0], ks[1], OH, OW))
+
+
+def _pixel_gram_accumulate(store: dict, key, x: Tensor, hyper: dict, n_data: int, ones_col: bool) -> None:
+    """``store[key] += [P | 1]^T [P | 1] / (N_data * O1 O2)`` through the pixel Gram of ``x`` ([B, C, H, W])."""
+    ks, st, pad, dl, (B, C_, H, W), (OH, OW) = _conv_geometry({**hyper, "groups": 1}, x)
+    d = C_ * ks[0] * ks[1] + (1 if ones_col else 0)
+    fresh = getattr(store, "fresh", None)
+    Cm = store.get(key)
+    first = Cm is None or (fresh is not None and key in fresh)
+    if Cm is None:
+        Cm = torch.empty(d, d, device=x.device, dtype=torch.float32)
+        store[key] = Cm
+    if fresh:
+        fresh.discard(key)
+    _hip.pixel_gram_accum(Cm, x, ks, st, pad, dl, alpha=1.0 / (n_data * OH * OW), beta=0.0 if first else 1.0,
+                          ones_col=ones_col)
+
+
 def _patch_gram_accumulate(store: dict, key, x: Tensor, hyper: dict, n_data: int, ones_col: bool) -> None:
     """``store[key] += [P | 1]^T [P | 1] / (N_data * O1 O2)`` for the patches ``P`` of ``x`` ([B, C, H, W])."""
     ks, st, dl = _pair(hyper["kernel_size"]), _pair(hyper["stride"]), _pair(hyper["dilation"])
@@ -372,6 +419,99 @@ def _patch_gram_accumulate(store: dict, key, x: Tensor, hyper: dict, n_data: int
         fresh.discard(key)
     _hip.im2col_syrk_accum(Cm, x, ks, st, pad, dl, alpha=1.0 / (n_data * OH * OW), beta=0.0 if first else 1.0,
                            ones_col=ones_col)
+
+
+# ------------------------------------------------------------------------------------------
+# graph-captured factor build (the analogue of the reference's traced + compiled backend,
+# computers/kfac_make_fx.py:26-111: trace the per-batch computation once, replay it per batch)
+# ------------------------------------------------------------------------------------------
+# One factor build of ResNet-18 is ~350 launches that the host dispatches in 7.5 ms (a bare gradient pass: 5.9 ms)
+# while the kernels themselves need less.  A mini-batch of a given shape is therefore CAPTURED once as a hipGraph --
+# forward pass, backpropagation, im2col / SYRK kernels on the factor stream (fork / join by events, so the overlap is
+# part of the graph) -- and replayed for every later batch of that shape: the batch is copied into the graph's static
+# input tensors, one graph launch recomputes everything from the LIVE parameters and buffers (their addresses are part
+# of the cache key; their values are read at replay time), and the factors are copied / added out of the graph's
+# static buffers.  Nothing is cached but the launch sequence.
+_CAPTURE = True        # module knob (tools / tests flip it for A/B runs)
+_CAPTURE_AFTER = 1     # eager runs of a configuration before it is captured
+_CAPTURE_MAX = 4       # captured configurations kept (each holds its activations' memory pool + static factor buffers)
+_CAPTURED: dict = {}   # signature -> int (eager runs so far) | _CapturedBatch | False (capture failed: stay eager)
+_CAPTURE_GENERATORS: dict = {}
+
+
+def _capture_generator(device: torch.device) -> torch.Generator:
+    """ONE generator per device for every captured build: graphs register it (``register_generator_state``), so a
+    replay draws from its current seed / offset and advances it exactly like the eager ops it recorded."""
+    gen = _CAPTURE_GENERATORS.get(device)
+    if gen is None:
+        gen = _CAPTURE_GENERATORS[device] = torch.Generator(device=device)
+    return gen
+
+
+def reset_captured_builds() -> None:
+    """Drop every captured factor build (frees their memory pools)."""
+    _CAPTURED.clear()
+
+
+class _CapturedBatch:
+    """The KFAC factor computation of ONE mini-batch shape as a replayable hipGraph."""
+
+    def __init__(self):
+        self.graph = None
+        self.X = self.y = None
+        self.store: _FactorStore | None = None
+        self.model_ref = None
+
+    @classmethod
+    def capture(cls, computer: "HipKFACComputer", X: Tensor, y: Tensor, mapping, sizes_a: dict, sizes_g: dict,
+                gen: torch.Generator, sig: tuple):
+        """Capture; on any failure the configuration is marked uncapturable (False) and the caller runs it eagerly."""
+        import weakref
+
+        self = cls()
+        dev = computer.device
+        try:
+            self.X, self.y = X.clone(), y.clone()
+            self.store = _FactorStore()
+            self.store.preallocate({("a", k): d for k, d in sizes_a.items()} | {("g", k): d for k, d in sizes_g.items()},
+                                   dev, torch.float32)
+            A, G = _FactorStore(), _FactorStore()
+            for (which, k), view in self.store.items():
+                (A if which == "a" else G)[k] = view
+            A.fresh, G.fresh = set(sizes_a), set(sizes_g)   # first touch of a factor writes (beta = 0): no memset
+            graph = torch.cuda.CUDAGraph()
+            graph.register_generator_state(gen)
+            state = gen.get_state()
+            with torch.cuda.graph(graph):
+                with _use_params(computer._model_module, computer._params):
+                    computer._run_batch(self.X, self.y, mapping, A, G)
+                for st in (A, G):            # factors no hook wrote (unused layers) are zero
+                    for k in st.fresh:
+                        st[k].zero_()
+            gen.set_state(state)             # (capture advanced the generator without drawing anything)
+            self.graph = graph
+            self.model_ref = weakref.ref(computer._model_module)
+        except Exception as error:  # noqa: BLE001 - any capture problem means: stay on the eager route
+            from warnings import warn
+
+            warn(f"KFAC factor build: hipGraph capture failed ({type(error).__name__}: {error}); this configuration "
+                 "keeps the eager route.", stacklevel=3)
+            _CAPTURED[sig] = False
+            torch.cuda.synchronize(dev)
+            return False
+        # bounded cache; ids of dead models must not alias new ones
+        for k in [k for k, v in _CAPTURED.items() if isinstance(v, _CapturedBatch) and v.model_ref() is None]:
+            del _CAPTURED[k]
+        live = [k for k, v in _CAPTURED.items() if isinstance(v, _CapturedBatch)]
+        for k in live[: max(0, len(live) + 1 - _CAPTURE_MAX)]:
+            del _CAPTURED[k]
+        _CAPTURED[sig] = self
+        return self
+
+    def replay(self, X: Tensor, y: Tensor) -> None:
+        self.X.copy_(X)
+        self.y.copy_(y)
+        self.graph.replay()
 
 
 class HipKFACComputer(EmpiricalRiskMixin):
@@ -443,6 +583,9 @@ class HipKFACComputer(EmpiricalRiskMixin):
 
     # ------------------------------------------------------------------ public
     def compute(self):
+        captured = self._compute_captured()
+        if captured is not None:
+            return captured
         with _use_params(self._model_module, self._params):
             return self._compute_kronecker_factors()
 
@@ -486,13 +629,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
         if self._distributed:
             # all factors of this rank in ONE flat buffer, accumulated in place and all-reduced in
             # place (A_l first, then G_l): sizes follow from the layer shapes
-            sizes_a, sizes_g = {}, {}
-            for group in mapping:
-                mod, key = self._module_of(group), tuple(group.values())
-                if "W" in group:
-                    sizes_a[key] = mod.weight[0].numel() + (1 if "b" in group else 0)
-                if self._fisher_type != FisherType.FORWARD_ONLY:
-                    sizes_g[key] = self._params[next(iter(group.values()))].shape[0]
+            sizes_a, sizes_g = self._factor_sizes(mapping)
             both = _FactorStore()
             both.preallocate({("a", k): d for k, d in sizes_a.items()} | {("g", k): d for k, d in sizes_g.items()},
                              self.device, self.dtype)
@@ -501,33 +638,21 @@ class HipKFACComputer(EmpiricalRiskMixin):
             A.fresh, G.fresh = set(sizes_a), set(sizes_g)
             flat = both.flat
             n_a = sum(d * d for d in sizes_a.values())  # flat[:n_a] = all A_l, flat[n_a:] = all G_l
-        handles = []
-        for group in mapping:
-            mod = self._module_of(group)
-            hyper = _conv_hyperparams(mod)
-            if "W" in group:
-                handles.append(mod.register_forward_pre_hook(partial(self._input_hook, group=group, hyper=hyper, store=A)))
-            handles.append(mod.register_forward_hook(partial(self._output_hook, group=group, hyper=hyper, store=G)))
         self._generator = seed_generator(self._generator, self.device, self._seed)
-        self._hooked_outputs = []
         work_a = None
-        try:
-            batches = iter(self._loop_over_data(desc="KFAC matrices"))
-            nxt = next(batches, None)
-            while nxt is not None:
-                (X, y), nxt = nxt, next(batches, None)
-                output = self._model_module(X)
-                if nxt is None and self._distributed:
-                    # The input covariances are complete once the LAST forward pass has run: their
-                    # all-reduce (all but ~2 % of the factor bytes: ResNet-18 369 of 376 MB) starts now and
-                    # travels over xGMI while this rank is still backpropagating.
+        batches = iter(self._loop_over_data(desc="KFAC matrices"))
+        nxt = next(batches, None)
+        while nxt is not None:
+            (X, y), nxt = nxt, next(batches, None)
+            after_forward = None
+            if nxt is None and self._distributed:
+                # The input covariances are complete once the LAST forward pass has run: their
+                # all-reduce (all but ~2 % of the factor bytes: ResNet-18 369 of 376 MB) starts now and
+                # travels over xGMI while this rank is still backpropagating.
+                def after_forward():
+                    nonlocal work_a
                     work_a = self._start_input_factor_allreduce(A, flat, n_a)
-                output, y = self._rearrange_output(output, y)
-                self._backpropagate(output, y)
-        finally:
-            for h in handles:
-                h.remove()
-            _join_factor_stream(self.device)
+            self._run_batch(X, y, mapping, A, G, after_forward)
         if self._distributed:
             from curvlinops_amd.dist import allreduce_flat_
 
@@ -544,6 +669,130 @@ class HipKFACComputer(EmpiricalRiskMixin):
                 p = self._params[next(iter(group.values()))]
                 G[tuple(group.values())] = torch.eye(p.shape[0], dtype=p.dtype, device=self.device)
         return dict(A), dict(G), mapping
+
+    def _run_batch(self, X, y: Tensor, mapping, A, G, after_forward=None) -> None:
+        """One mini-batch: forward pass with the input hooks (``A`` accumulation), backpropagation of the Fisher type's
+        vectors with the output-gradient hooks (``G`` accumulation); the factor stream is joined at the end."""
+        handles = []
+        for group in mapping:
+            mod = self._module_of(group)
+            hyper = _conv_hyperparams(mod)
+            if "W" in group:
+                handles.append(mod.register_forward_pre_hook(partial(self._input_hook, group=group, hyper=hyper, store=A)))
+            handles.append(mod.register_forward_hook(partial(self._output_hook, group=group, hyper=hyper, store=G)))
+        self._hooked_outputs = []
+        try:
+            output = self._model_module(X)
+            if after_forward is not None:
+                after_forward()
+            output, y = self._rearrange_output(output, y)
+            self._backpropagate(output, y)
+        finally:
+            for h in handles:
+                h.remove()
+            self._hooked_outputs = []
+            _join_factor_stream(self.device)
+
+    def _factor_sizes(self, mapping) -> tuple[dict, dict]:
+        """``{group key: order}`` of the input / gradient covariances this computer builds."""
+        sizes_a, sizes_g = {}, {}
+        for group in mapping:
+            mod, key = self._module_of(group), tuple(group.values())
+            if "W" in group:
+                sizes_a[key] = mod.weight[0].numel() + (1 if "b" in group else 0)
+            if self._fisher_type != FisherType.FORWARD_ONLY:
+                sizes_g[key] = self._params[next(iter(group.values()))].shape[0]
+        return sizes_a, sizes_g
+
+    # ------------------------------------------------------------------ graph-captured build
+    def _capture_signature(self, X: Tensor, y: Tensor) -> tuple | None:
+        """Everything a captured batch bakes in: shapes, normalisation constants, the Fisher type, and the ADDRESSES of
+        every tensor its kernels read in place (parameters, buffers) -- values stay live, a swapped storage re-captures."""
+        model = self._model_module
+        if not (isinstance(X, Tensor) and is_native_tensor(X) and isinstance(y, Tensor) and y.is_cuda
+                and X.device == self.device and y.device == self.device and X.shape[0] > 0):
+            return None
+        tensors = list(self._params.values())
+        mods = list(model.modules())
+        for m in mods:
+            tensors.extend(m._parameters.values())
+            tensors.extend(m._buffers.values())
+        if any(t is not None and not (t.is_cuda and t.device == self.device) for t in tensors):
+            return None
+        return (
+            id(model), type(self).__name__, type(self._loss_func).__name__, self._loss_func.reduction,
+            str(self._fisher_type), self._mc_samples, str(self._kfac_approx), self._separate_weight_and_bias,
+            self._N_data, self._num_per_example_loss_terms, tuple(self._params.keys()),
+            tuple(X.shape), tuple(y.shape), y.dtype, str(self.device), _FUSED_IM2COL, _FAST_BN, _OVERLAP,
+            tuple(m.training for m in mods),
+            tuple((0, 0) if t is None else (t.data_ptr(), t.dtype) for t in tensors),
+        )
+
+    def _compute_captured(self):
+        """The factor build with every mini-batch replayed as a hipGraph (``_CapturedBatch``) where one is available or
+        can be captured; None: take the eager route (not eligible, or capture failed once for this configuration)."""
+        # (several backpropagated vectors per datum -- type-2, multi-sample MC -- run ONE batched backward pass under
+        # vmap and feed the callbacks afterwards; that route is not captured: its replay was wrong on the first try,
+        # tests/test_nets.py, and it is not the configuration the metric is quoted on)
+        if not (_CAPTURE and self._CAPTURABLE and not self._manual_callbacks and not self._distributed and not self._progressbar
+                and isinstance(self._data, (list, tuple)) and self._data and self.device.type == "cuda"
+                and self.dtype == torch.float32 and isinstance(self._model_module, Module)):
+            return None
+        sigs = []
+        for X, y in self._data:
+            sig = self._capture_signature(X, y)
+            if sig is None or _CAPTURED.get(sig, 0) is False:
+                return None
+            sigs.append(sig)
+        mapping = self.compute_parameter_groups(self._params, self._model_module, self._separate_weight_and_bias)
+        sizes_a, sizes_g = self._factor_sizes(mapping)
+        gen = _capture_generator(self.device)
+        gen.manual_seed(self._seed)
+        self._generator = gen
+        out = _FactorStore()
+        out.preallocate({("a", k): d for k, d in sizes_a.items()} | {("g", k): d for k, d in sizes_g.items()},
+                        self.device, self.dtype)
+        A, G = _FactorStore(), _FactorStore()
+        for (which, k), view in out.items():
+            (A if which == "a" else G)[k] = view
+        A.fresh, G.fresh = set(sizes_a), set(sizes_g)
+        first = True
+        for (X, y), sig in zip(self._data, sigs):
+            entry = _CAPTURED.get(sig, 0)
+            if isinstance(entry, _CapturedBatch) and entry.model_ref() is not self._model_module:
+                entry = 0   # the id of a dead model, recycled
+            if isinstance(entry, int):
+                # a configuration is run eagerly the first time it is seen (library warm-up: MIOpen's solver search,
+                # workspaces) and captured when it comes back
+                if entry >= _CAPTURE_AFTER:
+                    entry = _CapturedBatch.capture(self, X, y, mapping, sizes_a, sizes_g, gen, sig)
+                else:
+                    _CAPTURED[sig] = entry + 1
+            if isinstance(entry, _CapturedBatch):
+                entry.replay(X, y)
+                if first and len(A.fresh) == len(sizes_a) and len(G.fresh) == len(sizes_g):
+                    out.flat.copy_(entry.store.flat)
+                else:
+                    for st in (A, G):
+                        for k in st.fresh:
+                            st[k].zero_()
+                    out.flat.add_(entry.store.flat)
+                A.fresh, G.fresh = set(), set()
+            else:
+                with _use_params(self._model_module, self._params):
+                    self._run_batch(X, y, mapping, A, G)
+            first = False
+        for st in (A, G):
+            for k in st.fresh:
+                st[k].zero_()
+            st.fresh = set()
+        if self._fisher_type == FisherType.FORWARD_ONLY:
+            for group in mapping:
+                p = self._params[next(iter(group.values()))]
+                G[tuple(group.values())] = torch.eye(p.shape[0], dtype=p.dtype, device=self.device)
+        return dict(A), dict(G), mapping
+
+    _CAPTURABLE = True
 
     def _start_input_factor_allreduce(self, A, flat: Tensor, n_a: int):
         """Asynchronous in-place all-reduce of the input-covariance part of the flat factor buffer, ordered
@@ -624,6 +873,13 @@ class HipKFACComputer(EmpiricalRiskMixin):
         with _factor_stream(inputs[0]):
             joint = "W" in group and "b" in group
             x_in = inputs[0].data.detach()
+            if (hyper and self._kfac_approx == KFACType.EXPAND and is_native_tensor(x_in) and x_in.dim() == 4
+                    and _use_pixel_gram(hyper, x_in)):
+                # Conv2d on a small feature map: A from the pixel Gram X^T X (X = x as [B, C H W]) folded over the taps --
+                # fewer flops than the product over patches, no patch matrix (csrc/conv.hip)
+                _pixel_gram_accumulate(store, tuple(group.values()), _group_mean(x_in, hyper["groups"]), hyper,
+                                       self._N_data, ones_col=joint)
+                return
             if (hyper and self._kfac_approx == KFACType.EXPAND and is_native_tensor(x_in) and x_in.dim() == 4
                     and _use_fused_patches(hyper, x_in, joint)):
                 # Conv2d, KFAC-expand: the patch matrix [B O1 O2, C K1 K2] is generated inside the SYRK's

@@ -2,6 +2,8 @@
 // kfac_utils.py:78-121: group-mean + torch unfold + transpose).  One launch for the whole
 // mini-batch (torch's unfold launches one im2col kernel per sample), written in the layout the
 // SYRK wants: out[(b, oh, ow)][(c, kh, kw)] row-major, coalesced along the patch axis.
+#include <algorithm>
+
 #include "clo_common.h"
 
 namespace clo {
@@ -31,9 +33,147 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colArgs p) {
   }
 }
 
+// ---- input covariance of a convolution from the PIXEL Gram matrix ---------------------------------------------------
+// KFAC-expand's A = P^T P over the patch matrix P [(b, oh, ow)][(c, kh, kw)] (kfac_utils.py:78-121 + kfac_hooks.py:350)
+// only ever multiplies input pixels of the same sample:
+//   A[(c1,t1)][(c2,t2)] = sum_b sum_pos x[b][c1][pos + t1] x[b][c2][pos + t2]
+//                       = sum_{pos : both taps inside the image} Gam[(c1, pos + t1)][(c2, pos + t2)],
+//   Gam = X^T X  with  X = x viewed as [B][C*H*W]  (the "pixel Gram", one dense SYRK with K = B).
+// For images smaller than the kernel's reach squared -- (H W)^2 < OH OW (KH KW)^2, e.g. every 3x3 layer of a
+// CIFAR-sized ResNet (8x8 ... 1x1 feature maps) -- Gam costs FEWER flops than P^T P (ResNet-18 layer4: 81 x fewer, most
+// patch entries are padding zeros), needs no patch matrix at all and runs on aligned dense operands.  This kernel is
+// the second half: the fold of Gam into A, one workgroup per (channel group, channel group) tile of Gam staged in LDS.
+struct FoldArgs {
+  float *C;
+  long ldc;
+  const float *G;   // [Cc*H*W][ldg] pixel Gram
+  long ldg;
+  const float *colsum;   // [Cc*H*W] sum_b x[b][c][q] (bias column) or nullptr
+  int Cc, H, W, KH, KW, SH, SW, PH, PW, DH, DW, OH, OW;
+  int g1, g2;       // channels per tile row / column group
+  int ones;         // 1: A has the extra bias row / column
+  float nrows;      // B * OH * OW  (corner entry, before alpha)
+  float alpha, beta;
+};
+
+constexpr int FOLD_T = 256;
+
+__global__ __launch_bounds__(FOLD_T) void patch_fold_kernel(const FoldArgs p) {
+  extern __shared__ float fold_lds[];
+  const int HW = p.H * p.W, P = p.OH * p.OW, T = p.KH * p.KW;
+  const int nb2 = (int)cdiv(p.Cc, p.g2);
+  const int tid = threadIdx.x;
+  int *qtab = reinterpret_cast<int *>(fold_lds);          // [T][P] input pixel of (tap, output position) or -1
+  float *tile = fold_lds + (((long)T * P + 3) & ~3L);
+  for (int i = tid; i < T * P; i += FOLD_T) {
+    const int t = i / P, pos = i - t * P;
+    const int oh = pos / p.OW, ow = pos - oh * p.OW, kh = t / p.KW, kw = t - kh * p.KW;
+    const int ih = oh * p.SH - p.PH + kh * p.DH, iw = ow * p.SW - p.PW + kw * p.DW;
+    qtab[i] = (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? ih * p.W + iw : -1;
+  }
+  const int by = blockIdx.y, bx = blockIdx.x;
+  const int c1_0 = by * p.g1, n1 = min(p.g1, p.Cc - c1_0);
+  if (bx == nb2) {
+    // bias column / row of this channel group, and (first group) the corner
+    __syncthreads();
+    for (int o = tid; o < n1 * T; o += FOLD_T) {
+      const int c1 = o / T, t1 = o - c1 * T;
+      float sacc = 0.f;
+      for (int pos = 0; pos < P; ++pos) {
+        const int q = qtab[t1 * P + pos];
+        if (q >= 0) sacc += p.colsum[(long)(c1_0 + c1) * HW + q];
+      }
+      const long f = (long)(c1_0 + c1) * T + t1, last = (long)p.Cc * T;
+      float *a = p.C + f * p.ldc + last, *b = p.C + last * p.ldc + f;
+      const float v = p.alpha * sacc;
+      *a = p.beta != 0.f ? p.beta * *a + v : v;
+      *b = p.beta != 0.f ? p.beta * *b + v : v;
+    }
+    if (by == 0 && tid == 0) {
+      float *c = p.C + (long)p.Cc * T * p.ldc + (long)p.Cc * T;
+      const float v = p.alpha * p.nrows;
+      *c = p.beta != 0.f ? p.beta * *c + v : v;
+    }
+    return;
+  }
+  const int c2_0 = bx * p.g2, n2 = min(p.g2, p.Cc - c2_0);
+  const int rows = n1 * HW, cols = n2 * HW;
+  const int ldt = cols | 1;   // odd row pitch: the gather's row index varies fastest across a tap's positions
+  const float *src = p.G + (long)c1_0 * HW * p.ldg + (long)c2_0 * HW;
+  for (int e = tid; e < rows * cols; e += FOLD_T) {
+    const int r = e / cols, c = e - r * cols;
+    tile[r * ldt + c] = src[(long)r * p.ldg + c];
+  }
+  __syncthreads();
+  const int no2 = n2 * T, nout = n1 * T * no2;
+  for (int o = tid; o < nout; o += FOLD_T) {
+    const int o1 = o / no2, o2 = o - o1 * no2;
+    const int c1 = o1 / T, t1 = o1 - c1 * T, c2 = o2 / T, t2 = o2 - c2 * T;
+    const int *q1p = qtab + t1 * P, *q2p = qtab + t2 * P;
+    const float *t0 = tile + (long)c1 * HW * ldt + c2 * HW;
+    float sacc = 0.f;
+    for (int pos = 0; pos < P; ++pos) {
+      const int q1 = q1p[pos], q2 = q2p[pos];
+      if ((q1 | q2) >= 0) sacc += t0[q1 * ldt + q2];
+    }
+    float *c = p.C + ((long)(c1_0 + c1) * T + t1) * p.ldc + (long)(c2_0 + c2) * T + t2;
+    const float v = p.alpha * sacc;
+    *c = p.beta != 0.f ? p.beta * *c + v : v;
+  }
+}
+
 }  // namespace clo
 
 using namespace clo;
+
+extern "C" int clo_patch_fold_supported(int Cc, int H, int W, int KH, int KW, int OH, int OW) {
+  if (Cc < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || OH < 1 || OW < 1) return 0;
+  const long HW = (long)H * W, P = (long)OH * OW, T = (long)KH * KW;
+  // the tile of ONE channel pair and the tap table must fit the workgroup's LDS
+  return ((T * P + 4) + HW * (HW + 1)) * 4 <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" int clo_patch_fold_f32(float *C, long ldc, const float *Gam, long ldg, const float *colsum, int B, int Cc,
+                                  int H, int W, int KH, int KW, int SH, int SW, int PH, int PW, int DH, int DW,
+                                  int OH, int OW, int ones_col, float alpha, float beta, void *stream) {
+  CLO_REQUIRE(B >= 0 && Cc > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && SH > 0 && SW > 0 && DH > 0 && DW > 0 && PH >= 0 &&
+                  PW >= 0,
+              "clo_patch_fold_f32: bad geometry");
+  CLO_REQUIRE(OH == (H + 2 * PH - DH * (KH - 1) - 1) / SH + 1 && OW == (W + 2 * PW - DW * (KW - 1) - 1) / SW + 1 &&
+                  OH > 0 && OW > 0,
+              "clo_patch_fold_f32: output size (%d, %d) inconsistent with the geometry", OH, OW);
+  CLO_REQUIRE(clo_patch_fold_supported(Cc, H, W, KH, KW, OH, OW), "clo_patch_fold_f32: image too large for the LDS tile");
+  const long d = (long)Cc * KH * KW + (ones_col ? 1 : 0);
+  CLO_REQUIRE(C && Gam && ldc >= d && ldg >= (long)Cc * H * W && (!ones_col || colsum),
+              "clo_patch_fold_f32: null operand / leading dimension too small");
+  FoldArgs a{};
+  a.C = C; a.ldc = ldc; a.G = Gam; a.ldg = ldg; a.colsum = colsum;
+  a.Cc = Cc; a.H = H; a.W = W; a.KH = KH; a.KW = KW; a.SH = SH; a.SW = SW; a.PH = PH; a.PW = PW; a.DH = DH; a.DW = DW;
+  a.OH = OH; a.OW = OW; a.ones = ones_col ? 1 : 0;
+  a.nrows = (float)((double)B * OH * OW);
+  a.alpha = alpha; a.beta = beta;
+  // channel groups: the largest square-ish tile of Gam that fits 48 KB, shrunk until the grid fills the chip
+  const long HW = (long)H * W, T = (long)KH * KW, P = (long)OH * OW;
+  (void)P;
+  const long budget = (48 * 1024) / 4;
+  int g1 = 1, g2 = 1;
+  auto fits = [&](int r, int c) { return (long)r * HW * (((long)c * HW) | 1) <= budget; };
+  for (bool grew = true; grew;) {   // columns first: a tile row is one contiguous run of Gam
+    grew = false;
+    if (g2 * 2 <= Cc && fits(g1, g2 * 2)) { g2 *= 2; grew = true; }
+    if (g1 * 2 <= Cc && fits(g1 * 2, g2)) { g1 *= 2; grew = true; }
+  }
+  while (cdiv(Cc, g1) * cdiv(Cc, g2) < 2L * kNumCU && (g1 > 1 || g2 > 1)) {
+    if (g1 >= g2 && g1 > 1) g1 /= 2; else g2 /= 2;
+  }
+  a.g1 = g1; a.g2 = g2;
+  const size_t lds = (size_t)(((T * P + 3) & ~3L) + (long)g1 * HW * (((long)g2 * HW) | 1)) * sizeof(float);
+  CLO_REQUIRE(lds <= 64 * 1024, "clo_patch_fold_f32: internal tile choice exceeds the LDS budget");
+  dim3 grid((unsigned)cdiv(Cc, g2) + (ones_col ? 1 : 0), (unsigned)cdiv(Cc, g1));
+  hipLaunchKernelGGL(patch_fold_kernel, grid, dim3(FOLD_T), lds, (hipStream_t)stream, a);
+  CLO_CHECK_LAUNCH("patch_fold_kernel");
+  return CLO_OK;
+}
 
 extern "C" int clo_im2col_f32(const float *x, float *out, int B, int C, int H, int W, int KH, int KW,
                               int SH, int SW, int PH, int PW, int DH, int DW, int OH, int OW,

@@ -356,7 +356,7 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
             # single vectors of nets with repeated layer shapes: the equal blocks as ONE batched product pair fill the
             # chip better than one product per block (ResNet-18, tools/probe_kron_blocks.py: KFAC 1.32 vs 1.38 ms, EKFAC
             # 2.44 vs 2.78 ms); everything else that is a vector or K-major goes through ONE foreign call
-            if len(self._blocks) >= 4 and X[0].shape[-1] == 1 and self.GROUP_FIRST and self.assume_frozen:
+            if len(self._blocks) >= 4 and X[0].shape[-1] == 1 and self.GROUP_FIRST:
                 out = self._matmat_grouped(parts)
                 if out is not None:
                     return out
@@ -375,10 +375,10 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
 
     @property
     def assume_frozen(self) -> bool:
-        """Opt-in promise that the blocks' factors are not modified any more.  Only then may equal-shape blocks run as
-        one batched product on STACKED COPIES of their factors (`_matmat_grouped`); by default every product reads
-        the live factor tensors through `clo_kron_matmat_blocks`, like the reference's loop over blocks
-        (`block_diagonal.py`), so `factor.data.mul_()`, `.copy_()` or an EMA update are seen."""
+        """Opt-in promise that the blocks' factors are not modified any more: the stacked factor copies of the batched
+        equal-shape products (`_matmat_grouped`) are then kept between products.  By default they are re-made from the
+        live factor tensors on every product, like the reference's loop over blocks (`block_diagonal.py`) reads them, so
+        `factor.data.mul_()`, `.copy_()` or an EMA update are seen."""
         return getattr(self, "_assume_frozen", False)
 
     @assume_frozen.setter
@@ -427,11 +427,13 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         identical factor shapes (repeated layer shapes), their factors stacked ONCE:
         ``[(block indices, S1 [n, A, a], S2 [n, B, b], lambda [n, A, B] | None), ...]``."""
         pairs = [self._kron_pair(B) for B in self._blocks]
-        # the stacks are COPIES of the factors: only kept under `assume_frozen` (version counters do not see
-        # `factor.data.mul_()`), and even then re-made when a factor object or its storage address changed
+        # The stacks are COPIES of the factors.  By default they are re-made on EVERY product (the reference's loop over
+        # blocks reads the live factors, `block_diagonal.py`; version counters do not see `factor.data.mul_()`): ResNet-18
+        # re-stacks 340 MB = ~0.2 ms of a 1.6 ms product, still well below the 2.5 - 3.2 ms of the unbatched routes.
+        # Under `assume_frozen` they are kept, and even then re-made when a factor object or its address changed.
         key = tuple((id(t), t.data_ptr()) for p in pairs if p is not None for t in (*p[0], p[1]) if t is not None)
         cached = getattr(self, "_group_cache", None)
-        if cached is not None and cached[0] == key:
+        if self.assume_frozen and cached is not None and cached[0] == key:
             return cached[1]
         by_shape: dict = {}
         for i, p in enumerate(pairs):
@@ -447,7 +449,7 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
             if pairs[idx[0]][1] is not None:
                 lam = torch.stack([pairs[i][1] for i in idx]).reshape(len(idx), S1.shape[1], S2.shape[1])
             groups.append((idx, S1, S2, lam))
-        self._group_cache = (key, groups)
+        self._group_cache = (key, groups) if self.assume_frozen else None
         return groups
 
     def _matmat_grouped(self, parts: list[list[Tensor]]) -> list[Tensor] | None:

@@ -118,6 +118,18 @@ int clo_im2col_syrk_accum_f32(float *C, long ldc, const float *x, int B, int Cc,
                               int OH, int OW, int ones_col, float alpha, float beta,
                               int splitk, float *ws, void *stream);
 
+/* Input covariance of a convolution from the PIXEL Gram matrix (round 5).  The patch product of
+ * kfac_utils.py:78-121 + kfac_hooks.py:350 only multiplies pixels of the same sample, so
+ *   A[(c1,t1)][(c2,t2)] = sum_{pos: both taps inside} Gam[(c1, pos+t1)][(c2, pos+t2)],  Gam = X^T X, X = x as [B][C*H*W]
+ * -- for feature maps with (H W)^2 < OH OW (KH KW)^2 (every 3x3 layer of a CIFAR-sized ResNet) fewer flops than the patch
+ * product and no patch matrix.  The caller computes Gam with clo_syrk_accum_f32 (alpha = 1) and, for joint weight + bias
+ * factors, colsum[c*H*W + q] = sum_b x[b][c][q]; this entry folds them: C = beta C + alpha A, C [(C KH KW + ones)^2].
+ * clo_patch_fold_supported: the LDS tile of one channel pair fits (H W <= ~120). */
+int clo_patch_fold_supported(int Cc, int H, int W, int KH, int KW, int OH, int OW);
+int clo_patch_fold_f32(float *C, long ldc, const float *Gam, long ldg, const float *colsum, int B, int Cc, int H, int W,
+                       int KH, int KW, int SH, int SW, int PH, int PW, int DH, int DW, int OH, int OW, int ones_col,
+                       float alpha, float beta, void *stream);
+
 /* Tall-skinny Gram matrix C = beta C + alpha [X | 1]^T [X | 1] for rows >> d, d + ones_col <= 128 (KFAC
  * factors of convolution layers: G_l with few output channels against B*H*W rows, A_1 with C_in k^2 + 1
  * columns; the Gram passes of the Hutch++ range basis).  X is streamed once, linearly; per-block

@@ -337,14 +337,62 @@ def test_fused_patch_factors_equal_materialised(dev, net, monkeypatch):
     params = kfac_params(model)
     kw = dict(fisher_type="empirical", separate_weight_and_bias=False, check_deterministic=False)
     facs = {}
-    for mode in ("0", "all", "1"):
-        monkeypatch.setattr(computers, "_FUSED_IM2COL", mode)
+    monkeypatch.setattr(computers, "_CAPTURE", False)
+    for mode in ("0", "all", "1", "pixel"):
+        monkeypatch.setattr(computers, "_FUSED_IM2COL", "1" if mode == "pixel" else mode)
+        monkeypatch.setattr(computers, "_PIXEL_GRAM", mode == "pixel")   # (pixel Gram + fold on small feature maps)
         K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y), (X.flip(0), y.flip(0))], **kw)
         facs[mode] = [blk[1] for blk in K[1] if len(blk) == 2]
-    for S0, S1, S2 in zip(facs["0"], facs["all"], facs["1"]):
-        assert torch.equal(S1, S1.T)
+    for S0, S1, S2, S3 in zip(facs["0"], facs["all"], facs["1"], facs["pixel"]):
+        assert torch.equal(S1, S1.T) and torch.equal(S3, S3.T)
         assert rel_err(S1, S0.double().cpu().numpy()) < 2e-5
         assert rel_err(S2, S0.double().cpu().numpy()) < 2e-5
+        assert rel_err(S3, S0.double().cpu().numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", ["resnet_toy", "lenet"])
+@pytest.mark.parametrize("fisher", ["mc", "empirical", "forward-only"])
+def test_captured_factor_build_equals_eager(dev, net, fisher, monkeypatch):
+    """The hipGraph-captured factor build (`computers._CapturedBatch`: the analogue of the reference's traced backend,
+    computers/kfac_make_fx.py:26-111) replays the SAME computation: factors equal the eager build's (same MC draws:
+    the graph registers the generator), for other data of the captured shape, after `.data` updates of the parameters
+    (addresses are baked, values are live), with a ragged last mini-batch (eager) accumulated behind captured ones."""
+    from curvlinops_amd import computers
+
+    torch.manual_seed(0)
+    if net == "resnet_toy":
+        model, mk = ResNetToy().to(dev).eval(), lambda n: (torch.rand(n, 3, 8, 8, device=dev), torch.randint(0, 5, (n,), device=dev))  # noqa: E731
+    else:
+        model, mk = lenet5().to(dev).eval(), lambda n: (torch.rand(n, 1, 32, 32, device=dev), torch.randint(0, 10, (n,), device=dev))  # noqa: E731
+    params = kfac_params(model)
+    kw = dict(fisher_type=fisher, separate_weight_and_bias=False, check_deterministic=False)
+    computers.reset_captured_builds()
+
+    def factors(data, capture):
+        monkeypatch.setattr(computers, "_CAPTURE", capture)
+        K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, data, **kw)
+        return [f for blk in K[1] for f in blk]
+
+    def same(a, b, tol=2e-5):
+        for x, y_ in zip(a, b):
+            assert rel_err(x, y_.double().cpu().numpy()) < tol
+
+    d1 = [mk(12), mk(12), mk(5)]
+    eager = factors(d1, False)
+    first = factors(d1, True)      # first 12-row batch eager (library warm-up), the second one captured + replayed
+    second = factors(d1, True)     # the 5-row batch comes back: captured too
+    assert sum(isinstance(v, computers._CapturedBatch) for v in computers._CAPTURED.values()) == 2
+    third = factors(d1, True)      # pure replay
+    same(first, eager), same(second, eager), same(third, eager)
+    d2 = [mk(12), mk(12), mk(5)]
+    same(factors(d2, True), factors(d2, False))
+    for p in params.values():
+        p.data.mul_(1.0 + 0.1 * torch.rand_like(p))
+    moved, replay = factors(d2, False), factors(d2, True)
+    same(replay, moved)
+    assert max(rel_err(a, b.double().cpu().numpy()) for a, b in zip(third, replay)) > 1e-3
+    computers.reset_captured_builds()
 
 
 @pytest.mark.gpu

@@ -521,9 +521,11 @@ def test_equal_shape_blocks_run_batched(dev, cls_name, sep):
     assert isinstance(K, BlockDiagonalLinearOperator) and K._kron_groups(), "equal-shape blocks must be grouped"
     v = torch.rand(op.shape[1], dtype=torch.float64)
     V = torch.rand(op.shape[1], 3, dtype=torch.float64)
-    assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4   # live factors, one foreign call
-    K.assume_frozen = True                                                        # stacked copies, batched products
+    assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4   # stacks re-made from the live factors
+    assert K._group_cache is None
+    K.assume_frozen = True                                                        # stacks kept
     assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4
+    assert K._group_cache is not None
     assert rel_err((op @ V.float().to(dev)).cpu(), (ref @ V).numpy()) < 1e-4
     assert rel_err((op.inverse(damping=1e-1) @ v.float().to(dev)).cpu(), (ref.inverse(damping=1e-1) @ v).numpy()) < 1e-3
 
@@ -772,7 +774,7 @@ def test_grouped_kronecker_blocks_see_inplace_factor_updates(dev):
     blocks[3][0].data.copy_(blocks[0][0].data * 0.3)
     assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL
     bd.assume_frozen = True
-    assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL     # grouped path on fresh stacks
+    assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL     # stacks kept from now on
     assert bd._group_cache is not None
     bd.assume_frozen = False
     blocks[0][0].data.mul_(2.0)
