@@ -225,8 +225,8 @@ class _factor_stream:
     """``with _factor_stream(t):`` -- on fp32 GPU tensors, run the body on the per-device factor
     stream once ``t`` (produced on the current stream) is ready; no-op elsewhere."""
 
-    def __init__(self, t: Tensor):
-        self._on = _OVERLAP and is_native_tensor(t)
+    def __init__(self, t: Tensor, on: bool = True):
+        self._on = on and _OVERLAP and is_native_tensor(t)
         self._t = t
 
     def __enter__(self):
@@ -433,6 +433,10 @@ def _patch_gram_accumulate(store: dict, key, x: Tensor, hyper: dict, n_data: int
 # of the cache key; their values are read at replay time), and the factors are copied / added out of the graph's
 # static buffers.  Nothing is cached but the launch sequence.
 _CAPTURE = True        # module knob (tools / tests flip it for A/B runs)
+_CAPTURE_FORK = "coarse"   # "fine": one fork of the factor stream per hook, as in eager mode (see `_run_batch`)
+_CAPTURE_G_CHUNK = 0   # coarse mode: gradient covariances per fork of the factor stream; 0 = inline on the main stream
+#                        (measured, tools/probe_kfac_fork.py: inline 4.3 - 4.8 ms, chunks of 6: 4.9 - 5.8 ms, one fork at
+#                        the end 4.75 ms per ResNet-18 build)
 _CAPTURE_AFTER = 1     # eager runs of a configuration before it is captured
 _CAPTURE_MAX = 4       # captured configurations kept (each holds its activations' memory pool + static factor buffers)
 _CAPTURED: dict = {}   # signature -> int (eager runs so far) | _CapturedBatch | False (capture failed: stay eager)
@@ -484,7 +488,7 @@ class _CapturedBatch:
             state = gen.get_state()
             with torch.cuda.graph(graph):
                 with _use_params(computer._model_module, computer._params):
-                    computer._run_batch(self.X, self.y, mapping, A, G)
+                    computer._run_batch(self.X, self.y, mapping, A, G, coarse_fork=_CAPTURE_FORK == "coarse")
                 for st in (A, G):            # factors no hook wrote (unused layers) are zero
                     for k in st.fresh:
                         st[k].zero_()
@@ -670,9 +674,19 @@ class HipKFACComputer(EmpiricalRiskMixin):
                 G[tuple(group.values())] = torch.eye(p.shape[0], dtype=p.dtype, device=self.device)
         return dict(A), dict(G), mapping
 
-    def _run_batch(self, X, y: Tensor, mapping, A, G, after_forward=None) -> None:
+    def _run_batch(self, X, y: Tensor, mapping, A, G, after_forward=None, coarse_fork: bool = False) -> None:
         """One mini-batch: forward pass with the input hooks (``A`` accumulation), backpropagation of the Fisher type's
-        vectors with the output-gradient hooks (``G`` accumulation); the factor stream is joined at the end."""
+        vectors with the output-gradient hooks (``G`` accumulation); the factor stream is joined at the end.
+
+        ``coarse_fork`` (graph capture): instead of one fork per hook -- 42 cross-stream edges in a ResNet-18 graph, each
+        a barrier packet with a completion signal in the main queue when the two branches sit on different hardware
+        queues -- the input-covariance work of ALL layers is queued on the factor stream behind ONE event at the end of
+        the forward pass (the layer inputs are alive until the backward pass anyway) and runs beside the backward pass;
+        the (small) gradient covariances run inline on the main stream (or in chunks of `_CAPTURE_G_CHUNK` layers, one
+        fork per chunk)."""
+        self._deferred_inputs = [] if coarse_fork else None
+        self._inline_grads = coarse_fork
+        self._deferred_grads = []
         handles = []
         for group in mapping:
             mod = self._module_of(group)
@@ -683,14 +697,24 @@ class HipKFACComputer(EmpiricalRiskMixin):
         self._hooked_outputs = []
         try:
             output = self._model_module(X)
+            if self._deferred_inputs:
+                jobs, self._deferred_inputs = self._deferred_inputs, None
+                with _factor_stream(output):
+                    for job in jobs:
+                        job()
+                del jobs
             if after_forward is not None:
                 after_forward()
             output, y = self._rearrange_output(output, y)
             self._backpropagate(output, y)
+            self._flush_deferred_grads(None)
         finally:
             for h in handles:
                 h.remove()
             self._hooked_outputs = []
+            self._deferred_inputs = None
+            self._deferred_grads = []
+            self._inline_grads = False
             _join_factor_stream(self.device)
 
     def _factor_sizes(self, mapping) -> tuple[dict, dict]:
@@ -723,7 +747,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
             id(model), type(self).__name__, type(self._loss_func).__name__, self._loss_func.reduction,
             str(self._fisher_type), self._mc_samples, str(self._kfac_approx), self._separate_weight_and_bias,
             self._N_data, self._num_per_example_loss_terms, tuple(self._params.keys()),
-            tuple(X.shape), tuple(y.shape), y.dtype, str(self.device), _FUSED_IM2COL, _FAST_BN, _OVERLAP,
+            tuple(X.shape), tuple(y.shape), y.dtype, str(self.device), _FUSED_IM2COL, _FAST_BN, _OVERLAP, _PIXEL_GRAM, _CAPTURE_FORK, _CAPTURE_G_CHUNK,
             tuple(m.training for m in mods),
             tuple((0, 0) if t is None else (t.data_ptr(), t.dtype) for t in tensors),
         )
@@ -870,27 +894,35 @@ class HipKFACComputer(EmpiricalRiskMixin):
     def _input_hook(self, module, inputs, group, hyper, store) -> None:
         if len(inputs) != 1:
             raise ValueError("Modules with multiple inputs are not supported.")
+        if getattr(self, "_deferred_inputs", None) is not None and is_native_tensor(inputs[0]):
+            x_keep = inputs[0].data.detach()
+            side = _FACTOR_STREAMS.get(x_keep.device) or side_stream(x_keep.device, 0)
+            x_keep.record_stream(side)
+            self._deferred_inputs.append(partial(self._input_job, x_keep, group, hyper, store))
+            return
         with _factor_stream(inputs[0]):
-            joint = "W" in group and "b" in group
-            x_in = inputs[0].data.detach()
-            if (hyper and self._kfac_approx == KFACType.EXPAND and is_native_tensor(x_in) and x_in.dim() == 4
-                    and _use_pixel_gram(hyper, x_in)):
-                # Conv2d on a small feature map: A from the pixel Gram X^T X (X = x as [B, C H W]) folded over the taps --
-                # fewer flops than the product over patches, no patch matrix (csrc/conv.hip)
-                _pixel_gram_accumulate(store, tuple(group.values()), _group_mean(x_in, hyper["groups"]), hyper,
-                                       self._N_data, ones_col=joint)
-                return
-            if (hyper and self._kfac_approx == KFACType.EXPAND and is_native_tensor(x_in) and x_in.dim() == 4
-                    and _use_fused_patches(hyper, x_in, joint)):
-                # Conv2d, KFAC-expand: the patch matrix [B O1 O2, C K1 K2] is generated inside the SYRK's
-                # tile loader and never written (reference materialises it, kfac_utils.py:78-121)
-                _patch_gram_accumulate(store, tuple(group.values()), _group_mean(x_in, hyper["groups"]), hyper,
-                                       self._N_data, ones_col=joint)
-                return
-            x = input_to_weight_sharing_format(x_in, self._kfac_approx, hyper)
-            shared = x.shape[1]
-            _gram_accumulate(store, tuple(group.values()), x.reshape(-1, x.shape[-1]),
-                             1.0 / (self._N_data * shared), ones_col=joint)
+            self._input_job(inputs[0].data.detach(), group, hyper, store)
+
+    def _input_job(self, x_in: Tensor, group, hyper, store) -> None:
+        joint = "W" in group and "b" in group
+        if (hyper and self._kfac_approx == KFACType.EXPAND and is_native_tensor(x_in) and x_in.dim() == 4
+                and _use_pixel_gram(hyper, x_in)):
+            # Conv2d on a small feature map: A from the pixel Gram X^T X (X = x as [B, C H W]) folded over the taps --
+            # fewer flops than the product over patches, no patch matrix (csrc/conv.hip)
+            _pixel_gram_accumulate(store, tuple(group.values()), _group_mean(x_in, hyper["groups"]), hyper,
+                                   self._N_data, ones_col=joint)
+            return
+        if (hyper and self._kfac_approx == KFACType.EXPAND and is_native_tensor(x_in) and x_in.dim() == 4
+                and _use_fused_patches(hyper, x_in, joint)):
+            # Conv2d, KFAC-expand: the patch matrix [B O1 O2, C K1 K2] is generated inside the SYRK's
+            # tile loader and never written (reference materialises it, kfac_utils.py:78-121)
+            _patch_gram_accumulate(store, tuple(group.values()), _group_mean(x_in, hyper["groups"]), hyper,
+                                   self._N_data, ones_col=joint)
+            return
+        x = input_to_weight_sharing_format(x_in, self._kfac_approx, hyper)
+        shared = x.shape[1]
+        _gram_accumulate(store, tuple(group.values()), x.reshape(-1, x.shape[-1]),
+                         1.0 / (self._N_data * shared), ones_col=joint)
 
     def _output_hook(self, module, inputs, output, group, hyper, store) -> None:
         self._track_output(output, partial(self._grad_hook, group=group, hyper=hyper, store=store))
@@ -902,9 +934,35 @@ class HipKFACComputer(EmpiricalRiskMixin):
             g = g.flatten(0, 1)
         corr = compute_loss_correction(batch_size, self._num_per_example_loss_terms,
                                        self._loss_func.reduction, self._N_data)
+        if getattr(self, "_inline_grads", False) and is_native_tensor(g):
+            # coarse fork (graph capture): the (small) gradient covariances run inline on the main stream
+            # (`_CAPTURE_G_CHUNK` = 0), or those of `_CAPTURE_G_CHUNK` consecutive layers share ONE fork of the factor
+            # stream (the gradients are kept alive until their chunk has been queued)
+            if _CAPTURE_G_CHUNK <= 0:
+                self._grad_job(g, corr, group, hyper, store)
+                return
+            side = _FACTOR_STREAMS.get(g.device) or side_stream(g.device, 0)
+            g.record_stream(side)
+            self._deferred_grads.append(partial(self._grad_job, g, corr, group, hyper, store))
+            if len(self._deferred_grads) >= _CAPTURE_G_CHUNK:
+                self._flush_deferred_grads(g)
+            return
         with _factor_stream(g):
-            g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
-            _gram_accumulate(store, tuple(group.values()), g.reshape(-1, g.shape[-1]), corr, ones_col=False)
+            self._grad_job(g, corr, group, hyper, store)
+
+    def _grad_job(self, g: Tensor, corr: float, group, hyper, store) -> None:
+        g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
+        _gram_accumulate(store, tuple(group.values()), g.reshape(-1, g.shape[-1]), corr, ones_col=False)
+
+    def _flush_deferred_grads(self, ready: Tensor | None) -> None:
+        jobs, self._deferred_grads = getattr(self, "_deferred_grads", []), []
+        if not jobs:
+            return
+        if ready is None:   # after the backward pass: everything on the current stream is ready
+            ready = torch.empty(0, device=self.device, dtype=torch.float32)
+        with _factor_stream(ready):
+            for job in jobs:
+                job()
 
 
 # ------------------------------------------------------------------------------------------

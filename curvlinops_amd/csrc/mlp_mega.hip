@@ -55,6 +55,12 @@ constexpr int MG_P1S = 8;                // k16 steps per wave in layer 1 (d0 <=
 #ifndef CLO_MG_XCD
 #define CLO_MG_XCD 1
 #endif
+// Skeleton builds (tools/run_mega_skeleton.sh): bit 0 drops the layer-1 / layer-2 MFMAs, bit 1 the delta_1 sweep's FMAs, bit 2
+// the FMAs of out_W2, bit 3 those of out_W1 -- every load, LDS copy, seam and store stays, each loaded value still feeds
+// (one add) what is stored, so the timing is that of the data movement and the exchanges alone; the results are garbage.
+#ifndef CLO_MG_ABLATE
+#define CLO_MG_ABLATE 0
+#endif
 constexpr int MG_PRE = CLO_MG_PRE;       // tile steps issued right behind the layer-1 loads
 // round 4: the compute waves keep requesting the layer-2 tile WHILE wave 7 runs the first seam, never
 // more than MG_PACE steps (3 KB per wave and step) ahead of what has landed: the vector-memory pipe of the CU stays busy
@@ -330,10 +336,14 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       const float bx = mg_and(bv.x, m), by = mg_and(bv.y, m), bz = mg_and(bv.z, m), bw = mg_and(bv.w, m);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
+#if CLO_MG_ABLATE & 1
+        acc[g] += f32x4{a1v[s][g].x + bx, a1v[s][g].y + by, a1v[s][g].z + bz, a1v[s][g].w + bw};
+#else
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[s][g].x, bx, acc[g], 0, 0, 0);
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[s][g].y, by, acc[g], 0, 0, 0);
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[s][g].z, bz, acc[g], 0, 0, 0);
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[s][g].w, bw, acc[g], 0, 0, 0);
+#endif
       }
     }
 #pragma unroll
@@ -447,10 +457,14 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
 #pragma unroll
         for (int g = 0; g < MG_MAXG; ++g) {
           const int gl = wave * MG_MAXG + g;
+#if CLO_MG_ABLATE & 1
+          acc[g] += f32x4{tv[s][g].x + bv.x, tv[s][g].y + bv.y, tv[s][g].z + bv.z, tv[s][g].w + bv.w};
+#else
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[s][g].x, bv.x, acc[g], 0, 0, 0);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[s][g].y, bv.y, acc[g], 0, 0, 0);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[s][g].z, bv.z, acc[g], 0, 0, 0);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[s][g].w, bv.w, acc[g], 0, 0, 0);
+#endif
           // branch-free copy of the W half (lanes idx < 8) into the LDS tile; other lanes hit a trash slot
           float *dst = (idx < 8 && gl < ng) ? &s_w[(gl * 8 + idx) * MG_LDW + s * 16 + s4] : &s_trash[lane * 4];
           *reinterpret_cast<float4 *>(dst) = tv[s][g];
@@ -706,12 +720,19 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
             if (jb + u * rpp < nj) {
               const float dn[MG_NB] = {da[u].x, da[u].y, da[u].z, da[u].w, db[u].x, db[u].y, db[u].z, db[u].w};
               const f32x2 w01 = {wv[u].x, wv[u].y}, w23 = {wv[u].z, wv[u].w};
+#if CLO_MG_ABLATE & 2
+              pa[0][0] += w01 + f32x2{dn[0], dn[1]};
+              pa[0][1] += w23 + f32x2{dn[2], dn[3]};
+              pa[1][0] += f32x2{dn[4], dn[5]};
+              pa[1][1] += f32x2{dn[6], dn[7]};
+#else
 #pragma unroll
               for (int n = 0; n < MG_NB; ++n) {
                 const f32x2 dd = {dn[n], dn[n]};
                 pa[n][0] = __builtin_elementwise_fma(dd, w01, pa[n][0]);
                 pa[n][1] = __builtin_elementwise_fma(dd, w23, pa[n][1]);
               }
+#endif
             }
           }
         }
@@ -759,12 +780,17 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
           const float4 da = mg_ld4(&s_d2[j * MG_NB]), db = mg_ld4(&s_d2[j * MG_NB + 4]);
           const float dn[MG_NB] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
           f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
+#if CLO_MG_ABLATE & 4
+          o01 = av[0][0] + f32x2{dn[0], dn[1]} + f32x2{dn[4], dn[5]};
+          o23 = av[0][1] + f32x2{dn[2], dn[3]} + f32x2{dn[6], dn[7]};
+#else
 #pragma unroll
           for (int n = 0; n < MG_NB; ++n) {
             const f32x2 dd = {dn[n], dn[n]};
             o01 = __builtin_elementwise_fma(dd, av[n][0], o01);
             o23 = __builtin_elementwise_fma(dd, av[n][1], o23);
           }
+#endif
           float4 o = make_float4(o01.x, o01.y, o23.x, o23.y);
           float *po = p.O2 + (long)(j0 + j) * d1 + k0 + cq * 4;
           if (ACCUM) {
@@ -840,11 +866,15 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
         const float4 da = mg_ld4(&s_m[MG_M_D1 + f * MG_NB]), db = mg_ld4(&s_m[MG_M_D1 + f * MG_NB + 4]);
         const float dn[MG_NB] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#if CLO_MG_ABLATE & 8
+        o = make_float4(xv[0].x + dn[0] + dn[4], xv[0].y + dn[1] + dn[5], xv[0].z + dn[2] + dn[6], xv[0].w + dn[3] + dn[7]);
+#else
 #pragma unroll
         for (int n = 0; n < MG_NB; ++n) {
           o.x = fmaf(dn[n], xv[n].x, o.x); o.y = fmaf(dn[n], xv[n].y, o.y);
           o.z = fmaf(dn[n], xv[n].z, o.z); o.w = fmaf(dn[n], xv[n].w, o.w);
         }
+#endif
         float *po = p.O1 + (long)(jA + f) * d0 + cq * 4;
         if (ACCUM) {
           const float4 od = mg_ld4(po);
