@@ -29,6 +29,9 @@ _PF = c_void_p  # float* passed as integer address
 _SIGNATURES = {
     "clo_version": (c_int, []),
     "clo_last_error": (c_char_p, []),
+    "clo_persistent_status": (c_int, [c_int]),
+    "clo_test_set_spin_limit": (c_int, [ctypes.c_uint]),
+    "clo_test_occupy": (c_int, [c_int, c_int, c_long, c_void_p]),
     "clo_prof_enable": (c_int, [c_int]),
     "clo_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_long), POINTER(ctypes.c_double)]),
     "clo_gemm_f32": (
@@ -219,6 +222,13 @@ def _device_safe(fn):
 def has(symbol: str) -> bool:
     """Whether this build of the library exports ``symbol``."""
     return symbol in _SIGNATURES and hasattr(load(), symbol)
+
+
+def persistent_status(device: int | None = None) -> int:
+    """Bit mask of the co-resident-grid modes the library has DISABLED on a device after one of their launches timed out
+    (bit 0 persistent MLP kernel, bit 1 tridiagonalisation panels, bit 2 stream-K GEMM): ``clo_persistent_status``."""
+    dev = torch.cuda.current_device() if device is None else int(device)
+    return int(load().clo_persistent_status(dev))
 
 
 def prof_enable(on: bool) -> None:

@@ -49,6 +49,20 @@ struct ProfScope {
   }
 };
 
+// ---- asynchronous faults of the kernels that wait on other workgroups (persistent grids, stream-K finishers) -----------
+// A wait that runs out of its spin budget -- the grid is not co-resident: another process or a CU mask holds compute units
+// -- does NOT trap (a trap is a sticky error of the whole HIP context).  The waiter raises the launch's device-side abort
+// word (every other wait of that launch then returns at once: the kernel runs to its end on garbage, all addresses are
+// shape-derived) and the device's fault word in host-pinned memory.  The NEXT call of the affected entry point sees the
+// word, disables the mode on that device (persistent MLP kernel -> launch chain, stream-K -> split-K, tridiagonalisation
+// -> half the workgroups) and returns CLO_EASYNC once, like HIP reports asynchronous errors: the results of the launch
+// that timed out are invalid, the context stays healthy.
+enum { FAULT_MEGA = 0, FAULT_SYTRD = 1, FAULT_STREAMK = 2, FAULT_KINDS = 3 };
+unsigned *fault_words_device(int dev);        // [FAULT_KINDS] device-visible address of the host-pinned words (nullptr: unavailable)
+bool fault_take(int dev, int kind);           // pending fault of `kind`: clears it, marks the mode disabled, returns true
+bool fault_disabled(int dev, int kind);       // the mode was disabled after a fault on this device
+unsigned spin_limit();                        // spin budget of every bounded wait (clo_test_set_spin_limit)
+
 __host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -50,6 +50,8 @@ struct V3Sched {
   float *slots;       // stream-K: workers x (BM BN) partial accumulators
   unsigned *flags;    // stream-K: one per worker; a worker publishes its partial by storing `epoch`
   unsigned epoch;     // stream-K: unique per launch on this (device, stream)
+  unsigned *fault;    // stream-K: host-pinned fault word of the device (or nullptr)
+  unsigned spin_limit;
 };
 
 __device__ __forceinline__ i32x4v v3_srd(const float *p) {
@@ -413,7 +415,10 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
               unsigned spins = 0;
               while (__hip_atomic_load(sf->flags + (long)(w2 * G + g) * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sf->epoch) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > V3_SPIN) __builtin_trap();   // fail loudly rather than add garbage
+                if (++spins > sf->spin_limit) {   // the partial never came: raise the device's fault word, go on (garbage)
+                  if (sf->fault) __hip_atomic_store(sf->fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  break;
+                }
               }
             }
             asm volatile("s_barrier" ::: "memory");
@@ -624,6 +629,19 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) workers = 0;
   }
+  if (workers > 0) {
+    // a finisher of an earlier stream-K launch on this device never saw a partial arrive (clo_common.h, "asynchronous
+    // faults"): reported once, here; split-K serves this device from now on
+    int fdev = 0;
+    if (hipGetDevice(&fdev) == hipSuccess) {
+      if (fault_take(fdev, FAULT_STREAMK)) {
+        set_error("GEMM: an EARLIER stream-K launch on device %d timed out waiting for a partial tile; its result is invalid. "
+                  "Split-K is used on this device from now on -- repeat the call.", fdev);
+        return CLO_EASYNC;
+      }
+      if (fault_disabled(fdev, FAULT_STREAMK)) workers = 0;
+    }
+  }
   const bool sk = workers > 0;
   if (sk) {
     s.streamk = 1;
@@ -643,6 +661,11 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
       s.team = G;
     const int rcf = v3_flags(stream, &s.flags, &s.epoch);
     if (rcf != CLO_OK) return rcf;
+    int fdev = 0;
+    (void)hipGetDevice(&fdev);
+    s.fault = fault_words_device(fdev);
+    if (s.fault) s.fault += FAULT_STREAMK;
+    s.spin_limit = spin_limit();
   }
   *used_streamk = sk;
   int dev_ = 0;

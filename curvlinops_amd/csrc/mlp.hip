@@ -3016,6 +3016,17 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
     CLO_REQUIRE(W[l] && VW[l] && OW[l], "clo_mlp_ggn_matvec: null weight pointer in layer %d", l);
   }
   hipStream_t st = (hipStream_t)stream;
+  {
+    // an earlier persistent launch on this device ran out of its spin budget (its grid was not co-resident): reported
+    // once, here; the launch chain serves this device from now on (clo_common.h, "asynchronous faults")
+    int fdev = 0;
+    if (hipGetDevice(&fdev) == hipSuccess && fault_take(fdev, FAULT_MEGA)) {
+      set_error("clo_mlp_ggn_matvec: an EARLIER product on device %d timed out inside the persistent kernel (its "
+                "workgroups were not co-resident: GPU shared with another process or CU-masked); that product's result is "
+                "invalid.  The launch chain is used on this device from now on -- repeat the call.", fdev);
+      return CLO_EASYNC;
+    }
+  }
   if (N == 0) {  // empty batch contributes nothing; still honour beta
     if (beta != 1.f)
       for (int l = 0; l < L; ++l) {

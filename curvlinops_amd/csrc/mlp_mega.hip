@@ -108,6 +108,8 @@ struct MegaArgs {
   float scale, beta;
   float *xch;       // exchange area, see mega_xch_floats
   unsigned *sync;   // counters, see mega_sync_words
+  unsigned *fault;  // host-pinned fault word of the device (or nullptr)
+  unsigned spin_limit;
 };
 
 // exchange area (floats): a1, da1 [NB][d1] | slab [16][2][NB][d2] | dphi2 [NB][d2] | hp [256][256] | gsum [16][256] | slab2 [16][NB][d1]
@@ -147,13 +149,19 @@ __device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void mg_arrive(unsigned *cnt) {
   __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void mg_wait(unsigned *cnt, unsigned target, unsigned *err) {
+// (bounded: on a timeout -- or when another workgroup of this launch has timed out -- the wait simply ends; see
+// "asynchronous faults" in clo_common.h)
+struct MgAbort { unsigned *err; unsigned *fault; unsigned limit; };
+__device__ __forceinline__ void mg_wait(unsigned *cnt, unsigned target, const MgAbort &ab) {
   unsigned spins = 0;
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > MG_SPIN) {  // ~seconds: the grid is not co-resident (or the counters were not initialised)
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_trap();         // fail loudly (launch failure on the host) rather than return garbage
+    ++spins;
+    if ((spins & 255u) == 0u && __hip_atomic_load(ab.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if (spins > ab.limit) {  // ~seconds: the grid is not co-resident (or the counters were not initialised)
+      __hip_atomic_store(ab.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ab.fault) __hip_atomic_store(ab.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
     }
   }
 }
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   unsigned *set = sy + 32 * (1 + (call & 1) * MG_SET_LINES);
   unsigned *c_colA = set + 32 * kb, *c_rowA = set + 32 * (16 + fb), *c_rowB = set + 32 * (32 + fb);
   unsigned *c_colB = set + 32 * (48 + kb), *c_top = set + 32 * 64;
-  unsigned *c_err = sy + 1;
+  const MgAbort c_err{sy + 1, p.fault, p.spin_limit};
   MG_STAMP(0);
   if (w == 0) {  // zero the other set for the next call
     unsigned *other = sy + 32 * (1 + ((call & 1) ^ 1) * MG_SET_LINES);
@@ -920,7 +928,25 @@ bool mega_ok(int L, const int *dims, const float *const *W, const float *const *
     c = prop.multiProcessorCount;
     __atomic_store_n(&ncu[dev], c, __ATOMIC_RELAXED);
   }
-  return c == MG_G;  // one workgroup per CU, all of them resident: the group counters rely on it
+  if (c != MG_G) return false;  // one workgroup per CU, all of them resident: the group counters rely on it
+  if (fault_disabled(dev, FAULT_MEGA)) return false;   // a launch on this device timed out before: the launch chain serves
+  // every workgroup needs a CU to itself AND one must fit at all (LDS carve, registers) on this device
+  static int occ[MG_MAXDEV];
+  static std::once_flag once_occ;
+  std::call_once(once_occ, [] { for (int &o : occ) o = -1; });
+  int o = __atomic_load_n(&occ[dev], __ATOMIC_RELAXED);
+  if (o < 0) {
+    int nb = 0;
+    const void *fn = reinterpret_cast<const void *>(mlp_mega_kernel<false>);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MG_LDS_FLOATS * sizeof(float)));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, MG_T, MG_LDS_FLOATS * sizeof(float)) != hipSuccess) {
+      (void)hipGetLastError();
+      nb = 0;
+    }
+    o = nb >= 1 ? 1 : 0;
+    __atomic_store_n(&occ[dev], o, __ATOMIC_RELAXED);
+  }
+  return o == 1;
 }
 
 int mega_launch(const int *dims, const int *acts, const float *const *W, const float *const *b,
@@ -937,6 +963,7 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
   a.act1 = acts[0]; a.act2 = acts[1];
   a.kind = loss_kind; a.aux = aux; a.aux_rank = aux_rank; a.scale = scale; a.beta = beta;
   a.xch = xch; a.sync = sync;
+  a.spin_limit = spin_limit();
   const size_t smem = (size_t)MG_LDS_FLOATS * sizeof(float);
   static bool attr_done[MG_MAXDEV][2];  // hipFuncSetAttribute is per device; guarded by `mu` below
   const int v = beta != 0.f ? 1 : 0;
@@ -959,6 +986,8 @@ int mega_launch(const int *dims, const int *acts, const float *const *W, const f
       attr_done[dev][v] = true;
     }
   }
+  a.fault = fault_words_device(dev);
+  if (a.fault) a.fault += FAULT_MEGA;
   PersistGate &gate = PersistGate::of(dev);
   {
     int rc = gate.admit(st, MG_G);

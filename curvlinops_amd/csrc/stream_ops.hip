@@ -3,6 +3,7 @@
 // scaling of EighDecomposed operators) and counter-based probe packing.
 #include "clo_common.h"
 
+#include <mutex>
 #include <vector>
 
 namespace clo {
@@ -14,6 +15,53 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- asynchronous fault words (clo_common.h) ------------------------------------------------------------------------
+namespace {
+struct FaultState {
+  unsigned *host = nullptr, *dev = nullptr;
+  bool tried = false;
+  bool disabled[FAULT_KINDS] = {false, false, false};
+};
+FaultState g_fault[64];
+std::mutex g_fault_mu;
+unsigned g_spin_limit = 1u << 22;
+FaultState &fault_state(int dev) {
+  FaultState &f = g_fault[dev & 63];
+  if (!f.tried) {
+    std::lock_guard<std::mutex> lock(g_fault_mu);
+    if (!f.tried) {
+      void *h = nullptr, *d = nullptr;
+      if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        f.host = static_cast<unsigned *>(h);
+        f.dev = static_cast<unsigned *>(d);
+        for (int i = 0; i < 16; ++i) f.host[i] = 0u;
+      } else {
+        (void)hipGetLastError();
+      }
+      f.tried = true;
+    }
+  }
+  return f;
+}
+}  // namespace
+unsigned *fault_words_device(int dev) { return fault_state(dev).dev; }
+bool fault_take(int dev, int kind) {
+  FaultState &f = fault_state(dev);
+  if (!f.host || __atomic_load_n(&f.host[kind], __ATOMIC_RELAXED) == 0u) return false;
+  __atomic_store_n(&f.host[kind], 0u, __ATOMIC_RELAXED);
+  f.disabled[kind] = true;
+  return true;
+}
+bool fault_disabled(int dev, int kind) { return g_fault[dev & 63].disabled[kind]; }
+unsigned spin_limit() { return g_spin_limit; }
+
+__global__ void occupy_kernel(long ticks) {
+  extern __shared__ float occ_lds[];
+  const unsigned long long t0 = wall_clock64();
+  if (threadIdx.x == 0) occ_lds[0] = 0.f;
+  while ((long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 // ---- event-based kernel timing -------------------------------------------------------------
@@ -324,6 +372,32 @@ extern "C" int clo_prof_collect(double *ms, long *count, double *alg_bytes) {
   return CLO_OK;
 }
 extern "C" const char *clo_last_error(void) { return g_err; }
+
+extern "C" int clo_persistent_status(int dev) {
+  int bits = 0;
+  for (int k = 0; k < FAULT_KINDS; ++k) {
+    (void)fault_take(dev, k);
+    if (fault_disabled(dev, k)) bits |= 1 << k;
+  }
+  return bits;
+}
+extern "C" int clo_test_set_spin_limit(unsigned polls) {
+  CLO_REQUIRE(polls >= 16, "clo_test_set_spin_limit: at least 16 polls");
+  g_spin_limit = polls;
+  return CLO_OK;
+}
+extern "C" int clo_test_occupy(int blocks, int lds_bytes, long ticks, void *stream) {
+  CLO_REQUIRE(blocks >= 1 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && ticks >= 0, "clo_test_occupy: bad arguments");
+  if (lds_bytes > 64 * 1024) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
+                       "clo_test_occupy: LDS attribute");
+    if (rc != CLO_OK) return rc;
+  }
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, ticks);
+  CLO_CHECK_LAUNCH("occupy_kernel");
+  return CLO_OK;
+}
 
 extern "C" int clo_axpby_f32(float *y, const float *x, long n, float alpha, float beta,
                              void *stream) {

@@ -86,18 +86,25 @@ struct TpArgs {
   long o_W, o_u0[2], o_vv[2], o_gpart[3], o_gam;   // float offsets inside ws
   float *D, *E, *tau;
   unsigned *cnt;             // [TD_GMAX / 16 + 1] counters (one per 128-byte line), zero at launch, then {err}
+  unsigned *fault;           // host-pinned fault word of the device (or nullptr)
+  unsigned spin_limit;
 };
 constexpr int TP_GROUP = 16;
 constexpr int TP_CNT_WORDS = 32 * (TD_GMAX / TP_GROUP + 2);   // group counters, top counter, error word: one line each
 constexpr unsigned TP_SPIN = 1u << 22;
 
-__device__ __forceinline__ void tp_wait(unsigned *cnt, unsigned target, unsigned *err) {
+// bounded wait; on a timeout (or when another workgroup of the launch has timed out) it simply ends: the reduction then
+// finishes on garbage, which the eigensolver's verification rejects (float64 retry) -- clo_common.h, "asynchronous faults"
+__device__ __forceinline__ void tp_wait(unsigned *cnt, unsigned target, unsigned *err, unsigned *fault, unsigned limit) {
   unsigned spins = 0;
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > TP_SPIN) {   // ~seconds: the grid is not co-resident
+    ++spins;
+    if ((spins & 255u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if (spins > limit) {   // ~seconds: the grid is not co-resident
       __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_trap();
+      if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
     }
   }
 }
@@ -497,10 +504,10 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
     const unsigned epoch = (unsigned)(c + 1);
     if (tid == 0) __hip_atomic_fetch_add(c_grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x % TP_GROUP == 0 && tid == 0) {   // the group's leader: everybody of the group has arrived -> top counter
-      tp_wait(c_grp, (unsigned)gsize * epoch, c_err);
+      tp_wait(c_grp, (unsigned)gsize * epoch, c_err, p.fault, p.spin_limit);
       __hip_atomic_fetch_add(c_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0) tp_wait(c_top, (unsigned)ngroups * epoch, c_err);
+    if (tid == 0) tp_wait(c_top, (unsigned)ngroups * epoch, c_err, p.fault, p.spin_limit);
     __syncthreads();
     TD_STAMP(6);   // barrier
   }
@@ -590,7 +597,14 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   // a panel grid spins on its own workgroups: never more of them than can be resident at once (one per CU of THIS
   // device -- a partition or a CU-masked queue has fewer than 256), whatever the caller asked for
-  const int gmax = std::min(max_blocks > 0 ? std::min(max_blocks, TD_GMAX) : TD_GMAX, device_cu_count(dev));
+  int gmax = std::min(max_blocks > 0 ? std::min(max_blocks, TD_GMAX) : TD_GMAX, device_cu_count(dev));
+  if (fault_take(dev, FAULT_SYTRD)) {
+    set_error("clo_sytrd_f32: an EARLIER reduction on device %d timed out waiting for its own workgroups (GPU shared with "
+              "another process or CU-masked); its result is invalid.  Panel launches use at most a quarter of the compute "
+              "units on this device from now on -- repeat the call.", dev);
+    return CLO_EASYNC;
+  }
+  if (fault_disabled(dev, FAULT_SYTRD)) gmax = std::max(1, std::min(gmax, device_cu_count(dev) / 4));
 
   const size_t lds = (2 * n4 + TD_WAVES * TD_NPART + 5 * TD_NB + 5 * TD_WAVES + 16) * sizeof(float);
   // several host threads may run reductions at once (linalg_native.eigh_many): the attribute must be in
@@ -637,6 +651,9 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
     a.o_gpart[0] = gpart[0] - ws; a.o_gpart[1] = gpart[1] - ws; a.o_gpart[2] = gpart[2] - ws;
     a.o_gam = gam - ws;
     a.D = D; a.E = E; a.tau = tau; a.cnt = cnt;
+    a.fault = fault_words_device(dev);
+    if (a.fault) a.fault += FAULT_SYTRD;
+    a.spin_limit = spin_limit();
     // (no partly resident persistent grids side by side: csrc/persist_gate.h)
     PersistGate &gate = PersistGate::of(dev);
     rc = gate.admit(st, G);

@@ -292,7 +292,11 @@ def _unit_scale(A: Tensor) -> tuple[Tensor, Tensor]:
     return A / s, s
 
 
-_ORTH_TOL = 1e-4   # healthy float32 eigenvectors: |Q^T Q - I| <= 2e-5 up to order 8000
+# healthy float32 eigenvectors: |Q^T Q - I| <= 2e-5 up to order 8000 (full-rank "Wishart" factors 1 ... 4e-6).  Covariances with
+# large clusters of (near-)equal eigenvalues -- dead ReLU units, repeated rows: tests/golden/eigh_regression.npz -- can come
+# back with 5e-5 ... 1e-4 from the divide & conquer; they are redone in float64 (the bound was 1e-4 while the absolute
+# residual test still rejected those cases for another reason)
+_ORTH_TOL = 4e-5
 
 
 def _orth_defect(Q: Tensor) -> Tensor:

@@ -26,6 +26,9 @@ extern "C" {
 #define CLO_EHIP -2     /* a HIP runtime call or kernel launch failed       */
 #define CLO_ENOTPD -3   /* Cholesky: matrix not positive definite           */
 #define CLO_EUNSUP -4   /* valid request this build does not implement      */
+#define CLO_EASYNC -5   /* an EARLIER launch of this entry point timed out waiting for its own workgroups (GPU shared
+                           with another process / CU mask): its results are invalid; the mode has been disabled on this
+                           device and the call can simply be repeated (reported once)                                    */
 
 /* Activation codes (elementwise nonlinearity after a Linear layer). */
 #define CLO_ACT_IDENTITY 0
@@ -42,6 +45,15 @@ extern "C" {
 
 int clo_version(void);
 const char *clo_last_error(void);
+
+/* Health of the modes that need a co-resident grid on device `dev`: bit 0 persistent MLP kernel, bit 1 persistent
+ * tridiagonalisation panels, bit 2 stream-K GEMM schedule -- set = disabled after a timeout (see CLO_EASYNC); a pending,
+ * not yet reported timeout is reported (and the mode disabled) by this call as well. */
+int clo_persistent_status(int dev);
+/* Diagnostics for the fail-soft tests: the spin budget of every bounded wait (default 1 << 22 polls, ~seconds), and a
+ * kernel that keeps `blocks` workgroups with `lds_bytes` of LDS each busy for `ticks` ticks of the 100 MHz wall clock. */
+int clo_test_set_spin_limit(unsigned polls);
+int clo_test_occupy(int blocks, int lds_bytes, long ticks, void *stream);
 
 /* Optional per-kernel timing (HIP events on the launch stream) for the roofline leg of bench.py.
  * clo_prof_collect fills arrays of 8 entries indexed by tag (0 forward+JVP weight stream,

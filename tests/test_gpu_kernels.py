@@ -957,6 +957,47 @@ def test_pixel_gram_fold_matches_patch_product(B, C_, H, W, k, s, p, d, ones):
     assert rel_err(Cf.cpu(), (0.75 * ref).cpu().numpy()) < 2e-5
 
 
+@pytest.mark.gpu
+def test_persistent_kernel_fails_soft_when_the_gpu_is_shared():
+    """The persistent <= 8-row kernel needs all its 256 workgroups resident.  While ANOTHER PROCESS holds 200 compute units
+    (tools/failsoft_hog.py) a launch cannot become co-resident: its bounded waits must END the kernel (garbage results) --
+    no trap, no sticky context error --, the next call reports the timeout once (CLO_EASYNC -> RuntimeError), the mode is
+    disabled on the device and the launch chain serves the following products (equal to the chain's reference)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    victim = subprocess.Popen([sys.executable, os.path.join(root, "tools", "failsoft_victim.py")], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    hog = None
+    try:
+        line = victim.stdout.readline()
+        assert "victim ready" in line, line + victim.stderr.read()
+        hog = subprocess.Popen([sys.executable, os.path.join(root, "tools", "failsoft_hog.py"), "10"], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True)
+        assert "hog running" in hog.stdout.readline()
+        time.sleep(0.5)
+        victim.stdin.write("go\n")
+        victim.stdin.flush()
+        out, err = victim.communicate(timeout=120)
+        res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    finally:
+        if hog is not None:
+            hog.wait(timeout=60)
+        if victim.poll() is None:
+            victim.kill()
+    assert victim.returncode == 0, err[-2000:]
+    assert res["persistent_equals_chain_when_free"] and res["status_before"] == 0
+    assert res["timed_out_launch_returned"], res          # the kernel ended on its own
+    assert res["timed_out_seconds"] < 8.0, res             # ... well before the hog released the CUs
+    assert res["reported"], res                            # ... and the next call said so, once
+    assert res["status_after"] & 1, res                    # persistent MLP kernel disabled on this device
+    assert res["next_product_equals_chain"] and res["context_alive"], res
+
+
 # ---------------------------------------------------------------------------------------------
 # Householder tridiagonalisation (clo_sytrd_f32) and the eigensolver built on it
 # ---------------------------------------------------------------------------------------------
