@@ -8,7 +8,8 @@ rows = list(con.execute("select name, start, end, grid_x from kernels order by s
 marks = [i for i, r in enumerate(rows) if "axpby" in r[0] and r[3] in (4352, 4099, 4096 + 256)]
 if len(marks) < 2:  # fall back: any axpby launches
     marks = [i for i, r in enumerate(rows) if "axpby" in r[0]][-3:]
-sections = [("factor build", marks[0], marks[1])] + ([("damped Cholesky inverses", marks[1], marks[2])] if len(marks) > 2 else [])
+import os
+sections = [(os.environ.get("SECTION_TITLE", "factor build"), marks[0], marks[1])] + ([("damped Cholesky inverses", marks[1], marks[2])] if len(marks) > 2 else [])
 for title, a, b in sections:
     sel = rows[a + 1:b]
     wall = (rows[b][1] - rows[a][2]) / 1e3
@@ -24,5 +25,5 @@ for title, a, b in sections:
     print("#  calls   total_us    avg_us  kernel")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
         print(f"{c:7d} {t:10.1f} {t / c:9.2f}  {k}")
-    if title == "factor build":
+    if a == marks[0]:
         print(f"clo_kernel_us {clo:.1f}")
