@@ -62,6 +62,9 @@ unsigned *fault_words_device(int dev);        // [FAULT_KINDS] device-visible ad
 bool fault_take(int dev, int kind);           // pending fault of `kind`: clears it, marks the mode disabled, returns true
 bool fault_disabled(int dev, int kind);       // the mode was disabled after a fault on this device
 unsigned spin_limit();                        // spin budget of every bounded wait (clo_test_set_spin_limit)
+// `blocks` one-wave workgroups that each idle for `ticks` ticks of the 100 MHz wall clock (dispatch-bound for small `ticks`):
+// the probe kernel of clo_test_occupy and of the helper-stream calibration in linalg.hip
+int launch_occupy(int blocks, int lds_bytes, long ticks, hipStream_t st);
 
 __host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 

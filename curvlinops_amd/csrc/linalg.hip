@@ -523,9 +523,10 @@ static int chol_rec(const CholCtx &c, int o, int m) {
 // so the critical path is nodes + two skinny products per block column (n = 4608: 36 x ~70 us) instead of everything.
 // Events are recorded before they are waited for in host order (no wait can precede its record in a hardware queue).
 struct CholAsync {
-  hipStream_t side = nullptr, inv = nullptr, inv2 = nullptr;
+  hipStream_t main = nullptr, side = nullptr, inv = nullptr, inv2 = nullptr;
   std::vector<hipEvent_t> ev;
-  hipEvent_t done = nullptr;   // recorded on the caller's stream at the end of the call that used the set last
+  hipEvent_t fork = nullptr;   // caller's stream -> main
+  hipEvent_t done = nullptr;   // recorded on `main` at the end of the call that used the set last (the caller's stream waits for it)
   int err = CLO_OK;
   hipEvent_t event(size_t i) {
     while (ev.size() <= i) {
@@ -541,6 +542,13 @@ struct CholAsync {
 // its previous call may still be queued: the helper streams are in order, and every wait below follows its record.
 static std::mutex g_chol_pool_mu;
 static std::vector<CholAsync *> g_chol_pool[64];
+// (Round 5, measured and not kept: the helper's hardware queue shares one of the command processor's four dispatch pipes
+// with the caller's queue whenever their creation ranks differ by a multiple of four -- tools/ubench_queue_pipes.py: a
+// dispatch-bound kernel beside the null stream takes 1.8 x its solo time on three of four fresh streams and 2.4 - 3.3 x on
+// every fourth -- and every kernel of the pipeline then runs ~1.4 x longer (42 ResNet-18 factors: 16.8 instead of 11.5 ms;
+// profiles/r05_cholesky_queue_pipes.txt).  Which rank the helper gets depends on how many streams the process created
+// before its first inverse.  Picking the helper among four back-to-back candidates by a timed probe, and running the
+// critical chain on a second stream of the set, were both tried: neither was reliably better than the lottery.)
 static CholAsync *chol_async_acquire(int *dev_out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -577,7 +585,19 @@ static CholAsync *chol_async_acquire(int *dev_out) {
 #define CLO_CHOL_HELPERS 1
 #endif
   static const int nhelp = CLO_CHOL_HELPERS;
-  bool ok = hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
+  // The critical chain runs on a stream of THIS set as well (`main`, created right before its helper), not on the caller's
+  // stream: two hardware queues that sit on the same dispatch pipe of the command processor halve each other's workgroup
+  // dispatch rate -- every kernel of the pipeline then runs ~1.4 x longer (rocprofv3: 19.3 instead of 13.8 ms of kernel time
+  // for ResNet-18's 42 factors, 16.8 instead of 11.5 ms wall) -- and which pipe the CALLER's queue sits on relative to a helper
+  // created much later is a lottery (it flipped when a captured hipGraph with a second branch was alive in the process).
+  // Two queues created back to back get consecutive ids, i.e. different pipes.
+#ifndef CLO_CHOL_OWN_MAIN
+#define CLO_CHOL_OWN_MAIN 0
+#endif
+  static const int own_main = CLO_CHOL_OWN_MAIN;
+  bool ok = !own_main || (hipStreamCreateWithPriority(&a->main, hipStreamNonBlocking, least) == hipSuccess &&
+                          hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) == hipSuccess);
+  ok = ok && hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
   if (ok && nhelp >= 3) {
     ok = hipStreamCreateWithPriority(&a->inv, hipStreamNonBlocking, least) == hipSuccess &&
          hipStreamCreateWithPriority(&a->inv2, hipStreamNonBlocking, least) == hipSuccess;
@@ -672,9 +692,20 @@ static int chol_pipe(const CholCtx &c, float *G_side, float *G_inv, float *G_inv
   int dev = 0;
   CholAsync *as = chol_async_acquire(&dev);
   if (!as) { set_error("cholesky inverse: cannot create the side streams"); return CLO_EHIP; }
-  int rc = chol_pipe_run(c, G_side, G_inv, G_inv2, as);
+  CholCtx cm = c;
+  int rc = CLO_OK;
+  if (as->main) {   // fork: the set's main stream takes over behind everything queued on the caller's stream
+    rc = check_hip(hipEventRecord(as->fork, c.st), "hipEventRecord");
+    if (rc == CLO_OK) rc = check_hip(hipStreamWaitEvent(as->main, as->fork, 0), "hipStreamWaitEvent");
+    cm.st = as->main;
+  }
+  if (rc == CLO_OK) rc = chol_pipe_run(cm, G_side, G_inv, G_inv2, as);
   if (!as->done && hipEventCreateWithFlags(&as->done, hipEventDisableTiming) != hipSuccess) as->done = nullptr;
-  if (as->done && rc == CLO_OK) rc = check_hip(hipEventRecord(as->done, c.st), "hipEventRecord");
+  if (as->done && rc == CLO_OK) rc = check_hip(hipEventRecord(as->done, cm.st), "hipEventRecord");
+  if (as->main && rc == CLO_OK) {   // join: the caller's stream continues when the pipeline is through
+    if (!as->done) rc = check_hip(hipStreamSynchronize(as->main), "hipStreamSynchronize");
+    else rc = check_hip(hipStreamWaitEvent(c.st, as->done, 0), "hipStreamWaitEvent");
+  }
   chol_async_release(as, dev);
   return rc;
 }

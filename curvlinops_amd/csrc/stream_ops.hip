@@ -64,6 +64,17 @@ __global__ void occupy_kernel(long ticks) {
   while ((long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+int launch_occupy(int blocks, int lds_bytes, long ticks, hipStream_t st) {
+  if (lds_bytes > 64 * 1024) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
+                       "occupy_kernel: LDS attribute");
+    if (rc != CLO_OK) return rc;
+  }
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), (size_t)lds_bytes, st, ticks);
+  return check_hip(hipGetLastError(), "occupy_kernel");
+}
+
 // ---- event-based kernel timing -------------------------------------------------------------
 struct ProfRec { hipEvent_t a, b; int tag; double bytes; };
 static bool g_prof_on = false;
@@ -388,15 +399,7 @@ extern "C" int clo_test_set_spin_limit(unsigned polls) {
 }
 extern "C" int clo_test_occupy(int blocks, int lds_bytes, long ticks, void *stream) {
   CLO_REQUIRE(blocks >= 1 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && ticks >= 0, "clo_test_occupy: bad arguments");
-  if (lds_bytes > 64 * 1024) {
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
-                       "clo_test_occupy: LDS attribute");
-    if (rc != CLO_OK) return rc;
-  }
-  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, ticks);
-  CLO_CHECK_LAUNCH("occupy_kernel");
-  return CLO_OK;
+  return launch_occupy(blocks, lds_bytes, ticks, (hipStream_t)stream);
 }
 
 extern "C" int clo_axpby_f32(float *y, const float *x, long n, float alpha, float beta,
