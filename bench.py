@@ -391,8 +391,17 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
         feat = o.shape[1] if isinstance(mod, nn.Conv2d) else o.shape[-1]
         return o.numel() // (o.shape[0] * feat)
 
-    hooks = [m.register_forward_hook(lambda mod, i, o: pos.__setitem__(mod, shared_positions(mod, o)))
-             for m in model.modules() if isinstance(m, (nn.Conv2d, nn.Linear))]
+    pix = {}   # conv layers whose input covariance comes from the pixel Gram (csrc/conv.hip): order of that Gram
+
+    def note(mod, i, o):
+        from curvlinops_amd import computers
+
+        pos[mod] = shared_positions(mod, o)
+        x = i[0]
+        if isinstance(mod, nn.Conv2d) and x.dim() == 4 and computers._use_pixel_gram(computers._conv_hyperparams(mod), x):
+            pix[mod] = (x.shape[1] // mod.groups) * x.shape[2] * x.shape[3]
+
+    hooks = [m.register_forward_hook(note) for m in model.modules() if isinstance(m, (nn.Conv2d, nn.Linear))]
     with torch.no_grad():
         model(X[:2])
     for h in hooks:
@@ -443,17 +452,20 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
         if clo_us:
             executed = 0.0
             for m, S in pos.items():
-                for d in (m.weight[0].numel() + (1 if m.bias is not None else 0), m.weight.shape[0]):
+                for which, d in (("a", m.weight[0].numel() + (1 if m.bias is not None else 0)), ("g", m.weight.shape[0])):
+                    k = rows * S
+                    if which == "a" and m in pix:   # X^T X of X = x as [rows, C H W]: K = rows, order C H W
+                        d, k = pix[m], rows
                     nt = max(1, -(-d // 128))
-                    executed += 2.0 * rows * S * d * d * (nt + 1) / (2.0 * nt)
+                    executed += 2.0 * k * d * d * (nt + 1) / (2.0 * nt)
             out["roofline"]["clo_kernels"] = {
                 "kernel_ms_rocprof": clo_us / 1e3, "executed_gflop": executed / 1e9,
                 "achieved_tflops_executed": executed / clo_us / 1e6,
                 "frac_of_f32_mfma_peak": executed / clo_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
                 "source": "profiles/" + os.path.basename(latest_profile("kfac_resnet18_build_kernels.txt") or "")
-                          + " (rocprofv3 --kernel-trace of one warm build: "
-                          "im2col, SYRK / Gram, split-K reduce kernels; they run on a side stream under the autograd "
-                          "kernels, and the build itself is bound by the host's dispatch of ~440 launches)"}
+                          + " (rocprofv3 --kernel-trace of one warm build = one replay of the captured hipGraph: pixel-Gram "
+                          "SYRKs + fold, SYRK / Gram, split-K reduce kernels; the input covariances run on the graph's "
+                          "second branch beside the backward pass)"}
         v = torch.rand(K.shape[1], device=device)
         K @ v
         torch.cuda.synchronize()
@@ -691,7 +703,8 @@ def main() -> None:
                 "alg_bytes_per_column": 8 * D,
                 "definition": "8 D algorithmic bytes per column (V read, result written; W shared; SURVEY 8d) x 32 columns / "
                               "time of one G @ [D, 32] product; K = 64 beside it in other_points",
-                "profile": "profiles/r04_c2_k32_kernel_stats.txt, profiles/r04_c2_k32_pmc_traffic.txt",
+                "profile": ", ".join("profiles/" + os.path.basename(latest_profile(f) or "?") for f in
+                                     ("c2_k32_kernel_stats.txt", "c2_k32_pmc_traffic.txt")),
             }
         try:
             result["other_points"].update(secondary_configs(device))

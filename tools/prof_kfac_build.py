@@ -8,6 +8,9 @@ import curvlinops_amd as C
 from curvlinops_amd import _hip
 from benchmarks.models import ResNet18, kfac_params
 
+if os.environ.get("KFAC_EAGER"):
+    from curvlinops_amd import computers
+    computers._CAPTURE = False
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = ResNet18().to(dev).eval()
