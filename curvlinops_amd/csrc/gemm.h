@@ -80,9 +80,11 @@ bool gemm_v2_eligible(const GemmArgs &a, int batch);
 // LDS-DMA engine (gemm_v3.hip): 128 x 128 x 32 tiles, optional stream-K schedule
 bool gemm_v3_eligible(const GemmArgs &a, int batch);
 bool gemm_v3_would_streamk(int M, int N, int K, long batch);
+bool gemm_v3_small(const GemmArgs &a, int batch);   // the 64 x 64 tile configuration of the LDS-DMA engine serves this problem
 long gemm_streamk_ws_floats();          // any tile configuration
 long gemm_streamk_ws_floats_square();   // 128 x 128 tiles only
-int launch_gemm_v3(const GemmArgs &a, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk);
+int launch_gemm_v3(const GemmArgs &a, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk,
+                   int *tile_m = nullptr, int *tile_n = nullptr);   // tile_m / tile_n: block tile extents of the configuration that ran
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream);
 int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int batch = 1);
 int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float *V, const float *b,

@@ -971,10 +971,14 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   else if (b_kc) CLO_V2(false, true, BKV, BMV, BNV, WM_, WN_)           \
   else CLO_V2(false, false, BKV, BMV, BNV, WM_, WN_)
     const long nblocks = (long)grid.x * grid.y;
-    if (cfg.bm == 128 && cfg.bk == 32 && gemm_v3_eligible(a, batch)) {
+    if (((cfg.bm == 128 && cfg.bk == 32) || (cfg.bk == 64 && gemm_v3_small(a, batch))) && gemm_v3_eligible(a, batch)) {
+      if (cfg.bk == 64) {   // (the LDS-DMA engine's k tiles are 32 deep)
+        a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), 32) * 32;
+        a.splitk = (int)cdiv(a.K, a.k_per_split);
+      }
       // LDS-DMA engine (gemm_v3.hip); with a stream-K workspace it may finish the split tiles itself
       bool used_streamk = false;
-      int rc3 = launch_gemm_v3(a, batch, a_kc, b_kc, stream, &used_streamk);
+      int rc3 = launch_gemm_v3(a, batch, a_kc, b_kc, stream, &used_streamk, &a.tbm, &a.tbn);
       if (rc3 != CLO_OK) return rc3;
       if (used_streamk) a.splitk = 1;
     }

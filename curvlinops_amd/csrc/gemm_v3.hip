@@ -184,7 +184,10 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
   using DA = V3Op<AKC, BMt, NW>;
   using DB = V3Op<BKC, BNt, NW>;
   constexpr int PER = DA::PPW + DB::PPW;  // DMA instructions per wave per k tile
-  static_assert(MT + NT + PER <= 4 * MT * NT, "one slot behind each MFMA");
+  constexpr int SLOTS = 4 * MT * NT;            // one slot behind each MFMA of an 8-k group
+  static_assert(MT + NT + 1 <= SLOTS, "fragment reads and the bookkeeping statement need a slot each");
+  constexpr int PER_SLOTTED = PER < SLOTS - (MT + NT) ? PER : SLOTS - (MT + NT);   // DMA pieces that get a slot; the rest
+                                                                                  // (small tiles: 2 of 4) follow the group
   static_assert(NST >= 3, "ring depth");
   extern __shared__ __attribute__((aligned(1024))) float lds3[];
 
@@ -343,11 +346,18 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
       V3_SB                                                                                                  \
       if (m < MT) fa[(BUF) ^ 1][m] = DA::frag(as_, wm * WM + m * 32 + li, GN, lh);                           \
       else if (m < MT + NT) fb[(BUF) ^ 1][m - MT] = DB::frag(bs_, wn * WNC + (m - MT) * 32 + li, GN, lh);    \
-      else if (DMA && m - (MT + NT) < PER) {                                                                 \
+      else if (DMA && m - (MT + NT) < PER_SLOTTED) {                                                         \
         const int q = m - (MT + NT);                                                                         \
         if (q < DA::PPW) da.issue_one(q, sa, lim_u, sbyte, wave);                                            \
         else db.issue_one(q - DA::PPW, sbd, lim_u, sbyte + A_FL * 4, wave);                                  \
       } else if (!DMA && m == MT + NT) { EXTRA; }                                                            \
+      V3_SB                                                                                                  \
+    }                                                                                                        \
+    if (DMA) {                                                                                               \
+      _Pragma("unroll") for (int q = PER_SLOTTED; q < PER; ++q) {                                            \
+        if (q < DA::PPW) da.issue_one(q, sa, lim_u, sbyte, wave);                                            \
+        else db.issue_one(q - DA::PPW, sbd, lim_u, sbyte + A_FL * 4, wave);                                  \
+      }                                                                                                      \
       V3_SB                                                                                                  \
     }                                                                                                        \
   }
@@ -578,9 +588,47 @@ static bool v3_use_tall(const GemmArgs &a, int batch) {
   return tall_tiles >= 2L * kNumCU;
 }
 
+// SMALL tiles, 64 x 64 (4 waves of 32 x 32, four stages of 16 KB: two workgroups per CU), round 5: for problems whose
+// 128 x 128 tiles do not fill the chip.  Splitting those tiles along K (stream-K or slabs) moves 64 KB partial accumulators
+// through each CU's ~30 GB/s memory pipe -- 1024^3: 15 us of MFMA work + 10 us of partial traffic --, while four times as
+// many quarter-size tiles need no (or 16 KB) partials; the register-staged 64 x 64 x 64 loop of gemm.hip that served these
+// shapes prefetches ONE k tile ahead, less than the memory latency at 0.4 us per k tile, and ran at half its MFMA rate.
+constexpr int V3S_BM = 64, V3S_BN = 64, V3S_WVM = 2, V3S_WVN = 2, V3S_NST = 4;
+static bool v3_use_small(const GemmArgs &a, int batch) {
+#ifndef CLO_GEMM_V3_SMALL
+#define CLO_GEMM_V3_SMALL 1
+#endif
+  static const int mode = CLO_GEMM_V3_SMALL;   // 0 never
+  if (!mode) return false;
+  const long tm = cdiv(a.M, V3_BM), tn = cdiv(a.N, V3_BN);
+  const long tiles = (a.sym ? tm * (tm + 1) / 2 : tm * tn) * batch;
+  // Measured (tools/probe_gemm_sweep_r5.py, profiles/r05_gemm_midsize_sweep.txt): a 64 x 64 tile needs 16 KB of operands per
+  // 0.43 us of MFMA work -- 38 GB/s per CU, above what a CU's memory pipe delivers (20 - 36 GB/s) --, so the small tiles only
+  // win where few of them are in flight per unit of K: skinny outputs (min(M, N) <= 384: 128 x 2304 x 2304 29.8 -> 27.9 us,
+  // 2688 x 256 x 2688 52.1 -> 46.3) and symmetric products (half the tiles: 512-row pixel Grams 46.7 -> 43.1 / 18.9 -> 17.6 us,
+  // the patch products of round 4 175 -> 140 us); 512 x 2304 x 2304 loses (64 -> 81 us) and keeps the 128 x 128 tiles.
+  if (a.epi != EPI_NONE) return false;   // (fused epilogues run the engine's generic store path per tile: C2 at 65 / 128 rows 180 -> 192 / 194 -> 201 us)
+  return tiles < kNumCU && (a.sym || std::min(a.M, a.N) <= 384);
+}
+
 // Tile configuration and stream-K worker count (0: one tile per workgroup) for a problem; streamk_level as GemmArgs::streamk
-static long v3_plan(const GemmArgs &a, int batch, int streamk_level, bool *tall_out) {
-  bool tall = v3_use_tall(a, batch);
+// *tall_out: 0 square 128 x 128, 1 tall 256 x 128, 2 small 64 x 64
+static long v3_plan(const GemmArgs &a, int batch, int streamk_level, int *tall_out) {
+  if (v3_use_small(a, batch)) {
+    const long tm = cdiv(a.M, V3S_BM), tn = cdiv(a.N, V3S_BN);
+    const long tiles = (a.sym ? tm * (tm + 1) / 2 : tm * tn) * batch;
+    *tall_out = 2;
+    // stream-K over the small tiles only where they, too, leave most of the chip idle or its second round half empty
+    long workers = 0;
+    if (streamk_level >= 1 && !a.tri && (tiles < kNumCU / 2 + kNumCU / 4 || (tiles > kNumCU && tiles < 2L * kNumCU - 32))) {
+      const int nkt = (int)cdiv(a.K, V3_BK);
+      const long units = tiles * nkt;
+      workers = std::min<long>({(long)kNumCU, units / 4, tiles * V3_SK_MAX_PARTS});   // (the flag array holds kNumCU flags)
+      if (workers <= tiles) workers = 0;
+    }
+    return workers;
+  }
+  int tall = v3_use_tall(a, batch) ? 1 : 0;
   long workers = 0;
   for (int pass = 0; pass < 2; ++pass) {
     const int bm = tall ? V3T_BM : V3_BM, bn = tall ? V3T_BN : V3_BN;
@@ -588,7 +636,7 @@ static long v3_plan(const GemmArgs &a, int batch, int streamk_level, bool *tall_
     const long tiles = (a.sym ? tm * (tm + 1) / 2 : tm * tn) * batch;
     workers = (streamk_level >= 1 && !a.tri && !tall) ? v3_streamk_workers(tiles, a.K) : 0;
     // the tall tiles without stream-K need enough tiles for every CU; otherwise fall back to the square ones
-    if (tall && workers == 0 && tiles < 2L * kNumCU && pass == 0) { tall = false; continue; }
+    if (tall && workers == 0 && tiles < 2L * kNumCU && pass == 0) { tall = 0; continue; }
     break;
   }
   *tall_out = tall;
@@ -597,15 +645,17 @@ static long v3_plan(const GemmArgs &a, int batch, int streamk_level, bool *tall_
 bool gemm_v3_would_streamk(int M, int N, int K, long batch) {
   GemmArgs a{};
   a.M = M; a.N = N; a.K = K;
-  bool tall = false;
+  int tall = 0;
   return v3_plan(a, (int)batch, 2, &tall) > 0;
 }
+bool gemm_v3_small(const GemmArgs &a, int batch) { return v3_use_small(a, batch); }
 
 // Launches the main kernel for `a` (k_per_split / splitk set by launch_gemm for 32-deep k tiles; the tile counts are
 // set here for the configuration that runs).  a.streamk != 0 asks for the stream-K schedule with a.ws as its workspace
 // (1: >= gemm_streamk_ws_floats(128 x 128 tiles) floats, 2: enough for the tall tiles too); *used_streamk tells the
 // caller that no split-K reduction is due.
-int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk) {
+int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk,
+                   int *tile_m, int *tile_n) {
   GemmArgs a = a0;
   V3Sched s{};
 #ifndef CLO_GEMM_STREAMK
@@ -613,14 +663,16 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
 #endif
   static const int sk_off = !CLO_GEMM_STREAMK;
   const bool sk_ok = a.streamk && a.ws && !a.tri && !sk_off;
-  bool tall = false;
+  int tall = 0;
   long workers = v3_plan(a, batch, sk_ok ? a.streamk : 0, &tall);
   const int nkt = (int)cdiv(a.K, V3_BK);
   {
-    const int bm = tall ? V3T_BM : V3_BM, bn = tall ? V3T_BN : V3_BN;
+    const int bm = tall == 1 ? V3T_BM : tall == 2 ? V3S_BM : V3_BM, bn = tall == 1 ? V3T_BN : tall == 2 ? V3S_BN : V3_BN;
     a.tiles_m = (int)cdiv(a.M, bm);
     a.tiles_n = (int)cdiv(a.N, bn);
     a.tbm = bm; a.tbn = bn;
+    if (tile_m) *tile_m = bm;   // (the split-K reduction of a symmetric product mirrors by THESE tile extents)
+    if (tile_n) *tile_n = bn;
   }
   const long tiles_mat = a.sym ? (long)a.tiles_m * (a.tiles_m + 1) / 2 : (long)a.tiles_m * a.tiles_n;
   const long tiles = tiles_mat * batch;
@@ -700,9 +752,12 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
   else if (a_kc) CLO_V3(true, false, SKV, BMV, BNV, WM_, WN_, NSTV)       \
   else if (b_kc) CLO_V3(false, true, SKV, BMV, BNV, WM_, WN_, NSTV)       \
   else CLO_V3(false, false, SKV, BMV, BNV, WM_, WN_, NSTV)
-  if (tall) {
+  if (tall == 1) {
     if (sk) { CLO_V3L(true, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
     else { CLO_V3L(false, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
+  } else if (tall == 2) {
+    if (sk) { CLO_V3L(true, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST) }
+    else { CLO_V3L(false, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST) }
   } else {
     if (sk) { CLO_V3L(true, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST) }
     else { CLO_V3L(false, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST) }
