@@ -23,6 +23,7 @@ _lib = None
 
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 LOSS_MSE, LOSS_CE, LOSS_BCE, LOSS_RANK1 = 0, 1, 2, 3
+LOSS_EF_MSE, LOSS_EF_CE, LOSS_EF_BCE = 4, 5, 6   # empirical Fisher, per-sample loss gradient formed in the kernel from the targets
 
 # name -> (restype, argtypes); mirrors include/curvlinops_amd.h one to one
 _PF = c_void_p  # float* passed as integer address

@@ -20,6 +20,7 @@
 //   clo_mlp_fwd_jvp_layer / clo_mlp_bwd_layer / clo_loss_hessian_apply  per-layer building blocks
 #include "clo_common.h"
 #include "gemm.h"
+#include "mlp_loss.h"
 
 namespace clo {
 
@@ -705,6 +706,21 @@ __global__ __launch_bounds__(256) void loss_hessian_kernel(const LossArgs p) {
       const float pc = __expf(fn[c] - mx) * inv;
       wn[c] = scale * pc * (un[c] - pu) * (dp ? dp[c] : 1.f);
     }
+  } else if (loss_is_ef(p.kind)) {  // empirical Fisher from the targets: w = scale g <g, u>, g from (f, target)
+    const float *t = ef_target_row(p.kind, p.aux, n, C);
+    float mx = -INFINITY, inv = 0.f;
+    if (p.kind == CLO_LOSS_EF_CE) {
+      for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmaxf(mx, fn[c]);
+      mx = block_max(mx, s_red);
+      float se = 0.f;
+      for (int c = threadIdx.x; c < C; c += blockDim.x) se += __expf(fn[c] - mx);
+      inv = 1.f / block_sum(se, s_red);
+    }
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s += ef_grad_at(p.kind, fn[c], t, c, mx, inv) * un[c];
+    s = block_sum(s, s_red);
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+      wn[c] = scale * ef_grad_at(p.kind, fn[c], t, c, mx, inv) * s * (dp ? dp[c] : 1.f);
   } else {  // CLO_LOSS_RANK1: H_n = sum_m g_nm g_nm^T
     for (int c = threadIdx.x; c < C; c += blockDim.x) wn[c] = 0.f;
     for (int m = 0; m < p.aux_rank; ++m) {
@@ -1148,6 +1164,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
           const float pc = __expf(s_f[n][c] - mx) * inv;
           s_dl[n][c] = p.scale * pc * (s_u[n][c] - pu);
         }
+      } else if (loss_is_ef(p.kind)) {
+        float g[HEAD_CMAX];
+        ef_grad_row<HEAD_CMAX>(p.kind, &s_f[n][0], ef_target_row(p.kind, p.aux, n, C), C, g);
+        float sdot = 0.f;
+        for (int c = 0; c < C; ++c) sdot += g[c] * s_u[n][c];
+        for (int c = 0; c < C; ++c) s_dl[n][c] = p.scale * g[c] * sdot;
       } else {
         for (int c = 0; c < C; ++c) s_dl[n][c] = 0.f;
         for (int m = 0; m < p.aux_rank; ++m) {
@@ -1761,6 +1783,12 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(const HeadBwdArgs p,
           const float pc = __expf(s_f[n][c] - mx) * inv;
           s_dl[n][c] = p.scale * pc * (s_u[n][c] - pu);
         }
+      } else if (loss_is_ef(p.kind)) {
+        float g[HEAD_CMAX];
+        ef_grad_row<HEAD_CMAX>(p.kind, &s_f[n][0], ef_target_row(p.kind, p.aux, n0 + n, C), C, g);
+        float sdot = 0.f;
+        for (int c = 0; c < C; ++c) sdot += g[c] * s_u[n][c];
+        for (int c = 0; c < C; ++c) s_dl[n][c] = p.scale * g[c] * sdot;
       } else {
         for (int m = 0; m < p.aux_rank; ++m) {
           const float *g = p.aux + ((long)(n0 + n) * p.aux_rank + m) * C;
@@ -2207,6 +2235,21 @@ __global__ void loss_cols_kernel(int kind, const float *__restrict__ f,
   float *un = u + e;
   const float *fn = f + (long)n * C;
   const float *dp = dphi_last ? dphi_last + (long)n * C : nullptr;
+  if (loss_is_ef(kind)) {   // empirical Fisher from the targets: g from (f, target) once per thread, then w = scale g <g, u>
+    const float *t = ef_target_row(kind, aux, n, C);
+    float mx = -INFINITY, inv = 0.f;
+    if (kind == CLO_LOSS_EF_CE) {
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, fn[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += __expf(fn[c] - mx);
+      inv = 1.f / se;
+    }
+    float sdot = 0.f;
+    for (int c = 0; c < C; ++c) sdot += ef_grad_at(kind, fn[c], t, c, mx, inv) * un[c * cs];
+    sdot *= scale;
+    for (int c = 0; c < C; ++c) un[c * cs] = ef_grad_at(kind, fn[c], t, c, mx, inv) * sdot * (dp ? dp[c] : 1.f);
+    return;
+  }
   if (C <= 16 && kind != CLO_LOSS_RANK1) {
     // narrow output: everything in registers, all loads issued before the first dependent use
     float uv[16], fv[16], dv[16];
@@ -2672,7 +2715,8 @@ extern "C" int clo_mlp_fwd_jvp_layer(const float *W, const float *b, const float
 extern "C" int clo_loss_hessian_apply(int kind, const float *f, const float *aux, int aux_rank,
                                       const float *u, const float *dphi_last, float *w, int N,
                                       int C, float scale, void *stream) {
-  CLO_REQUIRE(kind >= 0 && kind <= 3, "clo_loss_hessian_apply: unknown kind %d", kind);
+  CLO_REQUIRE(kind >= 0 && kind <= CLO_LOSS_EF_BCE, "clo_loss_hessian_apply: unknown kind %d", kind);
+  CLO_REQUIRE(!loss_is_ef(kind) || aux, "clo_loss_hessian_apply: EF_* needs the targets in aux");
   CLO_REQUIRE(N >= 0 && C > 0, "clo_loss_hessian_apply: bad sizes");
   if (N == 0) return CLO_OK;
   CLO_REQUIRE(f && u && w, "clo_loss_hessian_apply: null operand");
@@ -3006,10 +3050,10 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
               "clo_mlp_ggn_matvec: bad layer table");
   CLO_REQUIRE((flags & ~1) == 0, "clo_mlp_ggn_matvec: unknown flags 0x%x", flags);
   CLO_REQUIRE(N >= 0 && X && ws, "clo_mlp_ggn_matvec: bad batch / workspace");
-  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_ggn_matvec: unknown loss kind %d",
+  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= CLO_LOSS_EF_BCE, "clo_mlp_ggn_matvec: unknown loss kind %d",
               loss_kind);
-  CLO_REQUIRE(loss_kind != CLO_LOSS_RANK1 || (aux && aux_rank >= 1),
-              "clo_mlp_ggn_matvec: RANK1 needs aux and aux_rank >= 1");
+  CLO_REQUIRE((loss_kind != CLO_LOSS_RANK1 && !loss_is_ef(loss_kind)) || (aux && aux_rank >= 1),
+              "clo_mlp_ggn_matvec: RANK1 / EF_* need aux (backpropagated vectors / targets) and aux_rank >= 1");
   for (int l = 0; l <= L; ++l) CLO_REQUIRE(dims[l] > 0, "clo_mlp_ggn_matvec: dims[%d] <= 0", l);
   for (int l = 0; l < L; ++l) {
     CLO_REQUIRE(acts[l] >= 0 && acts[l] <= 3, "clo_mlp_ggn_matvec: unknown activation");
@@ -3352,9 +3396,9 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
                            float beta, float *ws, void *stream, const float *Gh) {
   CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W && VW && OW, "clo_mlp_ggn_matmat: bad layer table");
   CLO_REQUIRE(N >= 0 && X && ws && K >= 1, "clo_mlp_ggn_matmat: bad batch / workspace / K");
-  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= 3, "clo_mlp_ggn_matmat: unknown loss kind %d", loss_kind);
-  CLO_REQUIRE(loss_kind != CLO_LOSS_RANK1 || (aux && aux_rank >= 1),
-              "clo_mlp_ggn_matmat: RANK1 needs aux and aux_rank >= 1");
+  CLO_REQUIRE(loss_kind >= 0 && loss_kind <= CLO_LOSS_EF_BCE, "clo_mlp_ggn_matmat: unknown loss kind %d", loss_kind);
+  CLO_REQUIRE((loss_kind != CLO_LOSS_RANK1 && !loss_is_ef(loss_kind)) || (aux && aux_rank >= 1),
+              "clo_mlp_ggn_matmat: RANK1 / EF_* need aux (backpropagated vectors / targets) and aux_rank >= 1");
   bool ok = K % 4 == 0 && K >= 4 && K <= 64 && ldk % 4 == 0 && ldk >= K && aligned16(X) && aligned16(ws);
   for (int l = 0; l <= L; ++l) CLO_REQUIRE(dims[l] > 0, "clo_mlp_ggn_matmat: dims[%d] <= 0", l);
   for (int l = 0; l < L; ++l) {
@@ -3477,7 +3521,7 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
     }
     // ---- output-space curvature per (n, k), in place: dA_L becomes delta_L
     {
-      const float *auxn = aux ? aux + (long)n0 * aux_rank * dims[L] : nullptr;
+      const float *auxn = !aux ? nullptr : loss_is_ef(loss_kind) ? aux + ef_target_floats(loss_kind, n0, dims[L]) : aux + (long)n0 * aux_rank * dims[L];
       hipLaunchKernelGGL(loss_cols_kernel, dim3((unsigned)cdiv(NK, 64)), dim3(64), 0, st, loss_kind, a[L],
                          auxn, aux_rank, last_linear ? nullptr : dphi[L], dA[L], nn, K, dims[L],
                          loss_scale * alpha);

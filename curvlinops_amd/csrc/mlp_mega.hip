@@ -28,6 +28,7 @@
 // that must arrive quickly (x, the exchanged activations) is loaded by wave 7, which owns no weight tile.
 // All sums are taken in fixed orders: results are bit-for-bit repeatable.  Every spin is bounded.
 #include "clo_common.h"
+#include "mlp_loss.h"
 #include "persist_gate.h"
 
 #include <mutex>
@@ -508,7 +509,8 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       st_x(rs, o_slab + ((long)kb * 16 + wn) * d2 + j0 + q * 4, f32x4{src[0], src[1], src[2], src[3]});
     }
     // rank-M curvature: the backpropagated vectors (<= 4 KB) travel to LDS while the slabs are acknowledged
-    const int naux = p.kind == CLO_LOSS_RANK1 ? N * p.aux_rank * C : 0;   // <= MG_AUX_MAX (mega_ok)
+    const int naux = p.kind == CLO_LOSS_RANK1 ? N * p.aux_rank * C                    // <= MG_AUX_MAX (mega_ok)
+                     : loss_is_ef(p.kind) ? (int)ef_target_floats(p.kind, N, C) : 0;   // targets of the in-kernel EF
     const float *abase = naux ? p.aux : p.W3;
     float auxv[MG_AUX_MAX / MG_T];
 #pragma unroll
@@ -660,6 +662,12 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
           }
           const float inv = 1.f / se, pu = spu * inv;
           for (int c = 0; c < C; ++c) dl[c] = p.scale * (__expf(fn[c] - mx) * inv) * (un[c] - pu);
+        } else if (loss_is_ef(p.kind)) {
+          float g[MG_CMAX];
+          ef_grad_row<MG_CMAX>(p.kind, fn, ef_target_row(p.kind, &s_m[MG_M_AUX], n, C), C, g);
+          float sdot = 0.f;
+          for (int c = 0; c < C; ++c) sdot += g[c] * un[c];
+          for (int c = 0; c < C; ++c) dl[c] = p.scale * g[c] * sdot;
         } else {
           for (int m = 0; m < p.aux_rank; ++m) {
             const float *g = &s_m[MG_M_AUX + (n * p.aux_rank + m) * C];

@@ -214,23 +214,31 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
                 g = self._mc_sampler(self._model_func(self._params, X), y)  # [N, M, C]
             c = {"mean": float(N), "sum": 1.0}[self._loss_func.reduction]
             return _hip.LOSS_RANK1, 1.0 / c, g.reshape(N, g.shape[1], C).contiguous()
-        # empirical Fisher: H_n = (1/c) g_n g_n^T with g_n the UNREDUCED per-sample gradient
-        # of the loss w.r.t. the prediction (gradient_moments.py:48-87), recomputed on every product like
-        # the reference does (kept only under `assume_frozen`, `_aux_lookup`).
-        aux = self._aux_lookup(idx, X_user, y)
-        if aux is None:
-            with torch.no_grad():
-                f = self._model_func(self._params, X)
-                if isinstance(self._loss_func, MSELoss):
-                    g = 2.0 * (f - y)
-                elif isinstance(self._loss_func, CrossEntropyLoss):
-                    g = f.softmax(dim=1)
-                    g[torch.arange(N, device=f.device), y] -= 1.0
-                else:
-                    g = f.sigmoid() - y
-            aux = self._aux_store(idx, X_user, y, g.contiguous().unsqueeze(1))  # [N, 1, C]
+        # empirical Fisher: H_n = (1/c) g_n g_n^T with g_n the UNREDUCED per-sample gradient of the loss w.r.t. the
+        # prediction (gradient_moments.py:48-87).  The kernels form g_n themselves, from the prediction they hold anyway
+        # and the TARGETS (`CLO_LOSS_EF_*`, csrc/mlp_loss.h): re-derived on every product like the reference does,
+        # without a forward pass on the host and without anything to keep between products.
         red = self._loss_func.reduction
         c = 1.0 if red == "sum" else float(N if isinstance(self._loss_func, CrossEntropyLoss) else N * C)
+        if isinstance(self._loss_func, CrossEntropyLoss):
+            if y.dim() != 1 or y.dtype.is_floating_point:
+                return self._ef_host_gradients(idx, X, y, X_user, N, C, c)   # (class probabilities as targets: host route)
+            kind, tgt = _hip.LOSS_EF_CE, y.to(torch.float32).reshape(N, 1, 1)       # labels as floats, [N] in memory
+        else:
+            kind = _hip.LOSS_EF_MSE if isinstance(self._loss_func, MSELoss) else _hip.LOSS_EF_BCE
+            tgt = y.reshape(N, 1, C)
+            tgt = tgt if tgt.dtype == torch.float32 and tgt.is_contiguous() else tgt.to(torch.float32).contiguous()
+        return kind, 1.0 / c, tgt
+
+    def _ef_host_gradients(self, idx, X, y, X_user, N, C, c):
+        """Fallback of the EF product: per-sample output gradients from a forward pass on the host (`CLO_LOSS_RANK1`)."""
+        aux = self._aux_lookup(idx, X_user, y)
+        if aux is None:
+            with torch.enable_grad():
+                f = self._model_func(self._params, X).detach().requires_grad_(True)
+                lf = type(self._loss_func)(reduction="sum")
+                (g,) = torch.autograd.grad(lf(f, y), f)
+            aux = self._aux_store(idx, X_user, y, g.contiguous().unsqueeze(1))  # [N, 1, C]
         return _hip.LOSS_RANK1, 1.0 / c, aux
 
     _MERGE_MAX_ROWS = 1024
@@ -469,7 +477,8 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             return None
         # consecutive mini-batches as one larger batch where that pays off (concatenated copies)
         merged = self._merge_native_batches(entries)
-        live = live and len(merged) == len(entries) and all(e[3] is None for e in merged)
+        ys = {y.data_ptr() for _, y in self._data}
+        live = live and len(merged) == len(entries) and all(e[3] is None or e[3].data_ptr() in ys for e in merged)
         batches = [(Xn, Xn.data_ptr(), Xn.shape[0], kind, scale, None if aux is None else aux.data_ptr(),
                     1 if aux is None else aux.shape[1], aux, norm)
                    for Xn, kind, scale, aux, norm in merged]

@@ -42,6 +42,12 @@ extern "C" {
 #define CLO_LOSS_BCE 2       /* w = s * sig*(1-sig)*u             (ggn_utils.py:76-79) */
 #define CLO_LOSS_RANK1 3     /* w = s * sum_m g_m*(g_m.u), g given per row (gradient_moments.py:48-87,
                                 ggn.py:140-166: EF / MC pseudo-losses)                 */
+/* Empirical Fisher with the per-sample loss gradient g_n computed IN the kernel from the prediction it already holds and
+ * the TARGETS (aux, aux_rank = 1), as the reference re-derives it on every product (gradient_moments.py:48-87):
+ * w = s * g (g.u).  aux: [N][C] floats for MSE / BCE, [N] class labels stored as floats for CE. */
+#define CLO_LOSS_EF_MSE 4    /* g = 2 (f - y)                    */
+#define CLO_LOSS_EF_CE 5     /* g = softmax(f) - onehot(label)   */
+#define CLO_LOSS_EF_BCE 6    /* g = sigmoid(f) - y               */
 
 int clo_version(void);
 const char *clo_last_error(void);

@@ -709,7 +709,7 @@ def test_data_style_updates_of_params_and_data_are_seen(dev, cls, loss):
     kept = op @ v
     for p in params.values():
         p.data.mul_(1.05)
-    if cls is not C.GGNLinearOperator:   # EF / Hessian keep per-batch output gradients of the OLD parameters
+    if cls is C.HessianLinearOperator:   # keeps the per-batch output gradients of the OLD parameters (the EF forms them in-kernel)
         assert rel_err(op @ v, (cls(model, lf, params, data) @ v).cpu().numpy()) > 1e-6
     op.refresh()
     assert rel_err(op @ v, (cls(model, lf, params, data) @ v).cpu().numpy()) < 1e-6
