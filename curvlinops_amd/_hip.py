@@ -132,6 +132,8 @@ _SIGNATURES = {
         [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
          POINTER(c_void_p), _PF, c_int, _PF, _PF, c_void_p],
     ),
+    "clo_mlp_loss_grad": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), _PF, c_int, c_int,
+                                  _PF, c_float, _PF, _PF, c_void_p]),
     "clo_mlp_vjp": (
         c_int,
         [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
@@ -744,6 +746,16 @@ class MLPPlan:
                                 self._ptr_array(OW), self._ptr_array(Ob), _pc(X), N, _pc(U), alpha, beta,
                                 _pc(self._jac_workspace(N, X.device)), _stream())
         _check(rc, "clo_mlp_vjp")
+
+    def loss_grad(self, W, b, X: Tensor, targets: Tensor, loss_kind: int, scale: float) -> Tensor:
+        """``G [N, C] = scale * d l_n / d f_n`` at ``f = net(X)`` from the live parameters (``clo_mlp_loss_grad``): the
+        output gradient the exact-Hessian products take, without a forward / autograd pass on the host."""
+        N = X.shape[0]
+        G = torch.empty(N, self._dims_list[-1], device=X.device, dtype=torch.float32)
+        rc = load().clo_mlp_loss_grad(self.L, self.dims, self.acts, self._ptr_array(W), self._ptr_array(b), _pc(X), N,
+                                      loss_kind, _pc(targets), scale, _pc(G), _pc(self._jac_workspace(N, X.device)), _stream())
+        _check(rc, "clo_mlp_loss_grad")
+        return G
 
     def hessian_supported(self) -> bool:
         """Shape conditions of ``clo_mlp_hessian_matvec``: none any more (layer inputs that are not multiples

@@ -3816,6 +3816,62 @@ extern "C" int clo_mlp_jvp(int L, const int *dims, const int *acts, const float 
   return CLO_OK;
 }
 
+// G[n][c] = scale * d l_n / d f_n[c] for the MSE / CE / BCE loss of the prediction f = net(X): plain forward pass on the GEMM
+// engine, then the per-sample loss gradient from (f, targets) as in csrc/mlp_loss.h (targets [N][C] floats, CE: [N] labels
+// stored as floats).  What the exact-Hessian products take as `G` (hessian.py:13-69 differentiates the loss itself; the
+// reference re-evaluates model and loss on every product) -- computed on the device from the LIVE parameters instead of a
+// forward + autograd pass on the host.  ws: clo_mlp_jac_ws_floats(L, dims, N) floats.
+__global__ __launch_bounds__(256) void loss_grad_kernel(int ef_kind, const float *__restrict__ f, const float *__restrict__ tgt,
+                                                        float *__restrict__ out, int C, float scale) {
+  __shared__ float s_red[8];
+  const int n = blockIdx.x;
+  const float *fn = f + (long)n * C, *t = ef_target_row(ef_kind, tgt, n, C);
+  float mx = -INFINITY, inv = 0.f;
+  if (ef_kind == CLO_LOSS_EF_CE) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmaxf(mx, fn[c]);
+    mx = block_max(mx, s_red);
+    float se = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) se += __expf(fn[c] - mx);
+    inv = 1.f / block_sum(se, s_red);
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) out[(long)n * C + c] = scale * ef_grad_at(ef_kind, fn[c], t, c, mx, inv);
+}
+
+extern "C" int clo_mlp_loss_grad(int L, const int *dims, const int *acts, const float *const *W, const float *const *b,
+                                 const float *X, int N, int loss_kind, const float *targets, float scale, float *G,
+                                 float *ws, void *stream) {
+  CLO_REQUIRE(L >= 1 && L <= 64 && dims && acts && W, "clo_mlp_loss_grad: bad layer table");
+  CLO_REQUIRE(N >= 1 && X && targets && G && ws, "clo_mlp_loss_grad: bad batch / targets / output / workspace");
+  CLO_REQUIRE(loss_kind >= CLO_LOSS_MSE && loss_kind <= CLO_LOSS_BCE, "clo_mlp_loss_grad: loss kind %d is not MSE / CE / BCE", loss_kind);
+  for (int l = 0; l < L; ++l) {
+    CLO_REQUIRE(dims[l] > 0 && dims[l + 1] > 0 && acts[l] >= 0 && acts[l] <= 3, "clo_mlp_loss_grad: bad layer %d", l);
+    CLO_REQUIRE(W[l], "clo_mlp_loss_grad: null weight pointer in layer %d", l);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int dmax = 0;
+  for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
+  float *p = ws;
+  float *a[65], *dphi[65];
+  a[0] = const_cast<float *>(X);
+  for (int l = 1; l <= L; ++l) {
+    const long sz = (long)N * dims[l];
+    a[l] = p; p += sz; p += sz; dphi[l] = p; p += sz;
+  }
+  p += 2L * N * dmax;
+  float *gws = p;
+  const long gws_sz = gemm_ws_floats(N, dmax);
+  for (int l = 1; l <= L; ++l) {
+    const int di = dims[l - 1], dout = dims[l];
+    GemmArgs g = gemm_problem(N, dout, di, a[l - 1], di, 1, W[l - 1], 1, di, 0.f, a[l], dout);
+    g.epi = EPI_ACT; g.e_act = acts[l - 1]; g.e_vec = b ? b[l - 1] : nullptr; g.e_out2 = dphi[l];
+    int rc = launch_gemm_auto(g, gws, gws_sz, st);
+    if (rc != CLO_OK) return rc;
+  }
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(N), dim3(256), 0, st, loss_kind + CLO_LOSS_EF_MSE, a[L], targets, G, dims[L], scale);
+  CLO_CHECK_LAUNCH("loss_grad_kernel");
+  return CLO_OK;
+}
+
 // out = beta out + alpha J^T U for U [N][d_L]: plain forward pass (activations and their
 // derivatives), then the backward chain on the GEMM engine.  Any widths / alignment.
 extern "C" int clo_mlp_vjp(int L, const int *dims, const int *acts, const float *const *W,

@@ -201,9 +201,16 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
             kind, scale = loss_kind_and_scale(self._loss_func, N, C)
             G = self._aux_lookup(idx, X_user, y)
             if G is None:
-                with torch.enable_grad():
-                    f = self._model_func(self._params, X).detach().requires_grad_(True)
-                    (G,) = torch.autograd.grad(self._loss_func(f, y), f)
+                tgt = self._native_targets(y, N, C)
+                if tgt is not None:   # on the device, from the live parameters (clo_mlp_loss_grad): no host forward pass
+                    red = 1.0 if self._loss_func.reduction == "sum" else (
+                        1.0 / N if isinstance(self._loss_func, CrossEntropyLoss) else 1.0 / (N * C))
+                    nat = self._native
+                    G = nat.plan.loss_grad(nat.W, nat.b, X, tgt, kind, red)
+                else:
+                    with torch.enable_grad():
+                        f = self._model_func(self._params, X).detach().requires_grad_(True)
+                        (G,) = torch.autograd.grad(self._loss_func(f, y), f)
                 G = self._aux_store(idx, X_user, y, G.contiguous())
             return kind, scale, G
         if self._NATIVE_KIND == "mc":
@@ -220,15 +227,23 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         # without a forward pass on the host and without anything to keep between products.
         red = self._loss_func.reduction
         c = 1.0 if red == "sum" else float(N if isinstance(self._loss_func, CrossEntropyLoss) else N * C)
+        tgt = self._native_targets(y, N, C)
+        if tgt is None:
+            return self._ef_host_gradients(idx, X, y, X_user, N, C, c)   # (class probabilities as targets: host route)
+        kind = {MSELoss: _hip.LOSS_EF_MSE, CrossEntropyLoss: _hip.LOSS_EF_CE}.get(type(self._loss_func), _hip.LOSS_EF_BCE)
+        return kind, 1.0 / c, tgt.reshape(N, 1, -1)
+
+    def _native_targets(self, y: Tensor, N: int, C: int) -> Tensor | None:
+        """The targets as the kernels read them (csrc/mlp_loss.h): ``[N, C]`` fp32 for MSE / BCE -- the caller's tensor
+        itself when it already is --, class labels as ``[N]`` floats for CE; None if ``y`` is something else."""
         if isinstance(self._loss_func, CrossEntropyLoss):
-            if y.dim() != 1 or y.dtype.is_floating_point:
-                return self._ef_host_gradients(idx, X, y, X_user, N, C, c)   # (class probabilities as targets: host route)
-            kind, tgt = _hip.LOSS_EF_CE, y.to(torch.float32).reshape(N, 1, 1)       # labels as floats, [N] in memory
-        else:
-            kind = _hip.LOSS_EF_MSE if isinstance(self._loss_func, MSELoss) else _hip.LOSS_EF_BCE
-            tgt = y.reshape(N, 1, C)
-            tgt = tgt if tgt.dtype == torch.float32 and tgt.is_contiguous() else tgt.to(torch.float32).contiguous()
-        return kind, 1.0 / c, tgt
+            if y.dim() != 1 or y.dtype.is_floating_point or y.shape[0] != N:
+                return None
+            return y.to(torch.float32)
+        if y.numel() != N * C:
+            return None
+        t = y.reshape(N, C)
+        return t if t.dtype == torch.float32 and t.is_contiguous() else t.to(torch.float32).contiguous()
 
     def _ef_host_gradients(self, idx, X, y, X_user, N, C, c):
         """Fallback of the EF product: per-sample output gradients from a forward pass on the host (`CLO_LOSS_RANK1`)."""

@@ -269,6 +269,15 @@ long clo_mlp_ggn_ws_floats(int L, const int *dims, int N);
  * `stream`).  The kernel keeps them consistent from call to call by itself.  No-op for other shapes. */
 int clo_mlp_ggn_ws_init(int L, const int *dims, int N, float *ws, void *stream);
 
+/* G[n][c] = scale * d l_n / d f_n[c] of the MSE / CE / BCE loss at f = net(X) (plain forward pass on the GEMM engine, then the
+ * per-sample loss gradient from the targets: [N][C] floats, CE: [N] class labels stored as floats).  This is the `G`
+ * operand of clo_mlp_hessian_matvec / _matmat (scale = the reduction factor of the mini-batch loss), computed on the device
+ * from the live parameters on every product, as the reference re-evaluates model and loss (hessian.py:13-69).
+ * ws: clo_mlp_jac_ws_floats(L, dims, N) floats. */
+int clo_mlp_loss_grad(int L, const int *dims, const int *acts, const float *const *W, const float *const *b,
+                      const float *X, int N, int loss_kind, const float *targets, float scale, float *G,
+                      float *ws, void *stream);
+
 /* Jacobian and transposed-Jacobian products of an MLP (reference jacobian.py:14-358): the
  * forward+JVP half and the VJP half of the GGN product.
  *   clo_mlp_jvp: JV [N][d_L] = J v                             (any widths)
