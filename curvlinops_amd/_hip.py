@@ -7,6 +7,7 @@ the shared object is missing or a call fails, a ``RuntimeError`` is raised.
 
 from __future__ import annotations
 
+from contextlib import contextmanager
 import ctypes
 import threading
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
@@ -514,8 +515,8 @@ def cholesky_inverse_batched_into(As: list[Tensor], dampings: list[float], outs:
     _check(rc, "clo_cholesky_inverse_batched_f32")
 
 
-# cap on the workgroups of one persistent panel launch of clo_sytrd_f32 (0 = the library's 128): the eigensolver's
-# multi-stream driver lowers it so that the launches running side by side stay co-resident (two workgroups per CU)
+# cap on the workgroups of one persistent panel launch of clo_sytrd_f32 (0 = the library's own: one per compute unit of the
+# device, at most 256): the eigensolver's multi-stream driver lowers it so that the launches running side by side stay co-resident
 SYTRD_MAX_BLOCKS = 0
 
 
@@ -607,11 +608,27 @@ class MLPPlan:
 
     def __init__(self, dims: list[int], acts: list[int]):
         self.flags = MLP_DEFAULT
+        self._tls = threading.local()   # per-thread override of `flags` (`flags_override`): the plan is shared by threads
         self.L = len(acts)
         self.dims = (c_int * (self.L + 1))(*dims)
         self.acts = (c_int * self.L)(*acts)
         self._dims_list = list(dims)
         self._ws: dict[tuple[int, str], Tensor] = {}
+
+    def effective_flags(self) -> int:
+        """``flags`` OR-ed with the calling thread's override (none by default)."""
+        return self.flags | getattr(self._tls, "extra", 0)
+
+    @contextmanager
+    def flags_override(self, extra: int):
+        """Within the block, products issued by THIS thread carry ``flags | extra`` (an argument of their C calls); other
+        threads using the same operator are not affected and nothing on the shared object is mutated."""
+        prev = getattr(self._tls, "extra", 0)
+        self._tls.extra = prev | int(extra)
+        try:
+            yield
+        finally:
+            self._tls.extra = prev
 
     def _ptr_array(self, tensors):
         arr = (c_void_p * self.L)()
@@ -660,7 +677,7 @@ class MLPPlan:
                 Vb[l] = v_base + b_off[l]
                 Ob[l] = o_base + b_off[l]
         rc = self._fn(self.L, self.dims, self.acts, self._W_arr, self._b_arr, VW, Vb, OW, Ob, X_ptr, N,
-                      loss_kind, aux_ptr, aux_rank, loss_scale, alpha, beta, self.flags, ws_ptr, stream)
+                      loss_kind, aux_ptr, aux_rank, loss_scale, alpha, beta, self.effective_flags(), ws_ptr, stream)
         if rc != 0:
             _check(rc, "clo_mlp_ggn_matvec")
 
@@ -791,7 +808,7 @@ class MLPPlan:
         rc = lib.clo_mlp_ggn_matvec(
             self.L, self.dims, self.acts, self._ptr_array(W), self._ptr_array(b),
             self._ptr_array(VW), self._ptr_array(Vb), self._ptr_array(OW), self._ptr_array(Ob),
-            _pc(X), N, loss_kind, _pc(aux), rank, loss_scale, alpha, beta, self.flags,
+            _pc(X), N, loss_kind, _pc(aux), rank, loss_scale, alpha, beta, self.effective_flags(),
             _pc(self.workspace(N, X.device)), _stream(),
         )
         _check(rc, "clo_mlp_ggn_matvec")

@@ -169,7 +169,7 @@ def _affine_eval_batchnorm(module: Module, params: dict[str, Tensor]) -> list[Mo
     evaluated as ``x * scale + shift`` (ONE fused elementwise launch, same autograd semantics w.r.t. its input;
     BatchNorm parameters get no gradient here, which no KFAC pass asks for);
     BatchNorm parameters are never among the Kronecker-factored ones (`kfac_hooks.py:445-449`), so this changes
-    nothing but the rounding of the activations (~1e-7 relative).  ``CLO_KFAC_FAST_BN=0`` keeps the stock
+    nothing but the rounding of the activations (~1e-7 relative).  ``computers._FAST_BN = False`` keeps the stock
     kernels.  Returns the modules whose ``forward`` was shadowed."""
     if not _FAST_BN or not isinstance(module, Module):
         return []

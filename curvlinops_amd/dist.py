@@ -183,14 +183,12 @@ class AllReducedLinearOperator(PyTorchLinearOperator):
         # chip (csrc/mlp_mega.hip) would spin beside it, so overlapped products take the launch chain -- the choice
         # travels as the `flags` argument of THIS operator's C calls (clo_mlp_ggn_matvec), not as process state
         op = self._op
-        prev = getattr(op, "native_flags", None) if is_distributed() else None
-        if prev is not None:
-            op.native_flags = prev | _hip.MLP_NO_PERSISTENT
-        try:
+        nat = getattr(op, "_native", None) if is_distributed() else None
+        if nat is not None:   # (per call and per thread: nothing on the shared operator object is mutated)
+            with nat.plan.flags_override(_hip.MLP_NO_PERSISTENT):
+                Y = op @ X
+        else:
             Y = op @ X
-        finally:
-            if prev is not None:
-                op.native_flags = prev
         if not Y.is_contiguous():
             Y = Y.contiguous()
         work = dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self._group, async_op=True) if is_distributed() else None

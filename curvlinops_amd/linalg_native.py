@@ -224,7 +224,7 @@ INVERSE_WORKERS = 1
 def concurrent_inverses(num_streams: int | None = None, distributed: bool = False):
     """Inside the block, fp32 GPU calls of :func:`damped_cholesky_inverse` are collected and return
     their (still empty) output tensors immediately; on exit the factors are inverted concurrently
-    (worker threads with their own streams -- two by default: the big factors' calls are pipelines over a helper stream
+    (worker threads with their own streams -- ONE by default, `INVERSE_WORKERS`: the big factors' calls are pipelines over a helper stream
     of their own, and more than a handful of busy HIP streams share hardware queues: ResNet-18's 42 factors 9.2-9.5 ms
     with two workers, 10-12 with four, 19-30 ms with the equal-size groups split into concurrent single calls --),
     failed factorisations are redone in float64 into the

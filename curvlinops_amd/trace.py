@@ -40,7 +40,9 @@ def _gram_orthonormal_basis(X: Tensor, rel_tol: float = 1e-5) -> Tensor:
     ``sqrt(rel_tol)`` of the largest are numerically indistinguishable from zero in a float32 Gram
     matrix and are dropped, so the result has ``r <= n`` columns -- Hutch++ is exact for ANY
     orthonormal ``Q`` (trace on range(Q) + Hutchinson on the complement), a smaller basis only
-    moves work to the stochastic part."""
+    moves work to the stochastic part.  DEVIATION from the reference, which keeps all ``n`` columns of a Householder
+    ``Q`` (``meyer2020hutch.py:93``): for curvature spectra that decay by more than ``sqrt(rel_tol)`` = 3e-3 within the
+    sketch the dropped directions are estimated stochastically instead of exactly (same expectation, more variance)."""
     Q = X if X.is_contiguous() else X.contiguous()
     for it in range(2):
         n = Q.shape[1]
