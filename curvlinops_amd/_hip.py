@@ -80,6 +80,11 @@ _SIGNATURES = {
         [_PF, _PF, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
          c_int, c_int, c_void_p],
     ),
+    "clo_gemm_ptrs_f32": (
+        c_int,
+        [c_int, c_int, c_int, c_float, _PF, POINTER(c_void_p), c_long, c_long, c_long, _PF, POINTER(c_void_p), c_long, c_long,
+         c_long, c_float, _PF, c_long, c_long, c_int, c_int, _PF, c_void_p],
+    ),
     "clo_syrk_accum_f32": (
         c_int,
         [_PF, c_long, _PF, c_long, c_int, c_long, c_int, c_float, c_float, c_int, _PF, c_void_p],
@@ -348,6 +353,54 @@ def gemm(A: Tensor, B: Tensor, out: Tensor | None = None, alpha: float = 1.0, be
         _stream(),
     )
     _check(rc, "clo_gemm_f32")
+    return out
+
+
+GEMM_PTRS_MAX = 8   # members of one clo_gemm_ptrs_f32 launch
+
+
+def gemm_members(A, B, out: Tensor | None = None, alpha: float = 1.0, beta: float = 0.0) -> Tensor:
+    """Batched ``out[i] = alpha * A[i] @ B[i] + beta * out[i]`` where ``A`` and / or ``B`` is a LIST of equally shaped and
+    equally strided 2-D fp32 GPU tensors lying anywhere in memory (``clo_gemm_ptrs_f32``: no stacked copies), the other a
+    3-D tensor (or also a list).  ``out``: 3-D, row-major matrices."""
+    lib = load()
+    la, lb = isinstance(A, (list, tuple)), isinstance(B, (list, tuple))
+    n = len(A) if la else (len(B) if lb else A.shape[0])
+    a0, b0 = (A[0] if la else A[0]), (B[0] if lb else B[0])
+    M, K = a0.shape
+    K2, N = b0.shape
+    if K != K2:
+        raise ValueError(f"gemm_members shape mismatch: {tuple(a0.shape)} @ {tuple(b0.shape)}")
+    for lst in ([A] if la else []) + ([B] if lb else []):
+        if len(lst) != n or any(t.shape != lst[0].shape or t.stride() != lst[0].stride() for t in lst):
+            raise ValueError("gemm_members: list members must agree in shape and strides")
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an `out` tensor")
+        out = torch.empty(n, M, N, device=a0.device, dtype=torch.float32)
+    if out.shape != (n, M, N) or (N > 1 and out.stride(2) != 1):
+        raise ValueError(f"bad out tensor {tuple(out.shape)} / strides {out.stride()}")
+    if M == 0 or N == 0 or n == 0:
+        return out
+    for i0 in range(0, n, GEMM_PTRS_MAX):
+        cnt = min(GEMM_PTRS_MAX, n - i0)
+        ap = (c_void_p * cnt)(*[t.data_ptr() for t in A[i0:i0 + cnt]]) if la else None
+        bp = (c_void_p * cnt)(*[t.data_ptr() for t in B[i0:i0 + cnt]]) if lb else None
+        a_base, b_base = (None if la else A[i0]), (None if lb else B[i0])
+        splitk = lib.clo_gemm_suggest_splitk(M, N, K, cnt)
+        ws = None
+        if splitk > 1:
+            ws = torch.empty(cnt * splitk * M * N, device=a0.device, dtype=torch.float32)
+        elif splitk < 0:
+            ws = torch.empty(lib.clo_gemm_streamk_ws_floats(), device=a0.device, dtype=torch.float32)
+        o = out[i0:i0 + cnt]
+        _p(o)   # (sets the device the launch belongs to)
+        rc = lib.clo_gemm_ptrs_f32(
+            M, N, K, alpha, None if la else a_base.data_ptr(), ap, a0.stride(0), a0.stride(1), 0 if la else A.stride(0),
+            None if lb else b_base.data_ptr(), bp, b0.stride(0), b0.stride(1), 0 if lb else B.stride(0), beta,
+            o.data_ptr(), o.stride(1) if M > 1 else max(N, o.stride(1)), o.stride(0) if cnt > 1 else 0, cnt, splitk, _p(ws),
+            _stream())
+        _check(rc, "clo_gemm_ptrs_f32")
     return out
 
 

@@ -4,6 +4,8 @@
 
 namespace clo {
 
+constexpr int GEMM_TAB_MAX = 8;   // batch members of a pointer-table launch
+
 struct GemmArgs {
   int M, N, K;
   float alpha, beta;
@@ -55,7 +57,14 @@ struct GemmArgs {
   // engine decides whether the schedule pays (then no split-K reduction runs)
   int streamk;   // 0: no; 1: ws >= gemm_streamk_ws_floats_square(); 2: ws >= gemm_streamk_ws_floats()
   int cvC, cvH, cvW, cvKH, cvKW, cvSH, cvSW, cvPH, cvPW, cvDH, cvDW, cvOH, cvOW;
+  // batch members at arbitrary addresses (clo_gemm_ptrs_f32, round 5): with tab_a / tab_b set, matrix b of that operand
+  // starts at A + off_a[b] / B + off_b[b] floats (differences to member 0, any sign) instead of b * sa_b / b * sb_b --
+  // equal-shape Kronecker factors of different layers enter ONE batched launch where they lie, no stacked copies.
+  int tab_a, tab_b;
+  long off_a[GEMM_TAB_MAX], off_b[GEMM_TAB_MAX];
 };
+__host__ __device__ inline long gemm_off_a(const GemmArgs &p, int b) { return p.tab_a ? p.off_a[b] : (long)b * p.sa_b; }
+__host__ __device__ inline long gemm_off_b(const GemmArgs &p, int b) { return p.tab_b ? p.off_b[b] : (long)b * p.sb_b; }
 enum { EPI_NONE = 0, EPI_ACT = 1, EPI_MUL = 2, EPI_MUL_T = 3 };
 enum { TRI_KGE_M = 1, TRI_KLT_M = 2, TRI_KGE_N = 4, TRI_KLT_N = 8 };
 

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   float ra[8], rb[8];
 
   for (int bcur = b_begin; bcur < b_end; ++bcur) {
-  const float *A = p.A + (long)bcur * p.sa_b;
-  const float *B = p.B + (long)bcur * p.sb_b;
+  const float *A = p.A + gemm_off_a(p, bcur);
+  const float *B = p.B + gemm_off_b(p, bcur);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -541,8 +541,8 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
     la.init_patch(p, m0, p.M, tid);
     lb.init_patch(p, n0, p.N, tid);
   } else {
-    la.init(p.A + (long)batch * p.sa_b, p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
-    lb.init(p.B + (long)batch * p.sb_b, p.sb_n, p.sb_k, n0, p.N, tid, p.ones | p.ones_b);
+    la.init(p.A + gemm_off_a(p, batch), p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
+    lb.init(p.B + gemm_off_b(p, batch), p.sb_n, p.sb_k, n0, p.N, tid, p.ones | p.ones_b);
   }
 
   f32x16 acc[MT][NT];
@@ -811,7 +811,7 @@ __global__ void fwd3_reduce_kernel(const Fwd3Args p) {
 __global__ __launch_bounds__(256) void gemm_tiny_kernel(const GemmArgs p) {
   const long total = (long)p.M * p.N;
   const int b = blockIdx.y;
-  const float *A = p.A + (long)b * p.sa_b, *B = p.B + (long)b * p.sb_b;
+  const float *A = p.A + gemm_off_a(p, b), *B = p.B + gemm_off_b(p, b);
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int m = e / p.N, n = e % p.N;
     if (p.sym && n < m) continue;
@@ -908,7 +908,22 @@ bool gemm_v2_eligible(const GemmArgs &a, int batch) {
          (b_kc ? (a.K % 4 == 0 && Kc % 4 == 0) : (Nr % 4 == 0 && Nr >= 4));
 }
 
+// pointer tables: the vector loaders need every member 16-byte aligned relative to the first
+static bool tab_aligned(const long *off, int batch) {
+  for (int b = 0; b < batch; ++b)
+    if (off[b] % 4 != 0) return false;
+  return true;
+}
+
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
+  if (a.tab_a || a.tab_b) {
+    if (batch > GEMM_TAB_MAX || (a.tab_a && !tab_aligned(a.off_a, batch)) || (a.tab_b && !tab_aligned(a.off_b, batch))) {
+      set_error("clo_gemm: a pointer-table batch needs <= %d members, each 16-byte aligned relative to the first", GEMM_TAB_MAX);
+      return CLO_EUNSUP;
+    }
+    if (a.tab_a) a.sa_b = 4;   // (what the layout / alignment predicates see: "some aligned batch stride")
+    if (a.tab_b) a.sb_b = 4;
+  }
   a.tiles_m = (int)cdiv(a.M, BM);
   a.tiles_n = (int)cdiv(a.N, BN);
   a.tbm = BM; a.tbn = BN;
@@ -1160,6 +1175,35 @@ extern "C" int clo_gemm_f32(int M, int N, int K, float alpha, const float *A, lo
     CLO_REQUIRE(ws, "clo_gemm_f32: splitk = -1 (stream-K) needs a workspace of clo_gemm_streamk_ws_floats() floats");
     a.splitk = 1;
     a.streamk = 2;   // the workspace holds the partial tiles of any configuration
+  }
+  return launch_gemm(a, batch, (hipStream_t)stream);
+}
+
+// Batched product whose members of A and / or B lie at arbitrary addresses: A_ptrs / B_ptrs are HOST arrays of `batch` device
+// pointers (NULL: that operand is strided as in clo_gemm_f32, base A / B).  C is strided.  batch <= 8.
+extern "C" int clo_gemm_ptrs_f32(int M, int N, int K, float alpha, const float *A, const float *const *A_ptrs, long sa_m,
+                                 long sa_k, long sa_b, const float *B, const float *const *B_ptrs, long sb_k, long sb_n,
+                                 long sb_b, float beta, float *C, long ldc, long sc_b, int batch, int splitk, float *ws,
+                                 void *stream) {
+  CLO_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0 && batch <= GEMM_TAB_MAX, "clo_gemm_ptrs_f32: bad extents (batch <= %d)", GEMM_TAB_MAX);
+  CLO_REQUIRE(ldc >= N, "clo_gemm_ptrs_f32: ldc (%ld) < N (%d)", ldc, N);
+  if (M == 0 || N == 0 || batch == 0) return CLO_OK;
+  CLO_REQUIRE((A || A_ptrs) && (B || B_ptrs) && C, "clo_gemm_ptrs_f32: null operand");
+  GemmArgs a{};
+  a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.beta = beta;
+  a.A = A_ptrs ? A_ptrs[0] : A; a.sa_m = sa_m; a.sa_k = sa_k; a.sa_b = sa_b;
+  a.B = B_ptrs ? B_ptrs[0] : B; a.sb_k = sb_k; a.sb_n = sb_n; a.sb_b = sb_b;
+  a.C = C; a.ldc = ldc; a.sc_b = sc_b;
+  for (int b = 0; b < batch; ++b) {
+    if (A_ptrs) { CLO_REQUIRE(A_ptrs[b], "clo_gemm_ptrs_f32: null A member %d", b); a.off_a[b] = A_ptrs[b] - A_ptrs[0]; }
+    if (B_ptrs) { CLO_REQUIRE(B_ptrs[b], "clo_gemm_ptrs_f32: null B member %d", b); a.off_b[b] = B_ptrs[b] - B_ptrs[0]; }
+  }
+  a.tab_a = A_ptrs ? 1 : 0; a.tab_b = B_ptrs ? 1 : 0;
+  a.splitk = splitk; a.ws = ws; a.sym = 0;
+  if (splitk < 0) {
+    CLO_REQUIRE(ws, "clo_gemm_ptrs_f32: splitk = -1 (stream-K) needs a workspace of clo_gemm_streamk_ws_floats() floats");
+    a.splitk = 1;
+    a.streamk = 2;
   }
   return launch_gemm(a, batch, (hipStream_t)stream);
 }

@@ -276,8 +276,8 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
   auto prod_setup = [&](const V3Tile &t) {
     da.init(AKC ? p.sa_m : p.sa_k, t.m0, p.M, wave, lane);
     db.init(BKC ? p.sb_n : p.sb_k, t.n0, p.N, wave, lane);
-    Ab = (unsigned long)(p.A + (long)t.batch * p.sa_b + (AKC ? (long)t.m0 * p.sa_m : (long)t.m0));
-    Bb = (unsigned long)(p.B + (long)t.batch * p.sb_b + (BKC ? (long)t.n0 * p.sb_n : (long)t.n0));
+    Ab = (unsigned long)(p.A + gemm_off_a(p, t.batch) + (AKC ? (long)t.m0 * p.sa_m : (long)t.m0));
+    Bb = (unsigned long)(p.B + gemm_off_b(p, t.batch) + (BKC ? (long)t.n0 * p.sb_n : (long)t.n0));
     p_kb = t.kb; p_ke = t.ke;
     prod_seek();
   };

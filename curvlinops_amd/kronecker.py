@@ -341,12 +341,6 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         _expect_same_device(old, value)
         _expect_same_dtype(old, value)
         self._blocks[index] = value
-        self._group_cache = None
-
-    def __getstate__(self) -> dict:
-        state = self.__dict__.copy()
-        state["_group_cache"] = None  # derived data (stacked factor copies): rebuilt on first use
-        return state
 
     _POOL_STREAMS = 4
 
@@ -375,16 +369,13 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
 
     @property
     def assume_frozen(self) -> bool:
-        """Opt-in promise that the blocks' factors are not modified any more: the stacked factor copies of the batched
-        equal-shape products (`_matmat_grouped`) are then kept between products.  By default they are re-made from the
-        live factor tensors on every product, like the reference's loop over blocks (`block_diagonal.py`) reads them, so
-        `factor.data.mul_()`, `.copy_()` or an EMA update are seen."""
+        """Kept for symmetry with the curvature operators; a block-diagonal operator holds NO copies of its blocks' factors
+        any more (the batched equal-shape products reference them in place), so there is nothing to freeze or refresh."""
         return getattr(self, "_assume_frozen", False)
 
     @assume_frozen.setter
     def assume_frozen(self, value: bool) -> None:
         self._assume_frozen = bool(value)
-        self._group_cache = None
 
     def _matmat_single_call(self, parts: list[list[Tensor]]) -> list[Tensor] | None:
         """All blocks ``S1 (x) S2`` / ``(Q1 (x) Q2) diag(lam) (Q1 (x) Q2)^T`` of a KFAC / EKFAC operator in ONE foreign
@@ -422,34 +413,26 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
             return B, lam
         return None
 
-    def _kron_groups(self) -> list[tuple[list[int], Tensor, Tensor, Tensor | None]]:
-        """Blocks ``S1 (x) S2`` (KFAC) or ``(Q1 (x) Q2) diag(lambda) (Q1 (x) Q2)^T`` (EKFAC) with
-        identical factor shapes (repeated layer shapes), their factors stacked ONCE:
-        ``[(block indices, S1 [n, A, a], S2 [n, B, b], lambda [n, A, B] | None), ...]``."""
+    def _kron_groups(self) -> list[tuple[list[int], list[Tensor], list[Tensor], list[Tensor] | None]]:
+        """Blocks ``S1 (x) S2`` (KFAC) or ``(Q1 (x) Q2) diag(lambda) (Q1 (x) Q2)^T`` (EKFAC) with identical factor shapes
+        and strides (repeated layer shapes): ``[(block indices, [S1_i], [S2_i], [lambda_i] | None), ...]``.  The factors
+        are REFERENCED, not copied: the batched products take them where they lie (``_hip.gemm_members`` /
+        ``clo_gemm_ptrs_f32``), so every product reads the live factor tensors like the reference's loop over blocks
+        (``block_diagonal.py``) -- ``factor.data.mul_()``, an EMA update or a replaced factor need no refresh."""
         pairs = [self._kron_pair(B) for B in self._blocks]
-        # The stacks are COPIES of the factors.  By default they are re-made on EVERY product (the reference's loop over
-        # blocks reads the live factors, `block_diagonal.py`; version counters do not see `factor.data.mul_()`): ResNet-18
-        # re-stacks 340 MB = ~0.2 ms of a 1.6 ms product, still well below the 2.5 - 3.2 ms of the unbatched routes.
-        # Under `assume_frozen` they are kept, and even then re-made when a factor object or its address changed.
-        key = tuple((id(t), t.data_ptr()) for p in pairs if p is not None for t in (*p[0], p[1]) if t is not None)
-        cached = getattr(self, "_group_cache", None)
-        if self.assume_frozen and cached is not None and cached[0] == key:
-            return cached[1]
         by_shape: dict = {}
         for i, p in enumerate(pairs):
             if p is not None:
-                by_shape.setdefault((tuple(p[0][0].shape), tuple(p[0][1].shape), p[1] is None), []).append(i)
+                f1, f2 = p[0][0], p[0][1]
+                if f1.data_ptr() % 16 or f2.data_ptr() % 16:
+                    continue   # (the batched launch wants 16-byte aligned members; such a block takes the other routes)
+                by_shape.setdefault((tuple(f1.shape), tuple(f2.shape), f1.stride(), f2.stride(), p[1] is None), []).append(i)
         groups = []
         for idx in by_shape.values():
             if len(idx) < 2:
                 continue
-            S1 = torch.stack([pairs[i][0][0] for i in idx])
-            S2 = torch.stack([pairs[i][0][1] for i in idx])
-            lam = None
-            if pairs[idx[0]][1] is not None:
-                lam = torch.stack([pairs[i][1] for i in idx]).reshape(len(idx), S1.shape[1], S2.shape[1])
-            groups.append((idx, S1, S2, lam))
-        self._group_cache = (key, groups) if self.assume_frozen else None
+            lam = None if pairs[idx[0]][1] is None else [pairs[i][1] for i in idx]
+            groups.append((idx, [pairs[i][0][0] for i in idx], [pairs[i][0][1] for i in idx], lam))
         return groups
 
     def _matmat_grouped(self, parts: list[list[Tensor]]) -> list[Tensor] | None:
@@ -462,15 +445,15 @@ class BlockDiagonalLinearOperator(PyTorchLinearOperator):
         results: dict[int, list[Tensor]] = {}
         for idx, S1, S2, lam in groups:
             if lam is None:   # Y_i = S1_i X_i S2_i^T
-                a, b = S1.shape[2], S2.shape[2]
+                a, b = S1[0].shape[1], S2[0].shape[1]
                 Xb = torch.stack([parts[i][0].reshape(a, b) for i in idx])      # [n, a, b]
-                Y = _hip.gemm(_hip.gemm(S1, Xb), S2.transpose(1, 2))           # [n, A, B]
+                Y = _hip.gemm_members(_hip.gemm_members(S1, Xb), [f.T for f in S2])    # [n, A, B]
             else:             # Y_i = Q1_i (lambda_i * (Q1_i^T X_i Q2_i)) Q2_i^T
-                a, b = S1.shape[1], S2.shape[1]
+                a, b = S1[0].shape[0], S2[0].shape[0]
                 Xb = torch.stack([parts[i][0].reshape(a, b) for i in idx])
-                Z = _hip.gemm(_hip.gemm(S1.transpose(1, 2), Xb), S2)
-                Z.mul_(lam)
-                Y = _hip.gemm(_hip.gemm(S1, Z), S2.transpose(1, 2))
+                Z = _hip.gemm_members(_hip.gemm_members([f.T for f in S1], Xb), S2)
+                Z.mul_(torch.stack([l.reshape(S1[0].shape[1], S2[0].shape[1]) for l in lam]))
+                Y = _hip.gemm_members(_hip.gemm_members(S1, Z), [f.T for f in S2])
             for k, i in enumerate(idx):
                 results[i] = [Y[k].reshape(-1, 1)]
         rest = [i for i in range(len(self._blocks)) if i not in results]

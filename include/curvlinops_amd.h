@@ -109,6 +109,14 @@ int clo_gemm_sqsum_f32(int M, int N, int K, float alpha,
                        void *stream);
 int clo_gemm_sqsum_suggest_splits(int M, int N, int batch);
 
+/* clo_gemm_f32 for a batch whose members of A and / or B lie at ARBITRARY addresses: A_ptrs / B_ptrs are host arrays of
+ * `batch` <= 8 device pointers (NULL: that operand is strided from A / B as above); every member 16-byte aligned relative to
+ * the first, all with the same strides.  Equal-shape Kronecker factors of different layers (kfac.py builds one block per
+ * layer, block_diagonal.py loops over them) enter one batched launch where they lie -- no stacked copies to keep or refresh. */
+int clo_gemm_ptrs_f32(int M, int N, int K, float alpha, const float *A, const float *const *A_ptrs, long sa_m, long sa_k,
+                      long sa_b, const float *B, const float *const *B_ptrs, long sb_k, long sb_n, long sb_b, float beta,
+                      float *C, long ldc, long sc_b, int batch, int splitk, float *ws, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * KFAC factor accumulation: C[d][d] = beta*C + alpha * X^T X for row-major
  * X[rows][ldx] (first d columns used).  If ones_col != 0 the matrix is treated

@@ -521,11 +521,7 @@ def test_equal_shape_blocks_run_batched(dev, cls_name, sep):
     assert isinstance(K, BlockDiagonalLinearOperator) and K._kron_groups(), "equal-shape blocks must be grouped"
     v = torch.rand(op.shape[1], dtype=torch.float64)
     V = torch.rand(op.shape[1], 3, dtype=torch.float64)
-    assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4   # stacks re-made from the live factors
-    assert K._group_cache is None
-    K.assume_frozen = True                                                        # stacks kept
-    assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4
-    assert K._group_cache is not None
+    assert rel_err((op @ v.float().to(dev)).cpu(), (ref @ v).numpy()) < 1e-4   # batched products on the factors in place
     assert rel_err((op @ V.float().to(dev)).cpu(), (ref @ V).numpy()) < 1e-4
     assert rel_err((op.inverse(damping=1e-1) @ v.float().to(dev)).cpu(), (ref.inverse(damping=1e-1) @ v).numpy()) < 1e-3
 
@@ -757,7 +753,7 @@ def test_jacobian_operators_follow_swapped_parameter_storage(dev):
 def test_grouped_kronecker_blocks_see_inplace_factor_updates(dev):
     """A block-diagonal operator reads its blocks' LIVE factors on every product (reference ``block_diagonal.py`` loops
     over the blocks): in-place updates of a factor -- also ``.data`` ones, which no version counter sees -- show up.
-    Stacked factor copies (equal-shape blocks as one batched product) exist only under ``assume_frozen``."""
+    Equal-shape blocks run as one batched product that references the factors where they lie (``clo_gemm_ptrs_f32``)."""
     torch.manual_seed(0)
     blocks = []
     for _ in range(4):
@@ -773,10 +769,6 @@ def test_grouped_kronecker_blocks_see_inplace_factor_updates(dev):
     blocks[1][1].data.mul_(1.7)
     blocks[3][0].data.copy_(blocks[0][0].data * 0.3)
     assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL
-    bd.assume_frozen = True
-    assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL     # stacks kept from now on
-    assert bd._group_cache is not None
-    bd.assume_frozen = False
     blocks[0][0].data.mul_(2.0)
     assert rel_err(bd @ x, (dense() @ x).cpu().numpy()) < TOL
 
