@@ -403,3 +403,46 @@ def test_eigh_of_order_two_closed_form(entries):
     assert float((lam.double() - ref).abs().max()) <= 4e-7 * scale
     assert float((Q.T @ Q - torch.eye(2)).abs().max()) <= 4e-7
     assert float((Q @ torch.diag(lam) @ Q.T - A).abs().max()) <= 8e-7 * scale
+
+
+def test_factor_store_layout_is_aligned_and_sliceable():
+    """The flat factor buffer (data-parallel all-reduce, captured builds): every factor starts on a 256-byte boundary
+    whatever the (odd) orders before it, views do not overlap, `end_of` delimits the input-covariance prefix."""
+    from curvlinops_amd.computers import _FactorStore
+
+    sizes = {("a", "l1"): 577, ("a", "l2"): 65, ("a", "l3"): 4, ("g", "l1"): 64, ("g", "l2"): 3}
+    st = _FactorStore()
+    st.preallocate(sizes, torch.device("cpu"), torch.float32)
+    spans = []
+    for key, d in sizes.items():
+        v = st[key]
+        assert v.shape == (d, d) and v.is_contiguous()
+        off = (v.data_ptr() - st.flat.data_ptr()) // 4
+        assert off == st.offsets[key] and off % 64 == 0
+        spans.append((off, off + d * d))
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    n_a = st.end_of([k for k in sizes if k[0] == "a"])
+    assert spans[2][1] <= n_a <= spans[3][0] and n_a % 64 == 0
+    assert st.end_of([]) == 0 and st.flat.numel() == st.end_of(sizes)
+
+
+def test_live_semantics_on_the_torch_path_cpu():
+    """The CPU / float64 path re-reads parameters and data on every product like the reference (`_torch_base.py:923-944`):
+    `.data` updates and `assume_frozen` (a no-op here) leave the operator equal to a freshly built one."""
+    import curvlinops_amd as C
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3)).double()
+    params = dict(model.named_parameters())
+    X, y = torch.rand(6, 5, dtype=torch.float64), torch.rand(6, 3, dtype=torch.float64)
+    for cls in (C.GGNLinearOperator, C.EFLinearOperator, C.HessianLinearOperator):
+        op = cls(model, torch.nn.MSELoss(), params, [(X, y)])
+        v = torch.rand(op.shape[1], dtype=torch.float64)
+        op.assume_frozen = True
+        for p in params.values():
+            p.data.mul_(1.3)
+        X.data.add_(0.1)
+        fresh = cls(model, torch.nn.MSELoss(), params, [(X, y)])
+        assert torch.allclose(op @ v, fresh @ v, rtol=1e-12, atol=1e-14)
+        op.refresh()
+        assert not op.uses_native_kernels
