@@ -1044,8 +1044,9 @@ class HipEKFACComputer(HipKFACComputer):
         return output, y
 
     def compute(self):
+        factors = self._compute_captured()   # (the factor sweep as a replayed hipGraph where one is available, 3.6)
         with _use_params(self._model_module, self._params):
-            A, G, mapping = self._compute_kronecker_factors()
+            A, G, mapping = factors if factors is not None else self._compute_kronecker_factors()
             keys = [("a", k) for k in A] + [("g", k) for k in G]
             mats = [A[k] if w == "a" else G[k] for w, k in keys]
             if self._distributed:
