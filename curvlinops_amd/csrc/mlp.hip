@@ -3018,9 +3018,11 @@ extern "C" long clo_mlp_ggn_ws_floats(int L, const int *dims, int N) {
 extern "C" int clo_mlp_ggn_ws_init(int L, const int *dims, int N, float *ws, void *stream) {
   CLO_REQUIRE(L >= 1 && dims && N >= 0 && ws, "clo_mlp_ggn_ws_init: bad arguments");
   if (!mega_shape_ok(L, dims, N)) return CLO_OK;  // nothing to initialise
-  float *sync = ws + ggn_ws_mega_offset(L, dims, N) + cdiv(mega_xch_floats(dims[1], dims[2]), 64) * 64;
-  return check_hip(hipMemsetAsync(sync, 0, (size_t)mega_sync_words() * 4, (hipStream_t)stream),
-                   "hipMemsetAsync(matvec counters)");
+  // the counters AND the exchange area: its tagged slots (CLO_MG_TOPLL in mlp_mega.hip) must not show a tag of some earlier
+  // owner of this memory
+  float *xch = ws + ggn_ws_mega_offset(L, dims, N);
+  const size_t words = (size_t)cdiv(mega_xch_floats(dims[1], dims[2]), 64) * 64 + (size_t)mega_sync_words();
+  return check_hip(hipMemsetAsync(xch, 0, words * 4, (hipStream_t)stream), "hipMemsetAsync(matvec exchange area)");
 }
 static long ggn_ws_core_floats(int L, const int *dims, int N) {
   if (L <= 0 || !dims || N < 0) return 0;

@@ -62,6 +62,22 @@ constexpr int MG_P1S = 8;                // k16 steps per wave in layer 1 (d0 <=
 #ifndef CLO_MG_ABLATE
 #define CLO_MG_ABLATE 0
 #endif
+// Scalar memory path at the seams (round 5; tools/ubench/smem_seam_probe.hip, profiles/r05_scalar_seam.txt).  A CU's
+// vector-memory pipe returns in issue order, so a seam's poll and gather wait behind every weight byte requested before
+// them; s_load ... glc goes to L2 on the scalar cache's own path.  Tried and measured on the headline shape:
+//   * gather of [a1 ; da1] with s_load_dwordx16 by all eight waves, whole tile requested up front: 48.3 us (paced vector
+//     gather 44.5): the SGPR file holds four 64-byte chunks per wave, so 176 chunks take six ~0.9 us round trips;
+//   * publish with s_store_dwordx4 + s_dcache_wb: correct, 0.8 us slower than the sc1 vector stores;
+//   * POLL and ARRIVE of a counter: faster (below).  That is what is kept.
+// Scalar POLL of group counters, CLO_MG_SPOLL (the gathers stay on the vector path).  A wait is one wave spinning on
+// s_load_dword ... glc: it neither queues behind the weight loads / write-only stores of its CU nor adds to them.
+// Counters are monotonic within a call and the data is read with sc1 vector loads issued after the poll returned, so the
+// scalar read can only be late, never wrong (every 64th spin also reads the counter the architected way).  Measured per
+// seam (bits below): seam A -1.2 us, the fanned-out top flag -0.7 us, the other three nothing; polling ONE top line from
+// all 256 workgroups through the scalar path costs +15 us, hence CLO_MG_TOPFAN.
+#ifndef CLO_MG_SPOLL
+#define CLO_MG_SPOLL 9
+#endif
 constexpr int MG_PRE = CLO_MG_PRE;       // tile steps issued right behind the layer-1 loads
 // round 4: the compute waves keep requesting the layer-2 tile WHILE wave 7 runs the first seam, never
 // more than MG_PACE steps (3 KB per wave and step) ahead of what has landed: the vector-memory pipe of the CU stays busy
@@ -123,7 +139,12 @@ __host__ __device__ inline long mg_off_gsum(int d1, int d2) { return mg_off_hp(d
 __host__ __device__ inline long mg_off_slab2(int d1, int d2) { return mg_off_gsum(d1, d2) + 16L * 256; }
 long mega_xch_floats(int d1, int d2) { return mg_off_slab2(d1, d2) + 16L * MG_NB * d1 + 64; }
 // sync words: line 0 = {call, err}; two sets of 65 counters (colA[16], rowA[16], rowB[16], colB[16], top), one per 128-B line
-constexpr int MG_SET_LINES = 65;
+// The chip-wide "top" flag is fanned out (CLO_MG_TOPFAN): each of the 16 row-group leaders adds to 16 lines (one
+// instruction, lane = line) and a workgroup polls the line of its own row group -- 16 pollers per line instead of 256.
+#ifndef CLO_MG_TOPFAN
+#define CLO_MG_TOPFAN 1
+#endif
+constexpr int MG_SET_LINES = CLO_MG_TOPFAN ? 80 : 65;
 long mega_sync_words() { return 32L * (1 + 2 * MG_SET_LINES); }
 // -DCLO_MEGA_TIMING builds stamp wall_clock64() at 16 points per workgroup into the 8192 floats behind the counters
 long mega_debug_floats() { return 16384; }
@@ -173,6 +194,74 @@ __device__ __forceinline__ void mg_st4nt(float *p, const float4 &v) {
   __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4 *>(p));
 }
 __device__ __forceinline__ float mg_and(float x, unsigned m) { return __uint_as_float(__float_as_uint(x) & m); }
+
+__device__ __forceinline__ unsigned long mg_uniform64(const void *q) {
+  const unsigned long v = (unsigned long)q;
+  return ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+}
+// scalar poll of a group counter (every lane of the wave runs it; same abort protocol as mg_wait)
+__device__ __forceinline__ void mg_wait_scalar(unsigned *cnt, unsigned target, const MgAbort &ab, int lane) {
+  const unsigned long c = mg_uniform64(cnt), e = mg_uniform64(ab.err);
+  unsigned spins = 0;
+  for (;;) {
+    unsigned seen;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(c) : "memory");
+    if (seen >= target) return;
+    __builtin_amdgcn_s_sleep(1);
+    ++spins;
+    if ((spins & 63u) == 0u) {
+      // insurance: the architected device-scope read (sc1 vector load).  Were a scalar read ever served from a stale
+      // line, the wait would end here some tens of microseconds late instead of in the bounded-spin fault.
+      if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)target)
+        return;
+    }
+    if ((spins & 255u) == 0u) {
+      unsigned bad;
+      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(bad) : "s"(e) : "memory");
+      if (bad != 0u) return;
+    }
+    if (spins > ab.limit) {
+      if (lane == 0) {
+        __hip_atomic_store(ab.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ab.fault) __hip_atomic_store(ab.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
+}
+// arrival through the scalar path as well (s_atomic_add, no return)
+#ifndef CLO_MG_SARRIVE
+#define CLO_MG_SARRIVE 1
+#endif
+__device__ __forceinline__ void mg_arrive_scalar(unsigned *cnt) {
+  const unsigned long c = mg_uniform64(cnt);
+  const unsigned one = 1u;
+  asm volatile("s_atomic_add %0, %1, 0x0" ::"s"(one), "s"(c) : "memory");
+}
+// CLO_MG_SARRIVE bits as CLO_MG_SPOLL's
+#define MG_ARRIVE_B(cnt, bit)                                                   \
+  do {                                                                          \
+    if ((CLO_MG_SARRIVE) & (bit)) {                                             \
+      if (wave == 0) mg_arrive_scalar(cnt);                                     \
+    } else {                                                                    \
+      if (tid == 0) mg_arrive(cnt);                                             \
+    }                                                                           \
+  } while (0)
+#if CLO_MG_SARRIVE & 1
+#define MG_ARRIVE7(cnt) mg_arrive_scalar(cnt)
+#else
+#define MG_ARRIVE7(cnt) do { if (lane == 0) mg_arrive(cnt); } while (0)
+#endif
+// CLO_MG_SPOLL bits: 1 colA, 2 rowA, 4 rowB, 8 top, 16 colB
+#define MG_WAIT(cnt, target, bit)                                              \
+  do {                                                                          \
+    if ((CLO_MG_SPOLL) & (bit)) {                                               \
+      if (wave == 0) mg_wait_scalar((cnt), (target), c_err, lane);              \
+    } else {                                                                    \
+      if (tid == 0) mg_wait((cnt), (target), c_err);                            \
+    }                                                                           \
+  } while (0)
 
 template <bool ACCUM>
 __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
@@ -225,7 +314,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   const unsigned call = sy[0];
   unsigned *set = sy + 32 * (1 + (call & 1) * MG_SET_LINES);
   unsigned *c_colA = set + 32 * kb, *c_rowA = set + 32 * (16 + fb), *c_rowB = set + 32 * (32 + fb);
-  unsigned *c_colB = set + 32 * (48 + kb), *c_top = set + 32 * 64;
+  unsigned *c_colB = set + 32 * (48 + kb), *c_top = set + 32 * (64 + (CLO_MG_TOPFAN ? fb : 0));
   const MgAbort c_err{sy + 1, p.fault, p.spin_limit};
   MG_STAMP(0);
   if (w == 0) {  // zero the other set for the next call
@@ -423,10 +512,15 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     }
     drain_vm();
     MG_STAMP7(18);
+#if CLO_MG_SPOLL & 1
+    MG_ARRIVE7(c_colA);
+    mg_wait_scalar(c_colA, 16u, c_err, lane);
+#else
     if (lane == 0) {
       mg_arrive(c_colA);
       mg_wait(c_colA, 16u, c_err);
     }
+#endif
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     MG_STAMP7(19);
@@ -520,10 +614,8 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     for (int i = 0; i < MG_AUX_MAX / MG_T; ++i)
       if (i * MG_T + tid < naux) s_m[MG_M_AUX + i * MG_T + tid] = auxv[i];
     wg_barrier();
-    if (tid == 0) {
-      mg_arrive(c_rowA);
-      mg_wait(c_rowA, 16u, c_err);
-    }
+    MG_ARRIVE_B(c_rowA, 2);
+    MG_WAIT(c_rowA, 16u, 2);
     wg_barrier();
     MG_STAMP(6);
   }
@@ -586,10 +678,10 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     drain_vm();
     wg_barrier();
     MG_STAMP(7);
-    if (tid == 0) mg_arrive(c_rowB);
+    MG_ARRIVE_B(c_rowB, 4);
     // ---- leader of the row group: sum the 16 partials, publish, arrive on the chip-wide counter
     if (kb == 0) {
-      if (tid == 0) mg_wait(c_rowB, 16u, c_err);
+      MG_WAIT(c_rowB, 16u, 4);
       wg_barrier();
       if (tid < 64) {
         f32x4 t[16];
@@ -602,13 +694,15 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       }
       drain_vm();
       wg_barrier();
-      if (tid == 0) mg_arrive(c_top);
+#if CLO_MG_TOPFAN
+      if (tid < 16) mg_arrive(set + 32 * (64 + tid));
+#else
+      MG_ARRIVE_B(c_top, 8);
+#endif
     }
-    if (tid == 0) {
-      mg_wait(c_top, 16u, c_err);
-      // every workgroup has read the call counter long before all leaders arrived: safe to bump it now
-      if (w == 0) sy[0] = call + 1;
-    }
+    MG_WAIT(c_top, 16u, 8);
+    // every workgroup has read the call counter long before all leaders arrived: safe to bump it now
+    if (tid == 0 && w == 0) sy[0] = call + 1;
     wg_barrier();
     MG_STAMP(8);
     // operands of delta_2 for thread = (half of the rows, feature quad): the W3 columns of a quad are loaded ONCE
@@ -779,7 +873,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
       }
       drain_vm();
       wg_barrier();
-      if (tid == 0) mg_arrive(c_colB);
+      MG_ARRIVE_B(c_colB, 16);
       MG_STAMP(12);
     }
     // ---- write-only work: out_W2 tile, out_b2 / out_W3 of the finished slice, out_b3
@@ -853,7 +947,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     float4 xv[MG_NB];
 #pragma unroll
     for (int n = 0; n < MG_NB; ++n) xv[n] = mg_ld4(p.X + (long)min(n, N - 1) * d0 + (rl < lanes_r ? cq * 4 : 0));
-    if (tid == 0) mg_wait(c_colB, 16u, c_err);
+    MG_WAIT(c_colB, 16u, 16);
     wg_barrier();
     MG_STAMP(14);
     const int nq = nf1 >> 2;
