@@ -62,7 +62,7 @@ constexpr int MG_P1S = 8;                // k16 steps per wave in layer 1 (d0 <=
 #ifndef CLO_MG_ABLATE
 #define CLO_MG_ABLATE 0
 #endif
-// Scalar memory path at the seams (round 5; tools/ubench/smem_seam_probe.hip, profiles/r05_scalar_seam.txt).  A CU's
+// Scalar memory path at the seams (round 5; tools/ubench/smem_seam_probe.hip, profiles/r05_c2_scalar_seam.txt).  A CU's
 // vector-memory pipe returns in issue order, so a seam's poll and gather wait behind every weight byte requested before
 // them; s_load ... glc goes to L2 on the scalar cache's own path.  Tried and measured on the headline shape:
 //   * gather of [a1 ; da1] with s_load_dwordx16 by all eight waves, whole tile requested up front: 48.3 us (paced vector

@@ -21,9 +21,11 @@ names = ["entry", "loads issued", "L1 mfma+merge", "L1 epilogue", "seamA a1 gath
          "finish+hp pub", "top wait", "loss", "delta2", "delta1 mfma", "slab2 pub", "write-only", "colB wait", "end",
          "w7 merge start", "w7 merge done", "w7 publish issued", "w7 gather complete", "w7 a1 in LDS", "sweep done (wave 0)", "sweep barrier"] + ["-"] * 9
 acc = []
+B2B = int(os.environ.get("BACK2BACK", "1"))   # > 1: that many products queued back to back, the last one's stamps are read
 for i in range(30):
-    k = i % nv
-    plan.ggn_matvec(W, b, VW[k], Vb[k], OW[k], Ob[k], X, 0, 2.0 / 80, 1.0, 0.0)
+    for j in range(B2B):
+        k = (i * B2B + j) % nv
+        plan.ggn_matvec(W, b, VW[k], Vb[k], OW[k], Ob[k], X, 0, 2.0 / 80, 1.0, 0.0)
     torch.cuda.synchronize()
     ws = next(iter(plan._ws.values()))
     t = ws[-16384:].view(torch.int64).cpu().numpy()[:256 * 32].reshape(256, 32).astype(np.float64) * 0.01  # 100 MHz -> us
@@ -36,6 +38,8 @@ for i, n in enumerate(names):
         continue
     print(f"{i:2d} {n:18s} {t[:, i].min():7.2f}  {t[:, i].mean():7.2f}  {t[:, i].max():7.2f}")
 
+print("entry by XCD (workgroup w runs on XCD w % 8):", " ".join(f"{t[x::8, 0].mean():.2f}" for x in range(8)))
+print("end   by XCD:", " ".join(f"{t[x::8, 15].mean():.2f}" for x in range(8)))
 out = os.environ.get("STAMPS_OUT")
 if out:
     np.save(out, t)   # [256 workgroups][32 stamps], mean over the measured calls
