@@ -94,6 +94,51 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- grid-level waits through the SCALAR memory path (round 5; profiles/r05_c2_scalar_seam.txt) ----
+// A CU's vector-memory pipe returns in issue order, so a poll written as a vector load waits behind every byte the CU
+// requested before it; s_load ... glc reaches L2 on the scalar cache's own path.  The whole WAVE runs the poll (scalar
+// code); the counter must only grow while it is polled and whatever it guards must be read with device-scope (sc1)
+// vector loads issued afterwards, so a scalar read can only be late, never wrong.  Every 64th spin reads the counter the
+// architected way as well.  Same bounded-spin / abort protocol as the vector waits ("asynchronous faults" above).
+__device__ __forceinline__ unsigned long uniform_ptr(const void *q) {
+  const unsigned long v = (unsigned long)q;
+  return ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+}
+__device__ __forceinline__ void scalar_wait(unsigned *cnt, unsigned target, unsigned *err, unsigned *fault, unsigned limit,
+                                            int lane) {
+  const unsigned long c = uniform_ptr(cnt), e = uniform_ptr(err);
+  unsigned spins = 0;
+  for (;;) {
+    unsigned seen;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(c) : "memory");
+    if (seen >= target) return;
+    __builtin_amdgcn_s_sleep(1);
+    ++spins;
+    if ((spins & 63u) == 0u &&
+        (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= target)
+      return;
+    if ((spins & 255u) == 0u) {
+      unsigned bad;
+      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(bad) : "s"(e) : "memory");
+      if (bad != 0u) return;
+    }
+    if (spins > limit) {   // ~seconds: the grid is not co-resident (or the counters were not initialised)
+      if (lane == 0) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
+}
+// arrival of a whole wave through the scalar path (s_atomic_add, no return value)
+__device__ __forceinline__ void scalar_arrive(unsigned *cnt) {
+  const unsigned long c = uniform_ptr(cnt);
+  const unsigned one = 1u;
+  asm volatile("s_atomic_add %0, %1, 0x0" ::"s"(one), "s"(c) : "memory");
+}
+
 __device__ __forceinline__ float act_apply(int act, float z, float &dphi) {
   switch (act) {
     case CLO_ACT_RELU:

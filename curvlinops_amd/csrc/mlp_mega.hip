@@ -195,50 +195,15 @@ __device__ __forceinline__ void mg_st4nt(float *p, const float4 &v) {
 }
 __device__ __forceinline__ float mg_and(float x, unsigned m) { return __uint_as_float(__float_as_uint(x) & m); }
 
-__device__ __forceinline__ unsigned long mg_uniform64(const void *q) {
-  const unsigned long v = (unsigned long)q;
-  return ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-         (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
-}
-// scalar poll of a group counter (every lane of the wave runs it; same abort protocol as mg_wait)
+// scalar poll of a group counter (every lane of the wave runs it; clo_common.h)
 __device__ __forceinline__ void mg_wait_scalar(unsigned *cnt, unsigned target, const MgAbort &ab, int lane) {
-  const unsigned long c = mg_uniform64(cnt), e = mg_uniform64(ab.err);
-  unsigned spins = 0;
-  for (;;) {
-    unsigned seen;
-    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(c) : "memory");
-    if (seen >= target) return;
-    __builtin_amdgcn_s_sleep(1);
-    ++spins;
-    if ((spins & 63u) == 0u) {
-      // insurance: the architected device-scope read (sc1 vector load).  Were a scalar read ever served from a stale
-      // line, the wait would end here some tens of microseconds late instead of in the bounded-spin fault.
-      if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)target)
-        return;
-    }
-    if ((spins & 255u) == 0u) {
-      unsigned bad;
-      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(bad) : "s"(e) : "memory");
-      if (bad != 0u) return;
-    }
-    if (spins > ab.limit) {
-      if (lane == 0) {
-        __hip_atomic_store(ab.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ab.fault) __hip_atomic_store(ab.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      return;
-    }
-  }
+  scalar_wait(cnt, target, ab.err, ab.fault, ab.limit, lane);
 }
 // arrival through the scalar path as well (s_atomic_add, no return)
 #ifndef CLO_MG_SARRIVE
 #define CLO_MG_SARRIVE 1
 #endif
-__device__ __forceinline__ void mg_arrive_scalar(unsigned *cnt) {
-  const unsigned long c = mg_uniform64(cnt);
-  const unsigned one = 1u;
-  asm volatile("s_atomic_add %0, %1, 0x0" ::"s"(one), "s"(c) : "memory");
-}
+__device__ __forceinline__ void mg_arrive_scalar(unsigned *cnt) { scalar_arrive(cnt); }
 // CLO_MG_SARRIVE bits as CLO_MG_SPOLL's
 #define MG_ARRIVE_B(cnt, bit)                                                   \
   do {                                                                          \

@@ -90,24 +90,16 @@ struct TpArgs {
   unsigned spin_limit;
 };
 constexpr int TP_GROUP = 16;
-constexpr int TP_CNT_WORDS = 32 * (TD_GMAX / TP_GROUP + 2);   // group counters, top counter, error word: one line each
+// group counters [16], release lines [16] (the top level of the barrier, one per group: a leader adds to all of them with
+// one instruction, a workgroup polls its own group's -- 16 pollers per line, through the scalar path), error word: one
+// 128-byte line each.  (One top line polled by up to 256 workgroups was the slowest hop of the barrier, and through the
+// scalar path it is slower still: profiles/r05_c2_scalar_seam.txt.)
+constexpr int TP_CNT_WORDS = 32 * (2 * (TD_GMAX / TP_GROUP) + 2);
 constexpr unsigned TP_SPIN = 1u << 22;
 
-// bounded wait; on a timeout (or when another workgroup of the launch has timed out) it simply ends: the reduction then
-// finishes on garbage, which the eigensolver's verification rejects (float64 retry) -- clo_common.h, "asynchronous faults"
-__device__ __forceinline__ void tp_wait(unsigned *cnt, unsigned target, unsigned *err, unsigned *fault, unsigned limit) {
-  unsigned spins = 0;
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(1);
-    ++spins;
-    if ((spins & 255u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    if (spins > limit) {   // ~seconds: the grid is not co-resident
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-  }
-}
+// The waits are bounded (scalar_wait, clo_common.h); on a timeout (or when another workgroup of the launch has timed out)
+// a wait simply ends: the reduction then finishes on garbage, which the eigensolver's verification rejects (float64
+// retry) -- clo_common.h, "asynchronous faults".
 
 template <int RPW>
 __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p) {
@@ -143,7 +135,8 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
 
   const int G = p.G, ngroups = (G + TP_GROUP - 1) / TP_GROUP;
   const int grp = blockIdx.x / TP_GROUP, gsize = min(TP_GROUP, G - grp * TP_GROUP);
-  unsigned *c_grp = p.cnt + 32 * grp, *c_top = p.cnt + 32 * (TD_GMAX / TP_GROUP), *c_err = c_top + 32;
+  unsigned *c_grp = p.cnt + 32 * grp, *c_rel0 = p.cnt + 32 * (TD_GMAX / TP_GROUP), *c_rel = c_rel0 + 32 * grp;
+  unsigned *c_err = p.cnt + 32 * (2 * (TD_GMAX / TP_GROUP));
 
   // this wave's rows, fixed for the panel: the workgroup owns rpb consecutive rows, its waves rpw of them each (the rows
   // are dealt per WORKGROUP: dealing rpw rows per wave over the whole grid left a quarter of the CUs without rows at
@@ -503,11 +496,13 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
     TD_STAMP(5);   // stores acknowledged
     const unsigned epoch = (unsigned)(c + 1);
     if (tid == 0) __hip_atomic_fetch_add(c_grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x % TP_GROUP == 0 && tid == 0) {   // the group's leader: everybody of the group has arrived -> top counter
-      tp_wait(c_grp, (unsigned)gsize * epoch, c_err, p.fault, p.spin_limit);
-      __hip_atomic_fetch_add(c_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+      if (blockIdx.x % TP_GROUP == 0) {   // the group's leader: everybody of the group has arrived -> every release line
+        scalar_wait(c_grp, (unsigned)gsize * epoch, c_err, p.fault, p.spin_limit, lane);
+        if (lane < ngroups) __hip_atomic_fetch_add(c_rel0 + 32 * lane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      scalar_wait(c_rel, (unsigned)ngroups * epoch, c_err, p.fault, p.spin_limit, lane);
     }
-    if (tid == 0) tp_wait(c_top, (unsigned)ngroups * epoch, c_err, p.fault, p.spin_limit);
     __syncthreads();
     TD_STAMP(6);   // barrier
   }
