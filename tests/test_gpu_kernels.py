@@ -678,6 +678,30 @@ def test_ggn_matmat_columns_c2_width(hip):
         assert rel_err(np.concatenate([w[..., k].ravel() for w in gW]), np.concatenate([r.ravel() for r in rW])) < 1e-4
 
 
+@pytest.mark.parametrize("loss,N,K", [("mse", 8, 8), ("ce", 11, 12)])
+def test_ggn_matmat_columns_overlapped_layers(hip, loss, N, K):
+    """Layers wide enough (d_out d_in >= 2^20) for the two-stream schedule: the tangent GEMM of a layer next to its weight
+    stream (joined by one elementwise pass), the delta GEMM of the layer below next to the result stream; biases, two row
+    blocks, accumulation."""
+    g = np.random.default_rng(17 * N + K)
+    dims, acts = [128, 1088, 1088, 10], ["tanh", "relu", "identity"]
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [g.random(dims[i + 1]) - 0.5 for i in range(3)]
+    VWk = [g.random((*W.shape, K)) - 0.5 for W in Ws]
+    Vbk = [g.random((*b.shape, K)) - 0.5 for b in bs]
+    X = g.random((N, dims[0]))
+    y = g.integers(0, dims[-1], N) if loss == "ce" else g.random((N, dims[-1]))
+    scale = (2.0 if loss == "mse" else 1.0) * O.reduction_factor(loss, "mean", N, dims[-1])
+    out0 = ([g.random(v.shape) for v in VWk], [g.random(v.shape) for v in Vbk])
+    gW, gb = _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, Vbk, LOSS_KIND[loss], scale, 0.5, 1.0, out0=out0)
+    for k in (0, K // 2, K - 1):
+        rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", [v[..., k] for v in VWk], [v[..., k] for v in Vbk])
+        ref = O.flatten_params([0.5 * r + o[..., k] for r, o in zip(rW, out0[0])],
+                               [0.5 * r + o[..., k] for r, o in zip(rb, out0[1])])
+        got = O.flatten_params([w[..., k] for w in gW], [b[..., k] for b in gb])
+        assert rel_err(got, ref) < 1e-4, k
+
+
 def test_ggn_matmat_unsupported_shapes_report(hip):
     plan = hip.MLPPlan([6, 4], [0])
     assert not plan.matmat_supported(8, 8)       # input width not a multiple of 4
