@@ -2221,6 +2221,119 @@ __global__ __launch_bounds__(256) void kouter_stream_kernel(
   }
 }
 
+// Tangent of a NARROW last layer (d_out <= 16 outputs) in two launches instead of four (tangent GEMM, its split-K reduce and
+// the weight stream, 47 us on 2688 -> 10 at K = 32: the stream kernel deals features to blocks and has ten of them):
+//   dA_L[c][n][k] = phi'[n][c] (sum_i V[c][i][k] a[n][i] + W[c][i] dA_{L-1}[i][n][k] + Vb[c][k])
+// klast_partial: block g takes KL_ROWS rows i of the contraction, thread = (n, column quad), all d_out outputs in
+// registers; the partial [d_out][N][K] goes to slab g.  klast_finish: sums the slabs in a fixed order (16 lanes per output
+// quad over the slab index, then an LDS tree), bias, phi'.
+constexpr int KL_ROWS = 8, KL_CMAX = 16;
+// SLOTS row slots of PP = 256 / SLOTS threads: slot s takes rows i0 + s, i0 + s + SLOTS, ... (KL_ROWS / SLOTS of them, all their
+// loads in flight at once), thread = (slot, (n, column quad)); the slots are merged through LDS.
+template <int SLOTS>
+__global__ __launch_bounds__(256) void klast_partial_kernel(const float *__restrict__ V, long ldk, const float *__restrict__ W,
+                                                            const float *__restrict__ a, const float *__restrict__ dAp,
+                                                            float *__restrict__ slabs, int N, int K, int d_in, int C) {
+  constexpr int PP = 256 / SLOTS, RPT = KL_ROWS / SLOTS;
+  __shared__ float4 s_red[SLOTS - 1][KL_CMAX][PP];
+  const int G = K >> 2, pairs = N * G;
+  const int slot = threadIdx.x / PP, pp = threadIdx.x - slot * PP;
+  const bool live = pp < pairs;
+  const int pr = live ? pp : 0, n = pr / G, kq = pr - n * G;
+  const int i0 = blockIdx.x * KL_ROWS + slot;
+  float4 acc[KL_CMAX];
+#pragma unroll
+  for (int c = 0; c < KL_CMAX; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float an[RPT];
+  float4 t[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {   // rows beyond d_in: row 0 with a zero multiplier
+    const int i = i0 + r * SLOTS, ic = i < d_in ? i : 0;
+    an[r] = i < d_in ? a[(long)n * d_in + ic] : 0.f;
+    t[r] = dAp && i < d_in ? ld4(dAp + ((long)ic * N + n) * K + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int c = 0; c < KL_CMAX; ++c) {
+    if (c < C) {
+      float4 v[RPT];
+      float w[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int i = i0 + r * SLOTS, ic = i < d_in ? i : 0;
+        v[r] = ld4(V + ((long)c * d_in + ic) * ldk + 4 * kq);
+        w[r] = i < d_in ? W[(long)c * d_in + ic] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        acc[c].x = fmaf(v[r].x, an[r], fmaf(w[r], t[r].x, acc[c].x)); acc[c].y = fmaf(v[r].y, an[r], fmaf(w[r], t[r].y, acc[c].y));
+        acc[c].z = fmaf(v[r].z, an[r], fmaf(w[r], t[r].z, acc[c].z)); acc[c].w = fmaf(v[r].w, an[r], fmaf(w[r], t[r].w, acc[c].w));
+      }
+    }
+  }
+  if (slot > 0) {
+#pragma unroll
+    for (int c = 0; c < KL_CMAX; ++c)
+      if (c < C) s_red[slot - 1][c][pp] = acc[c];
+  }
+  __syncthreads();
+  if (slot == 0 && live) {
+    float *dst = slabs + (long)blockIdx.x * C * N * K + ((long)n * K + 4 * kq);
+#pragma unroll
+    for (int c = 0; c < KL_CMAX; ++c)
+      if (c < C) {
+        float4 o = acc[c];
+#pragma unroll
+        for (int q = 0; q < SLOTS - 1; ++q) { const float4 x = s_red[q][c][pp]; o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w; }
+        *reinterpret_cast<float4 *>(dst + (long)c * N * K) = o;
+      }
+  }
+}
+// four output quads per block, 64 lanes over the slab index each
+__global__ __launch_bounds__(256) void klast_finish_kernel(const float *__restrict__ slabs, int nslab, const float *__restrict__ Vb,
+                                                           long ldk, const float *__restrict__ dphi, float *__restrict__ dA,
+                                                           int N, int K, int C) {
+  __shared__ float4 s_p[4][64];
+  const int G = K >> 2;
+  const long quads = (long)C * N * G;
+  const int lane_g = threadIdx.x & 63, oq = threadIdx.x >> 6;
+  const long q = (long)blockIdx.x * 4 + oq;
+  float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < quads) {
+    const float *src = slabs + 4 * q;
+    const long stride = (long)C * N * K;
+    int g = lane_g;
+    for (; g + 192 < nslab; g += 256) {   // four loads in flight
+      const float4 t0 = ld4(src + (long)g * stride), t1 = ld4(src + (long)(g + 64) * stride);
+      const float4 t2 = ld4(src + (long)(g + 128) * stride), t3 = ld4(src + (long)(g + 192) * stride);
+      sacc.x += (t0.x + t1.x) + (t2.x + t3.x); sacc.y += (t0.y + t1.y) + (t2.y + t3.y);
+      sacc.z += (t0.z + t1.z) + (t2.z + t3.z); sacc.w += (t0.w + t1.w) + (t2.w + t3.w);
+    }
+    for (; g < nslab; g += 64) {
+      const float4 t0 = ld4(src + (long)g * stride);
+      sacc.x += t0.x; sacc.y += t0.y; sacc.z += t0.z; sacc.w += t0.w;
+    }
+  }
+  s_p[oq][lane_g] = sacc;
+  __syncthreads();
+  if (lane_g < 16) {   // 64 -> 16 -> 1, fixed order
+    float4 o = s_p[oq][lane_g];
+    for (int g = 1; g < 4; ++g) { const float4 x = s_p[oq][lane_g + 16 * g]; o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w; }
+    s_p[oq][lane_g] = o;
+  }
+  __syncthreads();
+  if (lane_g == 0 && q < quads) {
+    float4 o = s_p[oq][0];
+    for (int g = 1; g < 16; ++g) { const float4 x = s_p[oq][g]; o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w; }
+    const int kq = (int)(q % G), n = (int)((q / G) % N), c = (int)(q / ((long)G * N));
+    if (Vb) {
+      const float4 vb = ld4(Vb + (long)c * ldk + 4 * kq);
+      o.x += vb.x; o.y += vb.y; o.z += vb.z; o.w += vb.w;
+    }
+    const float dp = dphi ? dphi[(long)n * C + c] : 1.f;
+    *reinterpret_cast<float4 *>(dA + 4 * q) = make_float4(dp * o.x, dp * o.y, dp * o.z, dp * o.w);
+  }
+}
+
 // delta_L[c][n][k] = phi'_L[n][c] * scale * (H(f_n) u[:, n, k])[c]  in place on u = dA_L.
 // One thread per (n, k).
 constexpr int LC_RMAX = 16;  // rank-M curvature: at most 16 backpropagated vectors per sample
@@ -3482,6 +3595,26 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
       int rc = fwd_pass(W[l - 1], b ? b[l - 1] : nullptr, nullptr, nullptr, a[l - 1], nullptr, a[l],
                         nullptr, dphi[l], nn, di, dout, acts[l - 1], part, false, nullptr, st);
       if (rc != CLO_OK) return rc;
+#ifndef CLO_KC_LAST
+#define CLO_KC_LAST 1
+#endif
+      static const int kc_last = CLO_KC_LAST;
+      const int klast_slabs = (int)cdiv(di, KL_ROWS);
+      if (kc_last && l == L && l >= 2 && dout <= KL_CMAX && nn * G <= 128 &&
+          (long)klast_slabs * dout * NK <= gws_sz) {   // narrow last layer: tangent GEMM + weight stream in one pass
+        const float *dpl = last_linear ? nullptr : dphi[l];
+        if (nn * G <= 64)
+          hipLaunchKernelGGL(klast_partial_kernel<4>, dim3(klast_slabs), dim3(256), 0, st, VW[l - 1], ldk, W[l - 1], a[l - 1],
+                             dA[l - 1], gws, nn, K, di, dout);
+        else
+          hipLaunchKernelGGL(klast_partial_kernel<2>, dim3(klast_slabs), dim3(256), 0, st, VW[l - 1], ldk, W[l - 1], a[l - 1],
+                             dA[l - 1], gws, nn, K, di, dout);
+        CLO_CHECK_LAUNCH("klast_partial_kernel");
+        hipLaunchKernelGGL(klast_finish_kernel, dim3((unsigned)cdiv((long)dout * nn * G, 4)), dim3(256), 0, st, gws,
+                           klast_slabs, Vb ? Vb[l - 1] : nullptr, ldk, dpl, dA[l], nn, K, dout);
+        CLO_CHECK_LAUNCH("klast_finish_kernel");
+        continue;
+      }
       if (l >= 2) {  // dA_l = W_l dA_{l-1}   ([dout x di] [di x NK])
         GemmArgs g = gemm_problem(dout, NK, di, W[l - 1], di, 1, dA[l - 1], NK, 1, 0.f, dA[l], NK);
         rc = launch_gemm_auto(g, gws, gws_sz, st);
