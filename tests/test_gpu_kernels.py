@@ -702,6 +702,38 @@ def test_ggn_matmat_columns_overlapped_layers(hip, loss, N, K):
         assert rel_err(got, ref) < 1e-4, k
 
 
+@pytest.mark.parametrize("K", [32, 64])
+def test_ggn_matmat_columns_benchmark_network_vs_oracle(hip, K):
+    """The benchmarked K-column point itself: 1024-2688-2688-10 (ReLU), 8 rows, K = 32 / 64 tangent columns drawn on the
+    device, three of them checked block by block against the float64 oracle."""
+    g = np.random.default_rng(K)
+    dims, acts, N = [1024, 2688, 2688, 10], ["relu", "relu", "identity"], 8
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [g.random(dims[i + 1]) - 0.5 for i in range(3)]
+    X, y = g.random((N, dims[0])), g.random((N, dims[-1]))
+    scale = 2.0 * O.reduction_factor("mse", "mean", N, dims[-1])
+    gen = torch.Generator(device="cuda").manual_seed(K)
+    dV = [torch.rand(*W.shape, K, device="cuda", generator=gen) - 0.5 for W in Ws]
+    dVb = [torch.rand(*b.shape, K, device="cuda", generator=gen) - 0.5 for b in bs]
+    oW = [torch.full_like(v, float("nan")) for v in dV]
+    ob = [torch.full_like(v, float("nan")) for v in dVb]
+    plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    dW, db = [dev(W) for W in Ws], [dev(b) for b in bs]
+    plan.bind_params(dW, db)
+    Xd = dev(X)
+    ws = plan.matmat_workspace(K, "cuda")
+    ptr = lambda lst: [t.data_ptr() for t in lst]  # noqa: E731
+    plan.ggn_matmat_ptrs(ptr(dV), ptr(dVb), ptr(oW), ptr(ob), K, K, Xd.data_ptr(), N, 0, scale, 1.0, 0.0, None, 1,
+                         ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for k in (0, K // 2 + 1, K - 1):
+        vW = [v[..., k].double().cpu().numpy() for v in dV]
+        vb = [v[..., k].double().cpu().numpy() for v in dVb]
+        rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, "mse", "mean", vW, vb)
+        for blk, (got, ref) in enumerate(zip([w[..., k] for w in oW] + [b[..., k] for b in ob], rW + rb)):
+            assert rel_err(got.cpu().numpy(), ref) < 1e-4, (k, blk)
+
+
 def test_ggn_matmat_unsupported_shapes_report(hip):
     plan = hip.MLPPlan([6, 4], [0])
     assert not plan.matmat_supported(8, 8)       # input width not a multiple of 4
