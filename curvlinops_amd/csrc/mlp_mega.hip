@@ -83,6 +83,16 @@ constexpr int MG_PRE = CLO_MG_PRE;       // tile steps issued right behind the l
 // more than MG_PACE steps (3 KB per wave and step) ahead of what has landed: the vector-memory pipe of the CU stays busy
 // through the seam, and the seam's gather queues behind <= MG_PACE x 21 KB instead of behind the whole tile.
 constexpr int MG_PACE = CLO_MG_PACE;
+// round 5: only the first MG_HOLD steps of the tile are requested before / during seam A; the rest is requested inside
+// phase 2, MG_HOLD steps ahead of its use.  Phase 2 used to start with a wait for the WHOLE tile (the conditional requests
+// made hipcc count conservatively), and the seam's publish / gather queued behind whatever had been requested.  Measured:
+// seam A ends 1.6 us earlier (a1 in LDS at 12.9 instead of 14.5 us), phase 2 ends when it did before (19.9 us) -- it now
+// waits for the held-back steps: the 82 MB of W1, V1, W2, V2 arrive at ~4.2 TB/s whatever the request schedule (16 rows x
+// 64 bytes per request, 704 contiguous bytes per tile row).  MG_HOLD 3 .. 11: 40.8 .. 41.4 us per product.
+#ifndef CLO_MG_HOLD
+#define CLO_MG_HOLD 7
+#endif
+constexpr int MG_HOLD = CLO_MG_HOLD < MG_PRE ? MG_PRE : (CLO_MG_HOLD > MG_MAXS ? MG_MAXS : CLO_MG_HOLD);
 constexpr int MG_NB = 8, MG_CMAX = 16;
 constexpr int MG_MAXDEV = 64;            // device ordinals with per-device launch state
 constexpr unsigned MG_SPIN = 1u << 22;   // bound of every spin (each poll is a fabric round trip + s_sleep)
@@ -363,13 +373,13 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     const int row = j0 + gl * 8 + (idx & 7);
     pA2[g] = ((idx >= 8) ? p.V2 : p.W2) + (long)row * d1 + k0 + s4;
   }
+  // (every tile load is UNCONDITIONAL -- steps beyond the K range re-read its last step -- so that the issue order is one
+  // straight line and hipcc waits for a step by exact count instead of for everything issued so far)
   if (wave < MG_CWAVES) {
 #pragma unroll
     for (int s = 0; s < MG_PRE; ++s) {
-      if (s < ns) {
 #pragma unroll
-        for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
-      }
+      for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + min(s, ns - 1) * 16);
     }
   }
 #pragma unroll
@@ -427,12 +437,10 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
   //      wave 7: merge of the eight K parts, epilogue of layer 1 and column-group seam A
   if (wave < MG_CWAVES) {
 #pragma unroll
-    for (int s = MG_PRE; s < MG_MAXS; ++s) {
-      if (s < ns) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (MG_PACE - 1)) : "memory");
+    for (int s = MG_PRE; s < MG_HOLD; ++s) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (MG_PACE - 1)) : "memory");
 #pragma unroll
-        for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + s * 16);
-      }
+      for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + min(s, ns - 1) * 16);
     }
     MG_STAMP(3);
   } else {
@@ -520,6 +528,10 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     const float *pBs = s_b + idx * MG_LDB + s4;
 #pragma unroll
     for (int s = 0; s < MG_MAXS; ++s) {
+      if (s + MG_HOLD < MG_MAXS) {   // the steps held back during the seam are requested here, MG_HOLD steps ahead of their use
+#pragma unroll
+        for (int g = 0; g < MG_MAXG; ++g) tv[s + MG_HOLD][g] = mg_ld4(pA2[g] + min(s + MG_HOLD, ns - 1) * 16);
+      }
       if (s < ns) {
         const float4 bv = mg_ld4(pBs + s * 16);
 #pragma unroll
