@@ -268,68 +268,78 @@ def secondary_configs(device) -> dict:
         return ts[len(ts) // 2], [ts[0], ts[-1]], out
 
     out = {}
-    # ---- C3: LeNet-5 on 32 x 32 inputs, B = 1024, KFAC factor build + damped inverse + matvec (BASELINE configs[2])
-    from benchmarks.models import lenet5
+    skip = os.environ.get("CLO_BENCH_SKIP", "").split(",")   # diagnosis only: leave out c3 / c4 / c5
+    if "c3" not in skip:
+        # ---- C3: LeNet-5 on 32 x 32 inputs, B = 1024, KFAC factor build + damped inverse + matvec (BASELINE configs[2])
+        from benchmarks.models import lenet5
 
-    torch.manual_seed(0)
-    net3 = lenet5().to(device)
-    p3 = dict(net3.named_parameters())
-    X3, y3 = torch.rand(1024, 1, 32, 32, device=device), torch.randint(0, 10, (1024,), device=device)
-    kw3 = dict(separate_weight_and_bias=False, check_deterministic=False, num_data=1024)
-    c3 = {"rows": 1024}
-    for ft in ("mc", "type-2"):
-        ms, sp, K3 = median_of(lambda: C.KFACLinearOperator(net3, nn.CrossEntropyLoss(), p3, [(X3, y3)], fisher_type=ft, **kw3), 5)
-        c3[f"factor_build_ms_{ft}"] = ms
-        c3[f"factor_build_ms_{ft}_min_max"] = sp
-    c3["inverse_ms"], c3["inverse_ms_min_max"], K3inv = median_of(lambda: K3.inverse(damping=1e-3), 5)
-    v3 = torch.rand(K3.shape[1], device=device)
-    c3["matvec_ms"], _, _ = median_of(lambda: K3 @ v3, 5)
-    c3["inverse_matvec_ms"], _, _ = median_of(lambda: K3inv @ v3, 5)
-    c3["note"] = "LeNet-5, joint W+b, CE mean; medians of 5 after one warm-up; type-2 = ten backpropagated vectors in one batched pass"
-    out["c3_kfac_lenet5"] = c3
-    del net3, p3, K3, K3inv
-    torch.manual_seed(0)
-    model = ResNet18().to(device).eval()
-    params = kfac_params(model)
-    B = 512
-    X, y = torch.rand(B, 3, 32, 32, device=device), torch.randint(0, 10, (B,), device=device)
-    kw = dict(fisher_type="mc", separate_weight_and_bias=False, check_deterministic=False, num_data=B)
-    K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw)
-    facs = [S for blk in K[1] for S in blk]
-    ek = {"rows": B}
-    ek["eigh_ms"], ek["eigh_ms_min_max"], _ = median_of(lambda: linalg_native.eigh_many(facs), 5)   # six host threads: noisy
-    ek["ekfac_total_ms"], ek["ekfac_total_ms_min_max"], E = median_of(
-        lambda: C.EKFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw), 5)
-    v = torch.rand(E.shape[1], device=device)
-    ek["ekfac_matvec_ms"], _ = timed(lambda: E @ v, 3)
-    ek["note"] = ("EKFAC = factors + eigendecompositions of the 42 factors (dead-feature rows deflated, normalised, "
-                  "hand-written solver end to end: Householder reduction, tridiagonal divide & conquer batched per "
-                  "factor size, block-reflector back-transformation; 6 worker streams, units sized by a measured "
-                  "wall-time model; orthogonality / residual verified, float64 retry) + eigenvalue-correction sweep; "
-                  "eigh_ms / ekfac_total_ms = MEDIAN of 5 calls after one warm-up, [min, max] beside them")
-    ek["eigh_policy"] = "native (clo_sytrd_f32 persistent panels -> divide & conquer -> block reflectors)"
-    out["c4_ekfac_resnet18"] = ek
-    del K, E, facs, model, params
-    torch.cuda.empty_cache()
-    torch.manual_seed(0)
-    enc = Encoder().to(device).eval()
-    p5 = dict(enc.named_parameters())
-    X5, y5 = torch.rand(8, 128, 768, device=device), torch.randint(0, 10, (8,), device=device)
-    EF = C.EFLinearOperator(enc, nn.CrossEntropyLoss(), p5, [(X5, y5)], check_deterministic=False, num_data=8)
-    D5 = EF.shape[1]
-    v5 = torch.rand(D5, device=device)
-    c5 = {"D": D5, "rows": 8, "seq_len": 128}
-    c5["ef_matvec_ms"], c5["ef_matvec_ms_min_max"], _ = median_of(lambda: EF @ v5, 5)
-    t0 = time.perf_counter()
-    C.hutchpp_trace(EF, num_matvecs=96)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    tr = C.hutchpp_trace(EF, num_matvecs=96)
-    torch.cuda.synchronize()
-    c5["hutchpp_96_ms"] = 1e3 * min(t1 - t0, time.perf_counter() - t1)
-    c5["hutchpp_trace"] = float(tr)
-    c5["note"] = "general net: torch.func products on the GPU; probes, Gram-route range basis and reductions native"
-    out["c5_encoder_ef_hutchpp"] = c5
+        torch.manual_seed(0)
+        net3 = lenet5().to(device)
+        p3 = dict(net3.named_parameters())
+        X3, y3 = torch.rand(1024, 1, 32, 32, device=device), torch.randint(0, 10, (1024,), device=device)
+        kw3 = dict(separate_weight_and_bias=False, check_deterministic=False, num_data=1024)
+        c3 = {"rows": 1024}
+        for ft in ("mc", "type-2"):
+            if "c3" + ft in skip:
+                continue
+            ms, sp, K3 = median_of(lambda: C.KFACLinearOperator(net3, nn.CrossEntropyLoss(), p3, [(X3, y3)], fisher_type=ft, **kw3), 5)
+            c3[f"factor_build_ms_{ft}"] = ms
+            c3[f"factor_build_ms_{ft}_min_max"] = sp
+        K3inv = None
+        if "c3inv" not in skip:
+            c3["inverse_ms"], c3["inverse_ms_min_max"], K3inv = median_of(lambda: K3.inverse(damping=1e-3), 5)
+        v3 = torch.rand(K3.shape[1], device=device)
+        if "c3mv" not in skip:
+            c3["matvec_ms"], _, _ = median_of(lambda: K3 @ v3, 5)
+            if K3inv is not None:
+                c3["inverse_matvec_ms"], _, _ = median_of(lambda: K3inv @ v3, 5)
+        c3["note"] = "LeNet-5, joint W+b, CE mean; medians of 5 after one warm-up; type-2 = ten backpropagated vectors in one batched pass"
+        out["c3_kfac_lenet5"] = c3
+        del net3, p3, K3, K3inv
+    if "c4" not in skip:
+        torch.manual_seed(0)
+        model = ResNet18().to(device).eval()
+        params = kfac_params(model)
+        B = 512
+        X, y = torch.rand(B, 3, 32, 32, device=device), torch.randint(0, 10, (B,), device=device)
+        kw = dict(fisher_type="mc", separate_weight_and_bias=False, check_deterministic=False, num_data=B)
+        K = C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw)
+        facs = [S for blk in K[1] for S in blk]
+        ek = {"rows": B}
+        ek["eigh_ms"], ek["eigh_ms_min_max"], _ = median_of(lambda: linalg_native.eigh_many(facs), 5)   # six host threads: noisy
+        ek["ekfac_total_ms"], ek["ekfac_total_ms_min_max"], E = median_of(
+            lambda: C.EKFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw), 5)
+        v = torch.rand(E.shape[1], device=device)
+        ek["ekfac_matvec_ms"], _ = timed(lambda: E @ v, 3)
+        ek["note"] = ("EKFAC = factors + eigendecompositions of the 42 factors (dead-feature rows deflated, normalised, "
+                      "hand-written solver end to end: Householder reduction, tridiagonal divide & conquer batched per "
+                      "factor size, block-reflector back-transformation; 6 worker streams, units sized by a measured "
+                      "wall-time model; orthogonality / residual verified, float64 retry) + eigenvalue-correction sweep; "
+                      "eigh_ms / ekfac_total_ms = MEDIAN of 5 calls after one warm-up, [min, max] beside them")
+        ek["eigh_policy"] = "native (clo_sytrd_f32 persistent panels -> divide & conquer -> block reflectors)"
+        out["c4_ekfac_resnet18"] = ek
+        del K, E, facs, model, params
+        torch.cuda.empty_cache()
+    if "c5" not in skip:
+        torch.manual_seed(0)
+        enc = Encoder().to(device).eval()
+        p5 = dict(enc.named_parameters())
+        X5, y5 = torch.rand(8, 128, 768, device=device), torch.randint(0, 10, (8,), device=device)
+        EF = C.EFLinearOperator(enc, nn.CrossEntropyLoss(), p5, [(X5, y5)], check_deterministic=False, num_data=8)
+        D5 = EF.shape[1]
+        v5 = torch.rand(D5, device=device)
+        c5 = {"D": D5, "rows": 8, "seq_len": 128}
+        c5["ef_matvec_ms"], c5["ef_matvec_ms_min_max"], _ = median_of(lambda: EF @ v5, 5)
+        t0 = time.perf_counter()
+        C.hutchpp_trace(EF, num_matvecs=96)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr = C.hutchpp_trace(EF, num_matvecs=96)
+        torch.cuda.synchronize()
+        c5["hutchpp_96_ms"] = 1e3 * min(t1 - t0, time.perf_counter() - t1)
+        c5["hutchpp_trace"] = float(tr)
+        c5["note"] = "general net: torch.func products on the GPU; probes, Gram-route range basis and reductions native"
+        out["c5_encoder_ef_hutchpp"] = c5
     return out
 
 
