@@ -986,7 +986,14 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
   else if (b_kc) CLO_V2(false, true, BKV, BMV, BNV, WM_, WN_)           \
   else CLO_V2(false, false, BKV, BMV, BNV, WM_, WN_)
     const long nblocks = (long)grid.x * grid.y;
-    if (((cfg.bm == 128 && cfg.bk == 32) || (cfg.bk == 64 && gemm_v3_small(a, batch))) && gemm_v3_eligible(a, batch)) {
+#ifndef CLO_GEMM_V3_MIN_K
+#define CLO_GEMM_V3_MIN_K 129
+#endif
+    // (K <= 128 is four k tiles: the LDS-DMA ring of the v3 engine is barely full before it drains, the register-staged loop
+    // below wins -- 2688 x 2688 x 128: 34.8 -> 28.4 us, 2304 x 2304 x 128: 33.7 -> 30.3, 2688 x 1024 x 128: 21.8 -> 18.3; at
+    // K = 256 the engine is ahead again, 41.2 vs 44.8 us)
+    const bool v3_deep = a.K >= CLO_GEMM_V3_MIN_K || cfg.bk == 64;
+    if (v3_deep && ((cfg.bm == 128 && cfg.bk == 32) || (cfg.bk == 64 && gemm_v3_small(a, batch))) && gemm_v3_eligible(a, batch)) {
       if (cfg.bk == 64) {   // (the LDS-DMA engine's k tiles are 32 deep)
         a.k_per_split = (int)cdiv(cdiv(a.K, a.splitk), 32) * 32;
         a.splitk = (int)cdiv(a.K, a.k_per_split);

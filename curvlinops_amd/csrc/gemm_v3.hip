@@ -608,6 +608,7 @@ static bool v3_use_small(const GemmArgs &a, int batch) {
   // 2688 x 256 x 2688 52.1 -> 46.3) and symmetric products (half the tiles: 512-row pixel Grams 46.7 -> 43.1 / 18.9 -> 17.6 us,
   // the patch products of round 4 175 -> 140 us); 512 x 2304 x 2304 loses (64 -> 81 us) and keeps the 128 x 128 tiles.
   if (a.epi != EPI_NONE) return false;   // (fused epilogues run the engine's generic store path per tile: C2 at 65 / 128 rows 180 -> 192 / 194 -> 201 us)
+  if (mode == 2) return tiles < 2L * kNumCU;   // (probe builds: wherever the square tiles leave the second round half empty)
   return tiles < kNumCU && (a.sym || std::min(a.M, a.N) <= 384);
 }
 
