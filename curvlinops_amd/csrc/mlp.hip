@@ -1891,6 +1891,79 @@ __global__ __launch_bounds__(256) void head_rows_bwd_kernel(const float *__restr
   delta_prev[(long)n * d + i] = acc * dphi_prev[(long)n * d + i];
 }
 
+// Everything behind delta_L of a narrow head, up to HB_MAX_N rows, in ONE launch (round 5: the three outer-product launches
+// and head_rows_bwd_kernel took 22 of the 197 us of a 128-row product, each of them a few microseconds of latency):
+//   out_W[c][j]      = beta out_W[c][j] + sum_n dL[n][c] a_prev[n][j]            blocks [0, nbj): 64 columns, all rows
+//   out_b[c]         = beta out_b[c]    + sum_n dL[n][c]                         (block 0)
+//   delta_prev[n][j] = dphi_prev[n][j] * sum_c dL[n][c] W[c][j]                  blocks [nbj, ...): 64 columns x HB_DROWS rows
+// Every block has 8 waves = 8 row groups (rows n = grp, grp + 8, ...); dL sits in LDS (broadcast reads), the row groups'
+// partial out_W sums are merged through LDS in a fixed order.
+constexpr int HB_MAX_N = 256, HB_GROUPS = 8, HB_DROWS = 32;
+__global__ __launch_bounds__(HB_GROUPS * 64) void head_rows_back_kernel(
+    const float *__restrict__ dL, const float *__restrict__ a_prev, const float *__restrict__ W,
+    const float *__restrict__ dphi_prev, float *__restrict__ out_W, float *__restrict__ out_b,
+    float *__restrict__ delta_prev, int N, int d, int C, float beta, int nbj) {
+  __shared__ float s_dl[HB_MAX_N * HEAD_CMAX];
+  __shared__ float s_acc[HEAD_CMAX][HB_GROUPS][64];
+  const int lane = threadIdx.x & 63, grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool outer = (int)blockIdx.x < nbj;
+  const int jb = outer ? (int)blockIdx.x : ((int)blockIdx.x - nbj) % nbj, rb = outer ? 0 : ((int)blockIdx.x - nbj) / nbj;
+  const int j = jb * 64 + lane, jc = min(j, d - 1);
+  const int n0 = outer ? 0 : rb * HB_DROWS, n1 = outer ? N : min(N, n0 + HB_DROWS);
+  for (int e = n0 * C + (int)threadIdx.x; e < n1 * C; e += HB_GROUPS * 64) s_dl[e] = dL[e];
+  if (outer) {
+    float acc[HEAD_CMAX];
+#pragma unroll
+    for (int c = 0; c < HEAD_CMAX; ++c) acc[c] = 0.f;
+    __syncthreads();
+#pragma unroll 8
+    for (int n = grp; n < N; n += HB_GROUPS) {
+      const float x = a_prev[(long)n * d + jc];
+      const float *dn = &s_dl[n * C];
+#pragma unroll
+      for (int c = 0; c < HEAD_CMAX; ++c)
+        if (c < C) acc[c] = fmaf(dn[c], x, acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < HEAD_CMAX; ++c) s_acc[c][grp][lane] = acc[c];
+    __syncthreads();
+    for (int c = grp; c < C; c += HB_GROUPS) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < HB_GROUPS; ++q) t += s_acc[c][q][lane];
+      if (j < d) {
+        float *o = out_W + (long)c * d + j;
+        *o = (beta != 0.f ? beta * *o : 0.f) + t;
+      }
+    }
+    if (out_b && blockIdx.x == 0 && threadIdx.x < C) {
+      float t = 0.f;
+      for (int n = 0; n < N; ++n) t += s_dl[n * C + threadIdx.x];
+      out_b[threadIdx.x] = (beta != 0.f ? beta * out_b[threadIdx.x] : 0.f) + t;
+    }
+  } else {
+    float w[HEAD_CMAX];
+#pragma unroll
+    for (int c = 0; c < HEAD_CMAX; ++c) w[c] = c < C ? W[(long)c * d + jc] : 0.f;
+    float ph[HB_DROWS / HB_GROUPS];
+#pragma unroll
+    for (int r = 0; r < HB_DROWS / HB_GROUPS; ++r) ph[r] = dphi_prev[(long)min(n0 + grp + r * HB_GROUPS, N - 1) * d + jc];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < HB_DROWS / HB_GROUPS; ++r) {
+      const int n = n0 + grp + r * HB_GROUPS;
+      if (n < n1) {
+        const float *dn = &s_dl[n * C];
+        float sdot = 0.f;
+#pragma unroll
+        for (int c = 0; c < HEAD_CMAX; ++c)
+          if (c < C) sdot = fmaf(dn[c], w[c], sdot);
+        if (j < d) delta_prev[(long)n * d + j] = sdot * ph[r];
+      }
+    }
+  }
+}
+
 // out[c][j] = beta * out[c][j] + sum_n g[n][c] X[n][j]   (c < C <= 16; g == nullptr: ones, C = 1)
 // block = 64 columns x 8 row groups (one wave each), merged through LDS.  Used for the bias
 // gradients (column sums of delta) and the narrow last layer's weight block.
@@ -3333,15 +3406,26 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
       rc = launch_loss(loss_kind, a[L], aux, aux_rank, da[L], nullptr, dl0, N, C, loss_scale * alpha,
                        nullptr, 1, nullptr, nullptr, a[L], da[L], st);
     if (rc != CLO_OK) return rc;
-    rc = launch_small_outer(OW[L - 1], dl0, a[L - 1], N, d, C, beta, gws, gws_sz, st);
-    if (rc != CLO_OK) return rc;
-    if (Ob && Ob[L - 1]) {
-      rc = launch_small_outer(Ob[L - 1], nullptr, dl0, N, C, 1, beta, nullptr, 0, st);
+#ifndef CLO_HEAD_BACK_FUSED
+#define CLO_HEAD_BACK_FUSED 1
+#endif
+    static const int head_back_fused = CLO_HEAD_BACK_FUSED;
+    if (head_back_fused && N <= HB_MAX_N && C <= HEAD_CMAX) {
+      const int nbj = (int)cdiv(d, 64);
+      hipLaunchKernelGGL(head_rows_back_kernel, dim3((unsigned)(nbj * (1 + cdiv(N, HB_DROWS)))), dim3(HB_GROUPS * 64), 0, st, dl0,
+                         a[L - 1], W[L - 1], dphi[L - 1], OW[L - 1], Ob ? Ob[L - 1] : nullptr, dl1, N, d, C, beta, nbj);
+      CLO_CHECK_LAUNCH("head_rows_back_kernel");
+    } else {
+      rc = launch_small_outer(OW[L - 1], dl0, a[L - 1], N, d, C, beta, gws, gws_sz, st);
       if (rc != CLO_OK) return rc;
+      if (Ob && Ob[L - 1]) {
+        rc = launch_small_outer(Ob[L - 1], nullptr, dl0, N, C, 1, beta, nullptr, 0, st);
+        if (rc != CLO_OK) return rc;
+      }
+      hipLaunchKernelGGL(head_rows_bwd_kernel, dim3((unsigned)cdiv(d, 256), N), dim3(256), 0, st, dl0,
+                         W[L - 1], dphi[L - 1], dl1, d, C);
+      CLO_CHECK_LAUNCH("head_rows_bwd_kernel");
     }
-    hipLaunchKernelGGL(head_rows_bwd_kernel, dim3((unsigned)cdiv(d, 256), N), dim3(256), 0, st, dl0,
-                       W[L - 1], dphi[L - 1], dl1, d, C);
-    CLO_CHECK_LAUNCH("head_rows_bwd_kernel");
     dcur = dl1; dnext = dl0;
     lstart = L - 1;
   } else {
