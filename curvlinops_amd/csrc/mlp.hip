@@ -2407,6 +2407,29 @@ __global__ __launch_bounds__(256) void klast_finish_kernel(const float *__restri
   }
 }
 
+// delta_{L-1}[i][n][k] = phi'_{L-1}[n][i] sum_c W_L[c][i] delta_L[c][n][k] below a narrow last layer (d_out <= 16): a product
+// with K = d_out on the GEMM engine pads the contraction to 64 and took 14 us on 2688 x 256 x 10; this is one pass over the
+// output.  Thread = (feature i, (n, column quad)); delta_L (d_out x N K floats) is read through L1 by every block.
+__global__ __launch_bounds__(256) void klast_delta_kernel(const float *__restrict__ W, const float *__restrict__ dL,
+                                                          const float *__restrict__ dphi, float *__restrict__ dprev, int N,
+                                                          int K, int d_in, int C) {
+  const int Q = (N * K) >> 2;                      // float4 groups per feature
+  const long total = (long)d_in * Q;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e / Q), q = (int)(e - (long)i * Q), n = (4 * q) / K;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < KL_CMAX; ++c)
+      if (c < C) {
+        const float w = W[(long)c * d_in + i];
+        const float4 t = ld4(dL + (long)c * N * K + 4 * q);
+        acc.x = fmaf(w, t.x, acc.x); acc.y = fmaf(w, t.y, acc.y); acc.z = fmaf(w, t.z, acc.z); acc.w = fmaf(w, t.w, acc.w);
+      }
+    const float dp = dphi[(long)n * d_in + i];
+    *reinterpret_cast<float4 *>(dprev + 4 * e) = make_float4(dp * acc.x, dp * acc.y, dp * acc.z, dp * acc.w);
+  }
+}
+
 // delta_L[c][n][k] = phi'_L[n][c] * scale * (H(f_n) u[:, n, k])[c]  in place on u = dA_L.
 // One thread per (n, k).
 constexpr int LC_RMAX = 16;  // rank-M curvature: at most 16 backpropagated vectors per sample
@@ -3667,6 +3690,10 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
   }
   const int G = K / 4, FPT = 16 / G;
   const bool last_linear = acts[L - 1] == CLO_ACT_IDENTITY;
+#ifndef CLO_KC_LAST
+#define CLO_KC_LAST 1
+#endif
+  static const int kc_last = CLO_KC_LAST;   // narrow last layer: klast_* kernels instead of GEMM engine + weight stream
 
   for (int n0 = 0; n0 < N; n0 += NB) {
     const int nn = std::min(NB, N - n0);
@@ -3679,10 +3706,6 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
       int rc = fwd_pass(W[l - 1], b ? b[l - 1] : nullptr, nullptr, nullptr, a[l - 1], nullptr, a[l],
                         nullptr, dphi[l], nn, di, dout, acts[l - 1], part, false, nullptr, st);
       if (rc != CLO_OK) return rc;
-#ifndef CLO_KC_LAST
-#define CLO_KC_LAST 1
-#endif
-      static const int kc_last = CLO_KC_LAST;
       const int klast_slabs = (int)cdiv(di, KL_ROWS);
       if (kc_last && l == L && l >= 2 && dout <= KL_CMAX && nn * G <= 128 &&
           (long)klast_slabs * dout * NK <= gws_sz) {   // narrow last layer: tangent GEMM + weight stream in one pass
@@ -3784,7 +3807,12 @@ static int mlp_matmat_impl(const char *what, int L, const int *dims, const int *
                              ob, aT[l - 1], dA[l], nn, K, di, bw, bt, nchunk, chunk_rows);
         CLO_CHECK_LAUNCH("kouter_stream_kernel");
       }
-      if (l >= 2 && !Gh) {  // delta_{l-1} = phi'_{l-1} * (W_l^T delta_l)   ([di x dout] [dout x NK])
+      if (l >= 2 && !Gh && kc_last && l == L && dout <= KL_CMAX) {
+        const long quads = (long)di * (NK >> 2);
+        hipLaunchKernelGGL(klast_delta_kernel, dim3((unsigned)std::min<long>(cdiv(quads, 256), 8L * kNumCU)), dim3(256), 0, st,
+                           W[l - 1], dA[l], dphi[l - 1], dA[l - 1], nn, K, di, dout);
+        CLO_CHECK_LAUNCH("klast_delta_kernel");
+      } else if (l >= 2 && !Gh) {  // delta_{l-1} = phi'_{l-1} * (W_l^T delta_l)   ([di x dout] [dout x NK])
         GemmArgs g = gemm_problem(di, NK, dout, W[l - 1], 1, di, dA[l], NK, 1, 0.f, dA[l - 1], NK);
         g.epi = EPI_MUL_T; g.e_mul = dphi[l - 1]; g.ld_mul = di; g.e_div = K;
         int rc = launch_gemm_auto(g, gws, gws_sz, st);
