@@ -685,8 +685,7 @@ __global__ __launch_bounds__(256) void loss_hessian_kernel(const LossArgs p) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) wn[c] = scale * un[c] * (dp ? dp[c] : 1.f);
   } else if (p.kind == CLO_LOSS_BCE) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      const float s = 1.f / (1.f + __expf(-fn[c]));
-      wn[c] = scale * s * (1.f - s) * un[c] * (dp ? dp[c] : 1.f);
+      wn[c] = scale * sigmoid_prime(fn[c]) * un[c] * (dp ? dp[c] : 1.f);
     }
   } else if (p.kind == CLO_LOSS_CE) {
     float mx = -INFINITY;
@@ -1147,8 +1146,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
         for (int c = 0; c < C; ++c) s_dl[n][c] = p.scale * s_u[n][c];
       } else if (p.kind == CLO_LOSS_BCE) {
         for (int c = 0; c < C; ++c) {
-          const float sg = 1.f / (1.f + __expf(-s_f[n][c]));
-          s_dl[n][c] = p.scale * sg * (1.f - sg) * s_u[n][c];
+          s_dl[n][c] = p.scale * sigmoid_prime(s_f[n][c]) * s_u[n][c];
         }
       } else if (p.kind == CLO_LOSS_CE) {
         float mx = -INFINITY;
@@ -1766,8 +1764,7 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(const HeadBwdArgs p,
         for (int c = 0; c < C; ++c) s_dl[n][c] = p.scale * s_u[n][c];
       } else if (p.kind == CLO_LOSS_BCE) {
         for (int c = 0; c < C; ++c) {
-          const float sg = 1.f / (1.f + __expf(-s_f[n][c]));
-          s_dl[n][c] = p.scale * sg * (1.f - sg) * s_u[n][c];
+          s_dl[n][c] = p.scale * sigmoid_prime(s_f[n][c]) * s_u[n][c];
         }
       } else if (p.kind == CLO_LOSS_CE) {
         float mx = -INFINITY;
@@ -2485,7 +2482,7 @@ __global__ void loss_cols_kernel(int kind, const float *__restrict__ f,
     for (int c = 0; c < 16; ++c) if (c < C) {
       float w;
       if (kind == CLO_LOSS_MSE) w = uv[c];
-      else if (kind == CLO_LOSS_BCE) { const float sg = 1.f / (1.f + __expf(-fv[c])); w = sg * (1.f - sg) * uv[c]; }
+      else if (kind == CLO_LOSS_BCE) { w = sigmoid_prime(fv[c]) * uv[c]; }
       else w = fv[c] * inv * (uv[c] - pu);
       un[c * cs] = scale * w * dv[c];
     }
@@ -2495,8 +2492,7 @@ __global__ void loss_cols_kernel(int kind, const float *__restrict__ f,
     for (int c = 0; c < C; ++c) un[c * cs] = scale * un[c * cs] * (dp ? dp[c] : 1.f);
   } else if (kind == CLO_LOSS_BCE) {
     for (int c = 0; c < C; ++c) {
-      const float sg = 1.f / (1.f + __expf(-fn[c]));
-      un[c * cs] = scale * sg * (1.f - sg) * un[c * cs] * (dp ? dp[c] : 1.f);
+      un[c * cs] = scale * sigmoid_prime(fn[c]) * un[c * cs] * (dp ? dp[c] : 1.f);
     }
   } else if (kind == CLO_LOSS_CE) {
     float mx = -INFINITY;

@@ -719,8 +719,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
           for (int c = 0; c < C; ++c) dl[c] = p.scale * un[c];
         } else if (p.kind == CLO_LOSS_BCE) {
           for (int c = 0; c < C; ++c) {
-            const float sg = 1.f / (1.f + __expf(-fn[c]));
-            dl[c] = p.scale * sg * (1.f - sg) * un[c];
+            dl[c] = p.scale * sigmoid_prime(fn[c]) * un[c];
           }
         } else if (p.kind == CLO_LOSS_CE) {
           float mx = -INFINITY;
