@@ -1895,7 +1895,7 @@ __global__ __launch_bounds__(256) void head_rows_bwd_kernel(const float *__restr
 //   delta_prev[n][j] = dphi_prev[n][j] * sum_c dL[n][c] W[c][j]                  blocks [nbj, ...): 64 columns x HB_DROWS rows
 // Every block has 8 waves = 8 row groups (rows n = grp, grp + 8, ...); dL sits in LDS (broadcast reads), the row groups'
 // partial out_W sums are merged through LDS in a fixed order.
-constexpr int HB_MAX_N = 256, HB_GROUPS = 8, HB_DROWS = 32;
+constexpr int HB_MAX_N = 256, HB_FUSE_N = 192, HB_GROUPS = 8, HB_DROWS = 32;
 __global__ __launch_bounds__(HB_GROUPS * 64) void head_rows_back_kernel(
     const float *__restrict__ dL, const float *__restrict__ a_prev, const float *__restrict__ W,
     const float *__restrict__ dphi_prev, float *__restrict__ out_W, float *__restrict__ out_b,
@@ -3429,7 +3429,7 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
 #define CLO_HEAD_BACK_FUSED 1
 #endif
     static const int head_back_fused = CLO_HEAD_BACK_FUSED;
-    if (head_back_fused && N <= HB_MAX_N && C <= HEAD_CMAX) {
+    if (head_back_fused && N <= HB_FUSE_N && C <= HEAD_CMAX) {   // (256 rows: 317 us with the one launch, 308 with the four)
       const int nbj = (int)cdiv(d, 64);
       hipLaunchKernelGGL(head_rows_back_kernel, dim3((unsigned)(nbj * (1 + cdiv(N, HB_DROWS)))), dim3(HB_GROUPS * 64), 0, st, dl0,
                          a[L - 1], W[L - 1], dphi[L - 1], OW[L - 1], Ob ? Ob[L - 1] : nullptr, dl1, N, d, C, beta, nbj);
