@@ -23,6 +23,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int tbm, tbn;  // block tile extents of the engine that runs (set by launch_gemm)
   int nbatch, batch_per_split;  // SQSUM mode only
+  int n_mem;  // SQSUM mode only: floats per k row of B that exist in memory (0: N; else a multiple of 4 >= N)
   int ones;  // 1: outer index M-1 of A / N-1 of B is an implicit column of ones ([X | 1])
   // fused epilogue (single problem only), applied by whichever kernel writes the final C:
   //   EPI_ACT: v = act(v + e_vec[col]) ; e_out2[row][col] = act'      (e_out2 shares ldc)
@@ -95,6 +96,8 @@ long gemm_streamk_ws_floats_square();   // 128 x 128 tiles only
 int launch_gemm_v3(const GemmArgs &a, int batch, bool a_kc, bool b_kc, hipStream_t stream, bool *used_streamk,
                    int *tile_m = nullptr, int *tile_n = nullptr);   // tile_m / tile_n: block tile extents of the configuration that ran
 int launch_gemm(GemmArgs a, int batch, hipStream_t stream);
+// C = beta C + alpha sum_b (A_b B_b)^2 (elementwise square), the members split over `splits` slabs in a.ws (a.n_mem: see GemmArgs)
+int launch_gemm_sqsum(GemmArgs a, int batch, int splits, hipStream_t stream);
 int launch_gemm_auto(GemmArgs a, float *ws, long ws_floats, hipStream_t st, int batch = 1);
 int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float *V, const float *b,
                     const float *Vb, float *a, float *da, float *dphi, int N, int d_in, int d_out,

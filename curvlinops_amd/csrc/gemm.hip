@@ -470,7 +470,9 @@ struct PatchIO {
 //                                     two blocks on every CU
 //    64 x 256, 1 x 8 waves of 64x32 ; 32 x 256, 1 x 8 waves of 32x32 : few rows (M <= 64 / 32): no
 //                                     MFMA work on padding rows, the B operand streams once
-template <bool AKC, bool BKC, int BKT, int BMt, int BNt, int WVM, int WVN, bool PATCH = false>
+// SQ (clo_gemm_sqsum_f32): grid.y = batch splits; the block walks its members b, forms the tile of A_b B_b over the whole K
+// and adds its elementwise SQUARE to a second accumulator set, which is what the epilogue stores.
+template <bool AKC, bool BKC, int BKT, int BMt, int BNt, int WVM, int WVN, bool PATCH = false, bool SQ = false>
 __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmArgs p) {
   constexpr int NW = WVM * WVN;
   constexpr int WM = BMt / WVM, WNC = BNt / WVN;  // rows / columns per wave
@@ -517,10 +519,11 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
   }
 
   const int z = blockIdx.y;
-  const int batch = z / p.splitk, split = z % p.splitk;
+  const int batch = SQ ? 0 : z / p.splitk, split = SQ ? 0 : z % p.splitk;
   const int m0 = bm * BMt, n0 = bn * BNt;
-  int kb = split * p.k_per_split;
-  int ke = min(p.K, kb + p.k_per_split);
+  int kb = SQ ? 0 : split * p.k_per_split;
+  int ke = SQ ? p.K : min(p.K, kb + p.k_per_split);
+  const int b_begin = SQ ? z * p.batch_per_split : batch, b_end = SQ ? min(p.nbatch, b_begin + p.batch_per_split) : batch + 1;
   if (p.tri) {  // triangular operands: visit only the k range of this tile that can be nonzero
     int lo = 0, hi = p.K;
     if (p.tri & TRI_KGE_M) lo = max(lo, m0);
@@ -537,15 +540,25 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
 
   TA la;
   TB lb;
+  f32x16 acc[MT][NT], sq[SQ ? MT : 1][SQ ? NT : 1];
+  if (SQ) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sq[SQ ? i : 0][SQ ? j : 0][r] = 0.f;
+  }
+  for (int bcur = b_begin; bcur < b_end; ++bcur) {   // (one trip unless SQ)
   if constexpr (PATCH) {
     la.init_patch(p, m0, p.M, tid);
     lb.init_patch(p, n0, p.N, tid);
   } else {
-    la.init(p.A + gemm_off_a(p, batch), p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
-    lb.init(p.B + gemm_off_b(p, batch), p.sb_n, p.sb_k, n0, p.N, tid, p.ones | p.ones_b);
+    // (SQ: the B operand's rows may be padded to n_mem >= N floats, a multiple of 4, which the float4 loader may read)
+    la.init(p.A + gemm_off_a(p, bcur), p.sa_m, p.sa_k, m0, p.M, tid, p.ones);
+    lb.init(p.B + gemm_off_b(p, bcur), p.sb_n, p.sb_k, n0, SQ && p.n_mem ? p.n_mem : p.N, tid, p.ones | p.ones_b);
   }
 
-  f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -611,6 +624,21 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
       lb.store(Bs + (cur ^ 1) * TB::FLOATS, rb);
     }
     __syncthreads();
+  }
+  if (SQ) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sq[SQ ? i : 0][SQ ? j : 0][r] += acc[i][j][r] * acc[i][j][r];
+  }
+  }  // members
+  if (SQ) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = sq[SQ ? i : 0][SQ ? j : 0];
   }
 
   const bool to_ws = p.splitk > 1;
@@ -1057,8 +1085,43 @@ int launch_gemm_sqsum(GemmArgs a, int batch, int splits, hipStream_t stream) {
   a.mode_b = pick_mode(a.B, a.sb_n, a.sb_k, a.sb_b, batch);
   a.sym = 0;
   dim3 grid(a.tiles_m * a.tiles_n, splits);
-  hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, a);
-  CLO_CHECK_LAUNCH("gemm_f32_kernel<sqsum>");
+  // aligned operands: the SQ variant of the register-staged engine (float4 global loads, ds_read_b128 fragments); B may be
+  // padded to n_mem floats per k row (the EKFAC correction pads its rotated inputs: joint weight + bias blocks are d_in + 1
+  // = odd wide)
+  GemmArgs e = a;
+  if (a.n_mem) e.N = a.n_mem;
+#ifndef CLO_GEMM_SQSUM_V2
+#define CLO_GEMM_SQSUM_V2 1
+#endif
+  static const int sq_v2 = CLO_GEMM_SQSUM_V2;
+  if (sq_v2 && (a.n_mem == 0 || (a.n_mem % 4 == 0 && a.n_mem >= a.N && a.sb_n == 1)) && gemm_v2_eligible(e, batch)) {
+    const bool a_kc = a.mode_a == MODE_KC_VEC, b_kc = a.mode_b == MODE_KC_VEC;
+#define CLO_SQ(AK, BKC_)                                                                                          \
+  {                                                                                                               \
+    constexpr int nthr = 512;                                                                                     \
+    const size_t smem = 2 * (TileIO<AK, 32, nthr, 128>::FLOATS + TileIO<BKC_, 32, nthr, 128>::FLOATS) * sizeof(float); \
+    auto kern = gemm_v2_kernel<AK, BKC_, 32, 128, 128, 2, 4, false, true>;                                        \
+    static bool attr_set = false;                                                                                 \
+    if (smem > 64 * 1024 && !attr_set) {                                                                          \
+      int rc_ = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                               \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),             \
+                          "hipFuncSetAttribute");                                                                 \
+      if (rc_ != CLO_OK) return rc_;                                                                              \
+      attr_set = true;                                                                                            \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kern, grid, dim3(nthr), smem, stream, a);                                                  \
+  }
+    if (a_kc && b_kc) CLO_SQ(true, true)
+    else if (a_kc) CLO_SQ(true, false)
+    else if (b_kc) CLO_SQ(false, true)
+    else CLO_SQ(false, false)
+#undef CLO_SQ
+    CLO_CHECK_LAUNCH("gemm_v2_kernel<sqsum>");
+  } else {
+    a.n_mem = 0;
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, a);
+    CLO_CHECK_LAUNCH("gemm_f32_kernel<sqsum>");
+  }
   if (splits > 1) {
     const long total = (long)a.M * a.N;
     dim3 rgrid((unsigned)std::min<long>(cdiv(total, 256), 4096), 1);

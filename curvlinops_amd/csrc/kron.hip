@@ -148,7 +148,7 @@ inline long pad4l(long x) { return (x + 3) & ~3L; }
 
 extern "C" long clo_ekfac_correction_ws_floats(int V, int B, int S, int d_out, int d_in) {
   if (V < 1 || B < 1 || S < 1 || d_out < 1 || d_in < 1) return 0;
-  const long rot = pad4l((long)V * B * S * d_out) + pad4l((long)B * S * d_in);
+  const long rot = pad4l((long)V * B * S * d_out) + (long)B * S * pad4l(d_in);   // (rotated inputs: rows padded to 4 floats)
   const long sq = S == 1 ? pad4l((long)B * d_out) + pad4l((long)B * d_in) : 0;
   const long splits = S == 1 ? 0 : (long)clo_gemm_sqsum_suggest_splits(d_out, d_in, B) * d_out * d_in;
   return rot + sq + pad4l(splits) + KR_GWS;
@@ -163,8 +163,11 @@ extern "C" int clo_ekfac_correction_f32(float *lam, long ld_lam, const float *Qg
               "clo_ekfac_correction_f32: bad extents / flags");
   CLO_REQUIRE(ws_floats >= clo_ekfac_correction_ws_floats(V, B, S, d_out, d_in), "clo_ekfac_correction_f32: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const long ng = (long)V * B * S * d_out, na = (long)B * S * d_in;
-  float *g_rot = ws, *a_rot = g_rot + pad4l(ng), *p = a_rot + pad4l(na);
+  // rotated inputs with rows of lda_r = d_in rounded up to 4 floats (S > 1): the squared-product kernel's float4 loader
+  // then serves the joint weight + bias blocks too, whose width d_in + 1 is odd (it may read the pad, never stores it)
+  const int lda_r = S == 1 ? d_in : (int)pad4l(d_in);
+  const long ng = (long)V * B * S * d_out, na = (long)B * S * pad4l(d_in);
+  float *g_rot = ws, *a_rot = g_rot + pad4l(ng), *p = a_rot + na;
   float *g2 = nullptr, *a2 = nullptr, *sws = nullptr;
   int splits = 1;
   if (S == 1) {
@@ -177,18 +180,18 @@ extern "C" int clo_ekfac_correction_f32(float *lam, long ld_lam, const float *Qg
   float *gws = p;
   const long gws_floats = ws_floats - (gws - ws);
   // rotations into the eigenbases: g_rot = g Qg, a_rot = a Qa (arrays that hold the eigenvectors in their rows: Q = array^T)
-  auto rotate = [&](const float *X, long nrows, int d, const float *Q, long ldq, bool qrows, float *out) {
+  auto rotate = [&](const float *X, long nrows, int d, const float *Q, long ldq, bool qrows, float *out, long ld_out) {
     GemmArgs m{};
     m.M = (int)nrows; m.N = d; m.K = d; m.alpha = 1.f; m.beta = 0.f;
     m.A = X; m.sa_m = d; m.sa_k = 1;
     m.B = Q; m.sb_k = qrows ? 1 : ldq; m.sb_n = qrows ? ldq : 1;
-    m.C = out; m.ldc = d;
+    m.C = out; m.ldc = ld_out;
     return launch_gemm_auto(m, gws, gws_floats, st, 1);
   };
   CLO_REQUIRE((long)V * B * S <= 2147483647L, "clo_ekfac_correction_f32: more than 2^31 - 1 gradient rows");
-  int rc = rotate(g, (long)V * B * S, d_out, Qg, ldg, (rows & 1) != 0, g_rot);
+  int rc = rotate(g, (long)V * B * S, d_out, Qg, ldg, (rows & 1) != 0, g_rot, d_out);
   if (rc != CLO_OK) return rc;
-  rc = rotate(a, (long)B * S, d_in, Qa, lda, (rows & 2) != 0, a_rot);
+  rc = rotate(a, (long)B * S, d_in, Qa, lda, (rows & 2) != 0, a_rot, lda_r);
   if (rc != CLO_OK) return rc;
   if (S == 1) {   // sum_{v,n} (g_vn a_n^T)^2 = (sum_v g_vn^2)^T (a_n^2): ONE product with K = B
     const long n1 = (long)B * d_out, n2 = (long)B * d_in;
@@ -203,8 +206,13 @@ extern "C" int clo_ekfac_correction_f32(float *lam, long ld_lam, const float *Qg
     return launch_gemm_auto(m, gws, gws_floats, st, 1);
   }
   for (int v = 0; v < V; ++v) {   // per-example products P_n = g_rot_n^T a_rot_n [d_out, d_in], squared and summed over n, fused
-    rc = clo_gemm_sqsum_f32(d_out, d_in, S, alpha, g_rot + (long)v * B * S * d_out, 1, d_out, (long)S * d_out, a_rot, d_in, 1,
-                            (long)S * d_in, v == 0 ? beta : 1.f, lam, ld_lam, B, splits, splits > 1 ? sws : nullptr, stream);
+    GemmArgs q{};
+    q.M = d_out; q.N = d_in; q.K = S; q.alpha = alpha; q.beta = v == 0 ? beta : 1.f;
+    q.A = g_rot + (long)v * B * S * d_out; q.sa_m = 1; q.sa_k = d_out; q.sa_b = (long)S * d_out;
+    q.B = a_rot; q.sb_k = lda_r; q.sb_n = 1; q.sb_b = (long)S * lda_r;
+    q.C = lam; q.ldc = ld_lam; q.sc_b = 0; q.ws = splits > 1 ? sws : nullptr;
+    q.n_mem = lda_r;
+    rc = launch_gemm_sqsum(q, B, splits, st);
     if (rc != CLO_OK) return rc;
   }
   return CLO_OK;
