@@ -15,6 +15,13 @@ for _ in range(3): K @ v
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): K @ v
 torch.cuda.synchronize(); print(f"kfac matvec {1e3 * (time.perf_counter() - t0) / 20:.3f} ms", flush=True)
+from curvlinops_amd import _hip
+mark = torch.zeros(4099, device=dev)
+torch.cuda.synchronize()
+_hip.axpby(mark, mark, 1.0, 0.0)   # marker launches around ONE warm product (tools/kfac_trace_summary.py)
+K @ v
+_hip.axpby(mark, mark, 1.0, 0.0)
+torch.cuda.synchronize()
 V8 = torch.rand(K.shape[1], 8, device=dev)
 for _ in range(3): K @ V8
 torch.cuda.synchronize(); t0 = time.perf_counter()
