@@ -400,6 +400,51 @@ def test_ggn_matvec_large_layers(hip, N):
     assert rel_err(O.flatten_params(gW, gb), ref) < 1e-4
 
 
+@pytest.mark.parametrize("bias", [True, False])
+@pytest.mark.parametrize("N,C", [(65, 1), (65, 16), (97, 10), (128, 16), (191, 7), (192, 16), (193, 16), (256, 3)])
+def test_ggn_matvec_rows_path_narrow_heads(hip, N, C, bias):
+    """65 ... 256 rows with a narrow last layer: everything behind delta_L in one launch up to 192 rows (head_rows_back_kernel:
+    out_W_L, out_b_L, delta_{L-1}), the four-launch route beyond; head widths 1 ... 16, with and without biases,
+    accumulation into a filled output (beta = 1)."""
+    g = np.random.default_rng(1000 * N + C)
+    dims, acts = [128, 328, 200, C], ["tanh", "relu", "identity"]
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [g.random(dims[i + 1]) - 0.5 if bias else None for i in range(3)]
+    vWs = [g.random(W.shape) - 0.5 for W in Ws]
+    vbs = [g.random(b.shape) - 0.5 if bias else None for b in bs]
+    loss = "ce" if C > 1 else "mse"
+    X = g.random((N, dims[0]))
+    y = g.integers(0, C, N) if loss == "ce" else g.random((N, C))
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", vWs, vbs)
+    scale = (2.0 if loss == "mse" else 1.0) * O.reduction_factor(loss, "mean", N, C)
+    out0 = ([g.random(W.shape) for W in Ws], [g.random(b.shape) if bias else None for b in bs])
+    gW, gb = _run_ggn_native(hip, dims, acts, Ws, bs, X, vWs, vbs, LOSS_KIND[loss], scale, 0.5, 1.0, out0=out0)
+    for k, (got, r, o) in enumerate(zip(gW + (gb if bias else []), rW + (rb if bias else []), out0[0] + (out0[1] if bias else []))):
+        assert rel_err(got, 0.5 * r + o) < 1e-4, f"block {k}"
+
+
+@pytest.mark.parametrize("C", [1, 16])
+@pytest.mark.parametrize("N,K", [(8, 4), (5, 64), (19, 16)])
+def test_ggn_matmat_columns_narrowest_and_widest_head(hip, C, N, K):
+    """The two-launch tangent of a narrow last layer (klast_partial / klast_finish) and the elementwise delta below it at
+    the ends of their range: 1 and 16 outputs, K = 4 and 64 columns (one and two row-slot layouts), two row blocks."""
+    g = np.random.default_rng(100 * C + N + K)
+    dims, acts = [64, 136, 72, C], ["tanh", "sigmoid", "identity"]
+    Ws = [(g.random((dims[i + 1], dims[i])) - 0.5) * 2 / np.sqrt(dims[i]) for i in range(3)]
+    bs = [g.random(dims[i + 1]) - 0.5 for i in range(3)]
+    VWk = [g.random((*W.shape, K)) - 0.5 for W in Ws]
+    Vbk = [g.random((*b.shape, K)) - 0.5 for b in bs]
+    loss = "ce" if C > 1 else "mse"
+    X = g.random((N, dims[0]))
+    y = g.integers(0, C, N) if loss == "ce" else g.random((N, C))
+    scale = (2.0 if loss == "mse" else 1.0) * O.reduction_factor(loss, "mean", N, C)
+    gW, gb = _run_ggn_native_cols(hip, dims, acts, Ws, bs, X, VWk, Vbk, LOSS_KIND[loss], scale, 1.0, 0.0)
+    for k in (0, K - 1):
+        rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", [v[..., k] for v in VWk], [v[..., k] for v in Vbk])
+        got = O.flatten_params([w[..., k] for w in gW], [b[..., k] for b in gb])
+        assert rel_err(got, O.flatten_params(rW, rb)) < 1e-4, k
+
+
 @pytest.mark.parametrize("loss", ["mse", "ce", "bce"])
 @pytest.mark.parametrize("N", [9, 12, 16, 17, 25, 32, 33, 40, 48, 49, 57, 64])
 def test_ggn_matvec_mid_rows_chain(hip, N, loss):
