@@ -22,7 +22,7 @@ for kind in ("lowrank", "wishart"):
     rc = lib.clo_sytrd_f32(work.data_ptr(), ld, n, D.data_ptr(), E.data_ptr(), tau.data_ptr(), ws.data_ptr(), nb, maxb,
                            torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize(); assert rc == 0
-    off = 2 * n * 64 + 4 * n4 + 192 + 3 * 16 * 264 + 576
+    off = 2 * n * 64 + 4 * n4 + 192 + 3 * 16 * 264 + 1088   # (+ TP_CNT_WORDS of sytrd.hip)
     st = ws[off:off + 32].view(torch.int64).cpu().numpy().astype(np.float64) * 0.01 / 64   # us per column
     print(f"n={n} {kind}: us per column, first / last workgroup")
     for i, nm in enumerate(names):
