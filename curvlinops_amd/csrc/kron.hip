@@ -34,10 +34,85 @@ __global__ void kron_scale_kernel(float *__restrict__ Z, const float *__restrict
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) Z[e] *= lam[e % n];
 }
 
+inline long pad4k(long x) { return (x + 3) & ~3L; }
+// dst [rows][ldd] = src (element (r, c) at src[r sr + c sc]) for c < cols, zero for cols <= c < ldd; rows >= rows_src are zero
+__global__ void kron_pad_kernel(float *__restrict__ dst, long ldd, long rows, const float *__restrict__ src, long sr, long sc,
+                                long rows_src, long cols) {
+  const long q4 = ldd >> 2, total = rows * q4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / q4, c = (e - r * q4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows_src) {
+      const float *p = src + r * sr + c * sc;
+      if (c < cols) v.x = p[0];
+      if (c + 1 < cols) v.y = p[sc];
+      if (c + 2 < cols) v.z = p[2 * sc];
+      if (c + 3 < cols) v.w = p[3 * sc];
+    }
+    *reinterpret_cast<float4 *>(dst + r * ldd + c) = v;
+  }
+}
+// dst [rows][cols] (contiguous) = src [rows][lds][:cols]
+__global__ void kron_unpad_kernel(float *__restrict__ dst, long cols, long rows, const float *__restrict__ src, long lds) {
+  const long total = rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / cols, c = e - r * cols;
+    dst[e] = src[r * lds + c];
+  }
+}
+// Second factors of an order that is not a multiple of 4 (joint weight + bias blocks: d_in + 1) put both products on the
+// scalar-loader kernel (512 x 4609 x 4609: 382 us, 178 us padded to 4612).  From KR_PAD_MIN_FLOP on, the operands are
+// copied into zero-padded buffers with rows of pad4 floats, both products run on the aligned engines and the result is
+// copied back: three extra passes over the (live) factor per product instead of a value cache.
+constexpr double KR_PAD_MIN_FLOP = 2.0e8;
+inline bool kron_wants_pad(int K, int C1, int C2, int R2) {
+  return ((C2 & 3) || (R2 & 3)) && 2.0 * K * C1 * (double)C2 * R2 >= KR_PAD_MIN_FLOP;
+}
+inline long kron_pad_floats(int K, int C1, int R1, int C2, int R2) {   // S2p, Xp, Tp, Yp
+  return pad4k(R2) * pad4k(C2) + (long)K * C1 * pad4k(C2) + (long)K * C1 * pad4k(R2) + (long)K * R1 * pad4k(R2);
+}
+
 // Y_k [R1, R2] = E1 X_k E2^T for k < K;  X [K][C1*C2], Y [K][R1*R2], T: K*C1*R2 floats
 int kron_apply(float *Y, const Fac &E1, const Fac &E2, const float *X, int K, float *T, float *gws, long gws_floats,
                hipStream_t st) {
   const int C1 = E1.cols, C2 = E2.cols, R1 = E1.rows, R2 = E2.rows;
+#ifndef CLO_KRON_PAD
+#define CLO_KRON_PAD 1
+#endif
+  static const int pad_on = CLO_KRON_PAD;
+  if (pad_on && kron_wants_pad(K, C1, C2, R2) && gws_floats >= kron_pad_floats(K, C1, R1, C2, R2) + (1L << 20)) {
+    const long C2p = pad4k(C2), R2p = pad4k(R2);
+    float *S2p = gws, *Xp = S2p + R2p * C2p, *Tp = Xp + (long)K * C1 * C2p, *Yp = Tp + (long)K * C1 * R2p;
+    float *g2 = Yp + (long)K * R1 * R2p;
+    const long g2_floats = gws_floats - (g2 - gws);
+    auto grid = [](long n) { return dim3((unsigned)std::min<long>(cdiv(n, 256), 8192)); };
+    hipLaunchKernelGGL(kron_pad_kernel, grid(R2p * (C2p >> 2)), dim3(256), 0, st, S2p, C2p, R2p, E2.p, E2.sr, E2.sc, (long)R2, (long)C2);
+    CLO_CHECK_LAUNCH("kron_pad_kernel");
+    hipLaunchKernelGGL(kron_pad_kernel, grid((long)K * C1 * (C2p >> 2)), dim3(256), 0, st, Xp, C2p, (long)K * C1, X, (long)C2, 1L,
+                       (long)K * C1, (long)C2);
+    CLO_CHECK_LAUNCH("kron_pad_kernel");
+    {
+      GemmArgs g{};
+      g.M = K * C1; g.N = (int)R2p; g.K = (int)C2p; g.alpha = 1.f; g.beta = 0.f;
+      g.A = Xp; g.sa_m = C2p; g.sa_k = 1;
+      g.B = S2p; g.sb_k = 1; g.sb_n = C2p;            // B(k = c2, n = r2) = S2p[r2][c2]
+      g.C = Tp; g.ldc = R2p;
+      int rc = launch_gemm_auto(g, g2, g2_floats, st, 1);
+      if (rc != CLO_OK) return rc;
+    }
+    {
+      GemmArgs g{};
+      g.M = R1; g.N = (int)R2p; g.K = C1; g.alpha = 1.f; g.beta = 0.f;
+      g.A = E1.p; g.sa_m = E1.sr; g.sa_k = E1.sc; g.sa_b = 0;
+      g.B = Tp; g.sb_k = R2p; g.sb_n = 1; g.sb_b = (long)C1 * R2p;
+      g.C = Yp; g.ldc = R2p; g.sc_b = (long)R1 * R2p;
+      int rc = launch_gemm_auto(g, g2, g2_floats, st, K);
+      if (rc != CLO_OK) return rc;
+    }
+    hipLaunchKernelGGL(kron_unpad_kernel, grid((long)K * R1 * R2), dim3(256), 0, st, Y, (long)R2, (long)K * R1, Yp, R2p);
+    CLO_CHECK_LAUNCH("kron_unpad_kernel");
+    return CLO_OK;
+  }
   {
     GemmArgs g{};
     g.M = K * C1; g.N = R2; g.K = C2; g.alpha = 1.f; g.beta = 0.f;
@@ -61,6 +136,13 @@ long block_ws(int A, int a, int B, int b, int K, bool eig) {
   // T of the (larger) first product, and for eigen-decomposed blocks the coefficient block Z
   const long t = (long)K * std::max<long>((long)std::max(A, a) * std::max(B, b), 1);
   return (eig ? 2 : 1) * ((t + 3) & ~3L);
+}
+// floats behind the temporaries: split-K workspace, and the zero-padded operands of blocks whose second factor has an order
+// that is not a multiple of 4 (kron_apply; either orientation of the factors)
+long block_gws(int A, int a, int B, int b, int K) {
+  const int m1 = std::max(A, a), m2 = std::max(B, b);
+  const bool pad = ((B & 3) || (b & 3)) && 2.0 * K * m1 * (double)m2 * m2 >= KR_PAD_MIN_FLOP;
+  return KR_GWS + (pad ? kron_pad_floats(K, m1, m1, m2, m2) + (1L << 20) : 0);
 }
 
 int one_block(float *Y, const float *S1, long ld1, const float *S2, long ld2, const float *lam, const float *X, int A, int a,
@@ -90,7 +172,7 @@ using namespace clo;
 
 extern "C" long clo_kron_ws_floats(int A, int a, int B, int b, int K, int eig) {
   if (A < 1 || a < 1 || B < 1 || b < 1 || K < 1) return 0;
-  return block_ws(A, a, B, b, K, eig != 0) + KR_GWS;
+  return block_ws(A, a, B, b, K, eig != 0) + block_gws(A, a, B, b, K);
 }
 
 extern "C" int clo_kron_matmat(float *Y, const float *S1, long ld1, const float *S2, long ld2, const float *X, int A, int a,
