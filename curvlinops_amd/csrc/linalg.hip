@@ -549,7 +549,39 @@ static std::vector<CholAsync *> g_chol_pool[64];
 // profiles/r05_cholesky_queue_pipes.txt).  Which rank the helper gets depends on how many streams the process created
 // before its first inverse.  Picking the helper among four back-to-back candidates by a timed probe, and running the
 // critical chain on a second stream of the set, were both tried: neither was reliably better than the lottery.)
-static CholAsync *chol_async_acquire(int *dev_out) {
+// Which of `n` freshly created candidate streams dispatches most independently of the caller's stream?  Host-timed, the
+// way tools/ubench_queue_pipes.py measures it: a dispatch-bound kernel (40 k one-wave workgroups of ~1 us) on the caller's
+// stream and on the candidate at once takes 1.8 x the solo time when their hardware queues sit on different dispatch pipes
+// of the command processor and 2.4 - 3.3 x when they share one.  Run once per helper set (~2 ms, synchronises the caller's
+// stream); under stream capture or on any error the first candidate is taken.
+static int chol_pick_helper(hipStream_t caller, hipStream_t *cand, int n) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+  for (int i = 0; i < n; ++i)
+    if (launch_occupy(64, 0, 100, cand[i]) != CLO_OK) return 0;   // (first use: queue creation)
+  if (launch_occupy(64, 0, 100, caller) != CLO_OK || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return 0; }
+  int best = 0;
+  double tbest = 1e30;
+  for (int i = 0; i < n; ++i) {
+    double tmin = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (launch_occupy(40000, 0, 100, caller) != CLO_OK || launch_occupy(40000, 0, 100, cand[i]) != CLO_OK ||
+          hipStreamSynchronize(caller) != hipSuccess || hipStreamSynchronize(cand[i]) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+      }
+      tmin = std::min(tmin, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+#ifdef CLO_CHOL_PROBE_DEBUG
+    fprintf(stderr, "chol helper candidate %d: %.1f us\n", i, 1e6 * tmin);
+#endif
+    if (tmin < tbest) { tbest = tmin; best = i; }
+  }
+  return best;
+}
+
+static CholAsync *chol_async_acquire(int *dev_out, hipStream_t caller) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   *dev_out = dev & 63;
@@ -597,7 +629,25 @@ static CholAsync *chol_async_acquire(int *dev_out) {
   static const int own_main = CLO_CHOL_OWN_MAIN;
   bool ok = !own_main || (hipStreamCreateWithPriority(&a->main, hipStreamNonBlocking, least) == hipSuccess &&
                           hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) == hipSuccess);
-  ok = ok && hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
+#ifndef CLO_CHOL_PICK
+#define CLO_CHOL_PICK 4
+#endif
+  static const int npick = CLO_CHOL_PICK;   // candidates for the helper stream (1: take the first)
+  if (ok && npick > 1) {
+    hipStream_t cand[8] = {};
+    int made = 0;
+    for (; made < std::min(npick, 8); ++made)
+      if (hipStreamCreateWithPriority(&cand[made], hipStreamNonBlocking, least) != hipSuccess) break;
+    ok = made > 0;
+    if (ok) {
+      const int pick = made > 1 ? chol_pick_helper(caller, cand, made) : 0;
+      a->side = cand[pick];
+      for (int i = 0; i < made; ++i)
+        if (i != pick) (void)hipStreamDestroy(cand[i]);
+    }
+  } else {
+    ok = ok && hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
+  }
   if (ok && nhelp >= 3) {
     ok = hipStreamCreateWithPriority(&a->inv, hipStreamNonBlocking, least) == hipSuccess &&
          hipStreamCreateWithPriority(&a->inv2, hipStreamNonBlocking, least) == hipSuccess;
@@ -690,7 +740,7 @@ static int chol_inv_emit(const CholPipe &P, const CholInvOp &op) {
 static int chol_pipe_run(const CholCtx &c, float *G_side, float *G_inv, float *G_inv2, CholAsync *as);
 static int chol_pipe(const CholCtx &c, float *G_side, float *G_inv, float *G_inv2) {
   int dev = 0;
-  CholAsync *as = chol_async_acquire(&dev);
+  CholAsync *as = chol_async_acquire(&dev, c.st);
   if (!as) { set_error("cholesky inverse: cannot create the side streams"); return CLO_EHIP; }
   CholCtx cm = c;
   int rc = CLO_OK;

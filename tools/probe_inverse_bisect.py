@@ -2,7 +2,7 @@
 bench.py; variants chosen by argv[1]: plain | fwdbwd (run the plain gradient passes first) | nocapture."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["GPU_MAX_HW_QUEUES"] = "16"
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("HWQ", "16")
 import torch
 from torch import nn
 import curvlinops_amd as C
