@@ -542,13 +542,12 @@ struct CholAsync {
 // its previous call may still be queued: the helper streams are in order, and every wait below follows its record.
 static std::mutex g_chol_pool_mu;
 static std::vector<CholAsync *> g_chol_pool[64];
-// (Round 5, measured and not kept: the helper's hardware queue shares one of the command processor's four dispatch pipes
-// with the caller's queue whenever their creation ranks differ by a multiple of four -- tools/ubench_queue_pipes.py: a
-// dispatch-bound kernel beside the null stream takes 1.8 x its solo time on three of four fresh streams and 2.4 - 3.3 x on
-// every fourth -- and every kernel of the pipeline then runs ~1.4 x longer (42 ResNet-18 factors: 16.8 instead of 11.5 ms;
-// profiles/r05_cholesky_queue_pipes.txt).  Which rank the helper gets depends on how many streams the process created
-// before its first inverse.  Picking the helper among four back-to-back candidates by a timed probe, and running the
-// critical chain on a second stream of the set, were both tried: neither was reliably better than the lottery.)
+// (Round 5: the helper's hardware queue shares one of the command processor's four dispatch pipes with the caller's queue
+// whenever their creation ranks differ by a multiple of four -- tools/ubench_queue_pipes.py -- and every kernel of the
+// pipeline then runs ~1.4 x longer (42 ResNet-18 factors: 16.8 instead of 11.5 ms; profiles/r05_cholesky_queue_pipes.txt).
+// Which rank the helper gets depends on how many streams the process created before its first inverse, so the helper is
+// PICKED among four candidates by a probe when its set is made, chol_pick_helper below.  Running the critical chain on a
+// second stream of the set, and an event-timed probe inside the call, were tried and did not work.)
 // Which of `n` freshly created candidate streams dispatches most independently of the caller's stream?  Host-timed, the
 // way tools/ubench_queue_pipes.py measures it: a dispatch-bound kernel (40 k one-wave workgroups of ~1 us) on the caller's
 // stream and on the candidate at once takes 1.8 x the solo time when their hardware queues sit on different dispatch pipes
