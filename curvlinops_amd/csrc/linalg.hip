@@ -546,7 +546,7 @@ static std::vector<CholAsync *> g_chol_pool[64];
 // whenever their creation ranks differ by a multiple of four -- tools/ubench_queue_pipes.py -- and every kernel of the
 // pipeline then runs ~1.4 x longer (42 ResNet-18 factors: 16.8 instead of 11.5 ms; profiles/r05_cholesky_queue_pipes.txt).
 // Which rank the helper gets depends on how many streams the process created before its first inverse, so the helper is
-// PICKED among four candidates by a probe when its set is made, chol_pick_helper below.  Running the critical chain on a
+// PICKED among a few candidates by a probe when its set is made, chol_pick_helper below.  Running the critical chain on a
 // second stream of the set, and an event-timed probe inside the call, were tried and did not work.)
 // Which of `n` freshly created candidate streams dispatches most independently of the caller's stream?  Host-timed, the
 // way tools/ubench_queue_pipes.py measures it: a dispatch-bound kernel (40 k one-wave workgroups of ~1 us) on the caller's
@@ -629,20 +629,25 @@ static CholAsync *chol_async_acquire(int *dev_out, hipStream_t caller) {
   bool ok = !own_main || (hipStreamCreateWithPriority(&a->main, hipStreamNonBlocking, least) == hipSuccess &&
                           hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) == hipSuccess);
 #ifndef CLO_CHOL_PICK
-#define CLO_CHOL_PICK 4
+#define CLO_CHOL_PICK 3
 #endif
-  static const int npick = CLO_CHOL_PICK;   // candidates for the helper stream (1: take the first)
+  static const int npick = CLO_CHOL_PICK;   // candidates for the helper stream (1: take the first); consecutive ranks: at most one of them shares the caller's pipe
   if (ok && npick > 1) {
-    hipStream_t cand[8] = {};
-    int made = 0;
-    for (; made < std::min(npick, 8); ++made)
-      if (hipStreamCreateWithPriority(&cand[made], hipStreamNonBlocking, least) != hipSuccess) break;
-    ok = made > 0;
+    // the candidates that lose stay in a per-device pool for the next set (creating and destroying a stream costs ~1.5 ms
+    // each: hardware queues); a set picks among what the pool holds, topped up to `npick`
+    static std::vector<hipStream_t> cand_pool[64];
+    std::lock_guard<std::mutex> lk(g_chol_pool_mu);
+    auto &cp = cand_pool[dev & 63];
+    while ((int)cp.size() < std::min(npick, 8)) {
+      hipStream_t sn = nullptr;
+      if (hipStreamCreateWithPriority(&sn, hipStreamNonBlocking, least) != hipSuccess) break;
+      cp.push_back(sn);
+    }
+    ok = !cp.empty();
     if (ok) {
-      const int pick = made > 1 ? chol_pick_helper(caller, cand, made) : 0;
-      a->side = cand[pick];
-      for (int i = 0; i < made; ++i)
-        if (i != pick) (void)hipStreamDestroy(cand[i]);
+      const int pick = cp.size() > 1 ? chol_pick_helper(caller, cp.data(), (int)cp.size()) : 0;
+      a->side = cp[pick];
+      cp.erase(cp.begin() + pick);
     }
   } else {
     ok = ok && hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
