@@ -394,6 +394,39 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
         t = torch.tensor([best], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         best = float(t.item())
+    from curvlinops_amd import computers as _computers
+
+    captured_graphs = [v for v in _computers._CAPTURED.values() if isinstance(v, _computers._CapturedBatch)]
+    parts = {}
+    if world > 1:
+        # what the N-rank figure is made of: the SAME shard built without any collective (the single-GPU code path and
+        # graphs), and the all-reduce of a buffer of the factors' size on its own
+        kw1 = dict(kw, distributed=False)
+        C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw1)
+        C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw1)
+        t_local = float("inf")
+        for _ in range(repeats):
+            sync()
+            t0 = time.perf_counter()
+            C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw1)
+            torch.cuda.synchronize()
+            t_local = min(t_local, time.perf_counter() - t0)
+        nfl = sum(f.numel() for blk in K[1] for f in blk)
+        buf = torch.zeros(nfl, device=device)
+        dist.all_reduce(buf)
+        t_ar = float("inf")
+        for _ in range(repeats):
+            sync()
+            t0 = time.perf_counter()
+            dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            t_ar = min(t_ar, time.perf_counter() - t0)
+        tt = torch.tensor([t_local, t_ar], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        parts = {"local_build_ms_no_collective": 1e3 * float(tt[0]), "factor_allreduce_alone_ms": 1e3 * float(tt[1]),
+                 "factor_allreduce_MB": 4.0 * nfl / 1e6,
+                 "note": "ms_per_batch = split-graph replay with the input-covariance all-reduce started between the "
+                         "forward and the backward half; local_build = the single-GPU graph on the same shard"}
     # algorithmic work: sum_l 2 B S_l (d_in'^2 + V d_out^2) flop with V = 1 MC sample
     pos = {}
 
@@ -434,6 +467,9 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
                   "Linear/Conv2d parameters only" + (", sharded build + ONE all-reduce of the flat factor buffer"
                                                      if world > 1 else ""),
         "protocol": f"min of {repeats} after 1 warm-up, device (and ranks) synchronised around each build",
+        "route": {"captured_graphs": len(captured_graphs), "split": [g.split for g in captured_graphs],
+                  "branches": _computers._CAPTURE_BRANCHES, "graph_replays": _computers._CAPTURE_REPLAYS},
+        **({"parts": parts} if parts else {}),
         "factor_gflop_per_gpu": flops / 1e9,
         "factor_buffer_MB": 4.0 * factor_floats / 1e6,
         "roofline": {"bound": "mfma", "achieved": flops / best / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
@@ -616,6 +652,28 @@ def main() -> None:
     assert out is not None and torch.isfinite(out).all()
 
     ms_per_step = 1e3 * elapsed / args.steps
+    n_gt1 = None
+    if world > 1:
+        # the same K steps (a) strictly sequential -- persistent kernel, then a blocking all-reduce --, (b) without any
+        # collective (the shard product alone: the single-GPU kernel on this rank)
+        def timed(fn):
+            for i in range(min(args.warmup, 10)):
+                fn(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                fn(i)
+            sync()
+            tt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return 1e3 * float(tt.item()) / args.steps
+
+        n_gt1 = {"overlap_mode_of_value": "overlapped" if overlap else "sequential",
+                 "sequential_ms_per_step": timed(lambda i: op @ vs[i % nbuf]),
+                 "shard_product_alone_ms": timed(lambda i: G @ vs[i % nbuf]),
+                 "last_async_route": getattr(op, "async_route", None),
+                 "note": "overlapped steps take the persistent kernel whenever the previous collective has completed "
+                         "(event query), else the launch chain; sequential steps always take the persistent kernel"}
     result = {
         "metric": "curvature matvecs/s (GGN, D=10M MLP)",
         "value": world * args.steps / elapsed,
@@ -645,6 +703,9 @@ def main() -> None:
                             + (", overlapped with the next product)" if overlap else ")")) if world > 1 else "single GPU",
         },
     }
+
+    if n_gt1 is not None:
+        result["n_gt1"] = n_gt1
 
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- roofline leg: same steps with per-kernel HIP events on the launch stream

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "clo_version": (c_int, []),
     "clo_last_error": (c_char_p, []),
     "clo_persistent_status": (c_int, [c_int]),
+    "clo_fault_pending": (c_int, [c_int]),
     "clo_test_set_spin_limit": (c_int, [ctypes.c_uint]),
     "clo_test_occupy": (c_int, [c_int, c_int, c_long, c_void_p]),
     "clo_prof_enable": (c_int, [c_int]),
@@ -201,6 +202,8 @@ def load() -> ctypes.CDLL:
             )
         lib = ctypes.CDLL(str(_LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
+            if os.environ.get("CLO_HIP_LIB") and not hasattr(lib, name):
+                continue   # (A/B runs against an older build of the library: entry points added since are absent)
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
@@ -238,6 +241,22 @@ def persistent_status(device: int | None = None) -> int:
     (bit 0 persistent MLP kernel, bit 1 tridiagonalisation panels, bit 2 stream-K GEMM): ``clo_persistent_status``."""
     dev = torch.cuda.current_device() if device is None else int(device)
     return int(load().clo_persistent_status(dev))
+
+
+def raise_if_async_fault(device: int | None = None) -> None:
+    """For consumers that have just synchronised with the device (host copies of a result): a persistent / stream-K launch
+    that timed out since the last report makes THIS result suspect -- raise now instead of on the next call
+    (``clo_fault_pending``; the timed-out launch has also marked its own output with NaN)."""
+    if not torch.cuda.is_available():
+        return
+    dev = torch.cuda.current_device() if device is None else int(device)
+    bits = int(load().clo_fault_pending(dev))
+    if bits:
+        names = [n for k, n in enumerate(("persistent MLP kernel", "tridiagonalisation panels", "stream-K GEMM")) if bits >> k & 1]
+        raise RuntimeError(f"curvlinops_amd: a launch on device {dev} timed out waiting for its own workgroups "
+                           f"({', '.join(names)}; GPU shared with another process or CU-masked).  The result that was "
+                           "just read may be invalid (it carries NaN marks); repeat the call -- the library falls back "
+                           "to the multi-launch route on this device.")
 
 
 def prof_enable(on: bool) -> None:

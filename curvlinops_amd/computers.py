@@ -13,6 +13,8 @@ tensors are fp32 on the GPU.
 
 from __future__ import annotations
 
+import os
+
 
 from collections.abc import Callable, Iterable, MutableMapping
 from contextlib import contextmanager
@@ -453,9 +455,16 @@ _CAPTURE_G_CHUNK = 0   # coarse mode: gradient covariances per fork of the facto
 _CAPTURE_STREAM = None  # index of the package-wide worker stream to capture on (None: torch's own capture stream)
 _CAPTURE_AFTER = 1     # eager runs of a configuration before it is captured
 _CAPTURE_MAX = 4       # captured configurations kept (each holds its activations' memory pool + static factor buffers)
-_CAPTURE_TRIES = 3     # two-branch captures tried when the first one replays no faster than the one-branch capture (below)
+_CAPTURE_NOTES_MAX = 256   # bookkeeping entries (eager-run counters, "capture failed" marks) kept beside the graphs
+# Branches of a captured build: a FIXED rule, nothing is timed (round 6; the round-5 code replayed candidates against the
+# wall clock).  1: one in-order graph -- its replay time does not depend on which hardware queues the runtime hands a
+# graph's internal streams.  2: the input covariances on a second branch beside the backward pass (15 % faster when the
+# two branches land on independent dispatch pipes, up to 2 x slower when they do not: DESIGN 3.3 "queue pipes").
+_CAPTURE_BRANCHES = int(os.environ.get("CLO_KFAC_CAPTURE_BRANCHES", "1"))
 _CAPTURED: dict = {}   # signature -> int (eager runs so far) | _CapturedBatch | False (capture failed: stay eager)
 _CAPTURE_GENERATORS: dict = {}
+_CAPTURE_MANUAL = os.environ.get("CLO_KFAC_CAPTURE_MANUAL", "0") == "1"   # capture type-2 / multi-sample MC builds (one batched backward under vmap)
+_CAPTURE_REPLAYS = 0   # graph launches so far (tests assert that a captured route really ran)
 
 
 def _capture_generator(device: torch.device) -> torch.Generator:
@@ -472,19 +481,37 @@ def reset_captured_builds() -> None:
     _CAPTURED.clear()
 
 
+def _note_capture_state(sig: tuple, value) -> None:
+    """Bookkeeping entry (eager-run counter / False); the oldest ones go when there are too many -- a workload that
+    keeps re-allocating its parameters would otherwise grow the table without bound."""
+    _CAPTURED[sig] = value
+    notes = [k for k, v in _CAPTURED.items() if not isinstance(v, _CapturedBatch)]
+    for k in notes[: max(0, len(notes) - _CAPTURE_NOTES_MAX)]:
+        del _CAPTURED[k]
+
+
 class _CapturedBatch:
-    """The KFAC factor computation of ONE mini-batch shape as a replayable hipGraph."""
+    """The KFAC factor computation of ONE mini-batch shape as a replayable hipGraph -- or as TWO (``split``): the forward
+    pass with all input covariances, and the backward pass with the gradient covariances, so that a data-parallel build
+    can start the all-reduce of the input covariances (98 % of the factor bytes) between them."""
 
     def __init__(self):
-        self.graph = None
+        self.graph = None        # whole batch, or the forward half of a split capture
+        self.graph_bwd = None    # backward half of a split capture
         self.X = self.y = None
         self.store: _FactorStore | None = None
         self.model_ref = None
+        self._keep = None
+
+    @property
+    def split(self) -> bool:
+        return self.graph_bwd is not None
 
     @classmethod
     def _capture_once(cls, computer: "HipKFACComputer", X: Tensor, y: Tensor, mapping, sizes_a: dict, sizes_g: dict,
-                      gen: torch.Generator, overlap: bool):
-        """One capture of the build (``overlap``: input covariances on the graph's second branch, else one branch)."""
+                      gen: torch.Generator, overlap: bool, split: bool = False):
+        """One capture of the build (``overlap``: input covariances on the graph's second branch, else one branch;
+        ``split``: two graphs, cut behind the last input covariance)."""
         import weakref
 
         global _OVERLAP
@@ -498,84 +525,72 @@ class _CapturedBatch:
         for (which, k), view in self.store.items():
             (A if which == "a" else G)[k] = view
         A.fresh, G.fresh = set(sizes_a), set(sizes_g)   # first touch of a factor writes (beta = 0): no memset
-        graph = torch.cuda.CUDAGraph()
-        graph.register_generator_state(gen)
+        graphs = [torch.cuda.CUDAGraph()]
+        graphs[0].register_generator_state(gen)
         state = gen.get_state()
         cap_stream = None if _CAPTURE_STREAM is None else side_stream(dev, _CAPTURE_STREAM)
         keep = _OVERLAP
-        _OVERLAP = keep and overlap
+        _OVERLAP = keep and overlap and not split
+        ctx = [torch.cuda.graph(graphs[0], stream=cap_stream)]
+        entered = False
+
+        def cut():
+            """End of the forward half: every input covariance is complete (factors no hook wrote are zero)."""
+            nonlocal entered
+            for k in A.fresh:
+                A[k].zero_()
+            A.fresh = set()
+            ctx[-1].__exit__(None, None, None)
+            entered = False
+            graphs.append(torch.cuda.CUDAGraph())
+            graphs[-1].register_generator_state(gen)
+            ctx.append(torch.cuda.graph(graphs[-1], pool=graphs[0].pool(), stream=cap_stream))
+            ctx[-1].__enter__()
+            entered = True
+
         try:
-            with torch.cuda.graph(graph, stream=cap_stream):
-                with _use_params(computer._model_module, computer._params):
-                    computer._run_batch(self.X, self.y, mapping, A, G, coarse_fork=_CAPTURE_FORK == "coarse")
-                for st in (A, G):            # factors no hook wrote (unused layers) are zero
-                    for k in st.fresh:
-                        st[k].zero_()
+            ctx[0].__enter__()
+            entered = True
+            with _use_params(computer._model_module, computer._params):
+                # (a split build keeps the per-hook order of eager mode: the covariance of a layer's input is queued when
+                # the layer runs, so the forward half ends with all of them done)
+                computer._run_batch(self.X, self.y, mapping, A, G, after_forward=cut if split else None,
+                                    coarse_fork=_CAPTURE_FORK == "coarse" and not split)
+            for st in (A, G):            # factors no hook wrote (unused layers) are zero
+                for k in st.fresh:
+                    st[k].zero_()
+            ctx[-1].__exit__(None, None, None)
+            entered = False
+        except BaseException as error:
+            if entered:
+                try:
+                    ctx[-1].__exit__(type(error), error, None)
+                except Exception:  # noqa: BLE001 - the capture is already lost; report the first error
+                    pass
+            raise
         finally:
             _OVERLAP = keep
             gen.set_state(state)             # (capture advanced the generator without drawing anything)
-        self.graph = graph
+        self.graph = graphs[0]
+        self.graph_bwd = graphs[1] if split else None
+        self.n_a = self.store.end_of(("a", k) for k in sizes_a)
         self.model_ref = weakref.ref(computer._model_module)
         return self
 
-    def _replay_ms(self, gen: torch.Generator) -> float:
-        """Wall time of one replay on the graph's own static inputs (best of two; the generator is put back)."""
-        import time
-
-        state = gen.get_state()
-        best = float("inf")
-        for _ in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            self.graph.replay()
-            torch.cuda.synchronize()
-            best = min(best, time.perf_counter() - t0)
-        gen.set_state(state)
-        return 1e3 * best
-
     @classmethod
     def capture(cls, computer: "HipKFACComputer", X: Tensor, y: Tensor, mapping, sizes_a: dict, sizes_g: dict,
-                gen: torch.Generator, sig: tuple):
-        """Capture; on any failure the configuration is marked uncapturable (False) and the caller runs it eagerly.
-
-        The two-branch graph (input covariances beside the backward pass) is 15 - 20 % faster than the one-branch graph
-        -- when the runtime puts the branches on hardware queues that dispatch independently.  Which queues a graph's
-        internal streams get depends on what the process created before ("queue pipes"): the same build
-        replayed in 4.4 ms in a fresh process and in 6.4 - 8.5 ms behind other captured builds.  So the capture is
-        checked once: if the two-branch graph replays no faster than 0.92 x the one-branch graph, up to
-        ``_CAPTURE_TRIES`` - 1 more two-branch captures are made (each gets new internal streams) and the fastest
-        candidate of all is kept."""
+                gen: torch.Generator, sig: tuple, split: bool = False):
+        """Capture ONCE, by the fixed rule `_CAPTURE_BRANCHES` (no candidate graphs, no timing replays: a capture records
+        launches and executes nothing, so module buffers and RNG streams see every mini-batch exactly once, as in eager
+        mode).  On any failure the configuration is marked uncapturable (False) and the caller runs it eagerly."""
         try:
-            best = cls._capture_once(computer, X, y, mapping, sizes_a, sizes_g, gen, True)
-            if _CAPTURE_TRIES > 1 and _OVERLAP:
-                losers = []   # (kept alive until the choice is made: a freed graph would hand its queues to the next one)
-                t_best = best._replay_ms(gen)
-                serial = cls._capture_once(computer, X, y, mapping, sizes_a, sizes_g, gen, False)
-                t_serial = serial._replay_ms(gen)
-                tries = 1
-                while t_best > 0.92 * t_serial and tries < _CAPTURE_TRIES:
-                    cand = cls._capture_once(computer, X, y, mapping, sizes_a, sizes_g, gen, True)
-                    t_cand = cand._replay_ms(gen)
-                    tries += 1
-                    if t_cand < t_best:
-                        losers.append(best)
-                        best, t_best = cand, t_cand
-                    else:
-                        losers.append(cand)
-                if t_serial < t_best:
-                    losers.append(best)
-                    best, t_best = serial, t_serial
-                else:
-                    losers.append(serial)
-                best.replay_ms, best.serial_ms, best.tries = t_best, t_serial, tries
-                del losers
-            self = best
+            self = cls._capture_once(computer, X, y, mapping, sizes_a, sizes_g, gen, _CAPTURE_BRANCHES >= 2, split)
         except Exception as error:  # noqa: BLE001 - any capture problem means: stay on the eager route
             from warnings import warn
 
             warn(f"KFAC factor build: hipGraph capture failed ({type(error).__name__}: {error}); this configuration "
                  "keeps the eager route.", stacklevel=3)
-            _CAPTURED[sig] = False
+            _note_capture_state(sig, False)
             torch.cuda.synchronize(computer.device)
             return False
         # bounded cache; ids of dead models must not alias new ones
@@ -588,9 +603,22 @@ class _CapturedBatch:
         return self
 
     def replay(self, X: Tensor, y: Tensor) -> None:
+        self.replay_forward(X, y)
+        self.replay_backward()
+
+    def replay_forward(self, X: Tensor, y: Tensor) -> None:
+        """Whole batch, or (split capture) the forward pass + every input covariance."""
+        global _CAPTURE_REPLAYS
         self.X.copy_(X)
         self.y.copy_(y)
         self.graph.replay()
+        _CAPTURE_REPLAYS += 1
+
+    def replay_backward(self) -> None:
+        global _CAPTURE_REPLAYS
+        if self.graph_bwd is not None:
+            self.graph_bwd.replay()
+            _CAPTURE_REPLAYS += 1
 
 
 class HipKFACComputer(EmpiricalRiskMixin):
@@ -804,9 +832,21 @@ class HipKFACComputer(EmpiricalRiskMixin):
         return sizes_a, sizes_g
 
     # ------------------------------------------------------------------ graph-captured build
+    def _loss_signature(self) -> tuple:
+        """The loss configuration a captured graph bakes in (class weights, label smoothing, ignore_index, pos_weight ...):
+        plain attributes by value, tensors by address."""
+        loss = self._loss_func
+        items = []
+        for name, val in sorted({**vars(loss), **loss._buffers}.items()):
+            if name.startswith("_") or name == "training":
+                continue
+            items.append((name, (val.data_ptr(), tuple(val.shape), val.dtype) if isinstance(val, Tensor) else repr(val)))
+        return (type(loss).__module__, type(loss).__qualname__, tuple(items))
+
     def _capture_signature(self, X: Tensor, y: Tensor) -> tuple | None:
-        """Everything a captured batch bakes in: shapes, normalisation constants, the Fisher type, and the ADDRESSES of
-        every tensor its kernels read in place (parameters, buffers) -- values stay live, a swapped storage re-captures."""
+        """Everything a captured batch bakes in: shapes, normalisation constants, the Fisher type, the loss and its
+        settings, and the ADDRESSES of every tensor its kernels read in place (parameters, buffers) -- values stay live,
+        a swapped storage re-captures."""
         model = self._model_module
         if not (isinstance(X, Tensor) and is_native_tensor(X) and isinstance(y, Tensor) and y.is_cuda
                 and X.device == self.device and y.device == self.device and X.shape[0] > 0):
@@ -819,24 +859,31 @@ class HipKFACComputer(EmpiricalRiskMixin):
         if any(t is not None and not (t.is_cuda and t.device == self.device) for t in tensors):
             return None
         return (
-            id(model), type(self).__name__, type(self._loss_func).__name__, self._loss_func.reduction,
+            id(model), type(self).__name__, self._loss_signature(),
             str(self._fisher_type), self._mc_samples, str(self._kfac_approx), self._separate_weight_and_bias,
             self._N_data, self._num_per_example_loss_terms, tuple(self._params.keys()),
             tuple(X.shape), tuple(y.shape), y.dtype, str(self.device), _FUSED_IM2COL, _FAST_BN, _OVERLAP, _PIXEL_GRAM, _CAPTURE_FORK, _CAPTURE_G_CHUNK,
+            _CAPTURE_BRANCHES, bool(self._distributed),
             tuple(m.training for m in mods),
             tuple((0, 0) if t is None else (t.data_ptr(), t.dtype) for t in tensors),
         )
 
     def _compute_captured(self):
         """The factor build with every mini-batch replayed as a hipGraph (``_CapturedBatch``) where one is available or
-        can be captured; None: take the eager route (not eligible, or capture failed once for this configuration)."""
+        can be captured; None: take the eager route (not eligible, or capture failed once for this configuration).
+
+        ``distributed=True`` runs the SAME graphs (round 6; the reference has one code path for any data list,
+        ``kfac_hooks.py:219-224``): the shard's batches are replayed, the LAST one as a split capture -- forward pass +
+        input covariances, then the asynchronous all-reduce of the input-covariance part of the flat buffer is started,
+        and the backward half replays while it travels; the gradient covariances are reduced behind it.  Collectives are
+        issued in the same order (A, then G) as on the eager route, so ranks may mix routes."""
         # (several backpropagated vectors per datum -- type-2, multi-sample MC -- run ONE batched backward pass under
-        # vmap and feed the callbacks afterwards; that route is not captured: its replay was wrong on the first try,
-        # tests/test_nets.py, and it is not the configuration the metric is quoted on)
-        if not (_CAPTURE and self._CAPTURABLE and not self._manual_callbacks and not self._distributed and not self._progressbar
+        # vmap and feed the callbacks afterwards; `_CAPTURE_MANUAL` gates their capture)
+        if not (_CAPTURE and self._CAPTURABLE and (not self._manual_callbacks or _CAPTURE_MANUAL) and not self._progressbar
                 and isinstance(self._data, (list, tuple)) and self._data and self.device.type == "cuda"
                 and self.dtype == torch.float32 and isinstance(self._model_module, Module)):
             return None
+        dist_on = bool(self._distributed)
         sigs = []
         for X, y in self._data:
             sig = self._capture_signature(X, y)
@@ -855,8 +902,23 @@ class HipKFACComputer(EmpiricalRiskMixin):
         for (which, k), view in out.items():
             (A if which == "a" else G)[k] = view
         A.fresh, G.fresh = set(sizes_a), set(sizes_g)
-        first = True
-        for (X, y), sig in zip(self._data, sigs):
+        n_a = out.end_of(("a", k) for k in sizes_a)   # out.flat[:n_a] = all A_l, out.flat[n_a:] = all G_l
+        work_a = None
+
+        def take(entry, lo: int, hi: int, stores) -> None:
+            """out.flat[lo:hi] (+)= the graph's static factors; `stores`: the stores whose views lie in that range."""
+            if all(len(st.fresh) == len(st) for st in stores):
+                out.flat[lo:hi].copy_(entry.store.flat[lo:hi])
+            else:
+                for st in stores:
+                    for k in st.fresh:
+                        st[k].zero_()
+                out.flat[lo:hi].add_(entry.store.flat[lo:hi])
+            for st in stores:
+                st.fresh = set()
+
+        last = len(self._data) - 1
+        for i, ((X, y), sig) in enumerate(zip(self._data, sigs)):
             entry = _CAPTURED.get(sig, 0)
             if isinstance(entry, _CapturedBatch) and entry.model_ref() is not self._model_module:
                 entry = 0   # the id of a dead model, recycled
@@ -864,27 +926,40 @@ class HipKFACComputer(EmpiricalRiskMixin):
                 # a configuration is run eagerly the first time it is seen (library warm-up: MIOpen's solver search,
                 # workspaces) and captured when it comes back
                 if entry >= _CAPTURE_AFTER:
-                    entry = _CapturedBatch.capture(self, X, y, mapping, sizes_a, sizes_g, gen, sig)
+                    entry = _CapturedBatch.capture(self, X, y, mapping, sizes_a, sizes_g, gen, sig, split=dist_on)
                 else:
-                    _CAPTURED[sig] = entry + 1
+                    _note_capture_state(sig, entry + 1)
+            overlap_now = dist_on and i == last   # the shard's input covariances are complete after THIS forward pass
             if isinstance(entry, _CapturedBatch):
-                entry.replay(X, y)
-                if first and len(A.fresh) == len(sizes_a) and len(G.fresh) == len(sizes_g):
-                    out.flat.copy_(entry.store.flat)
+                if overlap_now and entry.split:
+                    entry.replay_forward(X, y)
+                    take(entry, 0, n_a, (A,))
+                    work_a = self._start_input_factor_allreduce(A, out.flat, n_a)
+                    entry.replay_backward()
+                    take(entry, n_a, out.flat.numel(), (G,))
                 else:
-                    for st in (A, G):
-                        for k in st.fresh:
-                            st[k].zero_()
-                    out.flat.add_(entry.store.flat)
-                A.fresh, G.fresh = set(), set()
+                    entry.replay(X, y)
+                    take(entry, 0, out.flat.numel(), (A, G))
             else:
+                after_forward = None
+                if overlap_now:
+                    def after_forward():
+                        nonlocal work_a
+                        work_a = self._start_input_factor_allreduce(A, out.flat, n_a)
                 with _use_params(self._model_module, self._params):
-                    self._run_batch(X, y, mapping, A, G)
-            first = False
+                    self._run_batch(X, y, mapping, A, G, after_forward)
         for st in (A, G):
             for k in st.fresh:
                 st[k].zero_()
             st.fresh = set()
+        if dist_on:
+            from curvlinops_amd.dist import allreduce_flat_
+
+            if work_a is None:
+                work_a = self._start_input_factor_allreduce(A, out.flat, n_a)
+            allreduce_flat_(out.flat[n_a:])
+            if work_a is not True:
+                work_a.wait()
         if self._fisher_type == FisherType.FORWARD_ONLY:
             for group in mapping:
                 p = self._params[next(iter(group.values()))]

@@ -66,6 +66,18 @@ unsigned spin_limit();                        // spin budget of every bounded wa
 // the probe kernel of clo_test_occupy and of the helper-stream calibration in linalg.hip
 int launch_occupy(int blocks, int lds_bytes, long ticks, hipStream_t st);
 
+// Bookkeeping calls of the library (event queries of its stream / admission pools, creation of its helper streams and
+// events) are harmless to a graph that ANOTHER thread is capturing in global mode, but the runtime would count them as
+// "potentially unsafe" and invalidate that capture.  The calling thread switches to relaxed mode for their duration (the
+// documented way, hipThreadExchangeStreamCaptureMode); its own captures are unaffected.
+struct RelaxedCaptureScope {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  RelaxedCaptureScope() { if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
+  ~RelaxedCaptureScope() { if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
+  RelaxedCaptureScope(const RelaxedCaptureScope &) = delete;
+  RelaxedCaptureScope &operator=(const RelaxedCaptureScope &) = delete;
+};
+
 __host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -416,6 +416,7 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
         if (tid == 0)
           __hip_atomic_store(sf->flags + (long)(w * G + g) * V3_FLAG_STRIDE, sf->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
+        bool sk_bad = false;
         if (SK && !whole_from_start) {
           // the workgroups before this one hold the first part of the tile's k range
           const long tstart = c_lin * sf->nkt;
@@ -425,8 +426,9 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
               unsigned spins = 0;
               while (__hip_atomic_load(sf->flags + (long)(w2 * G + g) * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sf->epoch) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > sf->spin_limit) {   // the partial never came: raise the device's fault word, go on (garbage)
+                if (++spins > sf->spin_limit) {   // the partial never came: raise the device's fault word and go on --
                   if (sf->fault) __hip_atomic_store(sf->fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  sk_bad = true;                   // the tile is garbage and will SAY so (NaN in its first entry, below)
                   break;
                 }
               }
@@ -448,6 +450,7 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
                 }
           }
         }
+        if (sk_bad) acc[0][0][0] = __builtin_nanf("");   // (thread 0 holds entry (m0, n0) of the tile: always inside C)
         // ---- epilogue of the finished tile
         const bool to_ws = !SK && pf->splitk > 1;
         const int z = blockIdx.y;
@@ -692,7 +695,7 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
                   "Split-K is used on this device from now on -- repeat the call.", fdev);
         return CLO_EASYNC;
       }
-      if (fault_disabled(fdev, FAULT_STREAMK)) workers = 0;
+      if (fault_disabled(fdev, FAULT_STREAMK) || !fault_words_device(fdev)) workers = 0;   // (no fault word: unmonitored -> off)
     }
   }
   const bool sk = workers > 0;

@@ -440,6 +440,7 @@ __global__ void chol_copy_out_kernel(const OutBatch ob, const float *__restrict_
 }
 
 }  // namespace clo
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -542,48 +543,18 @@ struct CholAsync {
 // its previous call may still be queued: the helper streams are in order, and every wait below follows its record.
 static std::mutex g_chol_pool_mu;
 static std::vector<CholAsync *> g_chol_pool[64];
-// (Round 5: the helper's hardware queue shares one of the command processor's four dispatch pipes with the caller's queue
-// whenever their creation ranks differ by a multiple of four -- tools/ubench_queue_pipes.py -- and every kernel of the
-// pipeline then runs ~1.4 x longer (42 ResNet-18 factors: 16.8 instead of 11.5 ms; profiles/r05_cholesky_queue_pipes.txt).
-// Which rank the helper gets depends on how many streams the process created before its first inverse, so the helper is
-// PICKED among a few candidates by a probe when its set is made, chol_pick_helper below.  Running the critical chain on a
-// second stream of the set, and an event-timed probe inside the call, were tried and did not work.)
-// Which of `n` freshly created candidate streams dispatches most independently of the caller's stream?  Host-timed, the
-// way tools/ubench_queue_pipes.py measures it: a dispatch-bound kernel (40 k one-wave workgroups of ~1 us) on the caller's
-// stream and on the candidate at once takes 1.8 x the solo time when their hardware queues sit on different dispatch pipes
-// of the command processor and 2.4 - 3.3 x when they share one.  Run once per helper set (~2 ms, synchronises the caller's
-// stream); under stream capture or on any error the first candidate is taken.
-static int chol_pick_helper(hipStream_t caller, hipStream_t *cand, int n) {
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
-  for (int i = 0; i < n; ++i)
-    if (launch_occupy(64, 0, 100, cand[i]) != CLO_OK) return 0;   // (first use: queue creation)
-  if (launch_occupy(64, 0, 100, caller) != CLO_OK || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return 0; }
-  int best = 0;
-  double tbest = 1e30;
-  for (int i = 0; i < n; ++i) {
-    double tmin = 1e30;
-    for (int rep = 0; rep < 2; ++rep) {
-      const auto t0 = std::chrono::steady_clock::now();
-      if (launch_occupy(40000, 0, 100, caller) != CLO_OK || launch_occupy(40000, 0, 100, cand[i]) != CLO_OK ||
-          hipStreamSynchronize(caller) != hipSuccess || hipStreamSynchronize(cand[i]) != hipSuccess) {
-        (void)hipGetLastError();
-        return 0;
-      }
-      tmin = std::min(tmin, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    }
-#ifdef CLO_CHOL_PROBE_DEBUG
-    fprintf(stderr, "chol helper candidate %d: %.1f us\n", i, 1e6 * tmin);
-#endif
-    if (tmin < tbest) { tbest = tmin; best = i; }
-  }
-  return best;
-}
-
+// (Round 5 found that the helper's hardware queue shares one of the command processor's four dispatch pipes with the
+// caller's queue whenever their creation ranks differ by a multiple of four -- tools/ubench_queue_pipes.py -- and picked the
+// helper among candidates with a HOST-TIMED probe behind a hipDeviceSynchronize.  Round 6 removed that: a library entry
+// point must not synchronise the device (it stalls the caller's other streams and is illegal while any thread captures a
+// graph), and a wall-clock lottery must not decide a stream layout.  The rule is fixed now: a set is TWO streams of its own,
+// created back to back (consecutive hardware-queue ranks = different dispatch pipes, whatever the caller's stream is), the
+// critical chain on the first and the bulk products on the second; the caller's stream only forks into the set and joins it.)
 static CholAsync *chol_async_acquire(int *dev_out, hipStream_t caller) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   *dev_out = dev & 63;
+  RelaxedCaptureScope relaxed;   // event queries / stream creation below: never invalidate another thread's capture
   {
     // only a set whose previous call has COMPLETED on the device is taken again: re-recording an event that a queued wait
     // still refers to, or queueing behind the previous call's helper work, couples successive calls (ResNet-18's 42 factors
@@ -623,34 +594,20 @@ static CholAsync *chol_async_acquire(int *dev_out, hipStream_t caller) {
   // created much later is a lottery (it flipped when a captured hipGraph with a second branch was alive in the process).
   // Two queues created back to back get consecutive ids, i.e. different pipes.
 #ifndef CLO_CHOL_OWN_MAIN
-#define CLO_CHOL_OWN_MAIN 0
+#define CLO_CHOL_OWN_MAIN 1
 #endif
-  static const int own_main = CLO_CHOL_OWN_MAIN;
+  static const int own_main = [] {
+    const char *e = getenv("CLO_CHOL_OWN_MAIN");   // (A/B runs of tools/probe_kfac_inverse.py; not a product knob)
+    return e ? atoi(e) : CLO_CHOL_OWN_MAIN;
+  }();
+  (void)caller;
   bool ok = !own_main || (hipStreamCreateWithPriority(&a->main, hipStreamNonBlocking, least) == hipSuccess &&
                           hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) == hipSuccess);
-#ifndef CLO_CHOL_PICK
-#define CLO_CHOL_PICK 3
-#endif
-  static const int npick = CLO_CHOL_PICK;   // candidates for the helper stream (1: take the first); consecutive ranks: at most one of them shares the caller's pipe
-  if (ok && npick > 1) {
-    // the candidates that lose stay in a per-device pool for the next set (creating and destroying a stream costs ~1.5 ms
-    // each: hardware queues); a set picks among what the pool holds, topped up to `npick`
-    static std::vector<hipStream_t> cand_pool[64];
-    std::lock_guard<std::mutex> lk(g_chol_pool_mu);
-    auto &cp = cand_pool[dev & 63];
-    while ((int)cp.size() < std::min(npick, 8)) {
-      hipStream_t sn = nullptr;
-      if (hipStreamCreateWithPriority(&sn, hipStreamNonBlocking, least) != hipSuccess) break;
-      cp.push_back(sn);
-    }
-    ok = !cp.empty();
-    if (ok) {
-      const int pick = cp.size() > 1 ? chol_pick_helper(caller, cp.data(), (int)cp.size()) : 0;
-      a->side = cp[pick];
-      cp.erase(cp.begin() + pick);
-    }
-  } else {
-    ok = ok && hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least) == hipSuccess;
+  if (ok) {
+    // first use creates the hardware queues: do it now, in this order (no synchronisation -- the kernels are empty)
+    if (a->main) (void)launch_occupy(1, 0, 1, a->main);
+    (void)launch_occupy(1, 0, 1, a->side);
   }
   if (ok && nhelp >= 3) {
     ok = hipStreamCreateWithPriority(&a->inv, hipStreamNonBlocking, least) == hipSuccess &&
@@ -924,7 +881,10 @@ extern "C" int clo_cholesky_inverse_batched_f32(const float *const *A, const lon
 #ifndef CLO_CHOL_PIPE
 #define CLO_CHOL_PIPE 1
 #endif
-  static const int pipe = CLO_CHOL_PIPE;
+  static const int pipe = [] {
+    const char *e = getenv("CLO_CHOL_PIPE");   // (A/B runs; not a product knob)
+    return e ? atoi(e) : CLO_CHOL_PIPE;
+  }();
   // (below ~1500 rows the single chain of chol_rec is as fast or faster: n = 512: 0.34 vs 0.43 ms, 1152: 0.90 vs 0.88 ms,
   // 2304: 2.11 vs 1.78 ms, 4608: 5.13 vs 3.95 ms)
 #ifndef CLO_CHOL_PIPE_MIN

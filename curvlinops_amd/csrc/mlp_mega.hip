@@ -924,6 +924,12 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
 #pragma unroll
     for (int n = 0; n < MG_NB; ++n) xv[n] = mg_ld4(p.X + (long)min(n, N - 1) * d0 + (rl < lanes_r ? cq * 4 : 0));
     MG_WAIT(c_colB, 16u, 16);
+    // Behind the LAST wait of the launch: was any wait of this launch cut short (here or in a workgroup this one waited
+    // for)?  Then what this workgroup computes is garbage, and it says so in its own output (below): a product that
+    // timed out contains NaN instead of plausible numbers ("asynchronous faults", clo_common.h).  The load returns
+    // behind the x rows requested above; it is consumed after the last store.
+    unsigned launch_bad = 0u;
+    if (tid == 0) launch_bad = __hip_atomic_load(c_err.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wg_barrier();
     MG_STAMP(14);
     const int nq = nf1 >> 2;
@@ -970,6 +976,8 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
         mg_st4nt(po, o);
       }
     }
+    // (thread 0 wrote the first four entries of row jA itself: same thread, same address, program order)
+    if (tid == 0 && launch_bad != 0u) p.O1[(long)jA * d0] = __builtin_nanf("");
   }
   MG_STAMP(15);
 }
@@ -1007,6 +1015,7 @@ bool mega_ok(int L, const int *dims, const float *const *W, const float *const *
     __atomic_store_n(&ncu[dev], c, __ATOMIC_RELAXED);
   }
   if (c != MG_G) return false;  // one workgroup per CU, all of them resident: the group counters rely on it
+  if (!fault_words_device(dev)) return false;           // no host-visible fault word: a timeout could not be reported
   if (fault_disabled(dev, FAULT_MEGA)) return false;   // a launch on this device timed out before: the launch chain serves
   // every workgroup needs a CU to itself AND one must fit at all (LDS carve, registers) on this device
   static int occ[MG_MAXDEV];

@@ -18,6 +18,7 @@ class PersistGate {
  public:
   // Call before queueing a persistent launch of `cus` workgroups (one per CU) on `st`; then launch; then done().
   int admit(hipStream_t st, int cus) {
+    RelaxedCaptureScope relaxed;   // (event queries: see clo_common.h)
     mu_.lock();
     int total = cus;
     for (Slot &s : slots_) {
@@ -48,6 +49,7 @@ class PersistGate {
     return CLO_OK;   // (the mutex stays locked until done(): launch order == admission order)
   }
   int done(hipStream_t st) {
+    RelaxedCaptureScope relaxed;
     Slot *mine = nullptr;
     for (Slot &s : slots_)
       if (s.st == st) mine = &s;

@@ -392,6 +392,14 @@ extern "C" int clo_persistent_status(int dev) {
   }
   return bits;
 }
+extern "C" int clo_fault_pending(int dev) {
+  int bits = 0;
+  const FaultState &f = g_fault[dev & 63];
+  if (f.tried && f.host)
+    for (int k = 0; k < FAULT_KINDS; ++k)
+      if (__atomic_load_n(&f.host[k], __ATOMIC_RELAXED) != 0u) bits |= 1 << k;
+  return bits;
+}
 extern "C" int clo_test_set_spin_limit(unsigned polls) {
   CLO_REQUIRE(polls >= 16, "clo_test_set_spin_limit: at least 16 polls");
   g_spin_limit = polls;

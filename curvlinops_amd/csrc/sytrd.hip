@@ -522,7 +522,10 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_kernel(const TpArgs p)
 __global__ __launch_bounds__(256) void sytrd_panel_end_kernel(float *A, long lda, int n, int i0, int ncol,
                                                               const float *Vp, float *Wp,
                                                               const float *part, int g, const float *tau,
-                                                              const float *gam) {
+                                                              const float *gam, const unsigned *err, float *D) {
+  // a wait of the panel launch was cut short (clo_common.h, "asynchronous faults"): the reduction is garbage and says so --
+  // NaN in the first diagonal entry fails every acceptance test of the eigensolver instead of passing as plausible numbers
+  if (blockIdx.x == 0 && threadIdx.x == 0 && *err != 0u) D[0] = __builtin_nanf("");
   __shared__ float s_part[256];
   __shared__ float s_g[TD_NB];
   const int jl = i0 + ncol - 1, cl = ncol - 1;
@@ -599,7 +602,7 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
               "units on this device from now on -- repeat the call.", dev);
     return CLO_EASYNC;
   }
-  if (fault_disabled(dev, FAULT_SYTRD)) gmax = std::max(1, std::min(gmax, device_cu_count(dev) / 4));
+  if (fault_disabled(dev, FAULT_SYTRD) || !fault_words_device(dev)) gmax = std::max(1, std::min(gmax, device_cu_count(dev) / 4));
 
   const size_t lds = (2 * n4 + TD_WAVES * TD_NPART + 5 * TD_NB + 5 * TD_WAVES + 16) * sizeof(float);
   // several host threads may run reductions at once (linalg_native.eigh_many): the attribute must be in
@@ -671,7 +674,8 @@ extern "C" int clo_sytrd_f32(float *A, long lda, int n, float *D, float *E, floa
     rc = gate.done(st);
     if (rc != CLO_OK) return rc;
     hipLaunchKernelGGL(sytrd_panel_end_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, A, lda, n, i0,
-                       ncol, Vp, Wp, gpart[flip], g_prev, tau, gam);
+                       ncol, Vp, Wp, gpart[flip], g_prev, tau, gam,
+                       cnt + 32 * (2 * (TD_GMAX / TP_GROUP)), D);
     CLO_CHECK_LAUNCH("sytrd_panel_end_kernel");
     // trailing update A[t:, t:] -= V W^T + W V^T on the MFMA GEMM engine (full square: the column
     // kernel reads complete rows)

@@ -179,12 +179,17 @@ class AllReducedLinearOperator(PyTorchLinearOperator):
         not block the host) makes ``Y`` the reduced product.  Consecutive independent products --
         probe vectors of a trace estimator, the steps of the benchmark -- overlap the 4 D K-byte
         all-reduce of one product with the kernels of the next."""
-        # the collective of the previous product may still hold CUs: a persistent grid that needs every CU of the
-        # chip (csrc/mlp_mega.hip) would spin beside it, so overlapped products take the launch chain -- the choice
-        # travels as the `flags` argument of THIS operator's C calls (clo_mlp_ggn_matvec), not as process state
+        # A collective that is still running holds CUs: a persistent grid that needs every CU of the chip
+        # (csrc/mlp_mega.hip) would spin beside it, so a product that is queued while the PREVIOUS collective of this
+        # operator has not completed (event query, no host wait) takes the launch chain; once it has completed -- or when
+        # the caller never overlaps -- the product runs the same persistent kernel as the single-GPU path.  The choice
+        # travels as the `flags` argument of THIS operator's C calls (clo_mlp_ggn_matvec), not as process state.
         op = self._op
         nat = getattr(op, "_native", None) if is_distributed() else None
-        if nat is not None:   # (per call and per thread: nothing on the shared operator object is mutated)
+        prev = getattr(self, "_last_work", None)
+        busy = prev is not None and not prev.is_completed()
+        self.async_route = "chain" if (nat is not None and busy) else "persistent"
+        if nat is not None and busy:   # (per call and per thread: nothing on the shared operator object is mutated)
             with nat.plan.flags_override(_hip.MLP_NO_PERSISTENT):
                 Y = op @ X
         else:
@@ -192,6 +197,7 @@ class AllReducedLinearOperator(PyTorchLinearOperator):
         if not Y.is_contiguous():
             Y = Y.contiguous()
         work = dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self._group, async_op=True) if is_distributed() else None
+        self._last_work = work
         return Y, work
 
     def _adjoint(self) -> "AllReducedLinearOperator":

@@ -243,7 +243,12 @@ class PyTorchLinearOperator:
             Y = f(torch.as_tensor(X, dtype=dtype, device=device))
             if Y.dtype == torch.bfloat16:  # numpy has no bf16
                 Y = Y.float()
-            return Y.detach().cpu().numpy().astype(X.dtype)
+            out = Y.detach().cpu().numpy().astype(X.dtype)
+            if Y.is_cuda:   # the copy synchronised with the device: a launch that timed out is reported HERE, not later
+                from curvlinops_amd import _hip
+
+                _hip.raise_if_async_fault(Y.device.index)
+            return out
 
         return g
 

@@ -56,6 +56,11 @@ const char *clo_last_error(void);
  * tridiagonalisation panels, bit 2 stream-K GEMM schedule -- set = disabled after a timeout (see CLO_EASYNC); a pending,
  * not yet reported timeout is reported (and the mode disabled) by this call as well. */
 int clo_persistent_status(int dev);
+/* Bit mask (as above) of timeouts that have happened on `dev` and have NOT been reported yet: a peek for consumers that
+ * have just synchronised with the device (the SciPy export copies the result to the host) -- nothing is cleared, the
+ * affected entry point still returns CLO_EASYNC on its next call.  A launch that timed out also marks its own result
+ * with NaN (mlp_mega.hip, gemm_v3.hip, sytrd.hip): invalid numbers are never plausible numbers. */
+int clo_fault_pending(int dev);
 /* Diagnostics for the fail-soft tests: the spin budget of every bounded wait (default 1 << 22 polls, ~seconds), and a
  * kernel that keeps `blocks` workgroups with `lds_bytes` of LDS each busy for `ticks` ticks of the 100 MHz wall clock. */
 int clo_test_set_spin_limit(unsigned polls);

@@ -874,6 +874,51 @@ def test_cholesky_pipeline_orders_and_repeatability(hip):
         assert torch.equal(X, X2) and residual(A, X, 1e-3) < 5e-4
 
 
+def test_cholesky_inverse_from_a_worker_thread_while_another_thread_captures(hip):
+    """`clo_cholesky_inverse_f32` never synchronises the device and its bookkeeping (stream / event pools) runs in relaxed
+    capture mode: a worker thread may run it -- the pipelined route, helper streams and all -- while the main thread is
+    inside a GLOBAL-mode `torch.cuda.graph` capture (the package captures KFAC builds itself); the capture stays valid and
+    both results are right.  (Round 5 held a process-wide mutex across a hipDeviceSynchronize in this entry point.)"""
+    import threading
+
+    lib = hip.load()
+    g = torch.Generator().manual_seed(5)
+    n = 1700   # >= 1536: the pipelined route with the set's own streams
+    X = torch.randn(n + 64, n, generator=g).cuda()
+    A = X.T @ X / (n + 64)
+    ref = hip.cholesky_inverse(A, 1e-3)   # warm: helper streams, events, workspaces exist
+    out = torch.empty_like(A)
+    status = torch.zeros(1, device="cuda", dtype=torch.int32)
+    ws = torch.empty(lib.clo_cholesky_inverse_ws_floats(n), device="cuda")
+    worker_stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    err = []
+
+    def work():
+        try:   # the raw entry point on preallocated buffers: nothing but the library's own calls happens in this thread
+            rc = lib.clo_cholesky_inverse_f32(A.data_ptr(), n, out.data_ptr(), n, n, 1e-3, ws.data_ptr(), status.data_ptr(),
+                                              worker_stream.cuda_stream)
+            if rc != 0:
+                err.append(hip.load().clo_last_error())
+        except Exception as e:  # noqa: BLE001
+            err.append(repr(e))
+
+    x = torch.ones(4096, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):   # capture_error_mode="global" (the default)
+        y = x * 2.0
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+        z = y + 1.0
+    assert not err, err
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float(z.min()) == 3.0 and float(z.max()) == 3.0
+    assert int(status.item()) == 0
+    assert torch.equal(out, ref)
+
+
 def test_cholesky_inverse_not_pd_raises(hip):
     A = torch.eye(70)
     A[40, 40] = -1.0
@@ -1094,6 +1139,7 @@ def test_persistent_kernel_fails_soft_when_the_gpu_is_shared():
     assert res["persistent_equals_chain_when_free"] and res["status_before"] == 0
     assert res["timed_out_launch_returned"], res          # the kernel ended on its own
     assert res["timed_out_seconds"] < 8.0, res             # ... well before the hog released the CUs
+    assert res["timed_out_result_has_nan"], res            # ... its result is NaN-marked, not plausible garbage
     assert res["reported"], res                            # ... and the next call said so, once
     assert res["status_after"] & 1, res                    # persistent MLP kernel disabled on this device
     assert res["next_product_equals_chain"] and res["context_alive"], res

@@ -352,7 +352,7 @@ def test_fused_patch_factors_equal_materialised(dev, net, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("net", ["resnet_toy", "lenet"])
-@pytest.mark.parametrize("fisher", ["mc", "empirical", "forward-only"])
+@pytest.mark.parametrize("fisher", ["mc", "empirical", "forward-only", "type-2"])
 def test_captured_factor_build_equals_eager(dev, net, fisher, monkeypatch):
     """The hipGraph-captured factor build (`computers._CapturedBatch`: the analogue of the reference's traced backend,
     computers/kfac_make_fx.py:26-111) replays the SAME computation: factors equal the eager build's (same MC draws:
@@ -368,6 +368,7 @@ def test_captured_factor_build_equals_eager(dev, net, fisher, monkeypatch):
     params = kfac_params(model)
     kw = dict(fisher_type=fisher, separate_weight_and_bias=False, check_deterministic=False)
     computers.reset_captured_builds()
+    monkeypatch.setattr(computers, "_CAPTURE_MANUAL", True)
 
     def factors(data, capture):
         monkeypatch.setattr(computers, "_CAPTURE", capture)

@@ -33,6 +33,7 @@ t0 = time.time()
 try:
     bad = product(_hip.MLP_DEFAULT)                    # cannot become co-resident: must END (garbage), not trap
     out["timed_out_launch_returned"] = True
+    out["timed_out_result_has_nan"] = bool(torch.isnan(bad).any())   # a timed-out product is loud, not plausible
     out["timed_out_seconds"] = time.time() - t0
 except Exception as e:  # noqa: BLE001
     out["timed_out_launch_returned"] = False
