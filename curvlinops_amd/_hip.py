@@ -149,6 +149,14 @@ _SIGNATURES = {
     "clo_gram_tall_supported": (c_int, [c_long, c_int, c_int]),
     "clo_gram_tall_ws_floats": (c_long, [c_long, c_int, c_int]),
     "clo_gram_tall_f32": (c_int, [_PF, c_long, _PF, c_long, c_int, c_long, c_int, c_float, c_float, _PF, c_void_p]),
+    "clo_syrk_grouped_max_problems": (c_int, []),
+    "clo_syrk_grouped_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clo_syrk_grouped_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, _PF, c_void_p, c_void_p]),
+    "clo_tall_gram_ws_bytes": (c_long, [c_long, c_int, c_int]),
+    "clo_tall_gram_f64": (c_int, [c_void_p, c_long, _PF, c_long, c_int, _PF, c_long, c_int, c_long, c_void_p, c_void_p]),
+    "clo_tall_apply_f32": (c_int, [_PF, c_long, _PF, c_long, c_float, _PF, c_long, _PF, c_long, c_long, c_int, c_int,
+                                   c_void_p]),
     "clo_axpby_f32": (c_int, [_PF, _PF, c_long, c_float, c_float, c_void_p]),
     "clo_dot_ws_bytes": (c_long, []),
     "clo_dot_f32": (c_int, [_PF, _PF, c_long, c_float, _PF, c_void_p, c_void_p]),
@@ -469,6 +477,99 @@ def syrk_accum(C: Tensor, X: Tensor, alpha: float = 1.0, beta: float = 1.0, ones
                                 splitk, _p(ws), _stream())
     _check(rc, "clo_syrk_accum_f32")
     return C
+
+
+def syrk_grouped(Cs: list[Tensor], Xs: list[Tensor], alphas: list[float], betas: list[float],
+                 ones_cols: list[bool] | None = None) -> None:
+    """``Cs[p] = betas[p] Cs[p] + alphas[p] [Xs[p] | 1]^T [Xs[p] | 1]`` for all p in ONE launch per group of up to
+    ``clo_syrk_grouped_max_problems`` problems (``clo_syrk_grouped_f32``): the small covariance products of a KFAC factor
+    build.  ``Xs[p]``: fp32 GPU ``[rows, d]`` with unit column stride; ``Cs[p]``: distinct ``[d(+1), d(+1)]`` row-major."""
+    import ctypes
+
+    lib = load()
+    n = len(Cs)
+    if n == 0:
+        return
+    ones_cols = [False] * n if ones_cols is None else list(ones_cols)
+    cap = int(lib.clo_syrk_grouped_max_problems())
+    for lo in range(0, n, cap):
+        hi = min(n, lo + cap)
+        P = hi - lo
+        C, X = Cs[lo:hi], [x if (x.dim() == 2 and (x.shape[1] <= 1 or x.stride(1) == 1)) else x.contiguous() for x in Xs[lo:hi]]
+        for c, x, o in zip(C, X, ones_cols[lo:hi]):
+            dd = x.shape[1] + (1 if o else 0)
+            if x.dim() != 2 or tuple(c.shape) != (dd, dd) or c.stride(1) != 1 or not (is_f32_gpu(c) and is_f32_gpu(x)):
+                raise ValueError(f"syrk_grouped: X {tuple(x.shape)} does not fit C {tuple(c.shape)} (fp32 GPU, row-major)")
+        ptr_t, long_t, int_t, float_t = ctypes.c_void_p * P, ctypes.c_long * P, ctypes.c_int * P, ctypes.c_float * P
+        rows = long_t(*[x.shape[0] for x in X])
+        d = int_t(*[x.shape[1] for x in X])
+        ones = int_t(*[int(o) for o in ones_cols[lo:hi]])
+        slab_n, cnt_n = ctypes.c_long(0), ctypes.c_long(0)
+        _check(lib.clo_syrk_grouped_ws(P, rows, d, ones, ctypes.byref(slab_n), ctypes.byref(cnt_n)), "clo_syrk_grouped_ws")
+        dev = X[0].device
+        slab = torch.empty(max(1, slab_n.value), device=dev, dtype=torch.float32)
+        cnt = torch.zeros(max(1, cnt_n.value), device=dev, dtype=torch.int32)
+        _tls.dev = dev
+        rc = lib.clo_syrk_grouped_f32(
+            P, ptr_t(*[c.data_ptr() for c in C]), long_t(*[c.stride(0) for c in C]), ptr_t(*[x.data_ptr() for x in X]), rows, d,
+            long_t(*[x.stride(0) if x.shape[0] > 1 else max(x.shape[1], 1) for x in X]), ones,
+            float_t(*[float(a) for a in alphas[lo:hi]]), float_t(*[float(b) for b in betas[lo:hi]]), slab.data_ptr(),
+            cnt.data_ptr(), _stream())
+        _check(rc, "clo_syrk_grouped_f32")
+
+
+def tall_gram_supported(X: Tensor, Y: Tensor | None = None) -> bool:
+    ok = is_f32_gpu(X) and X.dim() == 2 and 1 <= X.shape[1] <= 64 and (X.shape[1] == 1 or X.stride(1) == 1)
+    if Y is not None:
+        ok = ok and is_f32_gpu(Y) and Y.dim() == 2 and Y.shape[0] == X.shape[0] and 1 <= Y.shape[1] <= 64 \
+            and (Y.shape[1] == 1 or Y.stride(1) == 1) and Y.device == X.device
+    return bool(ok)
+
+
+def is_f32_gpu(t: Tensor) -> bool:
+    return isinstance(t, Tensor) and t.is_cuda and t.dtype == torch.float32
+
+
+def tall_gram(X: Tensor, Y: Tensor | None = None) -> Tensor:
+    """``X^T Y`` (``X^T X`` without ``Y``) of tall float32 blocks ``[m, <= 64]`` as a FLOAT64 ``[n1, n2]`` matrix: one
+    streaming pass, exact products, float64 accumulation (``clo_tall_gram_f64``)."""
+    lib = load()
+    m, n1 = X.shape
+    n2 = n1 if Y is None else Y.shape[1]
+    out = torch.empty(n1, n2, device=X.device, dtype=torch.float64)
+    ws = torch.empty(max(1, lib.clo_tall_gram_ws_bytes(m, n1, n2) // 8), device=X.device, dtype=torch.float64)
+    ldx = X.stride(0) if m > 1 else max(n1, 1)
+    ldy = 0 if Y is None else (Y.stride(0) if m > 1 else max(n2, 1))
+    px = _p(X)
+    rc = lib.clo_tall_gram_f64(out.data_ptr(), n2, px, ldx, n1, None if Y is None else Y.data_ptr(), ldy, n2, m,
+                               ws.data_ptr(), _stream())
+    _check(rc, "clo_tall_gram_f64")
+    return out
+
+
+def tall_apply_supported(Q: Tensor, C: Tensor, G: Tensor | None = None) -> bool:
+    ok = (is_f32_gpu(Q) and is_f32_gpu(C) and Q.dim() == 2 and C.dim() == 2 and Q.shape[1] == C.shape[0]
+          and 1 <= Q.shape[1] <= 64 and Q.shape[1] % 4 == 0 and 1 <= C.shape[1] <= 64 and Q.stride(1) == 1
+          and (Q.shape[0] <= 1 or Q.stride(0) % 4 == 0) and Q.data_ptr() % 16 == 0 and C.is_contiguous())
+    if G is not None:
+        ok = ok and is_f32_gpu(G) and G.shape == (Q.shape[0], C.shape[1]) and (G.shape[1] == 1 or G.stride(1) == 1)
+    return bool(ok)
+
+
+def tall_apply(Q: Tensor, C: Tensor, G: Tensor | None = None, beta: float = 1.0, out: Tensor | None = None) -> Tensor:
+    """``beta G + Q C`` for a tall ``Q [m, k]`` and a small ``C [k, n]`` (k, n <= 64) in one pass over ``Q``, ``G`` and the
+    result (``clo_tall_apply_f32``; rows = the M dimension of 16x16x4 MFMA tiles, ``C`` in registers)."""
+    lib = load()
+    m, k = Q.shape
+    n = C.shape[1]
+    if out is None:
+        out = torch.empty(m, n, device=Q.device, dtype=torch.float32)
+    ldq = Q.stride(0) if m > 1 else max(k, 4)
+    rc = lib.clo_tall_apply_f32(_p(out), out.stride(0) if m > 1 else n, None if G is None else G.data_ptr(),
+                                0 if G is None else (G.stride(0) if m > 1 else n), float(beta), _p(Q), ldq, _p(C), n, m, k,
+                                n, _stream())
+    _check(rc, "clo_tall_apply_f32")
+    return out
 
 
 def im2col(x: Tensor, kernel_size, stride, padding, dilation) -> Tensor:

@@ -461,9 +461,15 @@ _CAPTURE_NOTES_MAX = 256   # bookkeeping entries (eager-run counters, "capture f
 # graph's internal streams.  2: the input covariances on a second branch beside the backward pass (15 % faster when the
 # two branches land on independent dispatch pipes, up to 2 x slower when they do not: DESIGN 3.3 "queue pipes").
 _CAPTURE_BRANCHES = int(os.environ.get("CLO_KFAC_CAPTURE_BRANCHES", "1"))
+# Gradient covariances of a mini-batch in ONE grouped launch at the end of the backward pass (clo_syrk_grouped_f32) instead of
+# one split-K product + reduction per layer: ResNet-18's 21 of them are 6 GFLOP that took 0.9 ms as 61 small launches.
+_GROUP_G = os.environ.get("CLO_KFAC_GROUP_G", "1") == "1"
 _CAPTURED: dict = {}   # signature -> int (eager runs so far) | _CapturedBatch | False (capture failed: stay eager)
 _CAPTURE_GENERATORS: dict = {}
-_CAPTURE_MANUAL = os.environ.get("CLO_KFAC_CAPTURE_MANUAL", "0") == "1"   # capture type-2 / multi-sample MC builds (one batched backward under vmap)
+# type-2 / multi-sample MC builds (one batched backward pass under vmap, the callbacks fed afterwards) are captured too
+# (round 6: with the capture done once and nothing replayed while capturing, their replays equal the eager build --
+# test_captured_factor_build_equals_eager[type-2]; round 5 had excluded them)
+_CAPTURE_MANUAL = os.environ.get("CLO_KFAC_CAPTURE_MANUAL", "1") == "1"
 _CAPTURE_REPLAYS = 0   # graph launches so far (tests assert that a captured route really ran)
 
 
@@ -790,6 +796,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
         self._deferred_inputs = [] if coarse_fork else None
         self._inline_grads = coarse_fork
         self._deferred_grads = []
+        self._grouped_g = []
         handles = []
         for group in mapping:
             mod = self._module_of(group)
@@ -811,12 +818,14 @@ class HipKFACComputer(EmpiricalRiskMixin):
             output, y = self._rearrange_output(output, y)
             self._backpropagate(output, y)
             self._flush_deferred_grads(None)
+            self._flush_grouped_grads()
         finally:
             for h in handles:
                 h.remove()
             self._hooked_outputs = []
             self._deferred_inputs = None
             self._deferred_grads = []
+            self._grouped_g = None     # (outside a batch `_grad_job` accumulates at once)
             self._inline_grads = False
             _join_factor_stream(self.device)
 
@@ -863,7 +872,7 @@ class HipKFACComputer(EmpiricalRiskMixin):
             str(self._fisher_type), self._mc_samples, str(self._kfac_approx), self._separate_weight_and_bias,
             self._N_data, self._num_per_example_loss_terms, tuple(self._params.keys()),
             tuple(X.shape), tuple(y.shape), y.dtype, str(self.device), _FUSED_IM2COL, _FAST_BN, _OVERLAP, _PIXEL_GRAM, _CAPTURE_FORK, _CAPTURE_G_CHUNK,
-            _CAPTURE_BRANCHES, bool(self._distributed),
+            _CAPTURE_BRANCHES, bool(self._distributed), _GROUP_G,
             tuple(m.training for m in mods),
             tuple((0, 0) if t is None else (t.data_ptr(), t.dtype) for t in tensors),
         )
@@ -1102,7 +1111,35 @@ class HipKFACComputer(EmpiricalRiskMixin):
 
     def _grad_job(self, g: Tensor, corr: float, group, hyper, store) -> None:
         g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
-        _gram_accumulate(store, tuple(group.values()), g.reshape(-1, g.shape[-1]), corr, ones_col=False)
+        g2d = g.reshape(-1, g.shape[-1])
+        key = tuple(group.values())
+        pending = getattr(self, "_grouped_g", None)
+        if _GROUP_G and pending is not None and is_native_tensor(g2d) and _hip.has("clo_syrk_grouped_f32"):
+            # kept until the backward pass is over: ONE launch then forms every layer's G_l (`_flush_grouped_grads`)
+            if any(k == key and st is store for st, k, _, _ in pending):
+                self._flush_grouped_grads()   # a second vector for the same factor: the first group goes first
+            pending.append((store, key, g2d if g2d.stride(-1) == 1 else g2d.contiguous(), corr))
+            return
+        _gram_accumulate(store, key, g2d, corr, ones_col=False)
+
+    def _flush_grouped_grads(self) -> None:
+        """``G_l (+)= corr g_l^T g_l`` for every pending layer in one grouped launch (on the stream the gradients were
+        produced on; a factor's first contribution writes, later ones accumulate)."""
+        pending, self._grouped_g = getattr(self, "_grouped_g", None) or [], []
+        if not pending:
+            return
+        Cs, Xs, alphas, betas = [], [], [], []
+        for store, key, g2d, corr in pending:
+            d = g2d.shape[1]
+            fresh = getattr(store, "fresh", None)
+            C = store.get(key)
+            first = C is None or (fresh is not None and key in fresh)
+            if C is None:
+                C = store[key] = torch.empty(d, d, device=g2d.device, dtype=torch.float32)
+            if fresh:
+                fresh.discard(key)
+            Cs.append(C), Xs.append(g2d), alphas.append(corr), betas.append(0.0 if first else 1.0)
+        _hip.syrk_grouped(Cs, Xs, alphas, betas)
 
     def _flush_deferred_grads(self, ready: Tensor | None) -> None:
         jobs, self._deferred_grads = getattr(self, "_deferred_grads", []), []

@@ -14,7 +14,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent
 LIB_DIR = CSRC.parent / "lib"
 LIB_PATH = LIB_DIR / "libclo_hip.so"
-SOURCES = ["gemm.hip", "gemm_v3.hip", "mlp.hip", "mlp_mega.hip", "stream_ops.hip", "linalg.hip", "conv.hip", "gram.hip", "sytrd.hip", "eigh.hip", "eigh_driver.hip", "kron.hip"]
+SOURCES = ["gemm.hip", "gemm_v3.hip", "mlp.hip", "mlp_mega.hip", "stream_ops.hip", "linalg.hip", "conv.hip", "gram.hip", "syrk_grouped.hip", "sytrd.hip", "eigh.hip", "eigh_driver.hip", "kron.hip"]
 HEADERS = ["clo_common.h", "gemm.h", "persist_gate.h", "mlp_loss.h", "../../include/curvlinops_amd.h"]
 
 

@@ -216,7 +216,11 @@ extern "C" int clo_patch_fold_f32(float *C, long ldc, const float *Gam, long ldg
   a.alpha = alpha; a.beta = beta;
   // channel groups: the largest square-ish tile of Gam that fits 48 KB, shrunk until the grid fills the chip
   const long HW = (long)H * W, T = (long)KH * KW, P = (long)OH * OW;
-  const long budget = (44 * 1024) / 4;
+  // (the tap table and the pair list share the workgroup's 64 KB with the tile: a 9 x 9 kernel on an 8 x 8 map needs 26 KB
+  // for them, which a fixed 44 KB tile budget would push over the limit -- the tile grows only as far as the sum allows;
+  // g1 = g2 = 1 always fits, that is what clo_patch_fold_supported checks)
+  const long fixed_floats = ((T * P + 3) & ~3L) + 1 + T * T;
+  const long budget = std::min<long>((44 * 1024) / 4, (64 * 1024) / 4 - fixed_floats);
   int g1 = 1, g2 = 1;
   auto fits = [&](int r, int c) { return (long)r * HW * (((long)c * HW) | 1) <= budget; };
   for (bool grew = true; grew;) {   // columns first: a tile row is one contiguous run of Gam

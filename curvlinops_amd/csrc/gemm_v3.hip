@@ -176,8 +176,14 @@ __device__ __forceinline__ void v3_tile(const GemmArgs &p, long lin, int y, bool
   t.nk = t.ke > t.kb ? (t.ke - t.kb + V3_BK - 1) / V3_BK : 1;
 }
 
-template <bool AKC, bool BKC, int BMt, int BNt, int WVM, int WVN, int NST, bool SK>
-__global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p, const V3Sched s) {
+// KG = 2 (round 6, small tiles without stream-K): EIGHT waves per output tile -- two groups of WVM x WVN waves, each with an
+// LDS ring of its own, run the k loop on one half of the tile's k range each and meet at the same barrier once per k tile;
+// group 1 hands its accumulators to group 0 through LDS at the end.  A SIMD then holds two waves of DIFFERENT rings: while one
+// is parked at its s_waitcnt / barrier the other issues MFMAs (the four-wave 64 x 64 loop sat parked 39 % of its wave cycles,
+// SQ_WAIT_ANY, profiles/r05_gemm_midsize_sweep.txt), and a tile's k loop is half as long.
+template <bool AKC, bool BKC, int BMt, int BNt, int WVM, int WVN, int NST, bool SK, int KG = 1>
+__global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmArgs p, const V3Sched s) {
+  static_assert(KG == 1 || !SK, "the k-group form has no stream-K schedule");
   constexpr int NW = WVM * WVN, NTHR = NW * 64;
   constexpr int WM = BMt / WVM, WNC = BNt / WVN, MT = WM / 32, NT = WNC / 32;
   constexpr int A_FL = BMt * V3_BK, ST_FL = (BMt + BNt) * V3_BK;
@@ -189,9 +195,11 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
   constexpr int PER_SLOTTED = PER < SLOTS - (MT + NT) ? PER : SLOTS - (MT + NT);   // DMA pieces that get a slot; the rest
                                                                                   // (small tiles: 2 of 4) follow the group
   static_assert(NST >= 3, "ring depth");
-  extern __shared__ __attribute__((aligned(1024))) float lds3[];
+  extern __shared__ __attribute__((aligned(1024))) float lds_all[];
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & (NTHR - 1);   // (thread index inside the k group)
+  const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR) : 0;
+  float *lds3 = lds_all + (long)kg * NST * ST_FL;   // the group's own ring
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WVN, wn = wave % WVN;
   const int li = lane & 31, lh = lane >> 5;
@@ -246,6 +254,15 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
   }
   V3Tile ct;
   v3_tile<BMt, BNt>(p, SK ? c_lin * G + g : c_lin, blockIdx.y, SK, s.tiles_per_mat, ct);
+  if (KG > 1) {
+    // group 0: the first ceil(nk / 2) k tiles, group 1: the rest (an odd count leaves it one all-masked tile: `lim` <= 0
+    // zero-fills); BOTH run ceil(nk / 2) units, so they execute the same number of barriers
+    const int half = (ct.nk + 1) / 2;
+    const int mid = ct.kb + half * V3_BK;
+    if (kg == 0) ct.ke = min(ct.ke, mid);
+    else { ct.kb = mid; }   // (kb > ke: an empty range)
+    ct.nk = half;
+  }
   if (!SK) n_units = c_kend = ct.nk;
   int seg_kt0 = c_kt;  // first k tile of the consumer's current segment
 
@@ -451,6 +468,30 @@ __global__ __launch_bounds__(WVM *WVN * 64) void gemm_v3_kernel(const GemmArgs p
           }
         }
         if (sk_bad) acc[0][0][0] = __builtin_nanf("");   // (thread 0 holds entry (m0, n0) of the tile: always inside C)
+        if (KG > 1) {
+          // group 1's half of the k range joins group 0's through LDS (an area behind both rings: zero tiles issued past the
+          // end may still be landing in the rings); group 0 then runs the epilogue alone
+          float *red = lds_all + (long)KG * NST * ST_FL;
+          if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((i * NT + j) * 16 + r) * NTHR + tid] = acc[i][j][r];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (kg == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * NT + j) * 16 + r) * NTHR + tid];
+        }
         // ---- epilogue of the finished tile
         const bool to_ws = !SK && pf->splitk > 1;
         const int z = blockIdx.y;
@@ -736,10 +777,12 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
   } else {
     grid = dim3((unsigned)tiles_mat, (unsigned)(batch * a.splitk));
   }
-#define CLO_V3(AK, BK_, SKV, BMV, BNV, WM_, WN_, NSTV)                                                         \
+#define CLO_V3(AK, BK_, SKV, BMV, BNV, WM_, WN_, NSTV) CLO_V3K(AK, BK_, SKV, BMV, BNV, WM_, WN_, NSTV, 1)
+#define CLO_V3K(AK, BK_, SKV, BMV, BNV, WM_, WN_, NSTV, KGV)                                                   \
   {                                                                                                            \
-    auto kern = gemm_v3_kernel<AK, BK_, BMV, BNV, WM_, WN_, NSTV, SKV>;                                        \
-    const size_t smem = (size_t)NSTV * (BMV + BNV) * V3_BK * sizeof(float);                                    \
+    auto kern = gemm_v3_kernel<AK, BK_, BMV, BNV, WM_, WN_, NSTV, SKV, KGV>;                                   \
+    const size_t smem = (size_t)KGV * NSTV * (BMV + BNV) * V3_BK * sizeof(float) +                             \
+                        (KGV > 1 ? (size_t)BMV * BNV * sizeof(float) : 0);   /* + the k groups' hand-over area */ \
     static bool attr_done[64] = {};  /* per device: the attribute belongs to the device's copy of the kernel */ \
     bool &attr_set = attr_done[dev_ & 63];                                                                     \
     if (!attr_set) {                                                                                           \
@@ -749,7 +792,7 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
       if (rc_ != CLO_OK) return rc_;                                                                           \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), smem, stream, a, s);                                  \
+    hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64 * KGV), smem, stream, a, s);                            \
   }
 #define CLO_V3L(SKV, BMV, BNV, WM_, WN_, NSTV)                            \
   if (a_kc && b_kc) CLO_V3(true, true, SKV, BMV, BNV, WM_, WN_, NSTV)     \
@@ -760,13 +803,25 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
     if (sk) { CLO_V3L(true, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
     else { CLO_V3L(false, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
   } else if (tall == 2) {
+#ifndef CLO_GEMM_V3_KG
+#define CLO_GEMM_V3_KG 2
+#endif
+    // eight waves per small tile (two k groups) once the k loop is long enough to split
+    const long kspan = a.splitk > 1 ? a.k_per_split : a.K;
     if (sk) { CLO_V3L(true, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST) }
+    else if (CLO_GEMM_V3_KG == 2 && kspan >= 8 * V3_BK) {
+      if (a_kc && b_kc) CLO_V3K(true, true, false, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST, 2)
+      else if (a_kc) CLO_V3K(true, false, false, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST, 2)
+      else if (b_kc) CLO_V3K(false, true, false, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST, 2)
+      else CLO_V3K(false, false, false, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST, 2)
+    }
     else { CLO_V3L(false, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST) }
   } else {
     if (sk) { CLO_V3L(true, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST) }
     else { CLO_V3L(false, V3_BM, V3_BN, V3_WVM, V3_WVN, V3_NST) }
   }
 #undef CLO_V3L
+#undef CLO_V3K
 #undef CLO_V3
   CLO_CHECK_LAUNCH("gemm_v3_kernel");
   return CLO_OK;

@@ -248,3 +248,254 @@ extern "C" int clo_gram_tall_f32(float *C, long ldc, const float *X, long rows, 
   CLO_CHECK_LAUNCH("gram_reduce_kernel");
   return CLO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: the tall-skinny algebra of the randomised trace estimators (reference trace/meyer2020hutch.py:86-102,
+// trace/epperly2024xtrace.py:52-101) as HBM-streaming kernels.
+//
+//   clo_tall_gram_f64    out[n1][n2] = X^T Y  for X [m][n1], Y [m][n2] float32, n1, n2 <= 64, EXACT products and float64
+//                        accumulation (v_mfma_f64_16x16x4_f64: 24 x 24-bit products fit the 53-bit significand).  The
+//                        range basis of Hutch++ is built from Gram matrices of an [85 M, 32] block whose singular values
+//                        span many decades; a float32 Gram matrix resolves directions down to sigma / sigma_max ~ 3e-3
+//                        only (sqrt(eps)), this one down to the rounding noise of the float32 DATA (~1e-7), which is what
+//                        the reference's Householder QR of the same float32 block resolves.  Also the projections Q^T G.
+//   clo_tall_apply_f32   out = beta G + Q C  for Q [m][k], C [k][n] (k, n <= 64), G / out [m][n]: the rows are the M
+//                        dimension of v_mfma_f32_16x16x4 tiles, C lives in registers; one pass over Q, G and out
+//                        (Q = X T of the basis, G - Q (Q^T G) of the deflation).
+// Both read every operand exactly once with every lane of every CU streaming; bytes = 4 m (n1 + n2) resp. 4 m (k + 2 n).
+// ------------------------------------------------------------------------------------------------------------------
+namespace clo {
+
+using f64x4g = __attribute__((ext_vector_type(4))) double;
+
+constexpr int TG_THREADS = 256, TG_UNROLL = 8;
+
+struct TallGramArgs {
+  const float *X, *Y;
+  long ldx, ldy, m;
+  int n1, n2, sym;
+  double *slab;   // [grid][16 NI][16 NJ]
+};
+
+// NI x NJ tiles of 16 x 16; a wave's step = 4 consecutive rows (the K dimension of one MFMA): lane (c = lane % 16,
+// r = lane / 16) holds X[row r][column 16 ti + c] -- 64 contiguous bytes per row and tile.
+template <int NI, int NJ>
+__global__ __launch_bounds__(TG_THREADS) void tall_gram_kernel(const TallGramArgs p) {
+  __shared__ double S[4 * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, r = lane >> 4;
+  f64x4g acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f64x4g{0., 0., 0., 0.};
+  const long nsteps = cdiv(p.m, 4L);
+  const long stride = (long)gridDim.x * 4;
+  bool okx[NI], oky[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) okx[i] = 16 * i + c < p.n1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) oky[j] = 16 * j + c < p.n2;
+  for (long s0 = (long)blockIdx.x * 4 + wave; s0 < nsteps; s0 += stride * TG_UNROLL) {
+    float xa[TG_UNROLL][NI], yb[TG_UNROLL][NJ];
+#pragma unroll
+    for (int u = 0; u < TG_UNROLL; ++u) {   // every load of the group is issued before the first conversion
+      const long row = 4 * (s0 + u * stride) + r;
+      const bool okr = row < p.m;
+      const long rr = okr ? row : 0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const float v = p.X[rr * p.ldx + (okx[i] ? 16 * i + c : 0)];
+        xa[u][i] = (okr && okx[i]) ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (p.sym) { yb[u][j] = j < NI ? xa[u][j < NI ? j : 0] : 0.f; continue; }
+        const float v = p.Y[rr * p.ldy + (oky[j] ? 16 * j + c : 0)];
+        yb[u][j] = (okr && oky[j]) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TG_UNROLL; ++u) {
+      double a[NI], b[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = (double)xa[u][i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = (double)yb[u][j];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (p.sym && j < i) continue;   // (uniform: the reduce kernel mirrors)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // the four waves' tiles are summed through LDS in a fixed order; D layout of the f64 16x16x4 MFMA: row = (lane / 16) + 4 q,
+  // col = lane % 16 (one row per register and lane group -- NOT the 4 (lane / 16) + q of the f32 16x16x4 tile)
+  double *out = p.slab + (long)blockIdx.x * (16 * NI) * (16 * NJ);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (p.sym && j < i) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[wave * 256 + (r + 4 * q) * 16 + c] = acc[i][j][q];
+      __syncthreads();
+      {
+        const int e = tid, row = e >> 4, col = e & 15;
+        out[(long)(16 * i + row) * (16 * NJ) + 16 * j + col] = (S[e] + S[256 + e]) + (S[512 + e] + S[768 + e]);
+      }
+      __syncthreads();
+    }
+}
+
+// out[a][b] = sum over blocks (fixed order), mirrored for the symmetric form
+__global__ void tall_gram_reduce_kernel(double *__restrict__ out, long ldo, const double *__restrict__ slab, int nslab,
+                                        int n1, int n2, int P1, int P2, int sym) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n1 * n2) return;
+  const int a = e / n2, b = e - a * n2;
+  const bool upper = !sym || (a / 16) <= (b / 16);
+  const long src = upper ? (long)a * P2 + b : (long)b * P2 + a;
+  const long st = (long)P1 * P2;
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+  int k = 0;
+  for (; k + 3 < nslab; k += 4) {
+    s0 += slab[k * st + src]; s1 += slab[(k + 1) * st + src];
+    s2 += slab[(k + 2) * st + src]; s3 += slab[(k + 3) * st + src];
+  }
+  for (; k < nslab; ++k) s0 += slab[k * st + src];
+  out[(long)a * ldo + b] = (s0 + s1) + (s2 + s3);
+}
+
+static int tall_gram_grid(long m) {
+  return (int)std::max<long>(1, std::min<long>(cdiv(cdiv(m, 4L), 4L * TG_UNROLL), 2L * kNumCU));
+}
+
+struct TallApplyArgs {
+  float *out;
+  const float *G, *Q, *C;
+  long ldo, ldg, ldq, ldc, m;
+  int k, n;
+  float beta;
+};
+
+// KH = ceil(k / 16), NT = ceil(n / 16).  A tile = 16 rows: lane (i = lane % 16, g = lane / 16) loads float4
+// Q[row i][16 h + 4 g ..]; MFMA step (h, e) contracts over k = 16 h + 4 g + e on both operands.
+template <int KH, int NT>
+__global__ __launch_bounds__(256) void tall_apply_kernel(const TallApplyArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  float cb[KH][4][NT];
+#pragma unroll
+  for (int h = 0; h < KH; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int kk = 16 * h + 4 * g + e, col = 16 * t + i;
+        cb[h][e][t] = (kk < p.k && col < p.n) ? p.C[(long)kk * p.ldc + col] : 0.f;
+      }
+  const long ntiles = cdiv(p.m, 16L);
+  const long nw = (long)gridDim.x * 4;
+  const bool has_g = p.G != nullptr && p.beta != 0.f;
+  for (long t0 = (long)blockIdx.x * 4 + wave; t0 < ntiles; t0 += nw) {
+    const long r0 = t0 * 16;
+    const long rowq = min(r0 + i, p.m - 1);
+    float4 q4[KH];
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+      const int kk = 16 * h + 4 * g;
+      q4[h] = kk < p.k ? *reinterpret_cast<const float4 *>(p.Q + rowq * p.ldq + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4g acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long row = r0 + 4 * g + q;
+        const int col = 16 * t + i;
+        acc[t][q] = (has_g && row < p.m && col < p.n) ? p.beta * p.G[row * p.ldg + col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+#define CLO_TA_MM(E, EI)                                                                        \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                \
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[h].E, cb[h][EI][t], acc[t], 0, 0, 0);
+      CLO_TA_MM(x, 0) CLO_TA_MM(y, 1) CLO_TA_MM(z, 2) CLO_TA_MM(w, 3)
+#undef CLO_TA_MM
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long row = r0 + 4 * g + q;
+        const int col = 16 * t + i;
+        if (row < p.m && col < p.n) p.out[row * p.ldo + col] = acc[t][q];
+      }
+  }
+}
+
+}  // namespace clo
+
+extern "C" long clo_tall_gram_ws_bytes(long m, int n1, int n2) {
+  if (n1 < 1 || n2 < 1 || n1 > 64 || n2 > 64) return 0;
+  const long P1 = 16 * cdiv(n1, 16), P2 = 16 * cdiv(n2, 16);
+  return (long)tall_gram_grid(m) * P1 * P2 * (long)sizeof(double);
+}
+
+// out[n1][ldo] (float64) = X^T Y; Y == nullptr (or Y == X with n1 == n2, ldx == ldy): the symmetric Gram X^T X.
+extern "C" int clo_tall_gram_f64(double *out, long ldo, const float *X, long ldx, int n1, const float *Y, long ldy,
+                                 int n2, long m, void *ws, void *stream) {
+  CLO_REQUIRE(n1 >= 1 && n1 <= 64 && n2 >= 1 && n2 <= 64 && m >= 0, "clo_tall_gram_f64: needs 1 <= n1, n2 <= 64");
+  CLO_REQUIRE(out && X && ws && ldo >= n2 && ldx >= n1, "clo_tall_gram_f64: bad operand");
+  const bool sym = Y == nullptr || (Y == X && n1 == n2 && ldx == ldy);
+  if (!sym) CLO_REQUIRE(ldy >= n2, "clo_tall_gram_f64: ldy too small");
+  if (sym) CLO_REQUIRE(n1 == n2, "clo_tall_gram_f64: the symmetric form needs n1 == n2");
+  hipStream_t st = (hipStream_t)stream;
+  TallGramArgs a{};
+  a.X = X; a.Y = sym ? X : Y; a.ldx = ldx; a.ldy = sym ? ldx : ldy; a.m = m; a.n1 = n1; a.n2 = n2; a.sym = sym ? 1 : 0;
+  a.slab = static_cast<double *>(ws);
+  const int NI = (int)cdiv(n1, 16), NJ = (int)cdiv(n2, 16);
+  const int grid = tall_gram_grid(m);
+#define CLO_TG_CASE(I, J) \
+  if (NI == I && NJ == J) hipLaunchKernelGGL((tall_gram_kernel<I, J>), dim3(grid), dim3(TG_THREADS), 0, st, a);
+  CLO_TG_CASE(1, 1) CLO_TG_CASE(1, 2) CLO_TG_CASE(1, 3) CLO_TG_CASE(1, 4)
+  CLO_TG_CASE(2, 1) CLO_TG_CASE(2, 2) CLO_TG_CASE(2, 3) CLO_TG_CASE(2, 4)
+  CLO_TG_CASE(3, 1) CLO_TG_CASE(3, 2) CLO_TG_CASE(3, 3) CLO_TG_CASE(3, 4)
+  CLO_TG_CASE(4, 1) CLO_TG_CASE(4, 2) CLO_TG_CASE(4, 3) CLO_TG_CASE(4, 4)
+#undef CLO_TG_CASE
+  CLO_CHECK_LAUNCH("tall_gram_kernel");
+  hipLaunchKernelGGL(tall_gram_reduce_kernel, dim3((unsigned)cdiv(n1 * n2, 256)), dim3(256), 0, st, out, ldo,
+                     static_cast<const double *>(ws), grid, n1, n2, 16 * NI, 16 * NJ, a.sym);
+  CLO_CHECK_LAUNCH("tall_gram_reduce_kernel");
+  return CLO_OK;
+}
+
+// out[m][ldo] = beta G + Q C   (Q [m][ldq] with k columns, C [k][ldc] with n columns; G may be null or alias out)
+extern "C" int clo_tall_apply_f32(float *out, long ldo, const float *G, long ldg, float beta, const float *Q, long ldq,
+                                  const float *C, long ldc, long m, int k, int n, void *stream) {
+  CLO_REQUIRE(k >= 1 && k <= 64 && n >= 1 && n <= 64 && m >= 0, "clo_tall_apply_f32: needs 1 <= k, n <= 64");
+  CLO_REQUIRE(out && Q && C && ldo >= n && ldq >= k && ldc >= n && (!G || ldg >= n), "clo_tall_apply_f32: bad operand");
+  CLO_REQUIRE(k % 4 == 0 && ldq % 4 == 0 && aligned16(Q), "clo_tall_apply_f32: Q rows must be 16-byte aligned, k % 4 == 0");
+  if (m == 0) return CLO_OK;
+  hipStream_t st = (hipStream_t)stream;
+  TallApplyArgs a{};
+  a.out = out; a.G = G; a.Q = Q; a.C = C; a.ldo = ldo; a.ldg = ldg; a.ldq = ldq; a.ldc = ldc; a.m = m; a.k = k; a.n = n;
+  a.beta = beta;
+  const int KH = (int)cdiv(k, 16), NT = (int)cdiv(n, 16);
+  const int grid = (int)std::max<long>(1, std::min<long>(cdiv(cdiv(m, 16L), 4L), 8L * kNumCU));
+#define CLO_TA_CASE(H, T) \
+  if (KH == H && NT == T) hipLaunchKernelGGL((tall_apply_kernel<H, T>), dim3(grid), dim3(256), 0, st, a);
+  CLO_TA_CASE(1, 1) CLO_TA_CASE(1, 2) CLO_TA_CASE(1, 3) CLO_TA_CASE(1, 4)
+  CLO_TA_CASE(2, 1) CLO_TA_CASE(2, 2) CLO_TA_CASE(2, 3) CLO_TA_CASE(2, 4)
+  CLO_TA_CASE(3, 1) CLO_TA_CASE(3, 2) CLO_TA_CASE(3, 3) CLO_TA_CASE(3, 4)
+  CLO_TA_CASE(4, 1) CLO_TA_CASE(4, 2) CLO_TA_CASE(4, 3) CLO_TA_CASE(4, 4)
+#undef CLO_TA_CASE
+  CLO_CHECK_LAUNCH("tall_apply_kernel");
+  return CLO_OK;
+}

@@ -891,7 +891,12 @@ extern "C" int clo_cholesky_inverse_batched_f32(const float *const *A, const lon
 #define CLO_CHOL_PIPE_MIN 1536
 #endif
   static const int pipe_min = CLO_CHOL_PIPE_MIN;
-  if (pipe && np >= pipe_min && np > QNB)
+  // The pipeline serves the SINGLE large factor (n = 4608: 5.1 -> 4.0 ms).  Equal-size batches -- the groups of an
+  // operator-level inverse -- run the plain chain: their launches are already batch-wide, and the operator drives several
+  // groups side by side from worker threads (linalg_native.INVERSE_WORKERS); chain + 3 workers measured 10.3 - 11.5 ms for
+  // ResNet-18's 42 factors at 4 AND 16 hardware queues, first call included, against 13.4 - 15 ms with a pipeline per group
+  // (profiles/r06_cholesky_streams.txt).
+  if (pipe && batch == 1 && np >= pipe_min && np > QNB)
     rc = chol_pipe(c, c.G + c.gws, c.G + 2 * c.gws, c.G + 3 * c.gws);
   else
     rc = chol_rec(c, 0, np);

@@ -1232,7 +1232,11 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
     const float *__restrict__ W, const float *__restrict__ VW, const float *__restrict__ a_in,
     const float *__restrict__ da_in, float *__restrict__ part, int N, int d_in, int d_out,
     int k_per_block) {
-  constexpr int RG = 2, NP = 16 * NT;
+  // Round 6: a wave owns 16 features and runs THREE products per step -- z += W a, dz += W da, dz += V a -- with two
+  // A fragments (16 rows of W, the same 16 rows of V).  The round-2 form stacked [8 rows of W ; 8 rows of V] into one
+  // A tile and multiplied it with a AND da: four products, the fourth (V da) discarded -- a quarter of the MFMA time of
+  // the kernel that is MFMA-bound from 32 batch rows on (C2 layer 2: 25.6 us at 32 rows, 45.6 at 64).
+  constexpr int NP = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float s_b[];  // [(HAS_DA ? 2 : 1) * NP][k_per_block + 4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1241,22 +1245,19 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
   const int klen = min(d_in, kb0 + k_per_block) - kb0;  // multiple of 4
   const int ldb = k_per_block + 4;
 
-  const int j0 = (blockIdx.x * WV + wave) * RG * 8;
-  const float *pA[RG];
-#pragma unroll
-  for (int g = 0; g < RG; ++g) {
-    const int row = min(j0 + g * 8 + (idx & 7), d_out - 1);
-    // (no tangent weights: rows 8 .. 15 of the tile alias the W rows -- the same addresses inside one load instruction --
-    // and da_out is not written; the forward pass of the K-column products runs layers of <= 8 rows without slabs this way)
-    pA[g] = ((idx >= 8 && VW) ? VW : W) + (long)row * d_in + kb0 + s4;
-  }
+  const int j0 = (blockIdx.x * WV + wave) * 16;
+  const int row = min(j0 + idx, d_out - 1);
+  const bool has_v = VW != nullptr;
+  const float *pW = W + (long)row * d_in + kb0 + s4;
+  const float *pV = (has_v ? VW : W) + (long)row * d_in + kb0 + s4;   // (no tangent weights: valid dummy addresses)
   constexpr int U = 2;
-  struct Group { float4 av[U][RG]; };
+  struct Group { float4 w[U], v[U]; };
   auto load = [&](Group &gr, int st0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int g = 0; g < RG; ++g) gr.av[u][g] = CLO_LDW(pA[g] + (st0 + u) * 16);
+    for (int u = 0; u < U; ++u) {
+      gr.w[u] = CLO_LDW(pW + (st0 + u) * 16);
+      gr.v[u] = CLO_LDW(pV + (st0 + u) * 16);
+    }
   };
   const int nfull = klen >> 4, ngroups = nfull / U;
   Group ga, gb;
@@ -1275,36 +1276,32 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
   }
   __syncthreads();
 
-  f32x4 acc1[RG][NT], acc2[RG][NT];
+  f32x4 accz[NT], accd[NT], accv[NT];   // W a | W da | V a  (three independent chains: no back-to-back dependency)
 #pragma unroll
-  for (int g = 0; g < RG; ++g)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc1[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc2[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  for (int t = 0; t < NT; ++t) {
+    accz[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accd[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const float *pBa = s_b + idx * ldb + s4;
   const float *pBd = s_b + (NP + idx) * ldb + s4;
-  auto mma_step = [&](const float4 (&av)[RG], int st) {
+  auto mma_step = [&](const float4 &wv, const float4 &vv, int st) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float4 ba = ld4(pBa + t * 16 * ldb + st * 16);
       float4 bd = zero4();
       if (HAS_DA) bd = ld4(pBd + t * 16 * ldb + st * 16);
-      // component by component over the 2 RG (4 RG with da) independent accumulators: a dependent
-      // v_mfma_f32_16x16x4_f32 can issue after 40 cycles, an independent one after 32
-#define CLO_MID_MM(E)                                                                                  \
-  _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                     \
-    acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].E, ba.E, acc1[g][t], 0, 0, 0);              \
-    if (HAS_DA) acc2[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].E, bd.E, acc2[g][t], 0, 0, 0);  \
-  }
+#define CLO_MID_MM(E)                                                                              \
+  accz[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.E, ba.E, accz[t], 0, 0, 0);                    \
+  if (HAS_DA) accd[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.E, bd.E, accd[t], 0, 0, 0);        \
+  if (has_v) accv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.E, ba.E, accv[t], 0, 0, 0);
       CLO_MID_MM(x) CLO_MID_MM(y) CLO_MID_MM(z) CLO_MID_MM(w)
 #undef CLO_MID_MM
     }
   };
   auto mma = [&](const Group &gr, int st0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) mma_step(gr.av[u], st0 + u);
+    for (int u = 0; u < U; ++u) mma_step(gr.w[u], gr.v[u], st0 + u);
   };
   int step = 0;
   {
@@ -1320,36 +1317,23 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
   }
   for (; step * 16 < klen; ++step) {  // leftover full steps and the partial one (B is zero beyond klen)
     const bool ok = step * 16 + s4 < klen;
-    float4 av[RG];
-#pragma unroll
-    for (int g = 0; g < RG; ++g) av[g] = ld4(pA[g] + (ok ? step * 16 : 0));
-    mma_step(av, step);
+    const float4 wv = ld4(pW + (ok ? step * 16 : 0)), vv = ld4(pV + (ok ? step * 16 : 0));
+    mma_step(wv, vv, step);
   }
 
-  // D layout: row = (lane>>4)*4 + r (0..7: W rows, 8..15: V rows), col = lane&15 = batch row in the tile.
-  // z = acc1[rows 0..7], dz = acc1[rows 8..15] + acc2[rows 0..7]; lanes 0..31 hold four consecutive
-  // features each -> one float4 per (tile, quantity) into part[split][2][NP][d_out].
+  // D layout: row = (lane >> 4) * 4 + r = feature inside the wave's 16, col = lane & 15 = batch row in the tile: every
+  // lane holds four consecutive features -> one float4 per (tile, quantity) into part[split][2][NP][d_out].
   const int q = lane >> 4, col = lane & 15;
-#pragma unroll
-  for (int g = 0; g < RG; ++g)
+  const int j = j0 + q * 4;
+  if (j < d_out) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      float4 z4, d4;
-      float *pz = reinterpret_cast<float *>(&z4), *pd = reinterpret_cast<float *>(&d4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc1[g][t][r];
-        const float up = __shfl(v, (lane + 32) & 63, 64);
-        pz[r] = v;
-        pd[r] = up + (HAS_DA ? acc2[g][t][r] : 0.f);
-      }
-      const int j = j0 + g * 8 + q * 4;
-      if (q < 2 && j < d_out) {
-        float *dst = part + (((long)blockIdx.y * 2) * NP + t * 16 + col) * d_out + j;
-        st4(dst, z4);
-        st4(dst + (long)NP * d_out, d4);
-      }
+      float *dst = part + (((long)blockIdx.y * 2) * NP + t * 16 + col) * d_out + j;
+      st4(dst, make_float4(accz[t][0], accz[t][1], accz[t][2], accz[t][3]));
+      st4(dst + (long)NP * d_out, make_float4(accd[t][0] + accv[t][0], accd[t][1] + accv[t][1],
+                                                accd[t][2] + accv[t][2], accd[t][3] + accv[t][3]));
     }
+  }
 }
 
 // Forward + JVP of a layer of the 9 ... 64-row chain WITHOUT split-K slabs: fwd_mfma_first_kernel's scheme
@@ -3057,7 +3041,11 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     int wv = 4;
     long ksplit = 1, kpb = 32;
     double best = 1e300;
+#ifndef CLO_MLP_MID_WV
+#define CLO_MLP_MID_WV 0
+#endif
     for (int w : {4, 8}) {
+      if (CLO_MLP_MID_WV && w != CLO_MLP_MID_WV) continue;   // (A/B builds: force the waves per block)
       const long rb = cdiv(dout, w * 16);
       for (long ks = 1; ks <= KS_MAX; ++ks) {
         const long kp = cdiv(cdiv(di, ks), 32) * 32;

@@ -230,7 +230,15 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         tgt = self._native_targets(y, N, C)
         if tgt is None:
             return self._ef_host_gradients(idx, X, y, X_user, N, C, c)   # (class probabilities as targets: host route)
-        kind = {MSELoss: _hip.LOSS_EF_MSE, CrossEntropyLoss: _hip.LOSS_EF_CE}.get(type(self._loss_func), _hip.LOSS_EF_BCE)
+        # (isinstance, like the native gate `loss_kind_and_scale`: a user subclass of MSELoss / CrossEntropyLoss is that loss)
+        if isinstance(self._loss_func, MSELoss):
+            kind = _hip.LOSS_EF_MSE
+        elif isinstance(self._loss_func, CrossEntropyLoss):
+            kind = _hip.LOSS_EF_CE
+        elif isinstance(self._loss_func, BCEWithLogitsLoss):
+            kind = _hip.LOSS_EF_BCE
+        else:
+            return self._ef_host_gradients(idx, X, y, X_user, N, C, c)
         return kind, 1.0 / c, tgt.reshape(N, 1, -1)
 
     def _native_targets(self, y: Tensor, N: int, C: int) -> Tensor | None:
@@ -238,6 +246,16 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         itself when it already is --, class labels as ``[N]`` floats for CE; None if ``y`` is something else."""
         if isinstance(self._loss_func, CrossEntropyLoss):
             if y.dim() != 1 or y.dtype.is_floating_point or y.shape[0] != N:
+                return None
+            # labels equal to `ignore_index` (default -100) contribute NO gradient in torch; the kernels know no such
+            # rows (g = softmax - onehot): such batches take the host route.  Checked once per label tensor version.
+            key = (y.data_ptr(), tuple(y.shape), y._version)
+            seen = self.__dict__.setdefault("_ignored_label_checks", {})
+            if key not in seen:
+                if len(seen) > 64:
+                    seen.clear()
+                seen[key] = bool((y == self._loss_func.ignore_index).any())
+            if seen[key]:
                 return None
             return y.to(torch.float32)
         if y.numel() != N * C:

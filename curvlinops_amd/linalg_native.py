@@ -17,6 +17,8 @@ comparison routes of rounds 1-3 live in ``tools/`` (``tools/_rocsolver.py``, ``t
 
 from __future__ import annotations
 
+import os
+
 from contextlib import contextmanager
 from warnings import warn
 
@@ -217,7 +219,10 @@ _ACTIVE_BATCH: _InverseBatch | None = None
 # default number of worker streams of concurrent_inverses: ONE since round 4 -- every big factor's call is already a pipeline
 # over a helper stream of its own; in the bench process 1 / 2 / 4 workers take 11.8 - 12.1 / 14.1 - 15.0 / 14.2 ms for ResNet-18's
 # 42 factors (tools/run_inv_workers.sh; round 3, with four hardware queues, had two ahead)
-INVERSE_WORKERS = 1
+# Round 6: THREE again, with the equal-size groups on the plain batched chain (csrc/linalg.hip: the per-group pipeline and its
+# host-timed helper-stream probe are gone): 10.3 - 11.5 ms for ResNet-18's 42 factors at 4 and 16 hardware queues, first call
+# included (one worker 13.7 - 14.1, two 10.8 - 11.6; profiles/r06_cholesky_streams.txt).
+INVERSE_WORKERS = int(os.environ.get("CLO_INV_WORKERS", "3"))   # (the environment variable: A/B runs only)
 
 
 @contextmanager

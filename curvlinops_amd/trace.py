@@ -31,32 +31,83 @@ def frobenius_inner(X: Tensor, Y: Tensor) -> Tensor:
 _GRAM_MIN_ELEMS = 2**22  # above this, fp32 GPU blocks use the GEMM-rich Gram route
 
 
-def _gram_orthonormal_basis(X: Tensor, rel_tol: float = 1e-5) -> Tensor:
-    """Orthonormal basis of range(X) for a very tall fp32 GPU block from two Gram passes
-    (``Q = X V diag(lambda)^-1/2`` with ``X^T X = V diag(lambda) V^T`` solved in float64, then once
-    more on ``Q`` to push the loss of orthogonality from sqrt(eps) to eps).  Everything O(m) is a
-    SYRK / GEMM on the matrix pipe (Householder QR of an [85M, 32] block takes seconds in the
-    vendor solver, this takes tens of milliseconds).  Directions whose singular value is below
-    ``sqrt(rel_tol)`` of the largest are numerically indistinguishable from zero in a float32 Gram
-    matrix and are dropped, so the result has ``r <= n`` columns -- Hutch++ is exact for ANY
-    orthonormal ``Q`` (trace on range(Q) + Hutchinson on the complement), a smaller basis only
-    moves work to the stochastic part.  DEVIATION from the reference, which keeps all ``n`` columns of a Householder
-    ``Q`` (``meyer2020hutch.py:93``): for curvature spectra that decay by more than ``sqrt(rel_tol)`` = 3e-3 within the
-    sketch the dropped directions are estimated stochastically instead of exactly (same expectation, more variance)."""
+def _gram64(X: Tensor) -> Tensor:
+    """``X^T X`` in float64 (exact products, float64 accumulation) for a tall float32 GPU block."""
+    if _hip.tall_gram_supported(X):
+        return _hip.tall_gram(X)
+    gram = torch.empty(X.shape[1], X.shape[1], device=X.device, dtype=torch.float32)   # wider than 64 columns
+    _hip.syrk_accum(gram, X, alpha=1.0, beta=0.0)
+    return gram.double()
+
+
+def _times_small(X: Tensor, T: Tensor) -> Tensor:
+    """``X T`` for a tall block and a small square ``T`` (float64 in, rounded once)."""
+    T32 = T.float().contiguous()
+    if _hip.tall_apply_supported(X, T32):
+        return _hip.tall_apply(X, T32)
+    return _hip.gemm(X, T32)
+
+
+def project_out(Q: Tensor, G: Tensor) -> Tensor:
+    """``G - Q (Q^T G)`` (reference ``meyer2020hutch.py:97-99``): on float32 GPU blocks two streaming passes --
+    ``clo_tall_gram_f64`` for the coefficients (float64 accumulation over the 1e7 ... 1e8 rows), ``clo_tall_apply_f32`` for
+    the update -- instead of two library GEMMs with a [D, N] temporary between them."""
+    if _hip.tall_gram_supported(Q, G):
+        if Q.shape[1] % 4:   # (the update kernel reads Q in 16-byte pieces: zero columns change nothing)
+            Qp = Q.new_zeros(Q.shape[0], -(-Q.shape[1] // 4) * 4)
+            Qp[:, : Q.shape[1]] = Q
+            Q = Qp
+        C = _hip.tall_gram(Q, G).neg_().float().contiguous()
+        if _hip.tall_apply_supported(Q, C, G):
+            return _hip.tall_apply(Q, C, G, beta=1.0)
+    return G - Q @ (Q.T @ G)
+
+
+_RANK_TOL = 1e-13   # relative eigenvalue of the float64 Gram matrix below which a direction is EXACTLY dependent (zero
+#                     columns, repeated probes): its place in the basis is taken by a random direction (below)
+
+
+def _gram_orthonormal_basis(X: Tensor) -> Tensor:
+    """Orthonormal basis with ALL ``n`` columns (as the reference's Householder ``Q``, ``meyer2020hutch.py:89-93``) of a very
+    tall float32 GPU block from two Gram passes: ``Q = X V diag(lambda)^-1/2`` with ``X^T X = V diag(lambda) V^T``, then
+    once more on ``Q`` to push the loss of orthogonality to eps.  The Gram matrices are accumulated in FLOAT64 from exact
+    products (``clo_tall_gram_f64``), so directions are resolved down to the rounding noise of the float32 data
+    (sigma / sigma_max ~ 1e-7) -- a float32 Gram matrix loses everything below sqrt(eps) ~ 3e-3, and round 5 dropped
+    those directions from the basis, which made the estimator differ from the reference's on decaying spectra.
+    Directions that are exactly dependent (relative eigenvalue < 1e-13) are replaced by random directions orthogonalised
+    against the rest: Householder QR also returns n orthonormal columns for a rank-deficient block, and Hutch++ is exact
+    for any orthonormal basis that contains range(X).  Everything O(m) is a streaming kernel (Householder QR of an
+    [85M, 32] block takes seconds in the vendor solver, this takes tens of milliseconds)."""
     Q = X if X.is_contiguous() else X.contiguous()
-    for it in range(2):
-        n = Q.shape[1]
-        gram = torch.empty(n, n, device=Q.device, dtype=torch.float32)
-        _hip.syrk_accum(gram, Q, alpha=1.0, beta=0.0)
+    n = Q.shape[1]
+    missing = 0
+    for it in range(4):
+        gram = _gram64(Q)
         # (normalised: rocSOLVER's tridiagonal solver applies an absolute tolerance, linalg_native._unit_scale)
-        gscale = gram.abs().amax().clamp_min(torch.finfo(torch.float32).tiny).double()
-        lam, V = torch.linalg.eigh(gram.double() / gscale)
+        gscale = gram.abs().amax().clamp_min(torch.finfo(torch.float32).tiny)
+        lam, V = torch.linalg.eigh(gram / gscale)
         lam = lam * gscale
-        keep = lam > lam.max() * (rel_tol if it == 0 else 1e-12)
-        if not bool(keep.any()):
-            return torch.zeros(Q.shape[0], 1, device=Q.device, dtype=Q.dtype)
-        T = (V[:, keep] / lam[keep].sqrt()).float().contiguous()
-        Q = _hip.gemm(Q, T)
+        keep = lam > lam.max() * _RANK_TOL
+        kept = int(keep.sum())
+        if kept == 0:
+            Q, missing = Q[:, :0], n
+            break
+        if kept < Q.shape[1]:
+            missing = n - kept
+        Q = _times_small(Q, V[:, keep] / lam[keep].sqrt())
+        # the rounding of X T in float32 leaves |Q^T Q - I| ~ eps32 * cond(input): a pass whose INPUT was already
+        # well conditioned has produced an orthonormal block (two passes for any sketch that is not nearly singular,
+        # a third for spectra that reach the float32 noise floor)
+        if it >= 1 and float(lam[keep].min() / lam.max()) > 0.25:
+            break
+    if missing:
+        # complete the basis: random directions, twice projected off range(Q), orthonormalised among themselves
+        R = torch.randn(X.shape[0], missing, device=X.device, dtype=X.dtype)
+        if Q.shape[1]:
+            for _ in range(2):
+                R = project_out(Q, R)
+        R = _gram_orthonormal_basis(R.contiguous())
+        Q = torch.cat([Q, R], dim=1) if Q.shape[1] else R
     return Q
 
 
@@ -65,22 +116,21 @@ def _gram_qr(X: Tensor) -> tuple[Tensor, Tensor] | None:
     XTrace / XDiag need (``trace/epperly2024xtrace.py:52-60`` call ``torch.linalg.qr``, which is rocSOLVER on this
     platform).  Their leave-one-out vectors ``s_i`` are the directions of ``T^-T e_i``: the complement of
     ``range(X[:, != i])`` inside ``range(Q)`` whatever the shape of ``T``, so ``T`` need not be triangular.  Two Gram
-    passes on the matrix pipe (``clo_syrk_accum_f32`` / ``clo_gemm_f32``), the two small eigenproblems in float64;
+    passes (``clo_tall_gram_f64``: float64 accumulation; ``clo_tall_apply_f32``), the two small eigenproblems in float64;
     ``T = (L2^1/2 V2^T)(L1^1/2 V1^T)`` is inverted in closed form.  None if ``X`` is numerically rank-deficient (the
     caller then takes the float64 route)."""
     Q = X if X.is_contiguous() else X.contiguous()
     n = Q.shape[1]
     Tinv = torch.eye(n, device=X.device, dtype=torch.float64)
     for it in range(2):
-        gram = torch.empty(n, n, device=Q.device, dtype=torch.float32)
-        _hip.syrk_accum(gram, Q, alpha=1.0, beta=0.0)
-        gscale = gram.abs().amax().clamp_min(torch.finfo(torch.float32).tiny).double()
-        lam, V = torch.linalg.eigh(gram.double() / gscale)
+        gram = _gram64(Q)
+        gscale = gram.abs().amax().clamp_min(torch.finfo(torch.float32).tiny)
+        lam, V = torch.linalg.eigh(gram / gscale)
         lam = lam * gscale
-        if not bool((lam > lam.max() * (1e-5 if it == 0 else 1e-12)).all()):
+        if not bool((lam > lam.max() * (1e-10 if it == 0 else 1e-12)).all()):
             return None
         step = V / lam.sqrt()                      # X_it = X_{it+1} (L^1/2 V^T)  =>  X_{it+1} = X_it (V L^-1/2)
-        Q = _hip.gemm(Q, step.float().contiguous())
+        Q = _times_small(Q, step)
         Tinv = Tinv @ step
     return Q, Tinv.T.to(X.dtype)
 
@@ -161,8 +211,8 @@ def hutchpp_trace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribut
     Q = orthonormal_basis(A @ S)
     tr_range = frobenius_inner(Q, A @ Q)
     G = random_matrix(dim, N, distribution, dev, dt) if probes is None else probes[1]
-    AG = A @ (G - Q @ (Q.T @ G))
-    AG = AG - Q @ (Q.T @ AG)
+    AG = A @ project_out(Q, G)
+    AG = project_out(Q, AG)
     return tr_range + frobenius_inner(G, AG) / N
 
 

@@ -140,6 +140,18 @@ int clo_syrk_accum_f32(float *C, long ldc, const float *X, long rows, int d, lon
 int clo_im2col_f32(const float *x, float *out, int B, int C, int H, int W, int KH, int KW,
                    int SH, int SW, int PH, int PW, int DH, int DW, int OH, int OW, void *stream);
 
+/* All small covariance products of one factor build in ONE launch (round 6; computers/kfac_hooks.py:335-393, one einsum per
+ * layer and backpropagated vector): C_p = beta_p C_p + alpha_p [X_p | 1]^T [X_p | 1] for p < P <= clo_syrk_grouped_max_problems().
+ * Every (problem, 64 x 64 upper tile, row chunk) is a work item of one grid; split-K partials are summed in-kernel by the last
+ * arriver of a tile in chunk order (deterministic).  The C_p must be distinct matrices.  Pointer / size arrays are HOST arrays.
+ * Workspace from clo_syrk_grouped_ws: `slab_floats` floats (uninitialised) and `counters` unsigned that must be ZERO on entry
+ * (they are zero again on exit). */
+int clo_syrk_grouped_max_problems(void);
+int clo_syrk_grouped_ws(int P, const long *rows, const int *d, const int *ones_col, long *slab_floats, long *counters);
+int clo_syrk_grouped_f32(int P, float *const *C, const long *ldc, const float *const *X, const long *rows, const int *d,
+                         const long *ldx, const int *ones_col, const float *alpha, const float *beta, float *slab,
+                         unsigned *counters, void *stream);
+
 /* The two steps above in one: C = beta C + alpha [P | 1]^T [P | 1] with P = im2col(x) generated inside
  * the tile loader of the symmetric MFMA GEMM -- the [B*OH*OW][C*KH*KW] patch matrix is never written
  * (kfac_utils.py:78-121 + kfac_hooks.py:355-393; 604 MB for ResNet-18 layer1 at B = 4096).  Any patch
@@ -170,6 +182,19 @@ int clo_gram_tall_supported(long rows, int d, int ones_col);
 long clo_gram_tall_ws_floats(long rows, int d, int ones_col);
 int clo_gram_tall_f32(float *C, long ldc, const float *X, long rows, int d, long ldx, int ones_col,
                       float alpha, float beta, float *ws, void *stream);
+
+/* Tall-skinny algebra of the randomised trace estimators (trace/meyer2020hutch.py:86-102: the QR of the [D, N] sketch and
+ * the projections Q (Q^T G); trace/epperly2024xtrace.py:52-101), one streaming pass per call:
+ *   clo_tall_gram_f64   out[n1][ldo] (FLOAT64) = X^T Y for float32 X [m][ldx] (n1 columns), Y [m][ldy] (n2 columns),
+ *                       n1, n2 <= 64; exact products, float64 accumulation (f64 MFMA).  Y == NULL: the symmetric Gram
+ *                       X^T X.  ws: clo_tall_gram_ws_bytes(m, n1, n2) bytes.
+ *   clo_tall_apply_f32  out[m][ldo] = beta G + Q C with Q [m][ldq] (k columns, k % 4 == 0, 16-byte aligned rows),
+ *                       C [k][ldc] (n columns), k, n <= 64; G may be NULL (beta ignored) or alias out. */
+long clo_tall_gram_ws_bytes(long m, int n1, int n2);
+int clo_tall_gram_f64(double *out, long ldo, const float *X, long ldx, int n1, const float *Y, long ldy, int n2,
+                      long m, void *ws, void *stream);
+int clo_tall_apply_f32(float *out, long ldo, const float *G, long ldg, float beta, const float *Q, long ldq,
+                       const float *C, long ldc, long m, int k, int n, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Damped Cholesky inverse of a Kronecker factor (kronecker.py:328-373): the blocked algorithm

@@ -294,7 +294,7 @@ def main():
     import curvlinops
 
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["mlp", "columns", "jacobian", "ggn_diagonal", "linops", "kfac", "trace", "kfoc", "nets", "kfac_mc"]
+    which = sys.argv[1:] or ["mlp", "columns", "jacobian", "ggn_diagonal", "linops", "kfac", "trace", "trace_decay", "kfoc", "nets", "kfac_mc"]
     if "mlp" in which:
         gen_mlp(curvlinops)
     if "columns" in which:
@@ -313,6 +313,10 @@ def main():
         from make_golden_kfac import gen_trace
 
         gen_trace(curvlinops, OUT)
+    if "trace_decay" in which:
+        from make_golden_kfac import gen_trace_decay
+
+        gen_trace_decay(curvlinops, OUT)
     if "kfoc" in which:
         from make_golden_kfac import gen_kfoc
 

@@ -188,6 +188,47 @@ def gen_trace(curvlinops, OUT):
     print("trace.npz:", len(out), "arrays")
 
 
+def gen_trace_decay(curvlinops, OUT):
+    """Hutch++ / XTrace with injected probes on an operator whose spectrum DECAYS over six decades inside the sketch
+    (``A = U diag(lam) U^T``, 40 eigenvalues 1 ... 1e-6 in 512 dimensions, 32 probe columns per block): the regime in
+    which a range basis that drops small directions differs from the reference's Householder ``Q`` (all n columns,
+    ``meyer2020hutch.py:89-93``).  Stored: the factors of ``A`` (not the 512 x 512 matrix), the probes, the estimates."""
+    import curvlinops.trace.epperly2024xtrace as XT
+    import curvlinops.trace.meyer2020hutch as M
+    from curvlinops.examples import TensorLinearOperator
+
+    gen = torch.Generator().manual_seed(4242)
+    D, R, N = 512, 40, 32
+    U = torch.linalg.qr(torch.randn(D, R, generator=gen))[0]
+    lam = 10.0 ** (-6.0 * torch.arange(R, dtype=torch.float64) / (R - 1))
+    A = (U * lam) @ U.T
+    out = {"U": U.numpy(), "lam": lam.numpy(), "trace_exact": lam.sum().numpy()}
+    for dist in ("rademacher", "normal"):
+        pool = (torch.randint(0, 2, (D, 2 * N), generator=gen).double() * 2 - 1) if dist == "rademacher" \
+            else torch.randn(D, 2 * N, generator=gen)
+        state = {"i": 0}
+
+        def replay(dim, distribution, device, dtype, pool=pool, state=state):
+            v = pool[:, state["i"]].clone()
+            state["i"] += 1
+            return v
+
+        orig_m, orig_x = M.random_vector, XT.random_vector
+        M.random_vector = replay
+        XT.random_vector = replay
+        try:
+            op = TensorLinearOperator(A)
+            state["i"] = 0
+            out[f"{dist}/hutchpp"] = M.hutchpp_trace(op, 3 * N, dist).numpy()
+            state["i"] = 0
+            out[f"{dist}/xtrace"] = XT.xtrace(op, 2 * N, dist).numpy()
+        finally:
+            M.random_vector, XT.random_vector = orig_m, orig_x
+        out[f"{dist}/pool"] = pool.numpy()
+    np.savez_compressed(OUT / "trace_decay.npz", **{f"t/{k}": v for k, v in out.items()})
+    print("trace_decay.npz:", len(out), "arrays")
+
+
 KFOC_CASES = [
     # name, model factory, input shape, C, loss, reduction, batch
     ("mlp_mse_mean", lambda: mlp([7, 9, 6, 3]), (7,), 3, "mse", "mean", 12),

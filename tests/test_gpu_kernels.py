@@ -1075,6 +1075,7 @@ def test_im2col_syrk_fused_matches_materialised(B, C_, H, W, k, s, p, d, ones):
     (4, 3, 7, 5, (3, 2), (1, 2), (2, 0), (2, 1), True),       # anisotropic kernel / stride / padding / dilation
     (3, 6, 5, 5, (5, 5), (1, 1), (2, 2), (1, 1), False),      # 5x5 kernel
     (2, 7, 3, 3, (3, 3), (1, 1), (0, 0), (1, 1), True),       # no padding: a single output position
+    (2, 32, 8, 8, (9, 9), (1, 1), (4, 4), (1, 1), True),      # large kernel: tap table + pair list take 26 KB of the LDS
 ])
 def test_pixel_gram_fold_matches_patch_product(B, C_, H, W, k, s, p, d, ones):
     """Input covariance of a convolution from the pixel Gram ``X^T X`` (``X = x`` as ``[B, C H W]``) folded over the taps
@@ -1101,6 +1102,52 @@ def test_pixel_gram_fold_matches_patch_product(B, C_, H, W, k, s, p, d, ones):
     _hip.pixel_gram_accum(Cf, x, k, s, p, d, alpha=0.25, beta=1.0, ones_col=ones)
     assert torch.equal(Cf, Cf.T)
     assert rel_err(Cf.cpu(), (0.75 * ref).cpu().numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_syrk_grouped_matches_float64_and_is_repeatable():
+    """`clo_syrk_grouped_f32`: many covariance products of different shapes in one launch (the gradient covariances of a
+    factor build) against float64 -- one and many row chunks per tile, ragged widths, ones columns, strided rows, beta
+    accumulation, zero rows; results are bitwise symmetric and bitwise repeatable (slabs are summed in chunk order)."""
+    from curvlinops_amd import _hip
+
+    g = torch.Generator().manual_seed(21)
+    shapes = [(131072, 64, False), (32768, 64, False), (8192, 128, False), (2048, 256, False), (512, 512, False),
+              (512, 10, False), (4096, 65, True), (300, 129, False), (70000, 17, True), (0, 8, False), (1, 3, True),
+              (2048, 200, False)]
+    Xs, ones = [], []
+    for rows, d, o in shapes:
+        X = torch.randn(rows, d + 3, generator=g).cuda()[:, :d] if d % 2 else torch.randn(rows, d, generator=g).cuda()
+        Xs.append(X), ones.append(o)
+    dds = [d + (1 if o else 0) for _, d, o in shapes]
+    alphas = [0.5 + 0.1 * i for i in range(len(shapes))]
+
+    def ref(X, o, alpha):
+        Xd = X.double()
+        if o:
+            Xd = torch.cat([Xd, Xd.new_ones(Xd.shape[0], 1)], dim=1)
+        return alpha * (Xd.T @ Xd)
+
+    C1 = [torch.full((dd, dd), float("nan"), device="cuda") for dd in dds]
+    _hip.syrk_grouped(C1, Xs, alphas, [0.0] * len(shapes), ones)
+    C2 = [torch.full((dd, dd), float("nan"), device="cuda") for dd in dds]
+    _hip.syrk_grouped(C2, Xs, alphas, [0.0] * len(shapes), ones)
+    for c1, c2, X, o, a in zip(C1, C2, Xs, ones, alphas):
+        want = ref(X, o, a)
+        assert torch.equal(c1, c1.T) and torch.equal(c1, c2)
+        scale = float(want.abs().max()) or 1.0
+        assert float((c1.double() - want).abs().max()) / scale < 2e-5
+    _hip.syrk_grouped(C1, Xs, [0.25 * a for a in alphas], [1.0] * len(shapes), ones)   # accumulate
+    for c1, X, o, a in zip(C1, Xs, ones, alphas):
+        want = 1.25 * ref(X, o, a)
+        scale = float(want.abs().max()) or 1.0
+        assert torch.equal(c1, c1.T) and float((c1.double() - want).abs().max()) / scale < 2e-5
+    # more problems than one launch takes
+    many = [torch.randn(100 + 7 * i, 5 + i, generator=g).cuda() for i in range(55)]
+    Cm = [torch.empty(x.shape[1], x.shape[1], device="cuda") for x in many]
+    _hip.syrk_grouped(Cm, many, [1.0] * 55, [0.0] * 55)
+    for c, x in zip(Cm, many):
+        assert rel_err(c, (x.double().T @ x.double()).cpu().numpy()) < 2e-5
 
 
 @pytest.mark.gpu

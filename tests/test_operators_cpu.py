@@ -256,6 +256,20 @@ def test_kfac_mc_converges_to_type2():
 
 
 # ----------------------------------------------------------------------------- trace estimators
+def test_trace_estimators_decaying_spectrum_cpu():
+    """The host path (float64, Householder QR) against the reference's values on the decaying-spectrum operator
+    (`oracle/make_golden_kfac.py::gen_trace_decay`)."""
+    rec = load_golden("trace_decay")["t"]
+    U, lam = torch.from_numpy(rec["U"]), torch.from_numpy(rec["lam"])
+    op = C.KroneckerProductLinearOperator((U * lam) @ U.T)
+    N = 32
+    for dist in ("rademacher", "normal"):
+        pool = torch.from_numpy(rec[f"{dist}/pool"])
+        got = C.hutchpp_trace(op, 3 * N, dist, probes=(pool[:, :N].contiguous(), pool[:, N:2 * N].contiguous()))
+        assert rel_err(got, rec[f"{dist}/hutchpp"]) < 1e-9
+        assert rel_err(C.xtrace(op, 2 * N, dist, probes=pool[:, :N].contiguous()), rec[f"{dist}/xtrace"]) < 1e-9
+
+
 def test_trace_estimators_with_injected_probes():
     rec = load_golden("trace")["t"]
     A = t64(rec["A"])

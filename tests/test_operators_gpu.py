@@ -431,6 +431,65 @@ def test_trace_estimators_gpu(dev):
     assert abs(ests.mean() - A.trace()) / A.trace() < 0.05
 
 
+def test_trace_estimators_decaying_spectrum_gpu(dev):
+    """Hutch++ / XTrace on an operator whose spectrum decays over six decades INSIDE the sketch (golden from the reference,
+    `oracle/make_golden_kfac.py::gen_trace_decay`, injected probes): the fp32 device path keeps all n columns of the range
+    basis (`trace._gram_orthonormal_basis`: float64-accumulated Gram passes) like the reference's Householder Q
+    (`meyer2020hutch.py:89-93`), so the estimates agree to 1e-4 -- the round-5 basis, which dropped directions below 3e-3
+    of the largest, treated ~1e-2 of this trace stochastically.  Also the pieces: an orthonormal n-column basis for a
+    rank-deficient block, and `project_out` against float64."""
+    from curvlinops_amd import trace as T
+
+    rec = load_golden("trace_decay")["t"]
+    U, lam = torch.from_numpy(rec["U"]), torch.from_numpy(rec["lam"])
+    A = ((U * lam) @ U.T).float().to(dev)
+    op = C.KroneckerProductLinearOperator(A)
+    N = 32
+    for dist in ("rademacher", "normal"):
+        pool = g32(rec[f"{dist}/pool"], dev)
+        got = C.hutchpp_trace(op, 3 * N, dist, probes=(pool[:, :N].contiguous(), pool[:, N:2 * N].contiguous()))
+        assert rel_err(got, rec[f"{dist}/hutchpp"]) < 1e-4
+        assert rel_err(C.xtrace(op, 2 * N, dist, probes=pool[:, :N].contiguous()), rec[f"{dist}/xtrace"]) < 1e-4
+    # the basis itself: n orthonormal columns spanning the block, also when the block is rank-deficient
+    g = torch.Generator().manual_seed(3)
+    Y = torch.randn(70000, 24, generator=g).to(dev) * torch.logspace(0, -6, 24, device=dev)
+    Y[:, 5] = 0.0                       # an exactly dependent column
+    Y[:, 9] = Y[:, 2]
+    Q = T.orthonormal_basis(Y)
+    assert Q.shape == Y.shape
+    assert float((Q.double().T @ Q.double() - torch.eye(24, device=dev, dtype=torch.float64)).abs().max()) < 1e-5
+    resid = Y.double() - Q.double() @ (Q.double().T @ Y.double())
+    assert float(resid.abs().max() / Y.abs().max()) < 1e-6      # range(Y) is inside range(Q)
+    G = torch.randn(70000, 12, generator=g).to(dev)
+    want = G.double() - Q.double() @ (Q.double().T @ G.double())
+    assert rel_err(T.project_out(Q, G), want.cpu().numpy()) < 1e-5
+
+
+def test_tall_gram_and_apply_kernels(dev):
+    """`clo_tall_gram_f64` (exact products, float64 accumulation) and `clo_tall_apply_f32` against float64, ragged row and
+    column counts, strided views; the Gram is accurate far below float32 resolution."""
+    from curvlinops_amd import _hip
+
+    g = torch.Generator().manual_seed(8)
+    for m, n1, n2 in ((1, 4, 4), (37, 5, 3), (1000, 16, 16), (4099, 32, 20), (250001, 32, 32), (33333, 64, 48), (5000, 17, 64)):
+        X = torch.randn(m, n1 + 3, generator=g).to(dev)[:, :n1]
+        Y = torch.randn(m, n2, generator=g).to(dev)
+        ref = (X.double().T @ Y.double()).cpu()
+        got = _hip.tall_gram(X, Y).cpu()
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-13, (m, n1, n2)
+        sym = _hip.tall_gram(X).cpu()
+        refs = (X.double().T @ X.double()).cpu()
+        assert float((sym - refs).abs().max() / refs.abs().max()) < 1e-13 and torch.equal(sym, sym.T)
+    for m, k, n in ((1, 4, 4), (37, 8, 3), (1000, 16, 16), (4099, 32, 20), (250001, 32, 32), (33333, 64, 48), (777, 12, 64)):
+        Qm = torch.randn(m, k + 4, generator=g).to(dev)[:, :k]
+        Cm = torch.randn(k, n, generator=g).to(dev)
+        Gm = torch.randn(m, n, generator=g).to(dev)
+        assert _hip.tall_apply_supported(Qm, Cm, Gm)
+        ref = (0.5 * Gm.double() + Qm.double() @ Cm.double()).cpu().numpy()
+        assert rel_err(_hip.tall_apply(Qm, Cm, Gm, beta=0.5), ref) < 2e-6
+        assert rel_err(_hip.tall_apply(Qm, Cm), (Qm.double() @ Cm.double()).cpu().numpy()) < 2e-6
+
+
 def test_repeated_products_stress(dev):
     """The split-K / row-range slabs and the activation workspace are reused by every product:
     300 back-to-back products with changing vectors, each checked through linearity against

@@ -3,7 +3,7 @@ set -e
 cd /root/repo/curvlinops_amd/csrc
 name=$1; shift
 mkdir -p /tmp/obj_$name ../lib/variants
-for f in gemm gemm_v3 mlp mlp_mega stream_ops linalg conv gram sytrd eigh eigh_driver kron; do
+for f in gemm gemm_v3 mlp mlp_mega stream_ops linalg conv gram syrk_grouped sytrd eigh eigh_driver kron; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $f.hip -o /tmp/obj_$name/$f.o ) &
 done
 wait
