@@ -1093,6 +1093,17 @@ class HipKFACComputer(EmpiricalRiskMixin):
             g = g.flatten(0, 1)
         corr = compute_loss_correction(batch_size, self._num_per_example_loss_terms,
                                        self._loss_func.reduction, self._N_data)
+        if self._group_this_grad(g, hyper):
+            # kept until the backward pass is over: ONE launch then forms every layer's G_l (`_flush_grouped_grads`).
+            # Formatted HERE, on the stream autograd produced the gradient on -- the flush runs on that stream too (a
+            # copy made under `_factor_stream` would race with it).
+            g2d = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
+            g2d = g2d.reshape(-1, g2d.shape[-1])
+            key = tuple(group.values())
+            if any(k == key and st is store for st, k, _, _ in self._grouped_g):
+                self._flush_grouped_grads()   # a second vector for the same factor: the first group goes first
+            self._grouped_g.append((store, key, g2d if g2d.stride(-1) == 1 else g2d.contiguous(), corr))
+            return
         if getattr(self, "_inline_grads", False) and is_native_tensor(g):
             # coarse fork (graph capture): the (small) gradient covariances run inline on the main stream
             # (`_CAPTURE_G_CHUNK` = 0), or those of `_CAPTURE_G_CHUNK` consecutive layers share ONE fork of the factor
@@ -1109,18 +1120,18 @@ class HipKFACComputer(EmpiricalRiskMixin):
         with _factor_stream(g):
             self._grad_job(g, corr, group, hyper, store)
 
+    _GROUP_MIN_D = 48   # narrower factors (LeNet's 6 / 16 channels, a 10-class head) stay on the tall-skinny Gram kernel:
+    #                     a 64-wide MFMA tile would be mostly padding (LeNet-5 type-2 build 2.8 -> 9.5 ms when they were grouped)
+
+    def _group_this_grad(self, g: Tensor, hyper) -> bool:
+        if not (_GROUP_G and getattr(self, "_grouped_g", None) is not None and is_native_tensor(g)):
+            return False
+        d_out = g.shape[1] if hyper else g.shape[-1]   # Conv2d: (rows, C, H, W); Linear: (rows, [S,] d)
+        return d_out >= self._GROUP_MIN_D and _hip.has("clo_syrk_grouped_f32")
+
     def _grad_job(self, g: Tensor, corr: float, group, hyper, store) -> None:
         g = grad_to_weight_sharing_format(g, self._kfac_approx, hyper)
-        g2d = g.reshape(-1, g.shape[-1])
-        key = tuple(group.values())
-        pending = getattr(self, "_grouped_g", None)
-        if _GROUP_G and pending is not None and is_native_tensor(g2d) and _hip.has("clo_syrk_grouped_f32"):
-            # kept until the backward pass is over: ONE launch then forms every layer's G_l (`_flush_grouped_grads`)
-            if any(k == key and st is store for st, k, _, _ in pending):
-                self._flush_grouped_grads()   # a second vector for the same factor: the first group goes first
-            pending.append((store, key, g2d if g2d.stride(-1) == 1 else g2d.contiguous(), corr))
-            return
-        _gram_accumulate(store, key, g2d, corr, ones_col=False)
+        _gram_accumulate(store, tuple(group.values()), g.reshape(-1, g.shape[-1]), corr, ones_col=False)
 
     def _flush_grouped_grads(self) -> None:
         """``G_l (+)= corr g_l^T g_l`` for every pending layer in one grouped launch (on the stream the gradients were

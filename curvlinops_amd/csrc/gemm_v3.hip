@@ -803,10 +803,14 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
     if (sk) { CLO_V3L(true, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
     else { CLO_V3L(false, V3T_BM, V3T_BN, V3T_WVM, V3T_WVN, V3T_NST) }
   } else if (tall == 2) {
+    // Eight waves per small tile (two k groups, KG = 2 above) once the k loop is long enough to split: BUILT AND MEASURED in
+    // round 6, NOT the default -- it loses 10 - 25 % on every shape it applies to (profiles/r06_gemm_kgroup_ab.txt:
+    // 128 x 2304 x 2304 34.9 vs 28.6 us, 384 x 1152 x 1152 32.9 vs 26.2, 256 x 2304 x 2304 49.6 vs 44.1).  The four-wave
+    // tile needs 64 KB of LDS, so TWO of them share a CU already: eight waves per CU from two independent workgroups, whose
+    // barriers do not couple, beat eight waves of one workgroup (144 KB: one per CU) that all meet at every k tile.
 #ifndef CLO_GEMM_V3_KG
-#define CLO_GEMM_V3_KG 2
+#define CLO_GEMM_V3_KG 1
 #endif
-    // eight waves per small tile (two k groups) once the k loop is long enough to split
     const long kspan = a.splitk > 1 ? a.k_per_split : a.K;
     if (sk) { CLO_V3L(true, V3S_BM, V3S_BN, V3S_WVM, V3S_WVN, V3S_NST) }
     else if (CLO_GEMM_V3_KG == 2 && kspan >= 8 * V3_BK) {

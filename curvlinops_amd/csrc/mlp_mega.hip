@@ -199,6 +199,21 @@ __device__ __forceinline__ void mg_wait(unsigned *cnt, unsigned target, const Mg
 }
 
 __device__ __forceinline__ float4 mg_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// the weight stream (W1, V1, W2, V2: every byte is read by exactly ONE workgroup, once): CLO_MG_NTW = 1 marks these loads
+// nontemporal (the guide's "nt-weights" row: issued -> landed -18 % on an LDS-DMA weight stream).  A/B of round 6:
+// profiles/r06_c2_mega_nt_weights.txt.
+#ifndef CLO_MG_NTW
+#define CLO_MG_NTW 0
+#endif
+__device__ __forceinline__ float4 mg_ldw(const float *p) {
+#if CLO_MG_NTW
+  typedef float __attribute__((ext_vector_type(4))) v4;
+  const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4 *>(p);
+#endif
+}
 __device__ __forceinline__ void mg_st4nt(float *p, const float4 &v) {
   typedef float __attribute__((ext_vector_type(4))) v4;
   __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4 *>(p));
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     for (int s = 0; s < MG_P1S; ++s) {
       const bool ok = s * 16 + s4 < klen;
 #pragma unroll
-      for (int g = 0; g < 2; ++g) a1v[s][g] = mg_ld4(pA1[g] + (ok ? s * 16 : 0));
+      for (int g = 0; g < 2; ++g) a1v[s][g] = mg_ldw(pA1[g] + (ok ? s * 16 : 0));
     }
   }
   // layer-2 tile: fragments [W rows ; V rows] of this wave's feature groups, step-major issue order; only
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
 #pragma unroll
     for (int s = 0; s < MG_PRE; ++s) {
 #pragma unroll
-      for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + min(s, ns - 1) * 16);
+      for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ldw(pA2[g] + min(s, ns - 1) * 16);
     }
   }
 #pragma unroll
@@ -440,7 +455,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     for (int s = MG_PRE; s < MG_HOLD; ++s) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (MG_PACE - 1)) : "memory");
 #pragma unroll
-      for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ld4(pA2[g] + min(s, ns - 1) * 16);
+      for (int g = 0; g < MG_MAXG; ++g) tv[s][g] = mg_ldw(pA2[g] + min(s, ns - 1) * 16);
     }
     MG_STAMP(3);
   } else {
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(MG_T) void mlp_mega_kernel(const MegaArgs p) {
     for (int s = 0; s < MG_MAXS; ++s) {
       if (s + MG_HOLD < MG_MAXS) {   // the steps held back during the seam are requested here, MG_HOLD steps ahead of their use
 #pragma unroll
-        for (int g = 0; g < MG_MAXG; ++g) tv[s + MG_HOLD][g] = mg_ld4(pA2[g] + min(s + MG_HOLD, ns - 1) * 16);
+        for (int g = 0; g < MG_MAXG; ++g) tv[s + MG_HOLD][g] = mg_ldw(pA2[g] + min(s + MG_HOLD, ns - 1) * 16);
       }
       if (s < ns) {
         const float4 bv = mg_ld4(pBs + s * 16);

@@ -63,11 +63,17 @@ def project_out(Q: Tensor, G: Tensor) -> Tensor:
     return G - Q @ (Q.T @ G)
 
 
-_RANK_TOL = 1e-13   # relative eigenvalue of the float64 Gram matrix below which a direction is EXACTLY dependent (zero
-#                     columns, repeated probes): its place in the basis is taken by a random direction (below)
+# Relative eigenvalue of the float64 Gram matrix below which a direction of the block is numerically DEPENDENT: sigma below
+# 3e-6 of the largest singular value is inside the rounding noise of a float32 block that came out of an operator product
+# (~1e-6 sigma_max after the O(D) float32 accumulations) -- exact rank deficiency (repeated / zero columns, a rank-8 operator
+# sketched with 32 probes) sits at 1e-14.  Such directions are not range information: `orthonormal_basis` replaces them by
+# random directions (n columns, as Householder QR returns), Hutch++ leaves them out -- for a symmetric operator whose range
+# the kept columns contain they contribute exactly zero to both terms of the estimator, and with a decaying spectrum what
+# they could carry is < 1e-11 of the trace -- so the third operator product runs on r <= n columns.
+_RANK_TOL = 1e-11
 
 
-def _gram_orthonormal_basis(X: Tensor) -> Tensor:
+def _gram_orthonormal_basis(X: Tensor, complete: bool = True) -> Tensor:
     """Orthonormal basis with ALL ``n`` columns (as the reference's Householder ``Q``, ``meyer2020hutch.py:89-93``) of a very
     tall float32 GPU block from two Gram passes: ``Q = X V diag(lambda)^-1/2`` with ``X^T X = V diag(lambda) V^T``, then
     once more on ``Q`` to push the loss of orthogonality to eps.  The Gram matrices are accumulated in FLOAT64 from exact
@@ -100,7 +106,9 @@ def _gram_orthonormal_basis(X: Tensor) -> Tensor:
         # a third for spectra that reach the float32 noise floor)
         if it >= 1 and float(lam[keep].min() / lam.max()) > 0.25:
             break
-    if missing:
+    if not complete and Q.shape[1] == 0:
+        return torch.zeros(X.shape[0], 1, device=X.device, dtype=X.dtype)   # (a zero block: one zero column, no range)
+    if missing and complete:
         # complete the basis: random directions, twice projected off range(Q), orthonormalised among themselves
         R = torch.randn(X.shape[0], missing, device=X.device, dtype=X.dtype)
         if Q.shape[1]:
@@ -135,14 +143,14 @@ def _gram_qr(X: Tensor) -> tuple[Tensor, Tensor] | None:
     return Q, Tinv.T.to(X.dtype)
 
 
-def orthonormal_basis(X: Tensor) -> Tensor:
+def orthonormal_basis(X: Tensor, complete: bool = True) -> Tensor:
     """``Q`` of the reduced QR factorisation of a tall ``[m, n]`` matrix (``meyer2020hutch.py:93``).
     Above ``2^30`` elements the factorisation is done as TSQR -- Householder QR of row chunks, QR of
     the stacked triangular factors, one small GEMM per chunk -- which is as stable as the direct
     call, works for rank-deficient inputs, and keeps every library call within 32-bit indexing."""
     m, n = X.shape
     if is_native_tensor(X) and m >= 2 * n:   # fp32 on the GPU: always the Gram route on the own GEMM engine
-        return _gram_orthonormal_basis(X)
+        return _gram_orthonormal_basis(X, complete)
     if m * n <= _QR_MAX_ELEMS or m <= 2 * n:
         return torch.linalg.qr(X)[0]
     rows = max(2 * n, _QR_MAX_ELEMS // n)
@@ -208,7 +216,7 @@ def hutchpp_trace(A: Tensor | PyTorchLinearOperator, num_matvecs: int, distribut
     N = num_matvecs // 3
     dev, dt = A.device, A.dtype
     S = random_matrix(dim, N, distribution, dev, dt) if probes is None else probes[0]
-    Q = orthonormal_basis(A @ S)
+    Q = orthonormal_basis(A @ S, complete=False)   # (numerically dependent directions left out: see `_RANK_TOL`)
     tr_range = frobenius_inner(Q, A @ Q)
     G = random_matrix(dim, N, distribution, dev, dt) if probes is None else probes[1]
     AG = A @ project_out(Q, G)
