@@ -40,12 +40,10 @@ import os
 import sys
 import time
 
-# The multi-stream legs (six eigensolver workers, the pipelined Cholesky inverses, the factor stream of the KFAC build) run
-# on more HIP streams than the runtime's default of 4 hardware queues; streams that share a queue serialise, and WHICH
-# ones share one depends on creation order (tools/run_hwq.sh: eigh 119-121 / 130-136 / 107-108 ms and inverses 13.9 /
-# 12.4 / 12.6 ms at 4 / 8 / 16 queues).  One queue per stream takes the lottery out; the runtime reads this at
-# initialisation, so it is set before torch touches the device.  The headline matvec is single-stream and unaffected.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Round 6: the bench no longer sets GPU_MAX_HW_QUEUES (rounds 3-5 ran with 16): every figure is what a drop-in user of the
+# package gets with the runtime's default of 4 hardware queues.  What 16 queues change (profiles/r06_kfac_capture_rule.txt):
+# the twelve-stream eigensolver leg 101 -> 78 ms, the captured KFAC build 4.25 -> 5.06 ms (the package then captures a
+# one-branch graph, computers._CAPTURE_BRANCHES), the 42 Cholesky inverses 10.9 vs 11.2 ms, the headline matvec nothing.
 
 import numpy as np
 import torch
@@ -382,14 +380,17 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
     def build():
         return C.KFACLinearOperator(model, nn.CrossEntropyLoss(), params, [(X, y)], **kw)
 
-    K = build()  # warm-up
+    K = build()  # warm-up (first-seen shape: eager)
+    K = build()  # (the configuration comes back: captured)
     best = float("inf")
+    build_times = []
     for _ in range(repeats):
         sync()
         t0 = time.perf_counter()
         K = build()
         sync()
-        best = min(best, time.perf_counter() - t0)
+        build_times.append(time.perf_counter() - t0)
+        best = min(best, build_times[-1])
     if world > 1:
         t = torch.tensor([best], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -459,6 +460,8 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
     out = {
         "metric": "KFAC factor build ms/batch (ResNet-18, C4)",
         "ms_per_batch": 1e3 * best,
+        "ms_per_batch_median_min_max": [1e3 * sorted(build_times)[len(build_times) // 2], 1e3 * min(build_times),
+                                        1e3 * max(build_times)],
         "rows_per_gpu": rows,
         "global_batch": rows * world,
         "n_gpus": world,
@@ -466,16 +469,20 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
         "config": "ResNet-18 (torchvision topology, 10 classes, eval), 3x32x32, CE mean, fisher mc x1, joint W+b, "
                   "Linear/Conv2d parameters only" + (", sharded build + ONE all-reduce of the flat factor buffer"
                                                      if world > 1 else ""),
-        "protocol": f"min of {repeats} after 1 warm-up, device (and ranks) synchronised around each build",
+        "protocol": f"min of {repeats} after 2 warm-up builds, device (and ranks) synchronised around each build",
         "route": {"captured_graphs": len(captured_graphs), "split": [g.split for g in captured_graphs],
                   "branches": _computers._CAPTURE_BRANCHES, "graph_replays": _computers._CAPTURE_REPLAYS},
         **({"parts": parts} if parts else {}),
         "factor_gflop_per_gpu": flops / 1e9,
         "factor_buffer_MB": 4.0 * factor_floats / 1e6,
-        "roofline": {"bound": "mfma", "achieved": flops / best / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": flops / best / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                     "note": "factor SYRK flops (full figure, symmetry not discounted) over the WHOLE build time, "
-                             "which also contains the autograd forward/backward pass (host framework)"},
+        # (filled below at N = 1: the factor KERNELS' own figure first -- executed flops over their rocprofv3 time --, then
+        # SURVEY 8d's full algorithmic figure over the whole build, autograd included)
+        "roofline": {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "whole_build_survey_figure": {
+                         "achieved": flops / best / 1e12, "frac": flops / best / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "note": "SURVEY 8d's factor SYRK flops (patch products, full d x d, symmetry not discounted: NOT "
+                                 "what the pixel-Gram route executes) over the WHOLE build time, which also contains the "
+                                 "autograd forward / backward pass (host framework)"}},
     }
     if world == 1:
         def fwdbwd():
@@ -504,14 +511,15 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
                         d, k = pix[m], rows
                     nt = max(1, -(-d // 128))
                     executed += 2.0 * k * d * d * (nt + 1) / (2.0 * nt)
+            out["roofline"]["achieved"] = executed / clo_us / 1e6
+            out["roofline"]["frac"] = executed / clo_us / 1e6 / MFMA_F32_PEAK_TFLOPS
             out["roofline"]["clo_kernels"] = {
                 "kernel_ms_rocprof": clo_us / 1e3, "executed_gflop": executed / 1e9,
                 "achieved_tflops_executed": executed / clo_us / 1e6,
                 "frac_of_f32_mfma_peak": executed / clo_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
                 "source": "profiles/" + os.path.basename(latest_profile("kfac_resnet18_build_kernels.txt") or "")
                           + " (rocprofv3 --kernel-trace of one warm build = one replay of the captured hipGraph: pixel-Gram "
-                          "SYRKs + fold, SYRK / Gram, split-K reduce kernels; the input covariances run on the graph's "
-                          "second branch beside the backward pass)"}
+                          "SYRKs + fold, the grouped gradient-covariance launch, SYRK / Gram kernels)"}
         v = torch.rand(K.shape[1], device=device)
         K @ v
         torch.cuda.synchronize()
@@ -532,6 +540,7 @@ def kfac_leg(device, world: int, rank: int, rows: int = 512, repeats: int = 5) -
             times.append(1e3 * (time.perf_counter() - t0))
         out["cholesky_inverse_ms_second_call"] = times[0]
         out["cholesky_inverse_ms_mean_of_4"] = sum(times) / len(times)
+        out["cholesky_inverse_ms_median_min_max"] = [sorted(times)[len(times) // 2], min(times), max(times)]
         del Kinv
     return out
 
@@ -698,7 +707,7 @@ def main() -> None:
             "workload": "C2: GGNLinearOperator @ v, MLP 1024-2688-2688-10 (D=10010122), MSE mean, "
                         f"{args.batch} rows per GPU, K=1",
             "rows_per_gpu": args.batch,
-            "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+            "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default; not set by the bench)"),
             "parallelism": (f"dp{world} (data shards + RCCL all-reduce of the [D] result"
                             + (", overlapped with the next product)" if overlap else ")")) if world > 1 else "single GPU",
         },

@@ -456,11 +456,21 @@ _CAPTURE_STREAM = None  # index of the package-wide worker stream to capture on 
 _CAPTURE_AFTER = 1     # eager runs of a configuration before it is captured
 _CAPTURE_MAX = 4       # captured configurations kept (each holds its activations' memory pool + static factor buffers)
 _CAPTURE_NOTES_MAX = 256   # bookkeeping entries (eager-run counters, "capture failed" marks) kept beside the graphs
-# Branches of a captured build: a FIXED rule, nothing is timed (round 6; the round-5 code replayed candidates against the
-# wall clock).  1: one in-order graph -- its replay time does not depend on which hardware queues the runtime hands a
-# graph's internal streams.  2: the input covariances on a second branch beside the backward pass (15 % faster when the
-# two branches land on independent dispatch pipes, up to 2 x slower when they do not: DESIGN 3.3 "queue pipes").
-_CAPTURE_BRANCHES = int(os.environ.get("CLO_KFAC_CAPTURE_BRANCHES", "1"))
+# Branches of a captured build: a FIXED rule from the process configuration, nothing is timed (round 6; the round-5 code
+# replayed candidate graphs against the wall clock).  2: the input covariances on a second branch beside the backward
+# pass; 1: one in-order graph.  Measured on ResNet-18 / 512 rows inside the bench process (profiles/r06_kfac_capture_rule.txt):
+# with the runtime's default of 4 hardware queues the two-branch graph replays in 4.2 - 4.5 ms (one branch 5.0), with 16
+# queues in 6.5 - 6.8 ms (one branch 5.1: the branches' internal streams then sit on queues that share a dispatch pipe
+# with the origin stream's).  So: two branches up to 4 queues, one beyond.
+def _default_capture_branches() -> int:
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        queues = 4
+    return 2 if queues <= 4 else 1
+
+
+_CAPTURE_BRANCHES = int(os.environ.get("CLO_KFAC_CAPTURE_BRANCHES", "0")) or _default_capture_branches()
 # Gradient covariances of a mini-batch in ONE grouped launch at the end of the backward pass (clo_syrk_grouped_f32) instead of
 # one split-K product + reduction per layer: ResNet-18's 21 of them are 6 GFLOP that took 0.9 ms as 61 small launches.
 _GROUP_G = os.environ.get("CLO_KFAC_GROUP_G", "1") == "1"

@@ -20,7 +20,7 @@ constexpr int SG_MAXP = 40;       // problems per launch (the descriptor table t
 constexpr int SG_T = 64;          // tile edge
 constexpr int SG_ROWS = 32;       // rows per LDS slice
 constexpr int SG_LD = 2 * SG_T + 4;
-constexpr int SG_MAX_CHUNKS = 64;
+constexpr int SG_MAX_CHUNKS = 256;   // (a 131072-row stem factor: 228 chunks of 576 rows -- the longest item sets the launch's critical path)
 
 struct SgProb {
   const float *X;
@@ -37,7 +37,7 @@ struct SgArgs {
 };
 
 __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
-  __shared__ __attribute__((aligned(16))) float S[SG_ROWS * SG_LD];
+  __shared__ __attribute__((aligned(16))) float S2[2 * SG_ROWS * SG_LD];   // two slices: one barrier per slice
   __shared__ unsigned s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
       }
     }
   };
-  auto stash = [&](const float4 (&v)[4]) {
+  auto stash = [&](const float4 (&v)[4], float *S) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (u < nq) *reinterpret_cast<float4 *>(&S[lrow[u] * SG_LD + lcol[u]]) = v[u];
@@ -97,24 +97,28 @@ __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
 
   const int wi = wave >> 1, wj = wave & 1;
   const int li = lane & 31, lk = lane >> 5;
-  const float *pa = S + lk * SG_LD + wi * 32 + li;
-  const float *pb = S + lk * SG_LD + (diag ? 0 : SG_T) + wj * 32 + li;
+  const int oa = lk * SG_LD + wi * 32 + li, ob = lk * SG_LD + (diag ? 0 : SG_T) + wj * 32 + li;
   f32x16s acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  float4 cur[4], nxt[4];
-  fetch(r_begin, cur);
-  for (long r0 = r_begin; r0 < r_end; r0 += SG_ROWS) {
-    __syncthreads();            // everybody is done reading the previous slice
-    stash(cur);
-    if (r0 + SG_ROWS < r_end) fetch(r0 + SG_ROWS, nxt);
-    __syncthreads();
+  // three slices in flight in registers (the loads of slice s + 3 are issued before the MFMAs of slice s), the LDS image
+  // double-buffered: slice s + 1 is written while other waves may still read slice s - 1's neighbour -- never the same buffer
+  float4 r0v[4], r1v[4], r2v[4];
+  fetch(r_begin, r0v);
+  fetch(r_begin + SG_ROWS, r1v);        // (rows past r_end come back as zeros)
+  fetch(r_begin + 2 * SG_ROWS, r2v);
+  int buf = 0;
+  for (long r0 = r_begin; r0 < r_end; r0 += SG_ROWS, buf ^= 1) {
+    float *S = S2 + buf * (SG_ROWS * SG_LD);
+    stash(r0v, S);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { r0v[u] = r1v[u]; r1v[u] = r2v[u]; }
+    fetch(r0 + 3 * SG_ROWS, r2v);
+    __syncthreads();   // slice visible; everybody has finished the MFMAs of the slice before (which read the OTHER buffer)
 #pragma unroll
     for (int s = 0; s < SG_ROWS / 2; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s * SG_LD], pb[2 * s * SG_LD], acc, 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S[oa + 2 * s * SG_LD], S[ob + 2 * s * SG_LD], acc, 0, 0, 0);
   }
 
   // D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -125,13 +129,12 @@ __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
       const int il = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
       const int gi = bi * SG_T + il, gj = bj * SG_T + jl;
       if (gi < dd && gj < dd) {
+        // ONE value for the entry and its mirror image (C is symmetric on entry by contract: the mirrored entry's own old
+        // value would be the same number, but a second expression could be contracted into a different fma)
         float *c = pr.C + (long)gi * pr.ldc + gj;
         const float v = pr.alpha * acc[r] + (pr.beta != 0.f ? pr.beta * *c : 0.f);
         *c = v;
-        if (!diag) {
-          float *ct = pr.C + (long)gj * pr.ldc + gi;
-          *ct = pr.alpha * acc[r] + (pr.beta != 0.f ? pr.beta * *ct : 0.f);
-        }
+        if (!diag) pr.C[(long)gj * pr.ldc + gi] = v;
       }
     }
     return;
@@ -172,11 +175,9 @@ __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
       const int gi = bi * SG_T + il, gj = bj * SG_T + j0 + k;
       if (gi < dd && gj < dd) {
         float *c = pr.C + (long)gi * pr.ldc + gj;
-        *c = pr.alpha * sv[k] + (pr.beta != 0.f ? pr.beta * *c : 0.f);
-        if (!diag) {
-          float *ct = pr.C + (long)gj * pr.ldc + gi;
-          *ct = pr.alpha * sv[k] + (pr.beta != 0.f ? pr.beta * *ct : 0.f);
-        }
+        const float v = pr.alpha * sv[k] + (pr.beta != 0.f ? pr.beta * *c : 0.f);
+        *c = v;
+        if (!diag) pr.C[(long)gj * pr.ldc + gi] = v;
       }
     }
   }

