@@ -12,6 +12,8 @@
 // staged through LDS in 32-row slices (register double buffer), 16-byte loads where the rows allow it.
 #include "clo_common.h"
 
+#include <type_traits>
+
 namespace clo {
 
 using f32x16s = __attribute__((ext_vector_type(16))) float;
@@ -20,7 +22,13 @@ constexpr int SG_MAXP = 40;       // problems per launch (the descriptor table t
 constexpr int SG_T = 64;          // tile edge
 constexpr int SG_ROWS = 32;       // rows per LDS slice
 constexpr int SG_LD = 2 * SG_T + 4;
-constexpr int SG_MAX_CHUNKS = 256;   // (a 131072-row stem factor: 228 chunks of 576 rows -- the longest item sets the launch's critical path)
+#ifndef CLO_SG_MAX_CHUNKS
+#define CLO_SG_MAX_CHUNKS 64
+#endif
+#ifndef CLO_SG_PIPE
+#define CLO_SG_PIPE 0
+#endif
+constexpr int SG_MAX_CHUNKS = CLO_SG_MAX_CHUNKS;   // chunks per tile, at most (a 131072-row stem factor: 64 chunks of 2048 rows)
 
 struct SgProb {
   const float *X;
@@ -37,7 +45,10 @@ struct SgArgs {
 };
 
 __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
-  __shared__ __attribute__((aligned(16))) float S2[2 * SG_ROWS * SG_LD];   // two slices: one barrier per slice
+  // CLO_SG_PIPE = 1: two LDS slices (one barrier per slice) and three slices in flight in registers -- measured SLOWER than
+  // the plain form (ResNet-18's 20 gradient covariances: 284 vs 188 us, gpurun_out/r6_run7): 34 KB of LDS per workgroup
+  // halve the workgroups per CU, and it is the number of resident workgroups that hides this kernel's load latency
+  __shared__ __attribute__((aligned(16))) float S2[(CLO_SG_PIPE ? 2 : 1) * SG_ROWS * SG_LD];
   __shared__ unsigned s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,7 +68,6 @@ __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
   const long r_begin = (long)chunk * pr.chunk, r_end = min(pr.rows, r_begin + pr.chunk);
 
   // ---- loader: slice = 32 rows x (64 columns of block bi | 64 columns of block bj); 4 quads (16 B) per thread
-  const int nq = diag ? 2 : 4;
   int lrow[4], lcol[4], gcol[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -69,30 +79,39 @@ __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
     lcol[u] = qd * 4;                                            // column inside the slice (0 .. 127)
     gcol[u] = (qd < 16 ? bi * SG_T : bj * SG_T - SG_T) + qd * 4;   // column of [X | 1]
   }
-  auto fetch = [&](long r0, float4 (&v)[4]) {
+  // Loads are UNCONDITIONAL (clamped address + select): a predicated load makes hipcc branch and wait for vmcnt(0) right
+  // behind it, which serialises the four round trips of a slice (the first version of this kernel spent 6 us per slice that
+  // way).  `fast` (uniform per problem): 16-byte loads, every quad either fully inside the d columns or fully outside.
+  const bool fast = pr.vec && (d & 3) == 0;
+  const long rlast = max(r_end - 1, r_begin);
+  auto fetch = [&](auto FAST, auto DIAG, long r0, float4 (&v)[4]) {
+    constexpr int NQ = decltype(DIAG)::value ? 2 : 4;   // a diagonal tile loads one 64-column block only
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u >= nq) continue;
+    for (int u = 0; u < NQ; ++u) {
       const long r = r0 + lrow[u];
       const int c = gcol[u];
-      if (r < r_end && c < dd) {
-        const float *src = pr.X + r * pr.ldx + c;
-        if (pr.vec && c + 3 < d) {
-          v[u] = *reinterpret_cast<const float4 *>(src);
-        } else {
-          float t[4];
+      const bool rok = r < r_end;
+      const float *row = pr.X + min(r, rlast) * pr.ldx;
+      if constexpr (decltype(FAST)::value) {
+        const float4 t = *reinterpret_cast<const float4 *>(row + min(c, d - 4));
+        const bool in = rok && c < d;
+        const float one = (rok && c == d && pr.ones) ? 1.f : 0.f;
+        v[u] = make_float4(in ? t.x : one, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
+      } else {
+        float t[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = c + e < d ? src[e] : (c + e == d && pr.ones ? 1.f : 0.f);
-          v[u] = make_float4(t[0], t[1], t[2], t[3]);
+        for (int e = 0; e < 4; ++e) {
+          const float x = d > 0 ? row[min(c + e, d - 1)] : 0.f;
+          t[e] = !rok ? 0.f : (c + e < d ? x : (c + e == d && pr.ones ? 1.f : 0.f));
         }
+        v[u] = make_float4(t[0], t[1], t[2], t[3]);
       }
     }
   };
-  auto stash = [&](const float4 (&v)[4], float *S) {
+  auto stash = [&](auto DIAG, const float4 (&v)[4], float *S) {
+    constexpr int NQ = decltype(DIAG)::value ? 2 : 4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (u < nq) *reinterpret_cast<float4 *>(&S[lrow[u] * SG_LD + lcol[u]]) = v[u];
+    for (int u = 0; u < NQ; ++u) *reinterpret_cast<float4 *>(&S[lrow[u] * SG_LD + lcol[u]]) = v[u];
   };
 
   const int wi = wave >> 1, wj = wave & 1;
@@ -102,23 +121,49 @@ __global__ __launch_bounds__(256) void syrk_grouped_kernel(const SgArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  auto k_loop = [&](auto FAST, auto DIAG) {
+#if !CLO_SG_PIPE
+  float4 cur[4], nxt[4];
+  if (r_begin < r_end) fetch(FAST, DIAG, r_begin, cur);
+  for (long r0 = r_begin; r0 < r_end; r0 += SG_ROWS) {
+    float *S = S2;
+    __syncthreads();            // everybody is done reading the previous slice
+    stash(DIAG, cur, S);
+    fetch(FAST, DIAG, r0 + SG_ROWS, nxt);   // (unconditional: rows past r_end are masked, addresses clamped)
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SG_ROWS / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S[oa + 2 * s * SG_LD], S[ob + 2 * s * SG_LD], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < (decltype(DIAG)::value ? 2 : 4); ++u) cur[u] = nxt[u];
+  }
+#else
   // three slices in flight in registers (the loads of slice s + 3 are issued before the MFMAs of slice s), the LDS image
   // double-buffered: slice s + 1 is written while other waves may still read slice s - 1's neighbour -- never the same buffer
   float4 r0v[4], r1v[4], r2v[4];
-  fetch(r_begin, r0v);
-  fetch(r_begin + SG_ROWS, r1v);        // (rows past r_end come back as zeros)
-  fetch(r_begin + 2 * SG_ROWS, r2v);
+  if (r_begin < r_end) {
+    fetch(FAST, DIAG, r_begin, r0v);
+    fetch(FAST, DIAG, r_begin + SG_ROWS, r1v);        // (rows past r_end come back as zeros)
+    fetch(FAST, DIAG, r_begin + 2 * SG_ROWS, r2v);
+  }
   int buf = 0;
   for (long r0 = r_begin; r0 < r_end; r0 += SG_ROWS, buf ^= 1) {
     float *S = S2 + buf * (SG_ROWS * SG_LD);
-    stash(r0v, S);
+    stash(DIAG, r0v, S);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { r0v[u] = r1v[u]; r1v[u] = r2v[u]; }
-    fetch(r0 + 3 * SG_ROWS, r2v);
+    for (int u = 0; u < (decltype(DIAG)::value ? 2 : 4); ++u) { r0v[u] = r1v[u]; r1v[u] = r2v[u]; }
+    fetch(FAST, DIAG, r0 + 3 * SG_ROWS, r2v);
     __syncthreads();   // slice visible; everybody has finished the MFMAs of the slice before (which read the OTHER buffer)
 #pragma unroll
     for (int s = 0; s < SG_ROWS / 2; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S[oa + 2 * s * SG_LD], S[ob + 2 * s * SG_LD], acc, 0, 0, 0);
+  }
+#endif
+  };
+  if (fast) {
+    if (diag) k_loop(std::true_type{}, std::true_type{}); else k_loop(std::true_type{}, std::false_type{});
+  } else {
+    if (diag) k_loop(std::false_type{}, std::true_type{}); else k_loop(std::false_type{}, std::false_type{});
   }
 
   // D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -195,7 +240,10 @@ static void sg_plan(int P, const long *rows, const int *d, const int *ones, SgPl
     tile_rows += (double)pl.T[p] * (pl.T[p] + 1) / 2 * (double)rows[p];
   }
   // ~4 work items per compute unit; at least 256 rows each; at most SG_MAX_CHUNKS chunks per tile
-  long common = (long)(tile_rows / (4.0 * kNumCU));
+#ifndef CLO_SG_ITEMS_PER_CU
+#define CLO_SG_ITEMS_PER_CU 4
+#endif
+  long common = (long)(tile_rows / ((double)CLO_SG_ITEMS_PER_CU * kNumCU));
   common = std::max<long>(256, cdiv(common, SG_ROWS) * SG_ROWS);
   pl.nitems = 0;
   pl.ntiles = 0;

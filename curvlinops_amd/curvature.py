@@ -278,21 +278,21 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
 
     @staticmethod
     def _native_cost(n: int) -> float:
-        """Relative time of one native product over ``n`` rows (measured on C2,
-        profiles/r02_c2_batch_sweep.txt: 8 rows 52 us on the streaming kernels; 9-16 rows 62 us, 17-32 rows
-        87 us, 33-48 rows 117 us and 49-64 rows 137 us on their MFMA variants; beyond that the GEMM path,
-        ~180 us at 65 rows plus ~0.8 us per row)."""
+        """Relative time of one native product over ``n`` rows, re-fitted in round 6 on C2
+        (profiles/r06_c2_batch_sweep.txt: 8 rows 42 us on the persistent kernel; 9-16 rows 58-60 us, 17-32 rows 74-83 us,
+        33-48 rows 106-114 us and 49-64 rows 127 us on the MFMA chain; beyond that the GEMM path, 181 us at 65 rows,
+        196 at 128, 308 at 256, 515 at 512: ~3.9 + n / 54 in units of the 8-row product)."""
         if n <= 8:
             return 1.0
         if n <= 16:
-            return 1.19
+            return 1.42
         if n <= 32:
-            return 1.66
+            return 1.97
         if n <= 48:
-            return 2.23
+            return 2.70
         if n <= 64:
-            return 2.62
-        return 2.2 + n / 65.0
+            return 3.03
+        return 3.1 + n / 54.0
 
     def _merge_native_batches(self, entries: list[tuple]) -> list[tuple]:
         """``entries``: ``(X, kind, scale, aux, norm)`` per mini-batch.  The curvature is a sum over

@@ -51,8 +51,29 @@ def _worker(rank: int, world: int, port: int, ret):
         full = C.GGNLinearOperator(model, loss, params, data, check_deterministic=False)
         local = C.GGNLinearOperator(model, loss, params, mine, num_data=N, check_deterministic=False)
         assert local.uses_native_kernels
-        if rel(AllReducedLinearOperator(local) @ v, full @ v) > 1e-4:
+        red = AllReducedLinearOperator(local)
+        if rel(red @ v, full @ v) > 1e-4:
             failed.append("ggn")
+        # overlapped form: back-to-back products, each collective started asynchronously; a product queued behind a
+        # collective that is still running takes the launch chain, one behind a completed collective the single-GPU route
+        want1 = full @ v[:, 0].contiguous()
+        routes = set()
+        pending = []
+        for _ in range(4):
+            Y, work = red.matmul_async(v[:, 0].contiguous())
+            routes.add(red.async_route)
+            pending.append((Y, work))
+        for Y, work in pending:
+            work.wait()
+            if rel(Y, want1) > 1e-4:
+                failed.append("ggn matmul_async")
+        torch.cuda.synchronize()
+        Y, work = red.matmul_async(v[:, 0].contiguous())    # every earlier collective has completed
+        work.wait()
+        if red.async_route != "persistent" or rel(Y, want1) > 1e-4:
+            failed.append(f"ggn matmul_async after completion: route {red.async_route}")
+        if not routes <= {"chain", "persistent"}:
+            failed.append(f"routes {routes}")
         for cls in (C.KFACLinearOperator, C.EKFACLinearOperator):
             kw = dict(fisher_type="type-2", check_deterministic=False, separate_weight_and_bias=False)
             K1 = cls(model, loss, params, data, **kw)

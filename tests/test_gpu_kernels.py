@@ -1147,7 +1147,7 @@ def test_syrk_grouped_matches_float64_and_is_repeatable():
     Cm = [torch.empty(x.shape[1], x.shape[1], device="cuda") for x in many]
     _hip.syrk_grouped(Cm, many, [1.0] * 55, [0.0] * 55)
     for c, x in zip(Cm, many):
-        assert rel_err(c, (x.double().T @ x.double()).cpu().numpy()) < 2e-5
+        assert rel_err(c.cpu(), (x.double().T @ x.double()).cpu().numpy()) < 2e-5
 
 
 @pytest.mark.gpu
