@@ -460,3 +460,37 @@ def test_live_semantics_on_the_torch_path_cpu():
         assert torch.allclose(op @ v, fresh @ v, rtol=1e-12, atol=1e-14)
         op.refresh()
         assert not op.uses_native_kernels
+
+
+# ----------------------------------------------------------------------------- captured-build bookkeeping (host logic)
+def test_capture_key_contains_the_loss_settings_and_bookkeeping_is_bounded():
+    """Two computers that differ only in the loss configuration must not share a captured graph (the loss is baked into
+    it), and the table of eager-run counters / "capture failed" marks stays bounded."""
+    from torch import nn
+
+    from curvlinops_amd import computers
+
+    model = nn.Sequential(nn.Linear(4, 3))
+    params = dict(model.named_parameters())
+    X, y = torch.rand(5, 4), torch.randint(0, 3, (5,))
+
+    def sig(loss):
+        tgt = torch.randint(0, 2, (5, 3)).float() if isinstance(loss, nn.BCEWithLogitsLoss) else y
+        comp = computers.HipKFACComputer(model, loss, params, [(X, tgt)], check_deterministic=False, fisher_type="empirical",
+                                         num_per_example_loss_terms=3 if isinstance(loss, nn.BCEWithLogitsLoss) else 1)
+        return comp._loss_signature()
+
+    base = sig(nn.CrossEntropyLoss())
+    assert base == sig(nn.CrossEntropyLoss())
+    assert base != sig(nn.CrossEntropyLoss(label_smoothing=0.1))
+    assert base != sig(nn.CrossEntropyLoss(ignore_index=1))
+    assert base != sig(nn.CrossEntropyLoss(weight=torch.rand(3)))
+    assert base != sig(nn.CrossEntropyLoss(reduction="sum"))
+    assert sig(nn.BCEWithLogitsLoss()) != sig(nn.BCEWithLogitsLoss(pos_weight=torch.rand(3)))
+    computers.reset_captured_builds()
+    for i in range(computers._CAPTURE_NOTES_MAX + 50):
+        computers._note_capture_state(("cfg", i), 1 if i % 2 else False)
+    assert len(computers._CAPTURED) == computers._CAPTURE_NOTES_MAX
+    assert ("cfg", 0) not in computers._CAPTURED and ("cfg", computers._CAPTURE_NOTES_MAX + 49) in computers._CAPTURED
+    computers.reset_captured_builds()
+    assert computers._default_capture_branches() in (1, 2)

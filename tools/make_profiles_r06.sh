@@ -23,7 +23,8 @@ rm -rf /tmp/pkb /tmp/pkbe
 WITH_INVERSE=1 rocprofv3 --kernel-trace -d /tmp/pkb -o k -- python $R/tools/prof_kfac_build.py > /dev/null 2>&1
 { echo "# rocprofv3 --kernel-trace -- python tools/prof_kfac_build.py  (ResNet-18, C4: 512 rows, joint W+b, 1 MC sample; 4 warm-up builds,"
   echo "# MIOPEN_FIND_MODE=FAST; the section between two marker launches = ONE warm build = one replay of the captured hipGraph"
-  echo "# (coarse fork: input covariances on the factor stream behind one event, gradient covariances inline); tools/kfac_trace_summary.py)"
+  echo "# (two branches at the default 4 hardware queues: input covariances on the factor stream behind one event; the gradient"
+  echo "# covariances of all layers in ONE grouped launch, clo::syrk_grouped_kernel, at the end of the backward pass); tools/kfac_trace_summary.py)"
   python $R/tools/kfac_trace_summary.py /tmp/pkb/k_results.db 512; } > $OUT/r06_kfac_resnet18_build_kernels.txt
 KFAC_EAGER=1 rocprofv3 --kernel-trace -d /tmp/pkbe -o k -- python $R/tools/prof_kfac_build.py > /dev/null 2>&1
 { echo "# the same with computers._CAPTURE = False (eager build: one fork of the factor stream per hook, host-dispatch bound)"
@@ -44,7 +45,21 @@ cd $R
   echo "# python tools/diag_eigh_verify.py: residual of the float32 result in units of eps32 ||A||"
   python tools/diag_eigh_verify.py 577 1153 2305 4609 2>&1 | grep "n="; } > $OUT/r06_eigh_persistent_sytrd.txt
 # ---- batch sweep, columns, skeleton
-python tools/probe_c2.py 1 8 9 16 32 33 48 64 65 128 256 512 1024 2>&1 | grep "N=" > $OUT/r06_c2_batch_sweep.txt
+python tools/probe_c2.py 1 8 9 16 17 32 33 48 64 65 128 256 512 1024 2>&1 | grep "N=" > $OUT/r06_c2_batch_sweep.txt
+cd /tmp
+for n in 16 32 64; do
+rm -rf /tmp/pr$n
+rocprofv3 --kernel-trace --stats -d /tmp/pr$n -o k -- python $R/tools/probe_c2.py $n > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/pr$n/k_results.db $OUT/r06_c2_n${n}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python tools/probe_c2.py $n  (C2 GGN matvec, $n rows: the 9 ... 64-row MFMA chain, three-product forward)"
+done
+cd $R
+{ echo "# python tools/probe_gemm_sweep_r5.py (round 6 library; clo = the engine's automatic choice, torch = hipBLASLt)"
+  python tools/probe_gemm_sweep_r5.py 2>&1 | grep -v amdgpu; } > $OUT/r06_gemm_midsize_sweep.txt
+{ echo "# python tools/r6/probe_syrk_grouped.py: the 20 gradient covariances of a ResNet-18 batch (512 rows), one grouped launch vs one clo_syrk_accum_f32 each"
+  python tools/r6/probe_syrk_grouped.py 2>&1 | grep -v amdgpu; } > $OUT/r06_syrk_grouped.txt
+{ echo "# python tools/probe_kfac_inverse.py: K.inverse(damping) of ResNet-18's 42 factors, six calls (first includes workspace allocation), ms"
+  python tools/probe_kfac_inverse.py 2>&1 | grep -v amdgpu
+  GPU_MAX_HW_QUEUES=16 python tools/probe_kfac_inverse.py 2>&1 | grep -v amdgpu | sed 's/^/GPU_MAX_HW_QUEUES=16 /'; } > $OUT/r06_cholesky_42_inverses.txt
 python tools/probe_cols.py 8 32 64 2>&1 | grep "K=" > $OUT/r06_c2_columns.txt
 python tools/probe_fold.py 2>&1 | grep -v amdgpu > $OUT/r06_kfac_factor_kernels_per_shape.txt
 for q in 4 16; do python tools/probe_kfac_fork.py $q 2>&1 | grep queues=; done > $OUT/r06_kfac_capture_fork_modes.txt

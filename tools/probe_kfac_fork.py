@@ -25,6 +25,7 @@ for mode in ("coarse_inline", "coarse_tail", "coarse_chunk6", "fine", "serial"):
     computers._CAPTURE_FORK = "fine" if mode in ("serial", "fine") else "coarse"
     computers._CAPTURE_G_CHUNK = {"coarse_inline": 0, "coarse_tail": 10**6, "coarse_chunk6": 6}.get(mode, 0)
     computers._OVERLAP = mode != "serial"
+    computers._CAPTURE_BRANCHES = 1 if mode == "serial" else 2   # (round 6: the package's own rule is by queue count; here every form is forced)
     computers.reset_captured_builds()
     ts = []
     for i in range(10):
