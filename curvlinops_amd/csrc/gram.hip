@@ -273,73 +273,109 @@ constexpr int TG_THREADS = 256, TG_UNROLL = 8;
 struct TallGramArgs {
   const float *X, *Y;
   long ldx, ldy, m;
-  int n1, n2, sym;
+  int n1, n2, sym, vec;
   double *slab;   // [grid][16 NI][16 NJ]
 };
 
-// NI x NJ tiles of 16 x 16; a wave's step = 4 consecutive rows (the K dimension of one MFMA): lane (c = lane % 16,
-// r = lane / 16) holds X[row r][column 16 ti + c] -- 64 contiguous bytes per row and tile.
-template <int NI, int NJ>
+// NI x NJ tiles of 16 x 16.  A chunk of TG_RC rows of [X | Y] is staged in LDS with 16-byte global loads (unconditional,
+// clamped addresses; the loads of chunk c + 1 are in flight while chunk c is multiplied), then every wave walks its quarter of
+// the chunk in steps of 4 rows (the K dimension of one f64 MFMA): lane (c = lane % 16, r = lane / 16) reads row r, column
+// 16 t + c of the staged slice.  The first version let each lane load its element straight from global memory -- 64-byte
+// requests, 1.0 - 1.2 TB/s on the [85 M, 32] blocks of C5 (profiles/r06_c5_hutchpp_kernel_split.txt, first run: 13 ms per
+// projection); staged, the pass is bound by HBM and the f64 matrix pipe together (~2 ms).
+constexpr int TG_RC = 64;
+template <int NI, int NJ, bool SYM>
 __global__ __launch_bounds__(TG_THREADS) void tall_gram_kernel(const TallGramArgs p) {
+  constexpr int P1 = 16 * NI, P2 = SYM ? 0 : 16 * NJ;
+  constexpr int PT = P1 + P2;                              // (the symmetric form stages X only)
+  constexpr int PITCH = ((PT + 15) / 32) * 32 + 16;        // = 16 mod 32: the four rows of a ds_read_b32 hit disjoint banks
+  constexpr int QPR = PT / 4;                              // 16-byte pieces per staged row
+  constexpr int NLD = (TG_RC * QPR + TG_THREADS - 1) / TG_THREADS;
+  __shared__ __attribute__((aligned(16))) float St[TG_RC * PITCH];
   __shared__ double S[4 * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, r = lane >> 4;
+  constexpr bool sym = SYM;
+  const int n1 = p.n1, n2 = sym ? 0 : p.n2;
+  const bool vec = p.vec != 0;
   f64x4g acc[NI][NJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f64x4g{0., 0., 0., 0.};
-  const long nsteps = cdiv(p.m, 4L);
-  const long stride = (long)gridDim.x * 4;
-  bool okx[NI], oky[NJ];
+  // this thread's pieces of a chunk: (row, staged column); staged columns [0, P1) come from X, [P1, PT) from Y
+  int prow[NLD], pcol[NLD];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) okx[i] = 16 * i + c < p.n1;
+  for (int u = 0; u < NLD; ++u) {
+    const int e = min(tid + u * TG_THREADS, TG_RC * QPR - 1);
+    prow[u] = e / QPR;
+    pcol[u] = (e - prow[u] * QPR) * 4;
+  }
+  const long mlast = max(p.m - 1, 0L);
+  auto fetch = [&](long r0, float4 (&v)[NLD]) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) oky[j] = 16 * j + c < p.n2;
-  for (long s0 = (long)blockIdx.x * 4 + wave; s0 < nsteps; s0 += stride * TG_UNROLL) {
-    float xa[TG_UNROLL][NI], yb[TG_UNROLL][NJ];
+    for (int u = 0; u < NLD; ++u) {
+      const long row = r0 + prow[u];
+      const bool rok = row < p.m;
+      const int sc = pcol[u];
+      const bool fromx = sc < P1;
+      const int col = fromx ? sc : sc - P1;
+      const int nn = fromx ? n1 : n2;
+      const float *base = (fromx ? p.X + min(row, mlast) * p.ldx : p.Y + min(row, mlast) * p.ldy);
+      if (vec) {
+        const float4 t = *reinterpret_cast<const float4 *>(base + max(min(col, nn - 4), 0));
+        const bool in = rok && col < nn;
+        v[u] = make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
+      } else {
+        float t[4];
 #pragma unroll
-    for (int u = 0; u < TG_UNROLL; ++u) {   // every load of the group is issued before the first conversion
-      const long row = 4 * (s0 + u * stride) + r;
-      const bool okr = row < p.m;
-      const long rr = okr ? row : 0;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const float v = p.X[rr * p.ldx + (okx[i] ? 16 * i + c : 0)];
-        xa[u][i] = (okr && okx[i]) ? v : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (p.sym) { yb[u][j] = j < NI ? xa[u][j < NI ? j : 0] : 0.f; continue; }
-        const float v = p.Y[rr * p.ldy + (oky[j] ? 16 * j + c : 0)];
-        yb[u][j] = (okr && oky[j]) ? v : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const float x = nn > 0 ? base[min(col + e, nn - 1)] : 0.f;
+          t[e] = (rok && col + e < nn) ? x : 0.f;
+        }
+        v[u] = make_float4(t[0], t[1], t[2], t[3]);
       }
     }
+  };
+  const long nchunks = cdiv(p.m, (long)TG_RC);
+  float4 cur[NLD], nxt[NLD];
+  if ((long)blockIdx.x < nchunks) fetch((long)blockIdx.x * TG_RC, cur);
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    __syncthreads();   // everybody is done with the previous chunk
 #pragma unroll
-    for (int u = 0; u < TG_UNROLL; ++u) {
+    for (int u = 0; u < NLD; ++u)
+      if (tid + u * TG_THREADS < TG_RC * QPR) *reinterpret_cast<float4 *>(&St[prow[u] * PITCH + pcol[u]]) = cur[u];
+    fetch((ch + gridDim.x) * TG_RC, nxt);   // (past the end: masked, clamped)
+    __syncthreads();
+    const float *sp = St + (wave * (TG_RC / 4) + r) * PITCH + c;
+#pragma unroll
+    for (int st = 0; st < TG_RC / 16; ++st) {
       double a[NI], b[NJ];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = (double)xa[u][i];
+      for (int i = 0; i < NI; ++i) a[i] = (double)sp[st * 4 * PITCH + 16 * i];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = (double)yb[u][j];
+      for (int j = 0; j < NJ; ++j) b[j] = sym ? (j < NI ? a[j < NI ? j : 0] : 0.) : (double)sp[st * 4 * PITCH + P1 + 16 * j];
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if (p.sym && j < i) continue;   // (uniform: the reduce kernel mirrors)
+          if (sym && j < i) continue;   // (uniform: the reduce kernel mirrors)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) cur[u] = nxt[u];
   }
   // the four waves' tiles are summed through LDS in a fixed order; D layout of the f64 16x16x4 MFMA: row = (lane / 16) + 4 q,
   // col = lane % 16 (one row per register and lane group -- NOT the 4 (lane / 16) + q of the f32 16x16x4 tile)
+  __syncthreads();
   double *out = p.slab + (long)blockIdx.x * (16 * NI) * (16 * NJ);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      if (p.sym && j < i) continue;
+      if (sym && j < i) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) S[wave * 256 + (r + 4 * q) * 16 + c] = acc[i][j][q];
       __syncthreads();
@@ -371,7 +407,7 @@ __global__ void tall_gram_reduce_kernel(double *__restrict__ out, long ldo, cons
 }
 
 static int tall_gram_grid(long m) {
-  return (int)std::max<long>(1, std::min<long>(cdiv(cdiv(m, 4L), 4L * TG_UNROLL), 2L * kNumCU));
+  return (int)std::max<long>(1, std::min<long>(cdiv(m, (long)TG_RC), 4L * kNumCU));
 }
 
 struct TallApplyArgs {
@@ -460,10 +496,15 @@ extern "C" int clo_tall_gram_f64(double *out, long ldo, const float *X, long ldx
   TallGramArgs a{};
   a.X = X; a.Y = sym ? X : Y; a.ldx = ldx; a.ldy = sym ? ldx : ldy; a.m = m; a.n1 = n1; a.n2 = n2; a.sym = sym ? 1 : 0;
   a.slab = static_cast<double *>(ws);
+  a.vec = ((n1 & 3) == 0 && n1 >= 4 && (ldx & 3) == 0 && aligned16(X) &&
+           (sym || ((n2 & 3) == 0 && n2 >= 4 && (ldy & 3) == 0 && aligned16(Y)))) ? 1 : 0;
   const int NI = (int)cdiv(n1, 16), NJ = (int)cdiv(n2, 16);
   const int grid = tall_gram_grid(m);
-#define CLO_TG_CASE(I, J) \
-  if (NI == I && NJ == J) hipLaunchKernelGGL((tall_gram_kernel<I, J>), dim3(grid), dim3(TG_THREADS), 0, st, a);
+#define CLO_TG_CASE(I, J)                                                                                      \
+  if (NI == I && NJ == J) {                                                                                    \
+    if (sym) { if (I == J) hipLaunchKernelGGL((tall_gram_kernel<I, (I == J ? J : I), true>), dim3(grid), dim3(TG_THREADS), 0, st, a); } \
+    else hipLaunchKernelGGL((tall_gram_kernel<I, J, false>), dim3(grid), dim3(TG_THREADS), 0, st, a);          \
+  }
   CLO_TG_CASE(1, 1) CLO_TG_CASE(1, 2) CLO_TG_CASE(1, 3) CLO_TG_CASE(1, 4)
   CLO_TG_CASE(2, 1) CLO_TG_CASE(2, 2) CLO_TG_CASE(2, 3) CLO_TG_CASE(2, 4)
   CLO_TG_CASE(3, 1) CLO_TG_CASE(3, 2) CLO_TG_CASE(3, 3) CLO_TG_CASE(3, 4)

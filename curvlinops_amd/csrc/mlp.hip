@@ -1500,12 +1500,21 @@ __device__ __forceinline__ float mid_delta_at(const MidDelta &md, int n, int j, 
   return md.delta[(long)n * (md.ld_delta ? md.ld_delta : d_out) + j];
 }
 
+struct MidDprevArgs {
+  const float *W;
+  MidDelta md;
+  const float *dphi_prev;
+  float *dst;
+  int N, d_in, d_out, rows_per_block, final_write;
+};
 template <int NT>
-__global__ __launch_bounds__(512) void mid_dprev_kernel(
-    const float *__restrict__ W, const MidDelta md, const float *__restrict__ dphi_prev,
-    float *__restrict__ dst, int N, int d_in, int d_out, int rows_per_block, int final_write) {
+__device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, int by, float *smem) {
   constexpr int NP = 16 * NT, MID_LDD = mid_ldd(NT);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const float *__restrict__ W = dq.W;
+  const MidDelta &md = dq.md;
+  const float *__restrict__ dphi_prev = dq.dphi_prev;
+  float *__restrict__ dst = dq.dst;
+  const int N = dq.N, d_in = dq.d_in, d_out = dq.d_out, rows_per_block = dq.rows_per_block, final_write = dq.final_write;
   float *s_d = smem;                                  // [rows_per_block (padded to 8)][MID_LDD]
   const int rpad = (rows_per_block + 7) & ~7;
   float *s_red = smem + rpad * MID_LDD;               // [4 quarters][NT][4][4][64]
@@ -1513,8 +1522,8 @@ __global__ __launch_bounds__(512) void mid_dprev_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cq = wave & 3, rh = wave >> 2;
   const int c16 = lane & 15, kg = lane >> 4;
-  const int jbase = blockIdx.y * rows_per_block;
-  const int i0 = blockIdx.x * 256 + cq * 64 + c16 * 4;
+  const int jbase = by * rows_per_block;
+  const int i0 = bx * 256 + cq * 64 + c16 * 4;
   const bool col_ok = i0 < d_in;   // d_in % 4 == 0: the lane's four columns are all in or all out
   // rows of this wave: half of the block's range, in steps of 4
   const int half = ((rows_per_block + 1) / 2 + 3) & ~3;
@@ -1591,9 +1600,15 @@ __global__ __launch_bounds__(512) void mid_dprev_kernel(
           st4(dst + (long)n * d_in + i0, make_float4(v.x * dp.x, v.y * dp.y, v.z * dp.z, v.w * dp.w));
         }
       } else {
-        st4(dst + ((long)blockIdx.y * NP + n) * d_in + i0, v);
+        st4(dst + ((long)by * NP + n) * d_in + i0, v);
       }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void mid_dprev_kernel(const MidDprevArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  mid_dprev_body<NT>(q, blockIdx.x, blockIdx.y, smem);
 }
 
 // All outer products of a matvec for up to 64 rows: out_W_l = beta out_W_l + alpha delta_l^T a_{l-1}, bias
@@ -1614,16 +1629,15 @@ struct MidOuterArgs {
 // CW = columns per block (256: 4 column quarters x 2 row halves of two 16-row tiles; 128 beyond 32 batch rows
 // -- 2 column halves x 4 row quarters of one tile -- so that three blocks still fit a CU's LDS).
 template <int NT, bool ACCUM, int CW>
-__global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
+__device__ __forceinline__ void mid_outer_body(const MidOuterArgs &p, int block, float *smem_o) {
   constexpr int NP = 16 * NT;
   constexpr int NCQ = CW / 64, NRH = 8 / NCQ, RT = MIDO_ROWS / (16 * NRH);
   constexpr int LDR = MIDO_ROWS + 16;  // [NP][rows + 16]: conflict-free A-operand reads
-  extern __shared__ __attribute__((aligned(16))) float smem_o[];
   float *s_dT = smem_o;              // [NP][LDR]
   float *s_a = smem_o + NP * LDR;    // [NP][CW]
   int l = 0;
-  while (l + 1 < p.nlayers && (int)blockIdx.x >= p.first_block[l + 1]) ++l;
-  const int local = blockIdx.x - p.first_block[l];
+  while (l + 1 < p.nlayers && block >= p.first_block[l + 1]) ++l;
+  const int local = block - p.first_block[l];
   const int d_in = p.d_in[l], d_out = p.d_out[l], N = p.N;
   const int cchunks = (d_in + CW - 1) / CW;
   const int bx = local % cchunks, by = local / cchunks;
@@ -1688,6 +1702,25 @@ __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
         CLO_STW(po, v);
       }
     }
+}
+
+template <int NT, bool ACCUM, int CW>
+__global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_o[];
+  mid_outer_body<NT, ACCUM, CW>(p, blockIdx.x, smem_o);
+}
+
+// Round 6: the data chain's step delta_{l-1} = delta_l W_l and the outer products that only need delta_l (layer l, and the
+// head's layer at the first step) in ONE launch: the read-only sweep of W_l and the write-only stream of out_W_l are
+// independent, and as two launches each paid its own boundary, staging prologue and drain with one workgroup per CU
+// (C2, 16 rows: 11.6 + 12.3 us).  The data-chain blocks come first (the next step waits for them).
+template <int NT, bool ACCUM, int CW>
+__global__ __launch_bounds__(512) void mid_bwd_merged_kernel(const MidDprevArgs q, const MidOuterArgs p, int n_dprev,
+                                                             int dprev_gx) {
+  extern __shared__ __attribute__((aligned(16))) float smem_m[];
+  const int b = blockIdx.x;
+  if (b < n_dprev) mid_dprev_body<NT>(q, b % dprev_gx, b / dprev_gx, smem_m);
+  else mid_outer_body<NT, ACCUM, CW>(p, b - n_dprev, smem_m);
 }
 
 // delta_l [N][d] = (sum of the row-range slabs of mid_dprev_kernel) x act'(z_l): beyond 32 batch rows the
@@ -3104,9 +3137,38 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     hipLaunchKernelGGL(head_bwd_rows_kernel, dim3(head_nblk, (unsigned)cdiv(N, NB)), dim3(256), 0, st, ba, dLbuf);
     CLO_CHECK_LAUNCH("head_bwd_rows_kernel");
   }
-  // ---- data chain: delta_{l-1} for l = L-1 .. 2
+  // ---- data chain delta_{l-1} = delta_l W_l for l = L-1 .. 2, each step merged with the outer products that need delta_l
+  // only (layer l; at the first step also the head's layer L); the last launch forms the remaining outer products
+  constexpr int OCW = NT <= 2 ? 256 : 128;
+  const size_t osmem = (size_t)NP * (MIDO_ROWS + 16 + OCW) * sizeof(float);
+  // (MEASURED in round 6 and left OFF: the merged launch is 0.5 - 3 us SLOWER at every row count, profiles/
+  // r06_c2_mid_merged_backward_ab.txt -- a read-only sweep and a write-only stream sharing the chip slow each other down by
+  // more than the saved boundary, as round 1 found for a kernel that did both per tile)
+#ifndef CLO_MLP_MID_MERGE
+#define CLO_MLP_MID_MERGE 0
+#endif
+  static const bool merge_on = CLO_MLP_MID_MERGE != 0;
   MidDelta md[OUTER_MAXL + 2];
   md[L - 1] = MidDelta{dl[L - 1], nullptr, nullptr, 0, 0};
+  md[L] = MidDelta{dLbuf, nullptr, nullptr, 0, HEAD_CMAX};  // the head's delta, [N][HEAD_CMAX]
+  bool outer_done[OUTER_MAXL + 2] = {};
+  auto outer_args = [&](const int *layers, int count, MidOuterArgs &oa, double &bytes) {
+    oa = MidOuterArgs{};
+    oa.nlayers = count; oa.alpha = 1.f; oa.beta = beta; oa.N = N;
+    int nb = 0;
+    bytes = 0;
+    for (int k = 0; k < count; ++k) {
+      const int l = layers[k];
+      oa.first_block[k] = nb;
+      oa.md[k] = md[l]; oa.a_prev[k] = a[l - 1];
+      oa.out_W[k] = OW[l - 1]; oa.out_b[k] = Ob ? Ob[l - 1] : nullptr;
+      oa.d_in[k] = dims[l - 1]; oa.d_out[k] = dims[l];
+      nb += (int)(cdiv(dims[l - 1], OCW) * cdiv(dims[l], MIDO_ROWS));
+      bytes += 4.0 * dims[l - 1] * dims[l] * (beta != 0.f ? 2 : 1);
+    }
+    oa.first_block[count] = nb;
+    return nb;
+  };
   for (int l = L - 1; l >= 2; --l) {
     const int di = dims[l - 1], dout = dims[l];
     long JB = cdiv(kNumCU, cdiv(di, 256));
@@ -3117,13 +3179,38 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     if (JBe > JB_MAX) return CLO_EUNSUP;
     float *slab = dslab[l & 1];
     const size_t smem = ((size_t)((rpb + 7) & ~7) * mid_ldd(NT) + NT * 4096) * sizeof(float);
-    rc = set_smem(mid_dprev_kernel<NT>, smem);
-    if (rc != CLO_OK) return rc;
     const int fin = JBe == 1 ? 1 : 0;
-    ProfScope prof(2, 4.0 * di * dout, st);
-    hipLaunchKernelGGL((mid_dprev_kernel<NT>), dim3((unsigned)cdiv(di, 256), (unsigned)JBe), dim3(512), smem, st,
-                       W[l - 1], md[l], dphi[l - 1], fin ? dl[l - 1] : slab, N, di, dout, rpb, fin);
-    CLO_CHECK_LAUNCH("mid_dprev_kernel");
+    MidDprevArgs dq{W[l - 1], md[l], dphi[l - 1], fin ? dl[l - 1] : slab, N, di, dout, rpb, fin};
+    const int gx = (int)cdiv(di, 256);
+    if (merge_on) {
+      int layers[2] = {l, L};
+      const int count = l == L - 1 ? 2 : 1;
+      MidOuterArgs oa;
+      double obytes;
+      const int nbo = outer_args(layers, count, oa, obytes);
+      const size_t msmem = std::max(smem, osmem);
+      ProfScope prof(2, 4.0 * di * dout + obytes, st);
+      if (beta != 0.f) {
+        rc = set_smem(mid_bwd_merged_kernel<NT, true, OCW>, msmem);
+        if (rc != CLO_OK) return rc;
+        hipLaunchKernelGGL((mid_bwd_merged_kernel<NT, true, OCW>), dim3((unsigned)(gx * JBe + nbo)), dim3(512), msmem, st, dq,
+                           oa, gx * JBe, gx);
+      } else {
+        rc = set_smem(mid_bwd_merged_kernel<NT, false, OCW>, msmem);
+        if (rc != CLO_OK) return rc;
+        hipLaunchKernelGGL((mid_bwd_merged_kernel<NT, false, OCW>), dim3((unsigned)(gx * JBe + nbo)), dim3(512), msmem, st, dq,
+                           oa, gx * JBe, gx);
+      }
+      CLO_CHECK_LAUNCH("mid_bwd_merged_kernel");
+      outer_done[l] = true;
+      if (count == 2) outer_done[L] = true;
+    } else {
+      rc = set_smem(mid_dprev_kernel<NT>, smem);
+      if (rc != CLO_OK) return rc;
+      ProfScope prof(2, 4.0 * di * dout, st);
+      hipLaunchKernelGGL((mid_dprev_kernel<NT>), dim3((unsigned)gx, (unsigned)JBe), dim3(512), smem, st, dq);
+      CLO_CHECK_LAUNCH("mid_dprev_kernel");
+    }
     if (!fin && NT > 2) {   // one pass over the slabs instead of one per consumer block
       const long total4 = (long)N * di / 4;
       hipLaunchKernelGGL(mid_delta_finish_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st, slab, JBe,
@@ -3134,26 +3221,16 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
       md[l - 1] = fin ? MidDelta{dl[l - 1], nullptr, nullptr, 0, 0} : MidDelta{nullptr, slab, dphi[l - 1], JBe, 0};
     }
   }
-  // ---- all outer products of the hidden layers in one launch
+  // ---- the outer products not formed yet (layer 1; every layer of a two-layer net), one launch
   {
-    constexpr int OCW = NT <= 2 ? 256 : 128;
-    MidOuterArgs oa{};
-    oa.nlayers = L; oa.alpha = 1.f; oa.beta = beta; oa.N = N;
-    md[L] = MidDelta{dLbuf, nullptr, nullptr, 0, HEAD_CMAX};  // the head's delta, [N][HEAD_CMAX]
-    int nb = 0;
-    double bytes = 0;
-    for (int l = 1; l <= L; ++l) {
-      const int k = l - 1;
-      oa.first_block[k] = nb;
-      oa.md[k] = md[l]; oa.a_prev[k] = a[l - 1];
-      oa.out_W[k] = OW[l - 1]; oa.out_b[k] = Ob ? Ob[l - 1] : nullptr;
-      oa.d_in[k] = dims[l - 1]; oa.d_out[k] = dims[l];
-      nb += (int)(cdiv(dims[l - 1], OCW) * cdiv(dims[l], MIDO_ROWS));
-      bytes += 4.0 * dims[l - 1] * dims[l] * (beta != 0.f ? 2 : 1);
-    }
-    oa.first_block[L] = nb;
+    int layers[OUTER_MAXL + 1];
+    int count = 0;
+    for (int l = 1; l <= L; ++l)
+      if (!outer_done[l]) layers[count++] = l;
+    MidOuterArgs oa;
+    double bytes;
+    const int nb = outer_args(layers, count, oa, bytes);
     ProfScope prof(4, bytes, st);
-    const size_t osmem = (size_t)NP * (MIDO_ROWS + 16 + OCW) * sizeof(float);
     rc = beta != 0.f ? set_smem(mid_outer_kernel<NT, true, OCW>, osmem)
                      : set_smem(mid_outer_kernel<NT, false, OCW>, osmem);
     if (rc != CLO_OK) return rc;
