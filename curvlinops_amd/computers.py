@@ -547,7 +547,11 @@ class _CapturedBatch:
         cap_stream = None if _CAPTURE_STREAM is None else side_stream(dev, _CAPTURE_STREAM)
         keep = _OVERLAP
         _OVERLAP = keep and overlap and not split
-        ctx = [torch.cuda.graph(graphs[0], stream=cap_stream)]
+        # thread-local capture mode: only THIS thread's calls are checked against the capture.  Other threads of the process
+        # -- the RCCL watchdog of a data-parallel job polls its events, worker threads allocate -- must neither fail nor
+        # invalidate the capture (global mode, torch's default, does both).
+        mode = "thread_local"
+        ctx = [torch.cuda.graph(graphs[0], stream=cap_stream, capture_error_mode=mode)]
         entered = False
 
         def cut():
@@ -560,7 +564,7 @@ class _CapturedBatch:
             entered = False
             graphs.append(torch.cuda.CUDAGraph())
             graphs[-1].register_generator_state(gen)
-            ctx.append(torch.cuda.graph(graphs[-1], pool=graphs[0].pool(), stream=cap_stream))
+            ctx.append(torch.cuda.graph(graphs[-1], pool=graphs[0].pool(), stream=cap_stream, capture_error_mode=mode))
             ctx[-1].__enter__()
             entered = True
 

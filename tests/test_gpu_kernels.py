@@ -542,6 +542,32 @@ def test_ggn_matvec_persistent_kernel_c2(hip, N, loss):
             assert all(np.array_equal(a, b) for a, b in zip(got, first)), f"call {it} differs"
 
 
+@pytest.mark.parametrize("N,loss", [(9, "mse"), (16, "ce"), (17, "bce"), (32, "mse"), (33, "ce"), (48, "bce"), (64, "mse")])
+def test_ggn_matvec_mid_rows_chain_c2(hip, N, loss):
+    """The benchmark network at 9 ... 64 rows (the all-MFMA chain; round 6: three products per step in its forward kernel)
+    against the float64 oracle, every parameter block on its own scale, at every tile count NT = 1 ... 4 and on both sides
+    of each boundary; two calls are bit-identical."""
+    g = np.random.default_rng(100 + N)
+    dims, acts = [1024, 2688, 2688, 10], ["relu", "relu", "identity"]
+    Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, loss)
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", vWs, vbs)
+    scale = (2.0 if loss == "mse" else 1.0) * O.reduction_factor(loss, "mean", N, dims[-1])
+    plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    dW, db = [dev(W) for W in Ws], [dev(b) for b in bs]
+    dVW, dVb = [dev(v) for v in vWs], [dev(v) for v in vbs]
+    dX = dev(X)
+    outs = []
+    for _ in range(2):
+        oW = [torch.full_like(w, float("nan")) for w in dW]
+        ob = [torch.full_like(b, float("nan")) for b in db]
+        plan.ggn_matvec(dW, db, dVW, dVb, oW, ob, dX, LOSS_KIND[loss], scale, 1.0, 0.0)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in oW + ob])
+    for k, (a, r) in enumerate(zip(outs[0], rW + rb)):
+        assert rel_err(a, r) < 1e-4, f"block {k}"
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
+
+
 @pytest.mark.parametrize("side_gemm", [False, True])
 def test_ggn_matvec_persistent_kernel_concurrent_streams(hip, side_gemm):
     """Round 4: the persistent kernel next to other work.  Two HIP streams each issue 50 products of the benchmark
