@@ -21,6 +21,9 @@
 #include "clo_common.h"
 #include "gemm.h"
 #include "mlp_loss.h"
+#include "persist_gate.h"
+
+#include <mutex>
 
 namespace clo {
 
@@ -2977,6 +2980,430 @@ extern "C" int clo_mlp_bwd_layer(const float *W, const float *delta, const float
 // Scratch comes out of the GEMM slab area `gws` (unused on this path): forward slabs | head partials |
 // two regions of delta slabs (ping-pong over the layers).
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Round 6: layers 1 and 2 of the forward + JVP pass of the 9 ... 64-row chain in ONE persistent launch
+// (three-layer nets with a narrow head -- BASELINE config C2's class; reference ggn.py:61-66, the jvp half).
+// As separate launches (mid_full_kernel, mid_fwd_kernel) the two weight streams of 22 + 58 MB each paid a
+// launch boundary, a staging prologue and a drain with one workgroup per CU (C2, 16 / 32 / 64 rows:
+// 10 + 15 / 15 + 23 / 21 + 40 us).  Here 256 workgroups form the 16 x 16 grid of csrc/mlp_mega.hip over layer 2:
+// workgroup (fb, kb) first computes its <= 16 layer-1 features of K range kb for all rows (in-block split-K over the
+// eight waves, as mid_full_kernel), publishes them write-through, and meets the 15 other workgroups of its COLUMN
+// group on one counter -- the only seam; the W2 / V2 fragments of its tile are requested before it polls.  Then
+// the [a1 ; da1] operand of the K range is staged in LDS and the tile's partial z2 / dz2 (three products per step)
+// go to the slab of split kb: exactly what mid_fwd_kernel with 16 K ranges would write, so head_fwd_kernel finishes
+// the layer as before.  Counters are monotonic (target = 16 x launch number, the launch number from a 64-bit count of
+// finished workgroups), every spin is bounded; a timeout marks the slab with NaN and raises the device's fault word.
+// ------------------------------------------------------------------------------------------
+namespace clo {
+constexpr int MFU_G = 256, MFU_T = 512, MFU_MAXS = 11, MFU_KR = 16 * MFU_MAXS, MFU_MAXCH = 11;
+constexpr int MFU_SYNC_WORDS = 32 * 20 + 4096;   // (+ timing slots of -DCLO_MFU_TIMING builds)   // line 0: finished-workgroup count (64 bit); line 1: abort word; lines 2 .. 17: column groups
+
+struct MidFusedArgs {
+  const float *W1, *b1, *V1, *Vb1, *X, *W2, *V2;
+  float *a1, *da1, *dphi1;   // [N][d1]
+  float *part;               // [16][2][NP][d2]
+  int N, d0, d1, d2, act1;
+  unsigned *sync;
+  unsigned *fault;
+  unsigned spin_limit;
+};
+
+__device__ __forceinline__ f32x4 mfu_ld_sc1(__amdgpu_buffer_rsrc_t rs, long off_floats) {
+  typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(off_floats * 4), 0, 16));
+}
+__device__ __forceinline__ void mfu_st_sc1(__amdgpu_buffer_rsrc_t rs, long off_floats, f32x4 v) {
+  typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4m, v), rs, (unsigned)(off_floats * 4), 0, 16);
+}
+
+#ifdef CLO_MFU_TIMING
+#define MFU_STAMP(i) do { if ((tid & 63) == 0 && (blockIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(p.sync + 32 * 20)[((blockIdx.x >> 6) * 8 + (tid >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define MFU_STAMP(i) do { } while (0)
+#endif
+template <int NT>
+__global__ __launch_bounds__(MFU_T) void mid_fused_fwd_kernel(const MidFusedArgs p) {
+  constexpr int NP = 16 * NT, WAVES = 8, RG = 2, XW = WAVES - 1;   // wave XW: the exchange wave (owns no early tile loads)
+  constexpr int LDB = MFU_KR + 4;
+  constexpr int PRE = 4;                                            // tile steps requested before the seam
+  constexpr int SPC = (NP * (MFU_KR / 4) + MFU_T - 1) / MFU_T;      // 16-byte pieces per thread and staged array
+  extern __shared__ __attribute__((aligned(16))) float s_fu[];   // phase 1: [WAVES][RG][NT][2][4][32]; phase 2: [2 NP][LDB]
+  __shared__ unsigned s_flag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = lane & 15, s4 = (lane >> 4) * 4;
+  const int w = blockIdx.x;
+  const int N = p.N, d0 = p.d0, d1 = p.d1, d2 = p.d2;
+  // ---- geometry: workgroup w runs on XCD w % 8 (observed; used for speed only): a column group shares one L2
+  const int fb = w >> 4, kb = 2 * (w & 7) + ((w >> 3) & 1);
+  const int S1 = d1 >> 4;
+  const int ks0 = kb * S1 / 16, ns = (kb + 1) * S1 / 16 - ks0;            // k16 steps of the K range (<= MFU_MAXS)
+  const int k0 = ks0 * 16, kr = ns * 16;
+  const int kq = kr >> 2;
+  const int q0 = fb * kq / 16, nf1 = 4 * ((fb + 1) * kq / 16 - q0);       // layer-1 slice of this workgroup (<= 16 features)
+  const int jA = k0 + 4 * q0;
+  const int C2 = (d2 + 15) >> 4;                                           // 16-feature chunks of layer 2
+  const int c0 = fb * C2 / 16, nch = (fb + 1) * C2 / 16 - c0;              // chunks of block fb (<= MFU_MAXCH)
+  // ---- launch number from the count of finished workgroups (a late starter reads the same quotient)
+  unsigned *sy = p.sync;
+  const unsigned long long done = __hip_atomic_load(reinterpret_cast<unsigned long long *>(sy), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned target = (unsigned)(16ull * (done / MFU_G + 1ull));
+  unsigned *c_err = sy + 32, *c_col = sy + 32 * (2 + kb);
+  MFU_STAMP(0);
+
+  float4 tw[MFU_MAXS], tv[MFU_MAXS];   // fragments of one 16-feature chunk of the layer-2 tile: [W row | V row] per k16 step
+  auto rows_of = [&](int ch, const float *&pW, const float *&pV) {
+    const int row = min((c0 + ch) * 16 + idx, d2 - 1);
+    pW = p.W2 + (long)row * d1 + k0 + s4;
+    pV = p.V2 + (long)row * d1 + k0 + s4;
+  };
+  const float *pW0, *pV0;
+  rows_of(min(wave, max(nch - 1, 0)), pW0, pV0);   // the wave's first chunk (chunks wave, wave + 8)
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.a1, 0, (int)((long)N * d1 * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.da1, 0, (int)((long)N * d1 * 4), 0x00020000);
+
+  // =====================================================================================
+  // phase 1: layer 1 for features [jA, jA + nf1), all rows: the eight waves split K (as mid_full_kernel)
+  // =====================================================================================
+  {
+    const int kpw = (int)(((d0 + 7) / 8 + 15) / 16) * 16;
+    const int kb0 = min(wave * kpw, d0);
+    const int klen = min(d0, kb0 + kpw) - kb0;   // multiple of 4 (d0 % 16 == 0), may be 0
+    const int jlast = max(jA + nf1 - 1, jA);
+    const float *pA[RG];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const int row = min(jA + g * 8 + (idx & 7), jlast);
+      pA[g] = ((idx >= 8) ? p.V1 : p.W1) + (long)row * d0 + kb0 + s4;
+    }
+    long offB[NT];
+    unsigned bmask[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = t * 16 + idx;
+      bmask[t] = n < N ? 0xffffffffu : 0u;
+      offB[t] = (long)min(n, N - 1) * d0 + kb0 + s4;
+    }
+    f32x4 acc1[RG][NT];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc1[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto masked = [](float4 v, unsigned m) {
+      return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                         __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+    };
+    constexpr int U = NT <= 2 ? 4 : 2;
+    const int nfull = klen >> 4;
+    int step = 0;
+    for (; step + U <= nfull; step += U) {
+      float4 av[U][RG], bv[U][NT];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int g = 0; g < RG; ++g) av[u][g] = CLO_LDW(pA[g] + (step + u) * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[u][t] = ld4(p.X + offB[t] + (step + u) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 x = masked(bv[u][t], bmask[t]);
+#pragma unroll
+          for (int g = 0; g < RG; ++g) {
+            acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].x, x.x, acc1[g][t], 0, 0, 0);
+            acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].y, x.y, acc1[g][t], 0, 0, 0);
+            acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].z, x.z, acc1[g][t], 0, 0, 0);
+            acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g].w, x.w, acc1[g][t], 0, 0, 0);
+          }
+        }
+    }
+    for (; step * 16 < klen; ++step) {   // leftover full steps and the partial one
+      const bool ok = step * 16 + s4 < klen;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 x = masked(ld4(p.X + offB[t] + (ok ? step * 16 : 0)), ok ? bmask[t] : 0u);
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          const float4 a = ld4(pA[g] + (ok ? step * 16 : 0));
+          acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, acc1[g][t], 0, 0, 0);
+          acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, acc1[g][t], 0, 0, 0);
+          acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, acc1[g][t], 0, 0, 0);
+          acc1[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, acc1[g][t], 0, 0, 0);
+        }
+      }
+    }
+    MFU_STAMP(1);
+    // The first PRE steps of the wave's first tile chunk, behind the layer-1 loads.  A CU's vector-memory pipe delivers in
+    // issue order: whatever is requested here is in the way of the seam's traffic below, so it is only as much as the seam
+    // takes to run, and the exchange wave requests nothing.
+    if (wave != XW) {
+#pragma unroll
+      for (int st = 0; st < PRE; ++st) {
+        tw[st] = CLO_LDW(pW0 + min(st, ns - 1) * 16);
+        tv[st] = CLO_LDW(pV0 + min(st, ns - 1) * 16);
+      }
+    }
+    // per wave: z = D rows 0..7 (W1 x), dz = D rows 8..15 (V1 x), brought to the lanes q < 2; merge the waves through LDS
+    const int q = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc1[g][t][r];
+          const float up = __shfl(v, (lane + 32) & 63, 64);
+          if (q < 2) {
+            float *dst = s_fu + ((((wave * RG + g) * NT + t) * 2) * 4 + r) * 32 + lane;
+            dst[0] = v;
+            dst[4 * 32] = up;
+          }
+        }
+    __syncthreads();
+    MFU_STAMP(2);
+    if (wave == XW) {
+      // ---- the exchange wave: finish the slice (bias, activation), publish it write-through, arrive, poll
+      __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.dphi1, 0, (int)((long)N * d1 * 4), 0x00020000);
+      if (q < 2) {
+        for (int job = 0; job < RG * NT; ++job) {
+          const int g = job / NT, t = job % NT;
+          const int n = t * 16 + col, f0 = g * 8 + q * 4;   // four consecutive features of the slice
+          f32x4 av4, dv4, pv4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float z = 0.f, dz = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) {
+              const float *src = s_fu + ((((ww * RG + g) * NT + t) * 2) * 4 + r) * 32 + lane;
+              z += src[0];
+              dz += src[4 * 32];
+            }
+            const int j = min(jA + f0 + r, d1 - 1);
+            float dphi;
+            const float aval = act_apply(p.act1, z + (p.b1 ? p.b1[j] : 0.f), dphi);
+            av4[r] = aval;
+            pv4[r] = dphi;
+            dv4[r] = dphi * (dz + (p.Vb1 ? p.Vb1[j] : 0.f));
+          }
+          if (n < N && f0 < nf1) {   // (nf1 is a multiple of 4: the quad is all in or all out)
+            const long off = (long)n * d1 + jA + f0;
+            mfu_st_sc1(ra, off, av4);
+            mfu_st_sc1(rd, off, dv4);
+            mfu_st_sc1(rp, off, pv4);
+          }
+        }
+      }
+      MFU_STAMP(3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store of this wave acknowledged
+      __builtin_amdgcn_wave_barrier();
+      MFU_STAMP(4);
+      if (lane == 0) {
+        __hip_atomic_fetch_add(c_col, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0, bad = 0u;
+        for (;;) {
+          const unsigned seen = __hip_atomic_load(c_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(seen - target) >= 0) break;
+          __builtin_amdgcn_s_sleep(1);
+          ++spins;
+          if ((spins & 255u) == 0u && __hip_atomic_load(c_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1u; break; }
+          if (spins > p.spin_limit) {   // the grid is not co-resident: end the launch (NaN-marked below), raise the fault word
+            __hip_atomic_store(c_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.fault) __hip_atomic_store(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            bad = 1u;
+            break;
+          }
+        }
+        s_flag = bad;
+      }
+      MFU_STAMP(5);
+    }
+    __syncthreads();
+  }
+  MFU_STAMP(6);
+  const unsigned launch_bad = s_flag;
+  // ---- the [a1 ; da1] operand of the K range: requested FIRST (write-through data: sc1 loads, no L1), then the rest of the
+  // tile chunk; rows [0, NP) = a1, [NP, 2 NP) = da1 (one array at a time: the buffer resource is wave-uniform)
+  {
+    const int q4 = kr >> 2, tot = NP * q4;
+    f32x4 sv[2][SPC];
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int u = 0; u < SPC; ++u) {
+        const int e = min(tid + u * MFU_T, tot - 1);
+        const int n = e / q4, kk = (e - n * q4) * 4;
+        sv[which][u] = mfu_ld_sc1(which ? rd : ra, (long)min(n, N - 1) * d1 + k0 + kk);
+      }
+    if (wave != XW) {
+#pragma unroll
+      for (int st = PRE; st < MFU_MAXS; ++st) {
+        tw[st] = CLO_LDW(pW0 + min(st, ns - 1) * 16);
+        tv[st] = CLO_LDW(pV0 + min(st, ns - 1) * 16);
+      }
+    } else {
+#pragma unroll
+      for (int st = 0; st < MFU_MAXS; ++st) {
+        tw[st] = CLO_LDW(pW0 + min(st, ns - 1) * 16);
+        tv[st] = CLO_LDW(pV0 + min(st, ns - 1) * 16);
+      }
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int u = 0; u < SPC; ++u) {
+        const int e = tid + u * MFU_T;
+        if (e < tot) {
+          const int n = e / q4, kk = (e - n * q4) * 4;
+          *reinterpret_cast<f32x4 *>(&s_fu[(which * NP + n) * LDB + kk]) = n < N ? sv[which][u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+  }
+  MFU_STAMP(7);
+  __syncthreads();
+  MFU_STAMP(8);
+  // =====================================================================================
+  // phase 2: partial z2 / dz2 of tile (fb, kb): wave `wave` owns chunks wave, wave + 8 of the block; a chunk's fragments
+  // (<= 11 steps x [W row ; V row]) live in registers, the next chunk's are requested step by step as this one's are used
+  // =====================================================================================
+  const float *pBa = s_fu + idx * LDB + s4;
+  const float *pBd = s_fu + (NP + idx) * LDB + s4;
+  const int q = lane >> 4, col = lane & 15;
+  for (int ch = wave; ch < nch; ch += WAVES) {
+    const bool has_next = ch + WAVES < nch;
+    const float *pWn, *pVn;
+    rows_of(has_next ? ch + WAVES : ch, pWn, pVn);
+    f32x4 accz[NT], accd[NT], accv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      accz[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accd[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int st = 0; st < MFU_MAXS; ++st) {
+      if (st < ns) {
+        const float4 wv = tw[st], vv = tv[st];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 ba = ld4(pBa + t * 16 * LDB + st * 16);
+          const float4 bd = ld4(pBd + t * 16 * LDB + st * 16);
+#define CLO_MFU_MM(E)                                                                 \
+  accz[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.E, ba.E, accz[t], 0, 0, 0);      \
+  accd[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.E, bd.E, accd[t], 0, 0, 0);      \
+  accv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.E, ba.E, accv[t], 0, 0, 0);
+          CLO_MFU_MM(x) CLO_MFU_MM(y) CLO_MFU_MM(z) CLO_MFU_MM(w)
+#undef CLO_MFU_MM
+        }
+      }
+      if (has_next) {   // (wave-uniform) the slot just used takes the same step of the wave's next chunk
+        tw[st] = CLO_LDW(pWn + min(st, ns - 1) * 16);
+        tv[st] = CLO_LDW(pVn + min(st, ns - 1) * 16);
+      }
+    }
+    MFU_STAMP(ch == wave ? 9 : 10);
+    // D layout: row = (lane >> 4) * 4 + r = feature inside the chunk, col = batch row in the tile
+    const int j = (c0 + ch) * 16 + q * 4;
+    if (j < d2) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float *dst = p.part + (((long)kb * 2) * NP + t * 16 + col) * d2 + j;
+        st4(dst, make_float4(accz[t][0], accz[t][1], accz[t][2], accz[t][3]));
+        st4(dst + (long)NP * d2, make_float4(accd[t][0] + accv[t][0], accd[t][1] + accv[t][1],
+                                              accd[t][2] + accv[t][2], accd[t][3] + accv[t][3]));
+      }
+    }
+  }
+  MFU_STAMP(11);
+  __syncthreads();
+  if (tid == 0) {
+    // a launch whose wait was cut short says so in its own output (the slab entry this thread wrote itself)
+    if (launch_bad != 0u && nch > 0) p.part[(((long)kb * 2) * NP) * d2 + (long)c0 * 16] = __builtin_nanf("");
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(sy), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace clo
+
+static bool mid_fused_shape_ok(int L, const int *dims, int N) {
+  if (L != 3 || N <= NB || N > 64) return false;
+  const int d0 = dims[0], d1 = dims[1], d2 = dims[2];
+  if (d0 % 16 || d1 % 16 || d2 % 4 || d0 < 64 || dims[3] > HEAD_CMAX) return false;
+  if (d1 < 256 || cdiv(d1 / 16, 16) > MFU_MAXS) return false;        // K ranges of 1 .. 11 steps
+  if (d2 < 256 || cdiv(cdiv(d2, 16), 16) > MFU_MAXCH) return false;  // feature blocks of <= 11 chunks
+  return true;
+}
+template <int NT>
+static size_t mid_fused_smem() {
+  const size_t p1 = (size_t)8 * 2 * NT * 2 * 4 * 32, p2 = (size_t)2 * 16 * NT * (MFU_KR + 4);
+  return std::max(p1, p2) * sizeof(float);
+}
+// admission: the column-group counters need all 256 workgroups resident (one per CU), a host-visible fault word, 16-byte
+// aligned operands; otherwise the two-launch route serves
+template <int NT>
+static bool mid_fused_ok(int L, const int *dims, int N, const float *const *W, const float *const *VW, const float *X,
+                         const unsigned *sync) {
+  // BUILT, parity-green and MEASURED in round 6, OFF by default: 27.5 / 40.4 / 50.4 / 64.6 us at 16 / 32 / 48 / 64 rows against
+  // 25.2 / 37 / 51 / 60.5 us for the two launches it replaces (profiles/r06_c2_mid_fused_forward_timeline.txt: the phases of one
+  // workgroup per CU run back to back -- layer 1, slice epilogue, seam, operand staging, tile products -- where two launches
+  // with two workgroups per CU hide each other's prologues).
+#ifndef CLO_MLP_MID_FUSED
+#define CLO_MLP_MID_FUSED 0
+#endif
+  static const bool on = CLO_MLP_MID_FUSED != 0;
+  if (!on || !sync || !mid_fused_shape_ok(L, dims, N)) return false;
+  if (!W[0] || !VW[0] || !W[1] || !VW[1]) return false;
+  for (const void *q : {(const void *)W[0], (const void *)VW[0], (const void *)W[1], (const void *)VW[1], (const void *)X})
+    if (!aligned16(q)) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (device_cu_count(dev) != MFU_G) return false;
+  if (!fault_words_device(dev) || fault_disabled(dev, FAULT_MEGA)) return false;
+  static int occ[64];
+  static std::once_flag once;
+  std::call_once(once, [] { for (int &o : occ) o = -1; });
+  int o = __atomic_load_n(&occ[dev], __ATOMIC_RELAXED);
+  if (o < 0) {
+    int nb = 0;
+    const void *fn = reinterpret_cast<const void *>(mid_fused_fwd_kernel<NT>);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_fused_smem<NT>());
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, MFU_T, mid_fused_smem<NT>()) != hipSuccess) {
+      (void)hipGetLastError();
+      nb = 0;
+    }
+    o = nb >= 1 ? 1 : 0;
+    __atomic_store_n(&occ[dev], o, __ATOMIC_RELAXED);
+  }
+  return o == 1;
+}
+template <int NT>
+static int mid_fused_launch(const MidFusedArgs &a0, hipStream_t st) {
+  MidFusedArgs a = a0;
+  int dev = 0;
+  int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+  if (rc != CLO_OK) return rc;
+  a.fault = fault_words_device(dev);
+  if (a.fault) a.fault += FAULT_MEGA;
+  a.spin_limit = spin_limit();
+  PersistGate &gate = PersistGate::of(dev);
+  rc = gate.admit(st, MFU_G);
+  if (rc != CLO_OK) return rc;
+  {
+    ProfScope prof(0, 8.0 * ((double)a.d0 * a.d1 + (double)a.d1 * a.d2), st);
+    hipLaunchKernelGGL((mid_fused_fwd_kernel<NT>), dim3(MFU_G), dim3(MFU_T), mid_fused_smem<NT>(), st, a);
+  }
+  rc = check_hip(hipGetLastError(), "mid_fused_fwd_kernel");
+  if (rc != CLO_OK) {
+    gate.abort();
+    return rc;
+  }
+  return gate.done(st);
+}
+
 constexpr int MID_MAX_N = 64;
 
 static bool mid_chain_ok(int L, const int *dims, const float *const *W, const float *const *VW,
@@ -2998,7 +3425,7 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
                      const float *const *b, const float *const *VW, const float *const *Vb,
                      float *const *OW, float *const *Ob, int N, int loss_kind, const float *aux,
                      int aux_rank, float scale, float beta, float *const *a, float *const *da,
-                     float *const *dphi, float *const *dl, float *gws, long gws_sz, hipStream_t st) {
+                     float *const *dphi, float *const *dl, float *gws, long gws_sz, unsigned *fsync, hipStream_t st) {
   constexpr int NP = 16 * NT;
   int dmax = 0;
   for (int l = 0; l <= L; ++l) dmax = std::max(dmax, dims[l]);
@@ -3017,8 +3444,32 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   float *dslab[2] = {dLbuf + dL_sz, dLbuf + dL_sz + JB_MAX * NP * dmax};
   if (fslab_sz + hp_sz + dL_sz + 2 * JB_MAX * NP * dmax > gws_sz) return CLO_EUNSUP;
   int rc;
+  // ---- forward + JVP of layers 1 and 2 in ONE persistent launch where the network and the device allow it
+  int l_first = 1;
+  if (mid_fused_ok<NT>(L, dims, N, W, VW, a[0], fsync)) {
+    MidFusedArgs fa{};
+    fa.W1 = W[0]; fa.b1 = b ? b[0] : nullptr; fa.V1 = VW[0]; fa.Vb1 = Vb ? Vb[0] : nullptr; fa.X = a[0];
+    fa.W2 = W[1]; fa.V2 = VW[1];
+    fa.a1 = a[1]; fa.da1 = da[1]; fa.dphi1 = dphi[1]; fa.part = fslab;
+    fa.N = N; fa.d0 = dims[0]; fa.d1 = dims[1]; fa.d2 = dims[2]; fa.act1 = acts[0];
+    fa.sync = fsync;
+    rc = mid_fused_launch<NT>(fa, st);
+    if (rc != CLO_OK) return rc;
+    {  // finish layer 2 (16 K ranges) + partial products of the head: as behind mid_fwd_kernel
+      HeadFwdArgs ha{};
+      ha.part = fslab; ha.ksplit = 16; ha.part_rows = NP;
+      ha.b = b ? b[1] : nullptr; ha.Vb = Vb ? Vb[1] : nullptr;
+      ha.a = a[2]; ha.da = da[2]; ha.dphi = dphi[2];
+      ha.N = N; ha.d = dims[2]; ha.act = acts[1];
+      ha.WL = W[L - 1]; ha.VL = VW[L - 1]; ha.C = C; ha.hp = hp;
+      ProfScope pf(3, 0.0, st);
+      hipLaunchKernelGGL(head_fwd_kernel, dim3(head_nblk, N), dim3(256), 0, st, ha);
+      CLO_CHECK_LAUNCH("head_fwd_kernel");
+    }
+    l_first = L;   // (L == 3: both hidden layers are done)
+  }
   // ---- forward + JVP: hidden layers 1 .. L-1
-  for (int l = 1; l <= L - 1; ++l) {
+  for (int l = l_first; l <= L - 1; ++l) {
     const int di = dims[l - 1], dout = dims[l];
     const bool has_da = l > 1;
     // Layers without an incoming tangent (the first one) finish in their own launch (in-block split-K over the
@@ -3281,12 +3732,16 @@ static long ggn_ws_mega_offset(int L, const int *dims, int N) {
 }
 extern "C" long clo_mlp_ggn_ws_floats(int L, const int *dims, int N) {
   if (L <= 0 || !dims || N < 0) return 0;
+  if (mid_fused_shape_ok(L, dims, N)) return ggn_ws_mega_offset(L, dims, N) + MFU_SYNC_WORDS;
   if (!mega_shape_ok(L, dims, N)) return ggn_ws_core_floats(L, dims, N);
   return ggn_ws_mega_offset(L, dims, N) + cdiv(mega_xch_floats(dims[1], dims[2]), 64) * 64 + mega_sync_words() +
          mega_debug_floats();
 }
 extern "C" int clo_mlp_ggn_ws_init(int L, const int *dims, int N, float *ws, void *stream) {
   CLO_REQUIRE(L >= 1 && dims && N >= 0 && ws, "clo_mlp_ggn_ws_init: bad arguments");
+  if (mid_fused_shape_ok(L, dims, N))   // counters of the fused two-layer forward of the 9 ... 64-row chain
+    return check_hip(hipMemsetAsync(ws + ggn_ws_mega_offset(L, dims, N), 0, (size_t)MFU_SYNC_WORDS * 4, (hipStream_t)stream),
+                     "hipMemsetAsync(fused forward counters)");
   if (!mega_shape_ok(L, dims, N)) return CLO_OK;  // nothing to initialise
   // the counters AND the exchange area: its tagged slots (CLO_MG_TOPLL in mlp_mega.hip) must not show a tag of some earlier
   // owner of this memory
@@ -3396,9 +3851,11 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
                        xch, sync, st);
   }
   if (narrow && mid_chain_ok(L, dims, W, VW, OW, N)) {
+    // counters of the fused two-layer forward (behind the core workspace, zeroed by clo_mlp_ggn_ws_init)
+    unsigned *fsync = mid_fused_shape_ok(L, dims, N) ? reinterpret_cast<unsigned *>(ws + ggn_ws_mega_offset(L, dims, N)) : nullptr;
 #define CLO_MID_CHAIN(T)                                                                              \
   mid_chain<T>(L, dims, acts, W, b, VW, Vb, OW, Ob, N, loss_kind, aux, aux_rank, loss_scale * alpha, beta, \
-               a, da, dphi, dl, gws, gws_sz, st)
+               a, da, dphi, dl, gws, gws_sz, fsync, st)
 #ifndef CLO_MLP_MID_MAX
 #define CLO_MLP_MID_MAX MID_MAX_N
 #endif
