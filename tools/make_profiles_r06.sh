@@ -63,7 +63,8 @@ cd $R
 python tools/probe_cols.py 8 32 64 2>&1 | grep "K=" > $OUT/r06_c2_columns.txt
 python tools/probe_fold.py 2>&1 | grep -v amdgpu > $OUT/r06_kfac_factor_kernels_per_shape.txt
 for q in 4 16; do python tools/probe_kfac_fork.py $q 2>&1 | grep queues=; done > $OUT/r06_kfac_capture_fork_modes.txt
-# ---- the driver's line (full extras), twice
+# ---- the driver's line (full extras), twice; the traffic / kernel summaries of THIS library first, so the line cites them
+cp $OUT/r06_c2_n8_pmc_traffic.json $OUT/r06_c2_n8_pmc_traffic.txt $OUT/r06_c2_n8_bench_kernel_stats.txt $R/profiles/
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r06_bench_n1.json 2> $OUT/bench_stderr.txt
 python bench.py --gpus 1 > $OUT/r06_bench_n1_default_steps.json 2>> $OUT/bench_stderr.txt
 tail -c 1500 $OUT/r06_bench_n1.json
