@@ -40,6 +40,13 @@ constexpr unsigned V3_SPIN = 1u << 24;   // polls before a waiting workgroup giv
 constexpr long V3_SK_MAX_TILES = 1024;   // stream-K below this many output tiles
 constexpr int V3_SK_MAX_PARTS = 8;       // partial accumulators one finisher adds, at most (about)
 
+// Timing builds (tools/r6/probe_gemm_timeline.py): wall_clock64() stamps (100 MHz) of thread 0 of every workgroup.
+#ifdef CLO_V3_TIMING
+#define V3_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && s.stamps) s.stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define V3_STAMP(i) do { } while (0)
+#endif
+
 struct V3Sched {
   int streamk;        // 0: one tile per workgroup; 1: stream-K
   int nkt;            // stream-K: k tiles per output tile
@@ -52,6 +59,9 @@ struct V3Sched {
   unsigned epoch;     // stream-K: unique per launch on this (device, stream)
   unsigned *fault;    // stream-K: host-pinned fault word of the device (or nullptr)
   unsigned spin_limit;
+#ifdef CLO_V3_TIMING
+  unsigned long long *stamps;   // [1024][8]
+#endif
 };
 
 __device__ __forceinline__ i32x4v v3_srd(const float *p) {
@@ -122,17 +132,95 @@ struct V3Op {
   }
 };
 
+// Wide epilogue (round 6): a finished tile staged in LDS as R rows x CC columns (row pitch `pitch` floats, a multiple of 4) goes
+// out as 16-byte stores, one full 512-byte (CC = 128) or 256-byte (CC = 64) row segment per 32 / 16 lanes; C(row, col) =
+// epilogue(alpha t + beta C) with the fused epilogues of GemmArgs (store_final in gemm.h, same arithmetic).  (r0, c0) = the
+// tile's origin in C, rows >= rmax / columns >= cmax are outside the matrix.
+struct V3Epi {
+  int kind, act, div;
+  const float *vec, *mul;
+  long ld_mul;
+  float *out2;
+  const float *Cbase;
+};
+__device__ __forceinline__ float v3_epi_one(const V3Epi &E, float v, int row, int col, const float *c) {
+  if (E.kind == EPI_ACT) {
+    float dphi;
+    v = act_apply(E.act, v + (E.vec ? E.vec[col] : 0.f), dphi);
+    if (E.out2) E.out2[c - E.Cbase] = dphi;
+  } else if (E.kind == EPI_MUL) {
+    v = (v + (E.vec ? E.vec[col] : 0.f)) * E.mul[(long)row * E.ld_mul + col];
+  } else if (E.kind == EPI_MUL_T) {
+    v *= E.mul[(long)(col / E.div) * E.ld_mul + row];
+  }
+  return v;
+}
+template <int R, int CC, int NTHR>
+__device__ __forceinline__ void v3_store_rows(const float *T, int pitch, float *C, long ldc, int r0, int c0, int rmax, int cmax,
+                                              float alpha, float beta, int tid, const V3Epi &E) {
+  constexpr int V = CC / 4;
+  static_assert((R * V) % NTHR == 0, "whole passes");
+#pragma unroll
+  for (int it = 0; it < R * V / NTHR; ++it) {
+    const int idx = it * NTHR + tid, i = idx / V, c4 = idx % V;
+    const int row = r0 + i, col = c0 + 4 * c4;
+    if (row >= rmax || col >= cmax) continue;
+    const f32x4v t = *reinterpret_cast<const f32x4v *>(T + i * pitch + 4 * c4);
+    float *c = C + (long)row * ldc + col;
+    if (col + 3 < cmax) {
+      f32x4v v;
+      v[0] = alpha * t[0]; v[1] = alpha * t[1]; v[2] = alpha * t[2]; v[3] = alpha * t[3];
+      if (beta != 0.f) {
+        const f32x4v o = *reinterpret_cast<const f32x4v *>(c);
+        v[0] += beta * o[0]; v[1] += beta * o[1]; v[2] += beta * o[2]; v[3] += beta * o[3];
+      }
+      if (E.kind == EPI_ACT) {
+        f32x4v d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float dphi;
+          v[e] = act_apply(E.act, v[e] + (E.vec ? E.vec[col + e] : 0.f), dphi);
+          d[e] = dphi;
+        }
+        if (E.out2) *reinterpret_cast<f32x4v *>(E.out2 + (c - E.Cbase)) = d;   // (16-byte aligned: checked by the caller)
+      } else if (E.kind == EPI_MUL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] + (E.vec ? E.vec[col + e] : 0.f)) * E.mul[(long)row * E.ld_mul + col + e];
+      } else if (E.kind == EPI_MUL_T) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= E.mul[(long)((col + e) / E.div) * E.ld_mul + row];
+      }
+      *reinterpret_cast<f32x4v *>(c) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (col + e < cmax) {
+          float v = alpha * t[e];
+          if (beta != 0.f) v += beta * c[e];
+          c[e] = v3_epi_one(E, v, row, col + e, c + e);
+        }
+    }
+  }
+}
+
 static_assert(alignof(V3Sched) == 8 && alignof(GemmArgs) == 8, "kernel-argument layout: V3Sched follows GemmArgs at the next multiple of 8");
 
 struct V3Tile {
   int bm, bn, m0, n0, batch, split, kb, ke, nk;
 };
 
+// first unit of range w of W over U units.  W <= 256: below 2^23 units the product fits 32 bits (a 64-bit division is a
+// few hundred instructions on this machine, and the stream-K prologue takes several)
+__device__ __forceinline__ long v3_bound(int w, long U, int W) {
+  if (U < (1L << 23)) return (long)((unsigned)w * (unsigned)U / (unsigned)W);
+  return (long)w * U / W;
+}
+
 template <int BMt, int BNt>
 __device__ __forceinline__ void v3_tile(const GemmArgs &p, long lin, int y, bool sk, int tiles_per_mat, V3Tile &t) {
   int tl = (int)lin;
   if (sk) {
-    t.batch = (int)(lin / tiles_per_mat);
+    t.batch = lin < (1L << 31) ? (int)((unsigned)lin / (unsigned)tiles_per_mat) : (int)(lin / tiles_per_mat);
     tl = (int)(lin - (long)t.batch * tiles_per_mat);
     t.split = 0;
   } else {
@@ -196,6 +284,7 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
                                                                                   // (small tiles: 2 of 4) follow the group
   static_assert(NST >= 3, "ring depth");
   extern __shared__ __attribute__((aligned(1024))) float lds_all[];
+  V3_STAMP(0);
 
   const int tid = threadIdx.x & (NTHR - 1);   // (thread index inside the k group)
   const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR) : 0;
@@ -233,9 +322,9 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
       const int q = s.workers / kNumXCD, rem = s.workers % kNumXCD;
       w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
-    u0 = (long)w * U / W;
-    const long u1 = (long)(w + 1) * U / W;
-    c_lin = (u1 - 1) / s.nkt;
+    u0 = v3_bound(w, U, W);
+    const long u1 = v3_bound(w + 1, U, W);
+    c_lin = U < (1L << 23) ? (long)((unsigned)(u1 - 1) / (unsigned)s.nkt) : (u1 - 1) / s.nkt;
     c_kt = (int)(max(u0, c_lin * s.nkt) - c_lin * s.nkt);
     c_kend = (int)(u1 - c_lin * s.nkt);
     n_units = (int)(u1 - u0);
@@ -347,7 +436,9 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
     issue_all(t);
     prod_advance();
   }
+  V3_STAMP(7);
   v3_wait_vm_barrier<PER *(NST - 2)>();
+  V3_STAMP(1);
 
   f32x4v fa[2][MT], fb[2][NT];
 #define V3_SB __builtin_amdgcn_sched_barrier(0);
@@ -414,6 +505,7 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
       asm volatile("" : "+s"(ka));
       const auto *pf = reinterpret_cast<const __attribute__((address_space(4))) GemmArgs *>(ka);
       const auto *sf = reinterpret_cast<const __attribute__((address_space(4))) V3Sched *>(ka + ((sizeof(GemmArgs) + 7) & ~7ul));
+      V3_STAMP(tile_done ? 4 : 2);
       if (SK && !tile_done) {
         // partial accumulator -> slot of this workgroup, then the flag (the data is complete in memory first)
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -432,16 +524,21 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid == 0)
           __hip_atomic_store(sf->flags + (long)(w * G + g) * V3_FLAG_STRIDE, sf->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        V3_STAMP(3);
       } else {
         bool sk_bad = false;
         if (SK && !whole_from_start) {
-          // the workgroups before this one hold the first part of the tile's k range
+          // the workgroups before this one hold the first part of the tile's k range.  All their flags are awaited first,
+          // then the partials are added in the fixed order w - 1, w - 2, ... with the loads of the next one in flight behind the
+          // adds of the current one (round 6: "wait, load 64 KB, add" per partial was one memory round trip EACH -- 4.9 us for
+          // the three or four partials of a 512-row product, tools/r6/probe_gemm_timeline.py).
           const long tstart = c_lin * sf->nkt;
-          for (int w2 = w - 1; w2 >= 0; --w2) {
-            if ((long)(w2 + 1) * U / W <= tstart) break;
-            if (tid == 0) {
+          int np = 0;
+          for (int w2 = w - 1; w2 >= 0 && v3_bound(w2 + 1, U, W) > tstart; --w2) ++np;
+          if (tid == 0) {
+            for (int j = 0; j < np && !sk_bad; ++j) {
               unsigned spins = 0;
-              while (__hip_atomic_load(sf->flags + (long)(w2 * G + g) * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sf->epoch) {
+              while (__hip_atomic_load(sf->flags + (long)((w - 1 - j) * G + g) * V3_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sf->epoch) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > sf->spin_limit) {   // the partial never came: raise the device's fault word and go on --
                   if (sf->fault) __hip_atomic_store(sf->fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -450,23 +547,44 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
                 }
               }
             }
-            asm volatile("s_barrier" ::: "memory");
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                sf->slots + (long)(w2 * G + g) * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
+          }
+          asm volatile("s_barrier" ::: "memory");
+          constexpr int CH = MT * NT * 4;
+          float *const slots = sf->slots;
+          auto ld = [&](f32x4v(&b)[CH], int w2) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slots + (long)(w2 * G + g) * (BMt * BNt), 0, BMt * BNt * 4, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int c = 0; c < CH; ++c)
+              b[c] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((c * NTHR + tid) * 16), 0, 16));
+          };
+          auto add = [&](const f32x4v(&b)[CH]) {
 #pragma unroll
-              for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const f32x4v v = __builtin_bit_cast(
-                      f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
-                                  rs, (unsigned)(((((i * NT + j) * 4 + q) * NTHR) + tid) * 16), 0, 16));
-                  acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1];
-                  acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
-                }
+            for (int c = 0; c < CH; ++c) {
+              const int ij = c / 4, q = c % 4;
+              acc[ij / NT][ij % NT][4 * q] += b[c][0]; acc[ij / NT][ij % NT][4 * q + 1] += b[c][1];
+              acc[ij / NT][ij % NT][4 * q + 2] += b[c][2]; acc[ij / NT][ij % NT][4 * q + 3] += b[c][3];
+            }
+          };
+          if constexpr (CH <= 8) {
+            f32x4v b0[CH], b1[CH];
+            if (np > 0) ld(b0, w - 1);
+            for (int j = 0; j < np; j += 2) {
+              if (j + 1 < np) ld(b1, w - 2 - j);
+              add(b0);
+              if (j + 1 < np) {
+                if (j + 2 < np) ld(b0, w - 3 - j);
+                add(b1);
+              }
+            }
+          } else {
+            f32x4v b0[CH];
+            for (int j = 0; j < np; ++j) {
+              ld(b0, w - 1 - j);
+              add(b0);
+            }
           }
         }
+        V3_STAMP(5);
         if (sk_bad) acc[0][0][0] = __builtin_nanf("");   // (thread 0 holds entry (m0, n0) of the tile: always inside C)
         if (KG > 1) {
           // group 1's half of the k range joins group 0's through LDS (an area behind both rings: zero tiles issued past the
@@ -500,6 +618,52 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
         const float alpha = to_ws ? 1.f : pf->alpha;
         const float beta = to_ws ? 0.f : pf->beta;
         const bool mirror = pf->sym && !to_ws && ct.bm != ct.bn;
+#ifndef CLO_V3_WIDE_EPI
+#define CLO_V3_WIDE_EPI 1
+#endif
+        // Wide form: when this was the workgroup's last unit the ring is dead, and the tile (then its mirror image) is staged in
+        // it and leaves as full-row 16-byte stores.  The per-lane form below wrote 32 four-byte lanes per row segment -- 256
+        // store instructions per 128 x 128 tile, 4.7 - 5.6 us between the last MFMA and the end of the kernel -- and the mirror image
+        // of a symmetric product in 16-byte pieces of 32 different rows per instruction.
+        V3Epi E;
+        E.kind = to_ws ? EPI_NONE : pf->epi;
+        E.act = pf->e_act; E.div = pf->e_div; E.vec = pf->e_vec; E.mul = pf->e_mul; E.ld_mul = pf->ld_mul; E.out2 = pf->e_out2;
+        E.Cbase = pf->C;
+        const bool wide = CLO_V3_WIDE_EPI && KG == 1 && u + 1 == n_units && (ldc & 3) == 0 && ((unsigned long)C & 15ul) == 0 &&
+                          (E.kind == EPI_NONE || (!mirror && (E.kind != EPI_ACT || ((unsigned long)E.out2 & 15ul) == 0)));
+        if (wide) {
+          const int Mx = pf->M, Nx = pf->N;
+          asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // every fragment read and every DMA into the ring is over
+          float *T = lds3;
+          {
+            constexpr int PD = BNt + 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                  T[(wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PD + wn * WNC + nt * 32 + li] = acc[mt][nt][r];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            v3_store_rows<BMt, BNt, NTHR>(T, PD, C, ldc, ct.m0, ct.n0, Mx, Nx, alpha, beta, tid, E);
+          }
+          if (mirror) {
+            constexpr int PM = BMt + 4;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the direct image has been read
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  f32x4v v;
+                  v[0] = acc[mt][nt][4 * q]; v[1] = acc[mt][nt][4 * q + 1]; v[2] = acc[mt][nt][4 * q + 2]; v[3] = acc[mt][nt][4 * q + 3];
+                  *reinterpret_cast<f32x4v *>(T + (wn * WNC + nt * 32 + li) * PM + wm * WM + mt * 32 + 8 * q + 4 * lh) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            v3_store_rows<BNt, BMt, NTHR>(T, PM, C, ldc, ct.n0, ct.m0, Nx, Mx, alpha, beta, tid, E);
+          }
+        } else
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -545,6 +709,7 @@ __global__ __launch_bounds__(WVM *WVN * 64 * KG) void gemm_v3_kernel(const GemmA
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero tiles issued past the end
+  V3_STAMP(6);
 #undef V3_GROUP
 #undef V3_SB
 }
@@ -584,6 +749,9 @@ static int v3_flags(hipStream_t stream, unsigned **flags, unsigned *epoch) {
   return CLO_OK;
 }
 
+#ifdef CLO_V3_TIMING
+static unsigned long long *g_v3_stamps_host = nullptr;
+#endif
 // the schedule decision for `tiles` output tiles (all matrices of the batch) of 128 x 128 and k extent K
 static long v3_streamk_workers(long tiles, int K) {
   const int nkt = (int)cdiv(K, V3_BK);
@@ -637,7 +805,10 @@ static bool v3_use_tall(const GemmArgs &a, int batch) {
 // through each CU's ~30 GB/s memory pipe -- 1024^3: 15 us of MFMA work + 10 us of partial traffic --, while four times as
 // many quarter-size tiles need no (or 16 KB) partials; the register-staged 64 x 64 x 64 loop of gemm.hip that served these
 // shapes prefetches ONE k tile ahead, less than the memory latency at 0.4 us per k tile, and ran at half its MFMA rate.
-constexpr int V3S_BM = 64, V3S_BN = 64, V3S_WVM = 2, V3S_WVN = 2, V3S_NST = 4;
+#ifndef CLO_V3S_NST
+#define CLO_V3S_NST 4
+#endif
+constexpr int V3S_BM = 64, V3S_BN = 64, V3S_WVM = 2, V3S_WVN = 2, V3S_NST = CLO_V3S_NST;
 static bool v3_use_small(const GemmArgs &a, int batch) {
 #ifndef CLO_GEMM_V3_SMALL
 #define CLO_GEMM_V3_SMALL 1
@@ -651,9 +822,14 @@ static bool v3_use_small(const GemmArgs &a, int batch) {
   // win where few of them are in flight per unit of K: skinny outputs (min(M, N) <= 384: 128 x 2304 x 2304 29.8 -> 27.9 us,
   // 2688 x 256 x 2688 52.1 -> 46.3) and symmetric products (half the tiles: 512-row pixel Grams 46.7 -> 43.1 / 18.9 -> 17.6 us,
   // the patch products of round 4 175 -> 140 us); 512 x 2304 x 2304 loses (64 -> 81 us) and keeps the 128 x 128 tiles.
-  if (a.epi != EPI_NONE) return false;   // (fused epilogues run the engine's generic store path per tile: C2 at 65 / 128 rows 180 -> 192 / 194 -> 201 us)
+#ifndef CLO_V3_SMALL_EPI
+#define CLO_V3_SMALL_EPI 0
+#endif
+  if (a.epi != EPI_NONE && !CLO_V3_SMALL_EPI) return false;   // (fused epilogues run the engine's generic store path per tile: C2 at 65 / 128 rows 180 -> 192 / 194 -> 201 us)
   if (mode == 2) return tiles < 2L * kNumCU;   // (probe builds: wherever the square tiles leave the second round half empty)
-  return tiles < kNumCU && (a.sym || std::min(a.M, a.N) <= 384);
+  // round 6: also the products the register-staged 64 x 64 x 64 loop of gemm.hip used to keep (M N <= 2^20, e. g. 1024^3: at most
+  // one small tile per CU): 32.7 -> 29.5 us
+  return tiles < kNumCU && (a.sym || std::min(a.M, a.N) <= 384 || (long)a.M * a.N <= 1024L * 1024L);
 }
 
 // Tile configuration and stream-K worker count (0: one tile per workgroup) for a problem; streamk_level as GemmArgs::streamk
@@ -703,6 +879,9 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
                    int *tile_m, int *tile_n) {
   GemmArgs a = a0;
   V3Sched s{};
+#ifdef CLO_V3_TIMING
+  s.stamps = g_v3_stamps_host;
+#endif
 #ifndef CLO_GEMM_STREAMK
 #define CLO_GEMM_STREAMK 1
 #endif
@@ -832,3 +1011,7 @@ int launch_gemm_v3(const GemmArgs &a0, int batch, bool a_kc, bool b_kc, hipStrea
 }
 
 }  // namespace clo
+
+#ifdef CLO_V3_TIMING
+extern "C" void clo_v3_timing_set(unsigned long long *device_buffer) { clo::g_v3_stamps_host = device_buffer; }
+#endif

@@ -1,6 +1,9 @@
-cd /root/repo; R=$PWD; export TMPDIR=/tmp
-O=$R/gpurun_out/r6_run17; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "mid_rows_chain or ggn_matvec" > $O/t.log 2>&1; echo "tests rc=$?" | tee -a $O/summary.txt
-tail -6 $O/t.log
-timeout 300 python tools/probe_c2.py 9 16 17 32 33 48 64 2>&1 | grep "N=" | sed 's/^/fused   /' | tee -a $O/sweep.txt
-CLO_HIP_LIB=$R/curvlinops_amd/lib/variants/libclo_nofuse.so timeout 300 python tools/probe_c2.py 9 16 17 32 33 48 64 2>&1 | grep "N=" | sed 's/^/2-launch /' | tee -a $O/sweep.txt
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/r17
+cd /tmp && export TMPDIR=/tmp
+for n in 128 512; do
+rm -rf /tmp/pr$n
+rocprofv3 --kernel-trace --stats -d /tmp/pr$n -o k -- python $R/tools/probe_c2.py $n > /tmp/probe_$n.log 2>&1
+grep "N=" /tmp/probe_$n.log
+python $R/tools/prof_summary.py /tmp/pr$n/k_results.db $R/gpurun_out/r17/c2_n${n}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python tools/probe_c2.py $n"
+cut -c1-200 $R/gpurun_out/r17/c2_n${n}_kernel_stats.txt | head -24
+done
