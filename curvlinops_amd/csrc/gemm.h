@@ -86,6 +86,107 @@ __device__ __forceinline__ void store_final(const GemmArgs &p, float *c, int row
   *c = v;
 }
 
+using f32x4w = __attribute__((ext_vector_type(4))) float;
+
+// Wide epilogue (round 6, both MFMA engines): a finished tile staged in LDS as R rows x CC columns (row pitch `pitch` floats, a multiple of 4) goes
+// out as 16-byte stores, one full 512-byte (CC = 128) or 256-byte (CC = 64) row segment per 32 / 16 lanes; C(row, col) =
+// epilogue(alpha t + beta C) with the fused epilogues of GemmArgs (store_final in gemm.h, same arithmetic).  (r0, c0) = the
+// tile's origin in C, rows >= rmax / columns >= cmax are outside the matrix.
+struct V3Epi {
+  int kind, act, div;
+  const float *vec, *mul;
+  long ld_mul;
+  float *out2;
+  const float *Cbase;
+};
+__device__ __forceinline__ float v3_epi_one(const V3Epi &E, float v, int row, int col, const float *c) {
+  if (E.kind == EPI_ACT) {
+    float dphi;
+    v = act_apply(E.act, v + (E.vec ? E.vec[col] : 0.f), dphi);
+    if (E.out2) E.out2[c - E.Cbase] = dphi;
+  } else if (E.kind == EPI_MUL) {
+    v = (v + (E.vec ? E.vec[col] : 0.f)) * E.mul[(long)row * E.ld_mul + col];
+  } else if (E.kind == EPI_MUL_T) {
+    v *= E.mul[(long)(col / E.div) * E.ld_mul + row];
+  }
+  return v;
+}
+template <int R, int CC, int NTHR>
+__device__ __forceinline__ void v3_store_rows(const float *T, int pitch, float *C, long ldc, int r0, int c0, int rmax, int cmax,
+                                              float alpha, float beta, int tid, const V3Epi &E) {
+  constexpr int V = CC / 4;
+  static_assert((R * V) % NTHR == 0, "whole passes");
+#pragma unroll
+  for (int it = 0; it < R * V / NTHR; ++it) {
+    const int idx = it * NTHR + tid, i = idx / V, c4 = idx % V;
+    const int row = r0 + i, col = c0 + 4 * c4;
+    if (row >= rmax || col >= cmax) continue;
+    const f32x4w t = *reinterpret_cast<const f32x4w *>(T + i * pitch + 4 * c4);
+    float *c = C + (long)row * ldc + col;
+    if (col + 3 < cmax) {
+      f32x4w v;
+      v[0] = alpha * t[0]; v[1] = alpha * t[1]; v[2] = alpha * t[2]; v[3] = alpha * t[3];
+      if (beta != 0.f) {
+        const f32x4w o = *reinterpret_cast<const f32x4w *>(c);
+        v[0] += beta * o[0]; v[1] += beta * o[1]; v[2] += beta * o[2]; v[3] += beta * o[3];
+      }
+      if (E.kind == EPI_ACT) {
+        f32x4w d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float dphi;
+          v[e] = act_apply(E.act, v[e] + (E.vec ? E.vec[col + e] : 0.f), dphi);
+          d[e] = dphi;
+        }
+        if (E.out2) *reinterpret_cast<f32x4w *>(E.out2 + (c - E.Cbase)) = d;   // (16-byte aligned: checked by the caller)
+      } else if (E.kind == EPI_MUL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] + (E.vec ? E.vec[col + e] : 0.f)) * E.mul[(long)row * E.ld_mul + col + e];
+      } else if (E.kind == EPI_MUL_T) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= E.mul[(long)((col + e) / E.div) * E.ld_mul + row];
+      }
+      *reinterpret_cast<f32x4w *>(c) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (col + e < cmax) {
+          float v = alpha * t[e];
+          if (beta != 0.f) v += beta * c[e];
+          c[e] = v3_epi_one(E, v, row, col + e, c + e);
+        }
+    }
+  }
+}
+
+// The 32 x 32 MFMA accumulators of a BMt x BNt tile (wave (wm, wn) holds WM x WNC of it as MT x NT blocks; lane (li, lh), register r
+// = row (r & 3) + 8 (r >> 2) + 4 lh, column li of a block) into LDS, row-major [BMt][BNt + 4] ...
+template <int MT, int NT, int WM, int WNC, int PD, typename Acc>
+__device__ __forceinline__ void stage_tile_direct(float *T, const Acc &acc, int wm, int wn, int li, int lh) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        T[(wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PD + wn * WNC + nt * 32 + li] = acc[mt][nt][r];
+}
+// ... and transposed, [BNt][BMt + 4] (the mirror image of a symmetric product): four consecutive rows of a lane are one 16-byte
+// LDS write
+template <int MT, int NT, int WM, int WNC, int PM, typename Acc>
+__device__ __forceinline__ void stage_tile_mirror(float *T, const Acc &acc, int wm, int wn, int li, int lh) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4w v;
+        v[0] = acc[mt][nt][4 * q]; v[1] = acc[mt][nt][4 * q + 1]; v[2] = acc[mt][nt][4 * q + 2]; v[3] = acc[mt][nt][4 * q + 3];
+        *reinterpret_cast<f32x4w *>(T + (wn * WNC + nt * 32 + li) * PM + wm * WM + mt * 32 + 8 * q + 4 * lh) = v;
+      }
+}
+
 bool gemm_v2_eligible(const GemmArgs &a, int batch);
 // LDS-DMA engine (gemm_v3.hip): 128 x 128 x 32 tiles, optional stream-K schedule
 bool gemm_v3_eligible(const GemmArgs &a, int batch);

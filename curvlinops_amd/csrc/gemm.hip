@@ -647,6 +647,41 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_v2_kernel(const GemmAr
   const float alpha = to_ws ? 1.f : p.alpha;
   const float beta = to_ws ? 0.f : p.beta;
   const bool mirror = p.sym && !to_ws && bm != bn;
+#ifndef CLO_V2_WIDE_EPI
+#define CLO_V2_WIDE_EPI 1
+#endif
+  // Wide form (round 6, as in gemm_v3.hip): the tile is staged in LDS (the loop's buffers are dead behind its last barrier; the
+  // launch sizes the allocation for the larger of the two uses) and leaves as full-row 16-byte stores, its mirror image
+  // likewise; the separate destination of the last column (col_out) is served from the staged tile.
+  V3Epi E;
+  E.kind = to_ws ? EPI_NONE : p.epi;
+  E.act = p.e_act; E.div = p.e_div; E.vec = p.e_vec; E.mul = p.e_mul; E.ld_mul = p.ld_mul; E.out2 = p.e_out2; E.Cbase = p.C;
+  const bool has_col_out = !to_ws && p.col_out;
+  const bool wide = CLO_V2_WIDE_EPI && (ldc & 3) == 0 && ((unsigned long)C & 15ul) == 0 &&
+                    (E.kind == EPI_NONE || (!mirror && !has_col_out && (E.kind != EPI_ACT || ((unsigned long)E.out2 & 15ul) == 0)));
+  if (wide) {
+    constexpr int NTHR = NW * 64, PD = BNt + 4, PM = BMt + 4;
+    float *T = lds2;
+    stage_tile_direct<MT, NT, WM, WNC, PD>(T, acc, wm, wn, li, lh);
+    __syncthreads();
+    v3_store_rows<BMt, BNt, NTHR>(T, PD, C, ldc, m0, n0, p.M, has_col_out ? p.N - 1 : p.N, alpha, beta, tid, E);
+    if (has_col_out && n0 <= p.N - 1 && p.N - 1 < n0 + BNt) {
+      for (int i = tid; i < BMt; i += NTHR)
+        if (m0 + i < p.M) {
+          float *c = p.col_out + m0 + i;
+          float v = alpha * T[i * PD + (p.N - 1 - n0)];
+          if (beta != 0.f) v += beta * *c;
+          *c = v;
+        }
+    }
+    if (mirror) {
+      __syncthreads();
+      stage_tile_mirror<MT, NT, WM, WNC, PM>(T, acc, wm, wn, li, lh);
+      __syncthreads();
+      v3_store_rows<BNt, BMt, NTHR>(T, PM, C, ldc, n0, m0, p.N, p.M, alpha, beta, tid, E);
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -993,8 +1028,11 @@ int launch_gemm(GemmArgs a, int batch, hipStream_t stream) {
 #define CLO_V2X(AK, BKC_, BKV, BMV, BNV, WM_, WN_, PT)                                            \
   {                                                                                               \
     constexpr int nthr = WM_ * WN_ * 64;                                                          \
-    const size_t smem =                                                                           \
+    const size_t smem_loop =                                                                      \
         2 * (TileIO<AK, BKV, nthr, BMV>::FLOATS + TileIO<BKC_, BKV, nthr, BNV>::FLOATS) * sizeof(float); \
+    /* (the wide epilogue stages the finished tile, or its mirror image, in the same allocation) */ \
+    const size_t smem_epi = (size_t)std::max(BMV * (BNV + 4), BNV * (BMV + 4)) * sizeof(float);   \
+    const size_t smem = std::max(smem_loop, smem_epi);                                            \
     auto kern = gemm_v2_kernel<AK, BKC_, BKV, BMV, BNV, WM_, WN_, PT>;                            \
     if (smem > 64 * 1024) {                                                                       \
       static bool attr_set = false;                                                               \
@@ -1099,7 +1137,8 @@ int launch_gemm_sqsum(GemmArgs a, int batch, int splits, hipStream_t stream) {
 #define CLO_SQ(AK, BKC_)                                                                                          \
   {                                                                                                               \
     constexpr int nthr = 512;                                                                                     \
-    const size_t smem = 2 * (TileIO<AK, 32, nthr, 128>::FLOATS + TileIO<BKC_, 32, nthr, 128>::FLOATS) * sizeof(float); \
+    const size_t smem = std::max<size_t>(2 * (TileIO<AK, 32, nthr, 128>::FLOATS + TileIO<BKC_, 32, nthr, 128>::FLOATS) * sizeof(float), \
+                                         (size_t)128 * 132 * sizeof(float));   /* (loop buffers / staged tile of the wide epilogue) */ \
     auto kern = gemm_v2_kernel<AK, BKC_, 32, 128, 128, 2, 4, false, true>;                                        \
     static bool attr_set = false;                                                                                 \
     if (smem > 64 * 1024 && !attr_set) {                                                                          \
