@@ -1628,7 +1628,16 @@ struct MidOuterArgs {
   int d_in[OUTER_MAXL], d_out[OUTER_MAXL];
   float alpha, beta;
   int N;
+#ifdef CLO_MID_TIMING
+  unsigned long long *stamps;   // [blocks][8]: entry, staged, MFMAs done, end, HW_ID
+#endif
 };
+#ifdef CLO_MID_TIMING
+static unsigned long long *g_mid_stamps_host = nullptr;
+#define MIDO_STAMP(i) do { if (threadIdx.x == 0 && p.stamps && block < 4096) p.stamps[block * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MIDO_STAMP(i) do { } while (0)
+#endif
 // CW = columns per block (256: 4 column quarters x 2 row halves of two 16-row tiles; 128 beyond 32 batch rows
 // -- 2 column halves x 4 row quarters of one tile -- so that three blocks still fit a CU's LDS).
 template <int NT, bool ACCUM, int CW>
@@ -1649,6 +1658,10 @@ __device__ __forceinline__ void mid_outer_body(const MidOuterArgs &p, int block,
   const int cq = wave % NCQ, rh = wave / NCQ;
   const int l16 = lane & 15, kg = lane >> 4;
   const int jbase = by * MIDO_ROWS;
+  MIDO_STAMP(0);
+#ifdef CLO_MID_TIMING
+  if (threadIdx.x == 0 && p.stamps && block < 4096) { p.stamps[block * 8 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); p.stamps[block * 8 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
+#endif
   // stage delta^T [n][row] and a [n][256 columns]
   for (int e = tid; e < NP * MIDO_ROWS; e += 512) {
     const int n = e / MIDO_ROWS, jj = e - n * MIDO_ROWS;
@@ -1662,6 +1675,7 @@ __device__ __forceinline__ void mid_outer_body(const MidOuterArgs &p, int block,
     *reinterpret_cast<float4 *>(&s_a[n * CW + c4]) = v;
   }
   __syncthreads();
+  MIDO_STAMP(1);
   if (p.out_b[l] && bx == 0 && tid < MIDO_ROWS && jbase + tid < d_out) {
     float sb = 0.f;
     for (int n = 0; n < NP; ++n) sb += s_dT[n * LDR + tid];
@@ -1686,6 +1700,7 @@ __device__ __forceinline__ void mid_outer_body(const MidOuterArgs &p, int block,
     }
   }
   // D[row = 4 q + r][column l16 of component e] -> out_W[jbase + rh 32 + rt 16 + 4 q + r][i0 + e]
+  MIDO_STAMP(2);
   const int i0 = bx * CW + cq * 64 + l16 * 4;
   if (i0 >= d_in) return;
   const int q = lane >> 4;
@@ -1705,12 +1720,148 @@ __device__ __forceinline__ void mid_outer_body(const MidOuterArgs &p, int block,
         CLO_STW(po, v);
       }
     }
+#ifdef CLO_MID_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MIDO_STAMP(3);
 }
 
 template <int NT, bool ACCUM, int CW>
 __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem_o[];
   mid_outer_body<NT, ACCUM, CW>(p, blockIdx.x, smem_o);
+}
+
+// Round 6, second form of the outer products (tools/r6/probe_mid_outer_timeline.py showed why the tile-per-block kernel above takes
+// 28 us at 64 rows for 8.6 us of MFMA work and 7.6 us of stores: every block stages 48 KB for 32 KB of output, all resident blocks
+// stage, multiply and store in lock-step, and the grid takes two such rounds).  Here a block owns 128 output rows x a RANGE of columns:
+// each wave keeps its 16 rows of delta^T in REGISTERS (the A operand, NP / 4 values per lane, loaded once), the rows of a_{l-1} stream
+// through a double-buffered LDS tile 64 columns at a time (global loads of chunk c + 1 in flight behind the MFMAs and stores of chunk c,
+// one barrier per chunk), and the result leaves as 4 rows x 256 bytes per store instruction.  Ranges are sized so that the whole grid
+// is resident at once (about two blocks per CU).
+constexpr int MO2_ROWS = 128, MO2_CW = 64;
+struct MidOuter2Args {
+  int nlayers;
+  int first_block[OUTER_MAXL + 1];
+  MidDelta md[OUTER_MAXL];
+  const float *a_prev[OUTER_MAXL];
+  float *out_W[OUTER_MAXL];
+  float *out_b[OUTER_MAXL];
+  int d_in[OUTER_MAXL], d_out[OUTER_MAXL];
+  int nranges[OUTER_MAXL], cr[OUTER_MAXL];   // column ranges per 128-row strip; columns per range (a multiple of MO2_CW)
+  float alpha, beta;
+  int N;
+#ifdef CLO_MID_TIMING
+  unsigned long long *stamps;
+#endif
+};
+template <int NT, bool ACCUM>
+__global__ __launch_bounds__(512) void mid_outer2_kernel(const MidOuter2Args p) {
+  constexpr int NP = 16 * NT, KS = NP / 4;
+  constexpr int NF4 = NP * (MO2_CW / 4);           // float4 per staged chunk
+  constexpr int SL = (NF4 + 511) / 512;            // ... per thread
+  extern __shared__ __attribute__((aligned(16))) float s_o2[];   // [2][NP][MO2_CW]
+  const int block = blockIdx.x;
+  int l = 0;
+  while (l + 1 < p.nlayers && block >= p.first_block[l + 1]) ++l;
+  const int local = block - p.first_block[l];
+  const int strip = local / p.nranges[l], rg = local - strip * p.nranges[l];
+  const int d_in = p.d_in[l], d_out = p.d_out[l], N = p.N;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, kg = lane >> 4;
+  const int c_begin = rg * p.cr[l], c_end = min(d_in, c_begin + p.cr[l]);
+  const int nchunks = (c_end - c_begin + MO2_CW - 1) / MO2_CW;
+  const float *__restrict__ ap = p.a_prev[l];
+  MIDO_STAMP(0);
+#ifdef CLO_MID_TIMING
+  if (threadIdx.x == 0 && p.stamps && block < 4096) { p.stamps[block * 8 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); p.stamps[block * 8 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
+#endif
+
+  // chunk loader: thread -> (row n, 4 columns); rows beyond N and columns beyond the range are zeros
+  float4 pre[SL];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < SL; ++u) {
+      const int e = u * 512 + tid, n = e / (MO2_CW / 4), c4 = (e - n * (MO2_CW / 4)) * 4;
+      const int i = c_begin + c * MO2_CW + c4;
+      const bool ok = e < NF4 && n < N && i < c_end;
+      const float4 v = ld4(ap + (long)(ok ? n : 0) * d_in + (ok ? i : 0));   // (unconditional load, clamped address)
+      pre[u] = ok ? v : zero4();
+    }
+  };
+  auto store_chunk = [&](float *buf) {
+#pragma unroll
+    for (int u = 0; u < SL; ++u) {
+      const int e = u * 512 + tid;
+      if (e < NF4) *reinterpret_cast<float4 *>(buf + 4 * e) = pre[u];
+    }
+  };
+  if (nchunks > 0) load_chunk(0);
+
+  // the wave's 16 rows of delta^T: lane (l16, kg) holds delta[4 s + kg][j] for s = 0 .. KS - 1
+  const int j = strip * MO2_ROWS + wave * 16 + l16;
+  float af[KS];
+#pragma unroll
+  for (int s4 = 0; s4 < KS; ++s4) af[s4] = mid_delta_at<NT>(p.md[l], 4 * s4 + kg, j, N, d_out);
+  if (p.out_b[l] && rg == 0) {   // bias gradient: column sums of delta
+    float sb = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < KS; ++s4) sb += af[s4];
+    sb += __shfl_xor(sb, 16);
+    sb += __shfl_xor(sb, 32);
+    if (kg == 0 && j < d_out) {
+      float *pb = p.out_b[l] + j;
+      *pb = (ACCUM ? p.beta * *pb : 0.f) + p.alpha * sb;
+    }
+  }
+  if (nchunks <= 0) return;
+  store_chunk(s_o2);
+  __syncthreads();
+  MIDO_STAMP(1);
+
+  const int q = lane >> 4;
+  const int row0 = strip * MO2_ROWS + wave * 16 + q * 4;
+  float *__restrict__ ow = p.out_W[l];
+  for (int c = 0; c < nchunks; ++c) {
+    const float *buf = s_o2 + (c & 1) * (NP * MO2_CW);
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < KS; ++s4) {
+      const float4 bv = *reinterpret_cast<const float4 *>(buf + (4 * s4 + kg) * MO2_CW + l16 * 4);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], bv.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], bv.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], bv.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], bv.w, acc[3], 0, 0, 0);
+    }
+    // D[row = 4 q + r][column l16 of component e] -> out_W[row0 + r][i0 + e]
+    const int i0 = c_begin + c * MO2_CW + l16 * 4;
+    if (i0 < c_end) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jr = row0 + r;
+        if (jr < d_out) {
+          float4 v = make_float4(p.alpha * acc[0][r], p.alpha * acc[1][r], p.alpha * acc[2][r], p.alpha * acc[3][r]);
+          float *po = ow + (long)jr * d_in + i0;
+          if (ACCUM) {
+            const float4 od = ld4(po);
+            v.x += p.beta * od.x; v.y += p.beta * od.y; v.z += p.beta * od.z; v.w += p.beta * od.w;
+          }
+          CLO_STW(po, v);
+        }
+      }
+    }
+    if (c + 1 < nchunks) store_chunk(s_o2 + ((c + 1) & 1) * (NP * MO2_CW));
+    __syncthreads();
+  }
+  MIDO_STAMP(2);
+#ifdef CLO_MID_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MIDO_STAMP(3);
 }
 
 // Round 6: the data chain's step delta_{l-1} = delta_l W_l and the outer products that only need delta_l (layer l, and the
@@ -2841,8 +2992,9 @@ constexpr int SKINNY_MAX_N = 8;  // whole-network matvec: one 8-row streaming pa
                                  // GEMM engine (32-row tiles, fused forward) is faster (measured)
 
 static long gemm_ws_floats(int N, int dmax) {
-  // split-K partial slabs for the widest product of the large-batch path
-  return 32L * (long)std::max(N, 128) * dmax;
+  // split-K partial slabs for the widest product of the large-batch path; the 9 ... 64-row chain carves its forward slabs
+  // (<= 16 x 2 x 64 rows) and two sets of <= 24 row-range slabs of delta out of the same area
+  return 48L * (long)std::max(N, 128) * dmax;
 }
 
 // out[c][j] = beta out + sum_n g[n][c] X[n][j] (g == nullptr: column sums, C = 1); ws >= 16 C d
@@ -3435,7 +3587,7 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   float *fslab = gws;
   // the GEMM workspace this chain borrows holds 4096 dmax floats: 32 K ranges / 24 row ranges of up to 32
   // padded rows, half as many of 48 / 64
-  constexpr long KS_MAX = NT <= 2 ? 32 : 16, JB_MAX = NT <= 2 ? 24 : 12;
+  constexpr long KS_MAX = NT <= 2 ? 32 : 16, JB_MAX = 24;
   const long fslab_sz = KS_MAX * 2 * NP * dmax;
   float *hp = fslab + fslab_sz;
   const long hp_sz = (long)N * head_nblk * 2 * HEAD_CMAX + 64;
@@ -3520,7 +3672,7 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     // Besides the weights a launch moves the activations every block stages (row blocks x cols x d_in) and
     // the split-K slabs (written here, read by the finish): both cost like weight bytes.  Pick waves per
     // block (4 / 8 = 64 / 128 features) and the K split that minimise them at >= ~0.8 blocks per CU.
-    const long lds_b = NT <= 2 ? 65536 : 131072;   // the staged activations: one block per CU beyond 32 rows
+    const long lds_b = NT <= 2 ? 65536 : 150000;   // the staged activations: one block per CU beyond 32 rows
     const long kpb_max = std::min<long>(MF_KB_MAX, ((lds_b / (4 * cols) - 4) / 32) * 32);
     int wv = 4;
     long ksplit = 1, kpb = 32;
@@ -3537,7 +3689,12 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
         const long kse = cdiv(di, kp);
         const long blocks = rb * kse;
         if (blocks * 5 < kNumCU * 4 && !(ks == KS_MAX && best == 1e300)) continue;
-        const double traffic = (double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout;
+        // (round 6) ... weighted by how evenly the grid fills the chip: `slots` blocks run at a time (LDS and the 16 waves
+        // of a CU), a grid of 273 one-per-CU blocks takes two rounds for the work of 1.07
+        const long per_cu = std::max<long>(1, std::min<long>(160 * 1024 / ((long)cols * (kp + 4) * 4), 16 / w));
+        const long slots = per_cu * kNumCU, rounds = cdiv(blocks, slots);
+        const double traffic = ((double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout) * (double)(rounds * slots) /
+                               (double)blocks;
         if (traffic < best) { best = traffic; wv = w; ksplit = kse; kpb = kp; }
       }
     }
@@ -3605,6 +3762,9 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   bool outer_done[OUTER_MAXL + 2] = {};
   auto outer_args = [&](const int *layers, int count, MidOuterArgs &oa, double &bytes) {
     oa = MidOuterArgs{};
+#ifdef CLO_MID_TIMING
+    oa.stamps = g_mid_stamps_host;
+#endif
     oa.nlayers = count; oa.alpha = 1.f; oa.beta = beta; oa.N = N;
     int nb = 0;
     bytes = 0;
@@ -3622,7 +3782,9 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   };
   for (int l = L - 1; l >= 2; --l) {
     const int di = dims[l - 1], dout = dims[l];
-    long JB = cdiv(kNumCU, cdiv(di, 256));
+    // (beyond 32 rows a block's delta rows and merge buffer leave room for ONE block per CU: the grid must not exceed the CUs --
+    // round 6: JB_MAX was 12 there, C2's layer 2 ran on 11 x 12 = 132 of the 256 CUs, 28.8 us at 64 rows)
+    long JB = NT <= 2 ? cdiv(kNumCU, cdiv(di, 256)) : std::max<long>(1, kNumCU / cdiv(di, 256));
     JB = std::min<long>({JB, cdiv(dout, 64), JB_MAX});
     JB = std::max<long>(JB, cdiv(dout, NT <= 2 ? 512 : 256));   // LDS: rows x (Npad + 16) delta + merge buffer
     const int rpb = (int)(cdiv(cdiv(dout, JB), 8) * 8);
@@ -3682,6 +3844,41 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     double bytes;
     const int nb = outer_args(layers, count, oa, bytes);
     ProfScope prof(4, bytes, st);
+#ifndef CLO_MLP_MID_OUTER2
+#define CLO_MLP_MID_OUTER2 1
+#endif
+    bool aligned4 = true;
+    for (int k = 0; k < count; ++k) aligned4 = aligned4 && dims[layers[k] - 1] % 4 == 0;
+#ifndef CLO_MO2_PER_CU
+#define CLO_MO2_PER_CU 2
+#endif
+    // (measured: at <= 32 rows the tile-per-block kernel is 1.5 - 7 us faster -- its blocks are short there and delta_1 still
+    // arrives as row-range slabs that every block would sum again; from 33 rows on the streaming form wins)
+    if (CLO_MLP_MID_OUTER2 && aligned4 && NT >= 3) {
+      MidOuter2Args o2{};
+#ifdef CLO_MID_TIMING
+      o2.stamps = g_mid_stamps_host;
+#endif
+      o2.nlayers = count; o2.alpha = 1.f; o2.beta = beta; o2.N = N;
+      long strip_cols = 0;
+      for (int k = 0; k < count; ++k) strip_cols += cdiv(oa.d_out[k], MO2_ROWS) * (long)oa.d_in[k];
+      // about two resident blocks per CU, ranges of whole 64-column chunks
+      const int cr = (int)std::max<long>(MO2_CW, cdiv(cdiv(strip_cols, (long)CLO_MO2_PER_CU * kNumCU), MO2_CW) * MO2_CW);
+      int nb2 = 0;
+      for (int k = 0; k < count; ++k) {
+        o2.first_block[k] = nb2;
+        o2.md[k] = oa.md[k]; o2.a_prev[k] = oa.a_prev[k]; o2.out_W[k] = oa.out_W[k]; o2.out_b[k] = oa.out_b[k];
+        o2.d_in[k] = oa.d_in[k]; o2.d_out[k] = oa.d_out[k];
+        o2.cr[k] = cr; o2.nranges[k] = (int)cdiv(oa.d_in[k], cr);
+        nb2 += (int)cdiv(oa.d_out[k], MO2_ROWS) * o2.nranges[k];
+      }
+      o2.first_block[count] = nb2;
+      const size_t smem2 = (size_t)2 * NP * MO2_CW * sizeof(float);
+      if (beta != 0.f) hipLaunchKernelGGL((mid_outer2_kernel<NT, true>), dim3(nb2), dim3(512), smem2, st, o2);
+      else hipLaunchKernelGGL((mid_outer2_kernel<NT, false>), dim3(nb2), dim3(512), smem2, st, o2);
+      CLO_CHECK_LAUNCH("mid_outer2_kernel");
+      return CLO_OK;
+    }
     rc = beta != 0.f ? set_smem(mid_outer_kernel<NT, true, OCW>, osmem)
                      : set_smem(mid_outer_kernel<NT, false, OCW>, osmem);
     if (rc != CLO_OK) return rc;
@@ -4694,3 +4891,7 @@ extern "C" int clo_mlp_vjp(int L, const int *dims, const int *acts, const float 
   }
   return CLO_OK;
 }
+
+#ifdef CLO_MID_TIMING
+extern "C" void clo_mid_timing_set(unsigned long long *device_buffer) { clo::g_mid_stamps_host = device_buffer; }
+#endif

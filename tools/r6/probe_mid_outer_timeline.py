@@ -1,0 +1,40 @@
+"""Phase timeline of mid_outer_kernel (-DCLO_MID_TIMING build): per block entry / staged / MFMAs done / end (wall_clock64, 100 MHz) and
+the CU it ran on (HW_ID, XCC_ID)."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from curvlinops_amd import _hip
+lib = _hip.load()
+stamps = torch.zeros(4096, 8, dtype=torch.int64, device="cuda")
+lib.clo_mid_timing_set.argtypes = [ctypes.c_void_p]; lib.clo_mid_timing_set.restype = None
+lib.clo_mid_timing_set(ctypes.c_void_p(stamps.data_ptr()))
+dims, acts = [1024, 2816, 2688, 10], [1, 1, 0]
+torch.manual_seed(0)
+W = [torch.randn(dims[i + 1], dims[i], device="cuda") / dims[i] ** 0.5 for i in range(3)]
+b = [torch.randn(dims[i + 1], device="cuda") * 0.1 for i in range(3)]
+VW = [torch.rand_like(w) for w in W]; Vb = [torch.rand_like(x) for x in b]
+OW = [torch.empty_like(w) for w in W]; Ob = [torch.empty_like(x) for x in b]
+plan = _hip.MLPPlan(dims, acts)
+for N in [int(a) for a in sys.argv[1:]] or [16, 33, 64]:
+    X = torch.rand(N, dims[0], device="cuda")
+    for i in range(6):
+        plan.ggn_matvec(W, b, VW, Vb, OW, Ob, X, 0, 2.0 / (N * 10), 1.0, 0.0)
+    torch.cuda.synchronize()
+    stamps.zero_(); torch.cuda.synchronize()
+    plan.ggn_matvec(W, b, VW, Vb, OW, Ob, X, 0, 2.0 / (N * 10), 1.0, 0.0)
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy()
+    live = s[:, 0] > 0
+    nb = int(live.sum())
+    t0 = s[live, 0].min()
+    ent, stg, mf, end = [(s[live, i] - t0) / 100.0 for i in range(4)]
+    cu = (s[live, 5] & 0xf) * 4096 + (s[live, 4] >> 8 & 0xff)
+    print(f"N={N}: {nb} blocks on {len(set(cu.tolist()))} distinct (xcc, se/sh/cu) ids; kernel span {end.max():.2f} us")
+    print(f"   entry      min/mean/max {ent.min():6.2f} {ent.mean():6.2f} {ent.max():6.2f}")
+    print(f"   prologue   mean {np.mean(stg - ent):5.2f} max {np.max(stg - ent):5.2f} us   (entry -> operands in LDS)")
+    print(f"   chunk loop mean {np.mean(mf - stg):5.2f} max {np.max(mf - stg):5.2f} us")
+    print(f"   stores     mean {np.mean(end - mf):5.2f} max {np.max(end - mf):5.2f} us   (issue + drain, timing build only)")
+    print(f"   block life mean {np.mean(end - ent):5.2f} us; blocks resident (sum of lives / span / CUs) {np.sum(end - ent) / end.max() / 256:.2f} per CU")
+    # occupancy over time
+    ts = np.linspace(0, end.max(), 12)
+    print("   resident blocks at t:", " ".join(f"{t:.0f}us:{int(np.sum((ent <= t) & (end > t)))}" for t in ts))
