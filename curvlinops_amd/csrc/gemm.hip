@@ -1421,7 +1421,14 @@ int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float
   // tiny layers (small networks): one block's k loop is a chain of memory round trips, so small
   // tiles on more CUs with 64-deep k steps (as v2_config does for plain products)
   const bool tiny = (long)N * d_out <= 256L * 256L && d_in <= 1024;
-  const int bm = tiny ? 32 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128));
+  // (round 6: 64-row tiles also where they pad less than 128-row tiles -- 129 ... 192 rows are three tiles of 64 instead of two of
+  // 128, the second mostly padding: the 128 -> 129-row step of the matvec was 180 -> 257 us)
+#ifndef CLO_FWD3_PAD64
+#define CLO_FWD3_PAD64 1
+#endif
+  // (measured: 129 / 160 / 192 rows 267 -> 245 / 261 -> 243 / 276 -> 258 us; 257 ... 320 rows LOSE 23 us with five 64-row tiles)
+  const bool pad64 = CLO_FWD3_PAD64 && N > 128 && N <= 192;
+  const int bm = tiny ? 32 : (N <= 32 ? 32 : (N <= 64 || pad64 ? 64 : 128));
   const int bn = tiny ? 64 : (bm == 128 ? 64 : 128);
   const int bk = tiny ? 64 : 16;
   p.tiles_m = (int)cdiv(N, bm);

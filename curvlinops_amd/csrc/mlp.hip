@@ -1864,6 +1864,39 @@ __global__ __launch_bounds__(512) void mid_outer2_kernel(const MidOuter2Args p) 
   MIDO_STAMP(3);
 }
 
+// the outer products of `count` layers (fields of a MidOuterArgs filled as for mid_outer_kernel) in one mid_outer2_kernel launch
+#ifndef CLO_MO2_PER_CU
+#define CLO_MO2_PER_CU 2
+#endif
+template <int NT>
+static int launch_mid_outer2(const MidOuterArgs &oa, int count, float beta, int N, hipStream_t st) {
+  constexpr int NP = 16 * NT;
+  MidOuter2Args o2{};
+#ifdef CLO_MID_TIMING
+  o2.stamps = g_mid_stamps_host;
+#endif
+  o2.nlayers = count; o2.alpha = oa.alpha; o2.beta = beta; o2.N = N;
+  long strip_cols = 0;
+  for (int k = 0; k < count; ++k) strip_cols += cdiv(oa.d_out[k], MO2_ROWS) * (long)oa.d_in[k];
+  // about CLO_MO2_PER_CU resident blocks per CU (2, 3, 4 and 6 measured alike; 1 is 7 % slower), ranges of whole 64-column chunks
+  const int cr = (int)std::max<long>(MO2_CW, cdiv(cdiv(strip_cols, (long)CLO_MO2_PER_CU * kNumCU), MO2_CW) * MO2_CW);
+  int nb2 = 0;
+  for (int k = 0; k < count; ++k) {
+    o2.first_block[k] = nb2;
+    o2.md[k] = oa.md[k]; o2.a_prev[k] = oa.a_prev[k]; o2.out_W[k] = oa.out_W[k]; o2.out_b[k] = oa.out_b[k];
+    o2.d_in[k] = oa.d_in[k]; o2.d_out[k] = oa.d_out[k];
+    o2.cr[k] = cr; o2.nranges[k] = (int)cdiv(oa.d_in[k], cr);
+    nb2 += (int)cdiv(oa.d_out[k], MO2_ROWS) * o2.nranges[k];
+  }
+  o2.first_block[count] = nb2;
+  const size_t smem2 = (size_t)2 * NP * MO2_CW * sizeof(float);
+  static_assert(2 * NP * MO2_CW * sizeof(float) <= 64 * 1024, "within the default dynamic LDS limit");
+  if (beta != 0.f) hipLaunchKernelGGL((mid_outer2_kernel<NT, true>), dim3(nb2), dim3(512), smem2, st, o2);
+  else hipLaunchKernelGGL((mid_outer2_kernel<NT, false>), dim3(nb2), dim3(512), smem2, st, o2);
+  CLO_CHECK_LAUNCH("mid_outer2_kernel");
+  return CLO_OK;
+}
+
 // Round 6: the data chain's step delta_{l-1} = delta_l W_l and the outer products that only need delta_l (layer l, and the
 // head's layer at the first step) in ONE launch: the read-only sweep of W_l and the write-only stream of out_W_l are
 // independent, and as two launches each paid its own boundary, staging prologue and drain with one workgroup per CU
@@ -3849,36 +3882,9 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
 #endif
     bool aligned4 = true;
     for (int k = 0; k < count; ++k) aligned4 = aligned4 && dims[layers[k] - 1] % 4 == 0;
-#ifndef CLO_MO2_PER_CU
-#define CLO_MO2_PER_CU 2
-#endif
     // (measured: at <= 32 rows the tile-per-block kernel is 1.5 - 7 us faster -- its blocks are short there and delta_1 still
     // arrives as row-range slabs that every block would sum again; from 33 rows on the streaming form wins)
-    if (CLO_MLP_MID_OUTER2 && aligned4 && NT >= 3) {
-      MidOuter2Args o2{};
-#ifdef CLO_MID_TIMING
-      o2.stamps = g_mid_stamps_host;
-#endif
-      o2.nlayers = count; o2.alpha = 1.f; o2.beta = beta; o2.N = N;
-      long strip_cols = 0;
-      for (int k = 0; k < count; ++k) strip_cols += cdiv(oa.d_out[k], MO2_ROWS) * (long)oa.d_in[k];
-      // about two resident blocks per CU, ranges of whole 64-column chunks
-      const int cr = (int)std::max<long>(MO2_CW, cdiv(cdiv(strip_cols, (long)CLO_MO2_PER_CU * kNumCU), MO2_CW) * MO2_CW);
-      int nb2 = 0;
-      for (int k = 0; k < count; ++k) {
-        o2.first_block[k] = nb2;
-        o2.md[k] = oa.md[k]; o2.a_prev[k] = oa.a_prev[k]; o2.out_W[k] = oa.out_W[k]; o2.out_b[k] = oa.out_b[k];
-        o2.d_in[k] = oa.d_in[k]; o2.d_out[k] = oa.d_out[k];
-        o2.cr[k] = cr; o2.nranges[k] = (int)cdiv(oa.d_in[k], cr);
-        nb2 += (int)cdiv(oa.d_out[k], MO2_ROWS) * o2.nranges[k];
-      }
-      o2.first_block[count] = nb2;
-      const size_t smem2 = (size_t)2 * NP * MO2_CW * sizeof(float);
-      if (beta != 0.f) hipLaunchKernelGGL((mid_outer2_kernel<NT, true>), dim3(nb2), dim3(512), smem2, st, o2);
-      else hipLaunchKernelGGL((mid_outer2_kernel<NT, false>), dim3(nb2), dim3(512), smem2, st, o2);
-      CLO_CHECK_LAUNCH("mid_outer2_kernel");
-      return CLO_OK;
-    }
+    if (CLO_MLP_MID_OUTER2 && aligned4 && NT >= 3) return launch_mid_outer2<NT>(oa, count, beta, N, st);
     rc = beta != 0.f ? set_smem(mid_outer_kernel<NT, true, OCW>, osmem)
                      : set_smem(mid_outer_kernel<NT, false, OCW>, osmem);
     if (rc != CLO_OK) return rc;
@@ -4220,6 +4226,25 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
     return CLO_OK;
   }
   // ---- backward (two 8-row passes / GEMM path): layer by layer
+#ifndef CLO_MLP_ROWS_OUTER2
+#define CLO_MLP_ROWS_OUTER2 1
+#endif
+  const bool rows_outer2 = CLO_MLP_ROWS_OUTER2 && !skinny && N <= 128;
+  MidOuterArgs pend{};
+  pend.alpha = 1.f; pend.beta = beta; pend.N = N;
+  auto flush_outer2 = [&]() -> int {
+    if (pend.nlayers == 0) return CLO_OK;
+    int r;
+    switch ((N + 15) / 16) {
+      case 5: r = launch_mid_outer2<5>(pend, pend.nlayers, beta, N, st); break;
+      case 6: r = launch_mid_outer2<6>(pend, pend.nlayers, beta, N, st); break;
+      case 7: r = launch_mid_outer2<7>(pend, pend.nlayers, beta, N, st); break;
+      case 8: r = launch_mid_outer2<8>(pend, pend.nlayers, beta, N, st); break;
+      default: r = launch_mid_outer2<4>(pend, pend.nlayers, beta, N, st); break;   // (fewer rows on this path: padded to 64)
+    }
+    pend.nlayers = 0;
+    return r;
+  };
   for (int l = lstart; l >= 1; --l) {
     const int di = dims[l - 1], dout = dims[l];
     float *obl = Ob ? Ob[l - 1] : nullptr;
@@ -4231,6 +4256,21 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
     } else {
       // out_W = beta out_W + delta^T a_prev; with an implicit ones column appended to a_prev the
       // extra output column is the bias gradient (column sums of delta): one launch for both
+      // up to 128 rows (round 6): the streaming outer-product kernel of the 9 ... 64-row chain, delta^T in registers -- the K = N <= 128
+      // product on the GEMM engine is four k tiles per 128 x 128 output tile, all prologue and epilogue (2 x 23 us at 128 rows).
+      // delta_l and delta_{l-1} live in the two ping-pong buffers at the same time, so the products of two neighbouring layers
+      // share a launch, placed before the step that overwrites delta_l.
+      if (rows_outer2 && vec_ok(di, {a[l - 1], OW[l - 1]})) {
+        const int k = pend.nlayers++;
+        pend.md[k] = MidDelta{dcur, nullptr, nullptr, 0, 0};
+        pend.a_prev[k] = a[l - 1]; pend.out_W[k] = OW[l - 1]; pend.out_b[k] = obl; pend.d_in[k] = di; pend.d_out[k] = dout;
+        if (pend.nlayers == 2 || l == 1) {
+          rc = flush_outer2();
+          if (rc != CLO_OK) return rc;
+        }
+      } else {
+      rc = flush_outer2();   // (a pending neighbour's delta is overwritten by this layer's step below)
+      if (rc != CLO_OK) return rc;
       GemmArgs go = gemm_problem(dout, di, N, dcur, 1, dout, a[l - 1], di, 1, beta, OW[l - 1], di);
       bool bias_done = false;
       if (obl) {
@@ -4247,6 +4287,7 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
         rc = launch_small_outer(obl, nullptr, dcur, N, dout, 1, beta, nullptr, 0, st);
         if (rc != CLO_OK) return rc;
       }
+      }
       if (dprev) {  // delta_prev = act'_{l-1} * (delta W)
         GemmArgs gd = gemm_problem(N, di, dout, dcur, dout, 1, W[l - 1], di, 1, 0.f, dprev, di);
         gd.epi = EPI_MUL; gd.e_mul = dphi[l - 1]; gd.ld_mul = di;
@@ -4256,7 +4297,7 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
     }
     std::swap(dcur, dnext);
   }
-  return CLO_OK;
+  return flush_outer2();
 }
 
 // K-column exact Hessian (clo_mlp_hessian_matmat): the two elementwise pieces next to the GGN pipeline.
