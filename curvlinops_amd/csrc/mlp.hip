@@ -3726,8 +3726,9 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
         // of a CU), a grid of 273 one-per-CU blocks takes two rounds for the work of 1.07
         const long per_cu = std::max<long>(1, std::min<long>(160 * 1024 / ((long)cols * (kp + 4) * 4), 16 / w));
         const long slots = per_cu * kNumCU, rounds = cdiv(blocks, slots);
-        const double traffic = ((double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout) * (double)(rounds * slots) /
-                               (double)blocks;
+        // (a single, partly filled round costs nothing extra: its blocks share the bandwidth the missing ones would have used)
+        const double fill = rounds > 1 ? (double)(rounds * slots) / (double)blocks : 1.0;
+        const double traffic = ((double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout) * fill;
         if (traffic < best) { best = traffic; wv = w; ksplit = kse; kpb = kp; }
       }
     }
