@@ -3713,11 +3713,15 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
 #ifndef CLO_MLP_MID_WV
 #define CLO_MLP_MID_WV 0
 #endif
+#ifndef CLO_MID_KGRAN16
+#define CLO_MID_KGRAN16 0   // (measured neutral, same box: 64 rows 117.5 vs 117.2 us)
+#endif
     for (int w : {4, 8}) {
       if (CLO_MLP_MID_WV && w != CLO_MLP_MID_WV) continue;   // (A/B builds: force the waves per block)
       const long rb = cdiv(dout, w * 16);
       for (long ks = 1; ks <= KS_MAX; ++ks) {
-        const long kp = cdiv(cdiv(di, ks), 32) * 32;
+        const long kgran = (NT >= 3 && CLO_MID_KGRAN16) ? 16 : 32;   // (MFMA-bound beyond 32 rows: the finer K ranges fill the chip -- 21 x 12 blocks instead of 21 x 11)
+        const long kp = cdiv(cdiv(di, ks), kgran) * kgran;
         if (kp > kpb_max) continue;
         const long kse = cdiv(di, kp);
         const long blocks = rb * kse;
@@ -3726,8 +3730,10 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
         // of a CU), a grid of 273 one-per-CU blocks takes two rounds for the work of 1.07
         const long per_cu = std::max<long>(1, std::min<long>(160 * 1024 / ((long)cols * (kp + 4) * 4), 16 / w));
         const long slots = per_cu * kNumCU, rounds = cdiv(blocks, slots);
-        // (a single, partly filled round costs nothing extra: its blocks share the bandwidth the missing ones would have used)
-        const double fill = rounds > 1 ? (double)(rounds * slots) / (double)blocks : 1.0;
+        // (up to 32 rows the kernel is bandwidth-bound and a single, partly filled round costs nothing extra -- its blocks share the
+        // bandwidth the missing ones would have used; beyond that it is MFMA-bound and an idle CU is lost time: 64 rows 117 us with
+        // 231 blocks, 124 us with 210)
+        const double fill = (rounds > 1 || NT >= 3) ? (double)(rounds * slots) / (double)blocks : 1.0;
         const double traffic = ((double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout) * fill;
         if (traffic < best) { best = traffic; wv = w; ksplit = kse; kpb = kp; }
       }
