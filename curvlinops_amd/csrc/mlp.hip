@@ -3682,7 +3682,12 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
                      W[l - 1], b ? b[l - 1] : nullptr, VW[l - 1], Vb ? Vb[l - 1] : nullptr, a[l - 1],         \
                      DA ? da[l - 1] : nullptr, a[l], da[l], dphi[l], N, di, dout, acts[l - 1], kpw, fpb)
         if (!has_da) {
-          if (kpw == 128 && di % 128 == 0 && NT <= 2) { CLO_MIDFULL(false, 8); } else { CLO_MIDFULL(false, 4); }
+#ifndef CLO_MID_FULL_U8
+#define CLO_MID_FULL_U8 1
+#endif
+          // (all eight k steps of a wave in ONE batch of loads: a single memory round trip; round 6: also at 33 ... 48 rows, -1 ... -2 us;
+          // at 49 ... 64 rows the batch needs 250 registers per lane and measures 1 - 1.5 us slower than two batches of four)
+          if (kpw == 128 && di % 128 == 0 && (NT <= 2 || (CLO_MID_FULL_U8 && NT == 3))) { CLO_MIDFULL(false, 8); } else { CLO_MIDFULL(false, 4); }
         } else {
           if (NT <= 2) { CLO_MIDFULL(true, 4); } else { CLO_MIDFULL(true, 2); }
         }
