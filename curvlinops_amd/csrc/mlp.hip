@@ -1510,9 +1510,11 @@ struct MidDprevArgs {
   float *dst;
   int N, d_in, d_out, rows_per_block, final_write;
 };
-template <int NT>
+// CQ = column groups of 64 per block (4: 256 columns x 2 row halves; 2, round 6: 128 columns x 4 row quarters -- half as many
+// row-range slabs for the same number of blocks)
+template <int NT, int CQ = 4>
 __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, int by, float *smem) {
-  constexpr int NP = 16 * NT, MID_LDD = mid_ldd(NT);
+  constexpr int NP = 16 * NT, MID_LDD = mid_ldd(NT), RH = 8 / CQ;
   const float *__restrict__ W = dq.W;
   const MidDelta &md = dq.md;
   const float *__restrict__ dphi_prev = dq.dphi_prev;
@@ -1520,16 +1522,16 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
   const int N = dq.N, d_in = dq.d_in, d_out = dq.d_out, rows_per_block = dq.rows_per_block, final_write = dq.final_write;
   float *s_d = smem;                                  // [rows_per_block (padded to 8)][MID_LDD]
   const int rpad = (rows_per_block + 7) & ~7;
-  float *s_red = smem + rpad * MID_LDD;               // [4 quarters][NT][4][4][64]
+  float *s_red = smem + rpad * MID_LDD;               // [4 waves][NT][4][4][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cq = wave & 3, rh = wave >> 2;
+  const int cq = wave % CQ, rh = wave / CQ;
   const int c16 = lane & 15, kg = lane >> 4;
   const int jbase = by * rows_per_block;
-  const int i0 = bx * 256 + cq * 64 + c16 * 4;
+  const int i0 = bx * (64 * CQ) + cq * 64 + c16 * 4;
   const bool col_ok = i0 < d_in;   // d_in % 4 == 0: the lane's four columns are all in or all out
-  // rows of this wave: half of the block's range, in steps of 4
-  const int half = ((rows_per_block + 1) / 2 + 3) & ~3;
+  // rows of this wave: its part of the block's range, in steps of 4
+  const int half = ((rows_per_block + RH - 1) / RH + 3) & ~3;
   const int r0 = rh * half, r1 = min(rows_per_block, r0 + half);
   const float *pW = W + (long)(col_ok ? i0 : 0);
   auto wrow = [&](int jj) { return pW + (long)min(jbase + jj + kg, d_out - 1) * d_in; };
@@ -1575,17 +1577,32 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
       }
     }
   }
-  // merge the two row halves, then D[n = 4 q + r][column c16 of component e] -> P[n][i0 + e]
-  if (rh == 1) {
+  // merge the row parts pairwise through LDS (upper half of the parts -> lower half, RH / 2 = 4 / CQ waves x CQ column groups = 4 wave
+  // slots per round), then D[n = 4 q + r][column c16 of component e] -> P[n][i0 + e]
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+  for (int stride = RH / 2; stride >= 1; stride /= 2) {
+    if (rh >= stride && rh < 2 * stride) {
+      const int slot = (rh - stride) * CQ + cq;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_red[(((cq * NT + t) * 4 + e) * 4 + r) * 64 + lane] = acc[t][e][r];
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_red[(((slot * NT + t) * 4 + e) * 4 + r) * 64 + lane] = acc[t][e][r];
+    }
+    __syncthreads();
+    if (rh < stride && stride > 1) {
+      const int slot = rh * CQ + cq;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][e][r] += s_red[(((slot * NT + t) * 4 + e) * 4 + r) * 64 + lane];
+    }
+    if (stride > 1) __syncthreads();
   }
-  __syncthreads();
-  if (rh == 1 || !col_ok) return;
+  if (rh >= 1 || !col_ok) return;
   const int q = lane >> 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -1608,10 +1625,10 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
     }
 }
 
-template <int NT>
+template <int NT, int CQ = 4>
 __global__ __launch_bounds__(512) void mid_dprev_kernel(const MidDprevArgs q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  mid_dprev_body<NT>(q, blockIdx.x, blockIdx.y, smem);
+  mid_dprev_body<NT, CQ>(q, blockIdx.x, blockIdx.y, smem);
 }
 
 // All outer products of a matvec for up to 64 rows: out_W_l = beta out_W_l + alpha delta_l^T a_{l-1}, bias
@@ -3829,7 +3846,14 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     const int di = dims[l - 1], dout = dims[l];
     // (beyond 32 rows a block's delta rows and merge buffer leave room for ONE block per CU: the grid must not exceed the CUs --
     // round 6: JB_MAX was 12 there, C2's layer 2 ran on 11 x 12 = 132 of the 256 CUs, 28.8 us at 64 rows)
-    long JB = NT <= 2 ? cdiv(kNumCU, cdiv(di, 256)) : std::max<long>(1, kNumCU / cdiv(di, 256));
+#ifndef CLO_MID_DPREV_CQ2
+#define CLO_MID_DPREV_CQ2 1
+#endif
+    // (beyond 32 rows, round 6: blocks of 128 columns x 4 row quarters -- the same number of blocks with half the row ranges, i. e.
+    // half the slabs this launch writes and the finish launch reads)
+    constexpr int DCQ = (NT >= 3 && CLO_MID_DPREV_CQ2 && !CLO_MLP_MID_MERGE) ? 2 : 4;
+    constexpr int DCOLS = 64 * DCQ;
+    long JB = NT <= 2 ? cdiv(kNumCU, cdiv(di, DCOLS)) : std::max<long>(1, kNumCU / cdiv(di, DCOLS));
     JB = std::min<long>({JB, cdiv(dout, 64), JB_MAX});
     JB = std::max<long>(JB, cdiv(dout, NT <= 2 ? 512 : 256));   // LDS: rows x (Npad + 16) delta + merge buffer
     const int rpb = (int)(cdiv(cdiv(dout, JB), 8) * 8);
@@ -3839,7 +3863,7 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     const size_t smem = ((size_t)((rpb + 7) & ~7) * mid_ldd(NT) + NT * 4096) * sizeof(float);
     const int fin = JBe == 1 ? 1 : 0;
     MidDprevArgs dq{W[l - 1], md[l], dphi[l - 1], fin ? dl[l - 1] : slab, N, di, dout, rpb, fin};
-    const int gx = (int)cdiv(di, 256);
+    const int gx = (int)cdiv(di, DCOLS);
     if (merge_on) {
       int layers[2] = {l, L};
       const int count = l == L - 1 ? 2 : 1;
@@ -3863,10 +3887,10 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
       outer_done[l] = true;
       if (count == 2) outer_done[L] = true;
     } else {
-      rc = set_smem(mid_dprev_kernel<NT>, smem);
+      rc = set_smem(mid_dprev_kernel<NT, DCQ>, smem);
       if (rc != CLO_OK) return rc;
       ProfScope prof(2, 4.0 * di * dout, st);
-      hipLaunchKernelGGL((mid_dprev_kernel<NT>), dim3((unsigned)gx, (unsigned)JBe), dim3(512), smem, st, dq);
+      hipLaunchKernelGGL((mid_dprev_kernel<NT, DCQ>), dim3((unsigned)gx, (unsigned)JBe), dim3(512), smem, st, dq);
       CLO_CHECK_LAUNCH("mid_dprev_kernel");
     }
     if (!fin && NT > 2) {   // one pass over the slabs instead of one per consumer block
