@@ -568,6 +568,34 @@ def test_ggn_matvec_mid_rows_chain_c2(hip, N, loss):
     assert all(np.array_equal(a, b) for a, b in zip(*outs))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,loss", [(65, "mse"), (100, "ce"), (128, "bce"), (129, "mse"), (160, "ce")])
+def test_ggn_matvec_rows_chain_c2(hip, N, loss):
+    """The benchmark network at 65 ... 160 rows against the float64 oracle (round 6: up to 128 rows the outer products of the two
+    hidden layers leave in ONE launch of the streaming kernel, 5 ... 8 row tiles of 16; 129 ... 192 rows run the fused forward on
+    64-row tiles), accumulation into a filled output; two calls are bit-identical."""
+    g = np.random.default_rng(300 + N)
+    dims, acts = [1024, 2688, 2688, 10], ["relu", "relu", "identity"]
+    Ws, bs, vWs, vbs, X, y = _mega_case(g, dims, acts, N, loss)
+    rW, rb = O.ggn_matvec_batch(Ws, bs, acts, X, y, loss, "mean", vWs, vbs)
+    scale = (2.0 if loss == "mse" else 1.0) * O.reduction_factor(loss, "mean", N, dims[-1])
+    plan = hip.MLPPlan(dims, [ACT_CODE[a] for a in acts])
+    dW, db = [dev(W) for W in Ws], [dev(b) for b in bs]
+    dVW, dVb = [dev(v) for v in vWs], [dev(v) for v in vbs]
+    dX = dev(X)
+    fill = [g.random(r.shape) * np.abs(r).mean() for r in rW + rb]   # (on the scale of the block it is added to)
+    outs = []
+    for _ in range(2):
+        oW = [dev(f) for f in fill[:3]]
+        ob = [dev(f) for f in fill[3:]]
+        plan.ggn_matvec(dW, db, dVW, dVb, oW, ob, dX, LOSS_KIND[loss], scale, 1.0, 1.0)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in oW + ob])
+    for k, (a, r, f) in enumerate(zip(outs[0], rW + rb, fill)):
+        assert rel_err(a, r + f) < 1e-4, f"block {k}"
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
+
+
 @pytest.mark.parametrize("side_gemm", [False, True])
 def test_ggn_matvec_persistent_kernel_concurrent_streams(hip, side_gemm):
     """Round 4: the persistent kernel next to other work.  Two HIP streams each issue 50 products of the benchmark
