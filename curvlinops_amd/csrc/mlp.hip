@@ -3851,7 +3851,10 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
 #endif
     // (beyond 32 rows, round 6: blocks of 128 columns x 4 row quarters -- the same number of blocks with half the row ranges, i. e.
     // half the slabs this launch writes and the finish launch reads)
-    constexpr int DCQ = (NT >= 3 && CLO_MID_DPREV_CQ2 && !CLO_MLP_MID_MERGE) ? 2 : 4;
+#ifndef CLO_MID_DPREV_CQ2_ALL
+#define CLO_MID_DPREV_CQ2_ALL 0
+#endif
+    constexpr int DCQ = ((NT >= 3 || CLO_MID_DPREV_CQ2_ALL) && CLO_MID_DPREV_CQ2 && !CLO_MLP_MID_MERGE) ? 2 : 4;
     constexpr int DCOLS = 64 * DCQ;
     long JB = NT <= 2 ? cdiv(kNumCU, cdiv(di, DCOLS)) : std::max<long>(1, kNumCU / cdiv(di, DCOLS));
     JB = std::min<long>({JB, cdiv(dout, 64), JB_MAX});
