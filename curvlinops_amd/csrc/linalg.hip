@@ -56,6 +56,50 @@ __device__ __forceinline__ lf32x4 mm16(const float4 a, const float4 b, lf32x4 ac
   return acc;
 }
 
+// One chain of 16 steps for the Cholesky factor L of a 16 x 16 block AND X = L^-1 (round 6).  Lane (idx = lane & 15) holds row idx of
+// the block in s[] and column idx of X in x[]; every 16-lane row of the wave runs the same block.  Step k of the forward substitution
+// needs exactly column k of L and 1 / L_kk, which step k of the factorisation has just formed, and the SAME broadcast L[j][k] feeds both
+// updates; the broadcast is a DPP operand (row_newbcast: lane j of each row to all lanes of the row) instead of v_readlane through a
+// scalar register -- 2.5 -> 1.x us per block (tools/r6/probe_potrf_timeline.py).  Same operations per element, in the same order.
+template <int J>
+__device__ __forceinline__ float row_lane(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xF, 0xF, true));
+}
+template <int K, int J>
+struct Chol16Inner {
+  static __device__ __forceinline__ void run(float (&s)[16], float (&x)[16], float l, float xi) {
+    const float lj = row_lane<J>(l);
+    s[J] = fmaf(-l, lj, s[J]);
+    x[J] = fmaf(-lj, xi, x[J]);
+    Chol16Inner<K, J + 1>::run(s, x, l, xi);
+  }
+};
+template <int K>
+struct Chol16Inner<K, 16> {
+  static __device__ __forceinline__ void run(float (&)[16], float (&)[16], float, float) {}
+};
+template <int K>
+struct Chol16Step {
+  // bad: first non-positive pivot (1-based), kept as data: no exits inside the chain
+  static __device__ __forceinline__ void run(float (&s)[16], float (&x)[16], int idx, int &bad) {
+    const float d = row_lane<K>(s[K]);
+    // false for NaN too (padding rows have d == 1).  A bad pivot poisons the rest of the block with NaNs, which nobody reads
+    bad = (bad == 0 && !(d > 0.f)) ? K + 1 : bad;
+    const float inv = __builtin_amdgcn_rsqf(d);
+    const float l = (idx == K) ? d * inv : s[K] * inv;
+    s[K] = l;
+    const float xi = x[K] * inv;
+    x[K] = xi;  // X[K][idx]
+    Chol16Inner<K, K + 1>::run(s, x, l, xi);
+    Chol16Step<K + 1>::run(s, x, idx, bad);
+  }
+};
+template <>
+struct Chol16Step<16> {
+  static __device__ __forceinline__ void run(float (&)[16], float (&)[16], int, int &) {}
+};
+static_assert(PSB == 16, "the chain is written for 16 x 16 blocks");
+
 __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long ldin, float *A,
                                                         long lda, int nb, float *__restrict__ Linv,
                                                         long ldinv, int *__restrict__ status,
@@ -111,33 +155,14 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
         const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
         s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
       }
-      float my_inv = 1.f;
       int bad = 0;  // first non-positive pivot (1-based), kept as data: no exits inside the chain
 #pragma unroll
-      for (int k = 0; k < PSB; ++k) {
-        const float d = read_lane(s[k], k);
-        // uniform; false for NaN too (padding rows have d == 1).  A bad pivot poisons the rest of
-        // the block with NaNs, which nobody reads: the kernel leaves right after the chain.
-        bad = (bad == 0 && !(d > 0.f)) ? k + 1 : bad;
-        const float inv = __builtin_amdgcn_rsqf(d);
-        const float l = (idx == k) ? d * inv : s[k] * inv;
-        if (idx == k) my_inv = inv;
-        s[k] = l;
-#pragma unroll
-        for (int j = k + 1; j < PSB; ++j) s[j] = fmaf(-l, read_lane(l, j), s[j]);
-      }
+      for (int r = 0; r < PSB; ++r) x[r] = (r == idx) ? 1.f : 0.f;
+      Chol16Step<0>::run(s, x, idx, bad);   // (one chain of 16 steps for L and X = L^-1, above)
+      bad = __builtin_amdgcn_readfirstlane(bad);
       if (bad) {  // uniform
         if (lane == 0) *status = pivot_base + o + bad;
         return;
-      }
-#pragma unroll
-      for (int r = 0; r < PSB; ++r) x[r] = (r == idx) ? 1.f : 0.f;
-#pragma unroll
-      for (int i = 0; i < PSB; ++i) {
-        const float xi = x[i] * read_lane(my_inv, i);
-        x[i] = xi;  // X[i][idx]
-#pragma unroll
-        for (int r = i + 1; r < PSB; ++r) x[r] = fmaf(-read_lane(s[i], r), xi, x[r]);
       }
       if (lane < PSB) {
         float *dst = S + (o + idx) * PLD + o;
@@ -216,13 +241,28 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(const float *Ain, long l
 // stays sequential on wave 0 (registers, as above); the panel, the trailing update and the columns of the inverse are
 // spread over the waves.  LDS: S (becomes L) and X = L^-1, 128 x 132 floats each; X^T is not kept -- the one product
 // that wants it reads X by columns (four ds_read_b32 instead of one b128).
-constexpr int QNB = 128, QLD = QNB + 4, QW = 4, QBLK = QNB / PSB;
+#ifndef CLO_POTRF_QW
+#define CLO_POTRF_QW 8
+#endif
+// (QW = 8 since round 6: the panel, trailing-update and L^-1 phases are chains of LDS round trips per wave -- twice the waves, half the
+// chain per wave; the diagonal block stays with wave 0)
+constexpr int QNB = 128, QLD = QNB + 4, QW = CLO_POTRF_QW, QBLK = QNB / PSB;
 constexpr int QSMEM = (2 * QNB * QLD + QW * PSB * TLD) * (int)sizeof(float);
 
 __global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain, long ldin, float *A, long lda, int nb,
                                                                 float *__restrict__ Linv, long ldinv,
                                                                 int *__restrict__ status, int pivot_base,
-                                                                long batch_stride) {
+                                                                long batch_stride
+#ifdef CLO_POTRF_TIMING
+                                                                , unsigned long long *stamps
+#endif
+                                                                ) {
+#ifdef CLO_POTRF_TIMING
+#define PQ_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && stamps) stamps[(i)] = wall_clock64(); } while (0)
+#else
+#define PQ_STAMP(i) do { } while (0)
+#endif
+  PQ_STAMP(0);
   Ain += blockIdx.x * batch_stride;
   A += blockIdx.x * batch_stride;
   Linv += blockIdx.x * batch_stride;
@@ -234,21 +274,44 @@ __global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain
   const int idx = lane & 15, s4 = (lane >> 4) * 4;
   float *TT = TTall + wave * (PSB * TLD);
   if (tid == 0) bad_sh = 0;
+  // (16-byte path: every operand a multiple of four floats wide and 16-byte aligned -- the working matrices of the blocked recursion
+  // always are; nb is a multiple of 4 then)
+  const bool vec = ((ldin | lda | ldinv | (long)nb) & 3) == 0 &&
+                   (((unsigned long)Ain | (unsigned long)A | (unsigned long)Linv) & 15ul) == 0;
+  if (vec) {   // load: thread -> (row, four columns); rows / columns beyond nb: identity
+    float4 v[QNB * QNB / 4 / (QW * 64)];
+#pragma unroll
+    for (int it = 0; it < QNB * QNB / 4 / (QW * 64); ++it) {
+      const int e = it * (QW * 64) + tid, row = e / (QNB / 4), c4 = (e % (QNB / 4)) * 4;
+      v[it] = *reinterpret_cast<const float4 *>(Ain + (long)min(row, nb - 1) * ldin + min(c4, nb - 4));
+    }
+#pragma unroll
+    for (int it = 0; it < QNB * QNB / 4 / (QW * 64); ++it) {
+      const int e = it * (QW * 64) + tid, row = e / (QNB / 4), c4 = (e % (QNB / 4)) * 4;
+      float4 w = v[it];
+      if (row >= nb || c4 >= nb)
+        w = make_float4(row == c4 ? 1.f : 0.f, row == c4 + 1 ? 1.f : 0.f, row == c4 + 2 ? 1.f : 0.f, row == c4 + 3 ? 1.f : 0.f);
+      *reinterpret_cast<float4 *>(S + row * QLD + c4) = w;
+      *reinterpret_cast<float4 *>(X + row * QLD + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else
   // load: thread t owns column t & 127 of half the rows; rows / columns beyond nb: identity
   {
-    const int col = tid & (QNB - 1), r0 = (tid >> 7) * (QNB / 2);
+    constexpr int RPT = QNB / (QW * 64 / QNB);   // rows per thread: the block's threads form QW * 64 / QNB groups of QNB columns
+    const int col = tid & (QNB - 1), r0 = (tid >> 7) * RPT;
     const int cl = min(col, nb - 1);
-    float v[QNB / 2];
+    float v[RPT];
 #pragma unroll
-    for (int r = 0; r < QNB / 2; ++r) v[r] = Ain[(long)min(r0 + r, nb - 1) * ldin + cl];
+    for (int r = 0; r < RPT; ++r) v[r] = Ain[(long)min(r0 + r, nb - 1) * ldin + cl];
 #pragma unroll
-    for (int r = 0; r < QNB / 2; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       const int row = r0 + r;
       S[row * QLD + col] = (row < nb && col < nb) ? v[r] : ((row == col) ? 1.f : 0.f);
       X[row * QLD + col] = 0.f;
     }
   }
   __syncthreads();
+  PQ_STAMP(1);
 
   auto frag = [&](const float *M, int r0, int c0) {
     return *reinterpret_cast<const float4 *>(M + (r0 + idx) * QLD + c0 + s4);
@@ -263,9 +326,28 @@ __global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain
     for (int r = 0; r < 4; ++r) M[(r0 + s4 + r) * ld + c0 + idx] = scale * d[r];
   };
 
+  // block (ib, jb), jb < ib, of X = L^-1:  X_ij = -X_ii sum_{jb <= k < ib} L_ik X_kj  (needs row ib of L, X_ii and the rows < ib of X)
+  auto x_block = [&](int ib, int jb) {
+    lf32x4 t{0.f, 0.f, 0.f, 0.f};
+    for (int k = jb; k < ib; ++k)  // (L_ik X_kj)[i][n] = sum_kk L_ik[i][kk] X_kj[kk][n]
+      t = mm16(frag(S, ib * PSB, k * PSB), frag_t(X, QLD, k * PSB, jb * PSB), t);
+    store(TT, TLD, 0, 0, t, 1.f);   // t as it is: TT[i][n]
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes before its reads (other lanes' data)
+    // d = X_ii t: P = X_ii rows, Q rows = t^T rows = columns of TT
+    const lf32x4 d = mm16(frag(X, ib * PSB, ib * PSB), frag_t(TT, TLD, 0, 0), lf32x4{0.f, 0.f, 0.f, 0.f});
+    store(X, QLD, ib * PSB, jb * PSB, d, -1.f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
 #pragma unroll 1
   for (int kb = 0; kb < QBLK; ++kb) {
     const int o = kb * PSB;
+    // Round 6: while wave 0 factors diagonal block kb, the other waves -- idle in this phase before -- form row kb - 1 of the
+    // off-diagonal blocks of X = L^-1 (its L row, X_ii and the earlier rows of X are final since the previous step): the chains that
+    // ran after the loop (5.1 us of 27, tools/r6/probe_potrf_timeline.py) are hidden behind the diagonal blocks, only the last row is left.
+    if (wave != 0 && kb >= 2) {
+      for (int jb = wave - 1; jb < kb - 1; jb += QW - 1) x_block(kb - 1, jb);
+    }
     if (wave == 0) {  // ---- diagonal block in registers (every group of 16 lanes runs the same rows)
       float s[PSB], x[PSB];
       const float *src = S + (o + idx) * QLD + o;
@@ -274,31 +356,13 @@ __global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain
         const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
         s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
       }
-      float my_inv = 1.f;
       int bad = 0;
 #pragma unroll
-      for (int k = 0; k < PSB; ++k) {
-        const float d = read_lane(s[k], k);
-        bad = (bad == 0 && !(d > 0.f)) ? k + 1 : bad;
-        const float inv = __builtin_amdgcn_rsqf(d);
-        const float l = (idx == k) ? d * inv : s[k] * inv;
-        if (idx == k) my_inv = inv;
-        s[k] = l;
-#pragma unroll
-        for (int j = k + 1; j < PSB; ++j) s[j] = fmaf(-l, read_lane(l, j), s[j]);
-      }
+      for (int r = 0; r < PSB; ++r) x[r] = (r == idx) ? 1.f : 0.f;
+      Chol16Step<0>::run(s, x, idx, bad);   // (one chain of 16 steps for L and X = L^-1, above)
       if (bad && lane == 0) {
         *status = pivot_base + o + bad;
         bad_sh = 1;
-      }
-#pragma unroll
-      for (int r = 0; r < PSB; ++r) x[r] = (r == idx) ? 1.f : 0.f;
-#pragma unroll
-      for (int i = 0; i < PSB; ++i) {
-        const float xi = x[i] * read_lane(my_inv, i);
-        x[i] = xi;  // X[i][idx]
-#pragma unroll
-        for (int r = i + 1; r < PSB; ++r) x[r] = fmaf(-read_lane(s[i], r), xi, x[r]);
       }
       if (lane < PSB) {
         float *dst = S + (o + idx) * QLD + o;
@@ -310,6 +374,7 @@ __global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain
       }
     }
     __syncthreads();
+    PQ_STAMP(2 + 3 * kb);
     if (bad_sh) return;  // uniform: a non-positive pivot ends the factorisation (the caller reads *status)
     // ---- panel: L_ik = S_ik X_kk^T, block rows spread over the waves
     {
@@ -321,55 +386,93 @@ __global__ __launch_bounds__(QW * 64) void potrf_node128_kernel(const float *Ain
       }
     }
     __syncthreads();
-    // ---- trailing update: S_ij -= L_ik L_jk^T (lower blocks), pairs spread over the waves
+    PQ_STAMP(3 + 3 * kb);
+    // ---- trailing update: S_ij -= L_ik L_jk^T (lower blocks), pairs spread over the waves.  A wave takes its pairs FOUR at a time: all
+    // operand reads first, then four independent MFMA chains, then the writes (one pair at a time was one LDS round trip + one dependent
+    // chain of four MFMAs each, 0.34 us per pair: tools/r6/probe_potrf_timeline.py).  The block itself is the accumulator operand.
     {
-      int pair = 0;
-      for (int ib = kb + 1; ib < QBLK; ++ib)
-        for (int jb = kb + 1; jb <= ib; ++jb, ++pair) {
-          if (pair % QW != wave) continue;
-          const lf32x4 d = mm16(frag(S, ib * PSB, o), frag(S, jb * PSB, o), lf32x4{0.f, 0.f, 0.f, 0.f});
+      const int m = QBLK - kb - 1, npairs = m * (m + 1) / 2;
+      for (int p0 = wave; p0 < npairs; p0 += 4 * QW) {
+        float4 a[4], b[4];
+        lf32x4 c[4];
+        int ro[4], co[4];
+        bool ok[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) S[(ib * PSB + s4 + r) * QLD + jb * PSB + idx] -= d[r];
+        for (int u = 0; u < 4; ++u) {
+          const int pr = p0 + u * QW;
+          ok[u] = pr < npairs;   // (wave-uniform)
+          if (!ok[u]) continue;
+          const int pp = pr;
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= pp) ++i;
+          const int j = pp - i * (i + 1) / 2;
+          ro[u] = (kb + 1 + i) * PSB; co[u] = (kb + 1 + j) * PSB;
+          a[u] = frag(S, ro[u], o);
+          a[u].x = -a[u].x; a[u].y = -a[u].y; a[u].z = -a[u].z; a[u].w = -a[u].w;
+          b[u] = frag(S, co[u], o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[u][r] = S[(ro[u] + s4 + r) * QLD + co[u] + idx];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ok[u]) c[u] = mm16(a[u], b[u], c[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ok[u]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(ro[u] + s4 + r) * QLD + co[u] + idx] = c[u][r];
+          }
+      }
     }
     __syncthreads();
+    PQ_STAMP(4 + 3 * kb);
   }
 
-  // ---- off-diagonal blocks of X = L^-1: X_ij = -X_ii sum_{j <= k < i} L_ik X_kj.  The block columns are independent
-  // chains: wave w takes columns w, w + 4 (the long chains are paired with the short ones).
-#pragma unroll 1
-  for (int c = 0; c < 2; ++c) {
-    const int jb = c == 0 ? wave : QBLK - 2 - wave;   // 0..3, then 6..3 (column 3 once)
-    if (c == 1 && jb <= QW - 1) continue;
-    if (jb > QBLK - 2) continue;
-#pragma unroll 1
-    for (int ib = jb + 1; ib < QBLK; ++ib) {
-      lf32x4 t{0.f, 0.f, 0.f, 0.f};
-      for (int k = jb; k < ib; ++k)  // (L_ik X_kj)[i][n] = sum_kk L_ik[i][kk] X_kj[kk][n]
-        t = mm16(frag(S, ib * PSB, k * PSB), frag_t(X, QLD, k * PSB, jb * PSB), t);
-      store(TT, TLD, 0, 0, t, 1.f);   // t as it is: TT[i][n]
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes before its reads (other lanes' data)
-      // d = X_ii t: P = X_ii rows, Q rows = t^T rows = columns of TT
-      const lf32x4 d = mm16(frag(X, ib * PSB, ib * PSB), frag_t(TT, TLD, 0, 0), lf32x4{0.f, 0.f, 0.f, 0.f});
-      store(X, QLD, ib * PSB, jb * PSB, d, -1.f);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
+  // ---- the last row of the off-diagonal blocks of X = L^-1 (the other rows were formed under the diagonal blocks above)
+  for (int jb = wave; jb < QBLK - 1; jb += QW) x_block(QBLK - 1, jb);
   __syncthreads();
+  PQ_STAMP(26);
 
+  if (vec) {   // 16-byte stores, a full 512-byte row per 32 lanes: L^-1 with its zeros, L up to the diagonal
+#pragma unroll 4
+    for (int it = 0; it < QNB * QNB / 4 / (QW * 64); ++it) {
+      const int e = it * (QW * 64) + tid, row = e / (QNB / 4), c4 = (e % (QNB / 4)) * 4;
+      if (row < nb && c4 < nb) {
+        *reinterpret_cast<float4 *>(Linv + (long)row * ldinv + c4) = *reinterpret_cast<const float4 *>(X + row * QLD + c4);
+        if (c4 <= row) {
+          const float4 lv = *reinterpret_cast<const float4 *>(S + row * QLD + c4);
+          float *dst = A + (long)row * lda + c4;
+          if (c4 + 3 <= row) *reinterpret_cast<float4 *>(dst) = lv;
+          else {
+            dst[0] = lv.x;
+            if (c4 + 1 <= row) dst[1] = lv.y;
+            if (c4 + 2 <= row) dst[2] = lv.z;
+          }
+        }
+      }
+    }
+  } else
   // coalesced stores (thread = column of half the rows): L lower triangle, L^-1 with its zeros
   {
-    const int col = tid & (QNB - 1), r0 = (tid >> 7) * (QNB / 2);
+    constexpr int RPT = QNB / (QW * 64 / QNB);
+    const int col = tid & (QNB - 1), r0 = (tid >> 7) * RPT;
     if (col < nb) {
-      for (int r = r0; r < min(r0 + QNB / 2, nb); ++r) {
+      for (int r = r0; r < min(r0 + RPT, nb); ++r) {
         const float lv = S[r * QLD + col], xv = X[r * QLD + col];
         Linv[(long)r * ldinv + col] = xv;
         if (col <= r) A[(long)r * lda + col] = lv;
       }
     }
   }
+#ifdef CLO_POTRF_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  PQ_STAMP(27);
 }
 
+#ifdef CLO_POTRF_TIMING
+static unsigned long long *g_potrf_stamps = nullptr;
+#endif
 static int potrf_node128_launch(const float *Ain, long ldin, float *A, long lda, int nb, float *Linv, long ldinv,
                                 int *status, int pivot_base, long batch_stride, int batch, hipStream_t st) {
   static bool attr_done[64] = {};  // per device
@@ -384,8 +487,13 @@ static int potrf_node128_launch(const float *Ain, long ldin, float *A, long lda,
     if (rc != CLO_OK) return rc;
     attr_set = true;
   }
+#ifdef CLO_POTRF_TIMING
+  hipLaunchKernelGGL(potrf_node128_kernel, dim3(batch), dim3(QW * 64), QSMEM, st, Ain, ldin, A, lda, nb, Linv, ldinv,
+                     status, pivot_base, batch_stride, g_potrf_stamps);
+#else
   hipLaunchKernelGGL(potrf_node128_kernel, dim3(batch), dim3(QW * 64), QSMEM, st, Ain, ldin, A, lda, nb, Linv, ldinv,
                      status, pivot_base, batch_stride);
+#endif
   CLO_CHECK_LAUNCH("potrf_node128_kernel");
   return CLO_OK;
 }
@@ -944,3 +1052,7 @@ extern "C" int clo_potrf_diag_f32(float *A, long lda, int nb, float *Linv, long 
   CLO_CHECK_LAUNCH("potrf_diag_kernel");
   return CLO_OK;
 }
+
+#ifdef CLO_POTRF_TIMING
+extern "C" void clo_potrf_timing_set(unsigned long long *device_buffer) { clo::g_potrf_stamps = device_buffer; }
+#endif
