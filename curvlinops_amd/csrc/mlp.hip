@@ -1230,11 +1230,24 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
 // row stride of [row][Npad] delta tiles in LDS: Npad + 16 (conflict-free ds_read_b32 across the 4 k-groups)
 constexpr int mid_ldd(int NT) { return NT <= 2 ? 48 : 80; }
 
+#ifndef CLO_MIDF_SU
+#define CLO_MIDF_SU 16
+#endif
 template <int NT, bool HAS_DA, int WV>
 __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
     const float *__restrict__ W, const float *__restrict__ VW, const float *__restrict__ a_in,
     const float *__restrict__ da_in, float *__restrict__ part, int N, int d_in, int d_out,
-    int k_per_block) {
+    int k_per_block
+#ifdef CLO_MID_TIMING
+    , unsigned long long *stamps
+#endif
+    ) {
+#ifdef CLO_MID_TIMING
+#define MIDF_STAMP(i) do { if (threadIdx.x == 0 && stamps) stamps[(4096 + blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MIDF_STAMP(i) do { } while (0)
+#endif
+  MIDF_STAMP(0);
   // Round 6: a wave owns 16 features and runs THREE products per step -- z += W a, dz += W da, dz += V a -- with two
   // A fragments (16 rows of W, the same 16 rows of V).  The round-2 form stacked [8 rows of W ; 8 rows of V] into one
   // A tile and multiplied it with a AND da: four products, the fourth (V da) discarded -- a quarter of the MFMA time of
@@ -1266,18 +1279,34 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
   Group ga, gb;
   if (ngroups > 0) load(ga, 0);
 
-  {  // stage B: columns [0, NP) = rows of a, [NP, 2 NP) = rows of da; zero beyond N rows / klen
-    constexpr int NC = (HAS_DA ? 2 : 1) * NP;
-    const int q4 = (k_per_block + 3) >> 2;
-    for (int e = tid; e < NC * q4; e += WV * 64) {
-      const int c = e / q4, kq = (e - c * q4) * 4;
-      const int n = c < NP ? c : c - NP;
-      float4 v = zero4();
-      if (n < N && kq < klen) v = ld4((c < NP ? a_in : da_in) + (long)n * d_in + kb0 + kq);
-      *reinterpret_cast<float4 *>(&s_b[c * ldb + kq]) = v;
+  {  // stage B: columns [0, NP) = rows of a, [NP, 2 NP) = rows of da; zero beyond N rows / klen.  CLO_MIDF_SU loads in flight per thread
+    // (round 6: one load, one LDS write per trip was 16 dependent round trips at 64 rows -- 7.1 us before the first MFMA,
+    // tools/r6/probe_mid_fwd_timeline.py); unconditional loads at clamped addresses, zeroed afterwards
+    constexpr int NC = (HAS_DA ? 2 : 1) * NP, SU = NT >= 3 ? CLO_MIDF_SU : 8;   // (16 in flight lose 1.5 - 2 us up to 32 rows, win 1.2 us at 64)
+    const int q4 = (k_per_block + 3) >> 2, total = NC * q4;
+    for (int e0 = tid; e0 < total; e0 += SU * WV * 64) {
+      float4 v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int e = min(e0 + u * WV * 64, total - 1);
+        const int c = e / q4, kq = (e - c * q4) * 4;
+        const int n = c < NP ? c : c - NP;
+        const bool ok = n < N && kq < klen;
+        v[u] = ld4((c < NP ? a_in : da_in) + (long)(ok ? n : 0) * d_in + kb0 + (ok ? kq : 0));
+        if (!ok) v[u] = zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int e = e0 + u * WV * 64;
+        if (e < total) {
+          const int c = e / q4, kq = (e - c * q4) * 4;
+          *reinterpret_cast<float4 *>(&s_b[c * ldb + kq]) = v[u];
+        }
+      }
     }
   }
   __syncthreads();
+  MIDF_STAMP(1);
 
   f32x4 accz[NT], accd[NT], accv[NT];   // W a | W da | V a  (three independent chains: no back-to-back dependency)
 #pragma unroll
@@ -1324,6 +1353,7 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
     mma_step(wv, vv, step);
   }
 
+  MIDF_STAMP(2);
   // D layout: row = (lane >> 4) * 4 + r = feature inside the wave's 16, col = lane & 15 = batch row in the tile: every
   // lane holds four consecutive features -> one float4 per (tile, quantity) into part[split][2][NP][d_out].
   const int q = lane >> 4, col = lane & 15;
@@ -1337,6 +1367,10 @@ __global__ __launch_bounds__(WV * 64) void mid_fwd_kernel(
                                                 accd[t][2] + accv[t][2], accd[t][3] + accv[t][3]));
     }
   }
+#ifdef CLO_MID_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MIDF_STAMP(3);
 }
 
 // Forward + JVP of a layer of the 9 ... 64-row chain WITHOUT split-K slabs: fwd_mfma_first_kernel's scheme
@@ -3755,7 +3789,12 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
         // (up to 32 rows the kernel is bandwidth-bound and a single, partly filled round costs nothing extra -- its blocks share the
         // bandwidth the missing ones would have used; beyond that it is MFMA-bound and an idle CU is lost time: 64 rows 117 us with
         // 231 blocks, 124 us with 210)
-        const double fill = (rounds > 1 || NT >= 3) ? (double)(rounds * slots) / (double)blocks : 1.0;
+        // (blocks spread over the CUs first: 273 blocks with two slots per CU still leave 17 CUs with twice the work of the others --
+        // the last blocks of the 32-row forward ended at 24 us, the mean at 17)
+        const long cu_rounds = cdiv(blocks, (long)kNumCU);
+        const double fill = blocks > kNumCU ? (double)(cu_rounds * kNumCU) / (double)blocks
+                                            : (NT >= 3 ? (double)kNumCU / (double)blocks : 1.0);
+        (void)rounds;
         const double traffic = ((double)rb * cols * di + 2.0 * (double)kse * 2 * NP * dout) * fill;
         if (traffic < best) { best = traffic; wv = w; ksplit = kse; kpb = kp; }
       }
@@ -3766,11 +3805,16 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     dim3 grid((unsigned)row_blocks, (unsigned)ksplit), block(wv * 64);
     {
       ProfScope prof(0, 8.0 * di * dout, st);
+#ifdef CLO_MID_TIMING
+#define CLO_MIDF_STAMP_ARG , g_mid_stamps_host
+#else
+#define CLO_MIDF_STAMP_ARG
+#endif
 #define CLO_MIDF(DA, WVV)                                                                                  \
   rc = set_smem(mid_fwd_kernel<NT, DA, WVV>, smem);                                                        \
   if (rc != CLO_OK) return rc;                                                                             \
   hipLaunchKernelGGL((mid_fwd_kernel<NT, DA, WVV>), grid, block, smem, st, W[l - 1], VW[l - 1], a[l - 1],  \
-                     DA ? da[l - 1] : nullptr, fslab, N, di, dout, (int)kpb)
+                     DA ? da[l - 1] : nullptr, fslab, N, di, dout, (int)kpb CLO_MIDF_STAMP_ARG)
       if (has_da) { if (wv == 8) { CLO_MIDF(true, 8); } else { CLO_MIDF(true, 4); } }
       else { if (wv == 8) { CLO_MIDF(false, 8); } else { CLO_MIDF(false, 4); } }
 #undef CLO_MIDF
