@@ -1227,8 +1227,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdArgs p) {
 //   mid_dprev_kernel      delta_{l-1} slabs: A = delta^T from LDS, B = 4 rows x 64 columns of W per load
 //   mid_outer_kernel      out_W_l = beta out_W_l + delta_l^T a_{l-1} for all layers, 16 x 64 MFMA tiles
 // ------------------------------------------------------------------------------------------
-// row stride of [row][Npad] delta tiles in LDS: Npad + 16 (conflict-free ds_read_b32 across the 4 k-groups)
-constexpr int mid_ldd(int NT) { return NT <= 2 ? 48 : 80; }
+// row stride of [row][Npad] delta tiles in LDS: Npad + 17
+// (odd since round 6: the tile is filled row index fastest -- coalesced reads of delta[n][j ..] -- and 49 / 81 are coprime with the
+// 64 banks, so those writes are conflict-free too; the fragment reads pay one extra cycle on three banks)
+constexpr int mid_ldd(int NT) { return NT <= 2 ? 49 : 81; }
 
 #ifndef CLO_MIDF_SU
 #define CLO_MIDF_SU 16
@@ -1575,9 +1577,37 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
 #pragma unroll
   for (int u = 0; u < U; ++u) wv[u] = ld4(wrow(min(r0 + 4 * u, max(r1 - 1, r0))));
 
-  for (int e = tid; e < rpad * NP; e += 512) {
-    const int jj = e / NP, n = e - jj * NP;
-    s_d[jj * MID_LDD + n] = jj < rows_per_block ? mid_delta_at<NT>(md, n, jbase + jj, N, d_out) : 0.f;
+  if (!md.dslabs) {
+    // delta_l is a final array: consecutive threads take consecutive rows j of one batch row (coalesced), EIGHT unconditional loads at
+    // clamped addresses in flight per thread, zeroed afterwards.  (Round 6: one element per trip, batch row fastest, was up to 31
+    // dependent round trips of 64 four-byte requests each -- the staging, not the weight stream, set this kernel's time beyond 16 rows.)
+    constexpr int SU = 8;
+    const long ldd = md.ld_delta ? md.ld_delta : d_out;
+    const int total = rpad * NP;
+    for (int e0 = tid; e0 < total; e0 += SU * 512) {
+      float v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int e = min(e0 + u * 512, total - 1);
+        const int n = e / rpad, jj = e - n * rpad;
+        const bool ok = jj < rows_per_block && n < N && jbase + jj < d_out;
+        v[u] = md.delta[(ok ? (long)n * ldd + jbase + jj : 0L)];
+        if (!ok) v[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int e = e0 + u * 512;
+        if (e < total) {
+          const int n = e / rpad, jj = e - n * rpad;
+          s_d[jj * MID_LDD + n] = v[u];
+        }
+      }
+    }
+  } else {
+    for (int e = tid; e < rpad * NP; e += 512) {
+      const int n = e / rpad, jj = e - n * rpad;
+      s_d[jj * MID_LDD + n] = jj < rows_per_block ? mid_delta_at<NT>(md, n, jbase + jj, N, d_out) : 0.f;
+    }
   }
   __syncthreads();
 
