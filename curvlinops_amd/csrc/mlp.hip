@@ -1545,12 +1545,22 @@ struct MidDprevArgs {
   const float *dphi_prev;
   float *dst;
   int N, d_in, d_out, rows_per_block, final_write;
+#ifdef CLO_MID_TIMING
+  unsigned long long *stamps;
+  int gx;
+#endif
 };
+#ifdef CLO_MID_TIMING
+#define MIDD_STAMP(i) do { if (threadIdx.x == 0 && dq.stamps) dq.stamps[(6144 + by * dq.gx + bx) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MIDD_STAMP(i) do { } while (0)
+#endif
 // CQ = column groups of 64 per block (4: 256 columns x 2 row halves; 2, round 6: 128 columns x 4 row quarters -- half as many
 // row-range slabs for the same number of blocks)
 template <int NT, int CQ = 4>
 __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, int by, float *smem) {
   constexpr int NP = 16 * NT, MID_LDD = mid_ldd(NT), RH = 8 / CQ;
+  MIDD_STAMP(0);
   const float *__restrict__ W = dq.W;
   const MidDelta &md = dq.md;
   const float *__restrict__ dphi_prev = dq.dphi_prev;
@@ -1573,9 +1583,15 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
   auto wrow = [&](int jj) { return pW + (long)min(jbase + jj + kg, d_out - 1) * d_in; };
   constexpr int U = 8;
   float4 wv[U];
-  // first loads in flight while delta is staged
+  // first weight loads in flight while delta is staged -- issued BEHIND the first batch of delta loads where delta is a plain array
+  // (a CU's memory pipe delivers in issue order: delta, 64 KB from L2, would wait for 64 KB of weights from HBM)
+  auto issue_w = [&]() {
 #pragma unroll
-  for (int u = 0; u < U; ++u) wv[u] = ld4(wrow(min(r0 + 4 * u, max(r1 - 1, r0))));
+    for (int u = 0; u < U; ++u) wv[u] = ld4(wrow(min(r0 + 4 * u, max(r1 - 1, r0))));
+  };
+  const bool delta_vec = !md.dslabs && (((md.ld_delta ? md.ld_delta : d_out) | d_out | rows_per_block) & 3) == 0 &&
+                         (((unsigned long)md.delta) & 15ul) == 0;
+  if (!delta_vec) issue_w();
 
   if (!md.dslabs) {
     // delta_l is a final array: consecutive threads take consecutive rows j of one batch row (coalesced), EIGHT unconditional loads at
@@ -1584,6 +1600,40 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
     constexpr int SU = 8;
     const long ldd = md.ld_delta ? md.ld_delta : d_out;
     const int total = rpad * NP;
+    if (delta_vec) {
+      // 16 bytes = four rows j per load: a quarter of the load instructions, ONE batch in flight for up to 64 batch rows x 256 rows
+      // (tools/r6/probe_mid_dprev_timeline.py: four batches of eight scalar loads, queued behind the weight loads issued above, took
+      // 9.0 of the kernel's 20 us at 64 rows)
+      const int rq = rpad >> 2, total4 = rq * NP;
+      bool w_done = false;
+      for (int e0 = tid; e0 < total4; e0 += SU * 512) {
+        float4 v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int e = min(e0 + u * 512, total4 - 1);
+          const int n = e / rq, jj = (e - n * rq) * 4;
+          const bool ok = jj < rows_per_block && n < N && jbase + jj < d_out;
+          v[u] = ld4(md.delta + (ok ? (long)n * ldd + jbase + jj : 0L));
+          if (!ok) v[u] = zero4();
+        }
+        if (!w_done) {   // (first batch)
+          issue_w();
+          w_done = true;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int e = e0 + u * 512;
+          if (e < total4) {
+            const int n = e / rq, jj = (e - n * rq) * 4;
+            s_d[jj * MID_LDD + n] = v[u].x;
+            s_d[(jj + 1) * MID_LDD + n] = v[u].y;
+            s_d[(jj + 2) * MID_LDD + n] = v[u].z;
+            s_d[(jj + 3) * MID_LDD + n] = v[u].w;
+          }
+        }
+      }
+      if (!w_done) issue_w();   // (threads beyond the tile)
+    } else
     for (int e0 = tid; e0 < total; e0 += SU * 512) {
       float v[SU];
 #pragma unroll
@@ -1610,6 +1660,7 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
     }
   }
   __syncthreads();
+  MIDD_STAMP(1);
 
   f32x4 acc[NT][4];
 #pragma unroll
@@ -1641,6 +1692,7 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
       }
     }
   }
+  MIDD_STAMP(2);
   // merge the row parts pairwise through LDS (upper half of the parts -> lower half, RH / 2 = 4 / CQ waves x CQ column groups = 4 wave
   // slots per round), then D[n = 4 q + r][column c16 of component e] -> P[n][i0 + e]
 #pragma unroll
@@ -1666,6 +1718,7 @@ __device__ __forceinline__ void mid_dprev_body(const MidDprevArgs &dq, int bx, i
     }
     if (stride > 1) __syncthreads();
   }
+  MIDD_STAMP(3);
   if (rh >= 1 || !col_ok) return;
   const int q = lane >> 4;
 #pragma unroll
@@ -3941,6 +3994,9 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     const int fin = JBe == 1 ? 1 : 0;
     MidDprevArgs dq{W[l - 1], md[l], dphi[l - 1], fin ? dl[l - 1] : slab, N, di, dout, rpb, fin};
     const int gx = (int)cdiv(di, DCOLS);
+#ifdef CLO_MID_TIMING
+    dq.stamps = g_mid_stamps_host; dq.gx = gx;
+#endif
     if (merge_on) {
       int layers[2] = {l, L};
       const int count = l == L - 1 ? 2 : 1;
