@@ -2065,11 +2065,15 @@ __global__ __launch_bounds__(256) void mid_delta_finish_kernel(const float *__re
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total4) return;
   float4 acc = zero4();
-  for (int jb = 0; jb < njb; ++jb) {
-    const float4 v = ld4(slabs + (long)jb * slab_stride + 4 * e);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-  }
   const float4 dp = ld4(dphi + 4 * e);
+  for (int jb = 0; jb < njb; jb += 8) {   // eight slabs in flight: clamped index + zero weight, no branches (the order of the sum is kept)
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = ld4(slabs + (long)min(jb + k, njb - 1) * slab_stride + 4 * e);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (jb + k < njb) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+  }
   st4(out + 4 * e, make_float4(acc.x * dp.x, acc.y * dp.y, acc.z * dp.z, acc.w * dp.w));
 }
 
