@@ -2261,14 +2261,45 @@ __global__ __launch_bounds__(HB_GROUPS * 64) void head_rows_back_kernel(
   const int jb = outer ? (int)blockIdx.x : ((int)blockIdx.x - nbj) % nbj, rb = outer ? 0 : ((int)blockIdx.x - nbj) / nbj;
   const int j = jb * 64 + lane, jc = min(j, d - 1);
   const int n0 = outer ? 0 : rb * HB_DROWS, n1 = outer ? N : min(N, n0 + HB_DROWS);
-  for (int e = n0 * C + (int)threadIdx.x; e < n1 * C; e += HB_GROUPS * 64) s_dl[e] = dL[e];
+  // (round 6: every global load of the block is in flight before the first wait -- delta_L for LDS in one batch, and in the outer-product
+  // blocks all rows of a_prev this wave will use; they used to be 2 - 3 dependent trips for delta_L, then two batches of eight)
+  constexpr int DLS = (HB_FUSE_N * HEAD_CMAX + HB_GROUPS * 64 - 1) / (HB_GROUPS * 64);   // staged elements per thread, at most
+  constexpr int XR = HB_FUSE_N / HB_GROUPS;                                              // rows per wave, at most
+  float dls[DLS];
+  {
+    const int e0 = n0 * C + (int)threadIdx.x, e1 = n1 * C;
+#pragma unroll
+    for (int u = 0; u < DLS; ++u) dls[u] = dL[min(e0 + u * HB_GROUPS * 64, max(e1 - 1, 0))];
+  }
+  float xr[XR];
+  if (outer) {
+#pragma unroll
+    for (int r = 0; r < XR; ++r) xr[r] = a_prev[(long)min(grp + r * HB_GROUPS, N - 1) * d + jc];
+  }
+  {
+    const int e0 = n0 * C + (int)threadIdx.x, e1 = n1 * C;
+#pragma unroll
+    for (int u = 0; u < DLS; ++u)
+      if (e0 + u * HB_GROUPS * 64 < e1) s_dl[e0 + u * HB_GROUPS * 64] = dls[u];
+    for (int e = e0 + DLS * HB_GROUPS * 64; e < e1; e += HB_GROUPS * 64) s_dl[e] = dL[e];   // (N beyond HB_FUSE_N: not launched that way)
+  }
   if (outer) {
     float acc[HEAD_CMAX];
 #pragma unroll
     for (int c = 0; c < HEAD_CMAX; ++c) acc[c] = 0.f;
     __syncthreads();
-#pragma unroll 8
-    for (int n = grp; n < N; n += HB_GROUPS) {
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+      const int n = grp + r * HB_GROUPS;
+      if (n < N) {   // (wave-uniform)
+        const float x = xr[r];
+        const float *dn = &s_dl[n * C];
+#pragma unroll
+        for (int c = 0; c < HEAD_CMAX; ++c)
+          if (c < C) acc[c] = fmaf(dn[c], x, acc[c]);
+      }
+    }
+    for (int n = grp + XR * HB_GROUPS; n < N; n += HB_GROUPS) {   // (N beyond HB_FUSE_N)
       const float x = a_prev[(long)n * d + jc];
       const float *dn = &s_dl[n * C];
 #pragma unroll
