@@ -4030,7 +4030,11 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
 #endif
     constexpr int DCQ = ((NT >= 3 || CLO_MID_DPREV_CQ2_ALL) && CLO_MID_DPREV_CQ2 && !CLO_MLP_MID_MERGE) ? 2 : 4;
     constexpr int DCOLS = 64 * DCQ;
-    long JB = NT <= 2 ? cdiv(kNumCU, cdiv(di, DCOLS)) : std::max<long>(1, kNumCU / cdiv(di, DCOLS));
+#ifndef CLO_MID_DPREV_FLOOR
+#define CLO_MID_DPREV_FLOOR 1
+#endif
+    // (never more blocks than CUs: 11 x 24 = 264 blocks left eight CUs with two blocks each -- twice the time of the other 248)
+    long JB = (NT <= 2 && !CLO_MID_DPREV_FLOOR) ? cdiv(kNumCU, cdiv(di, DCOLS)) : std::max<long>(1, kNumCU / cdiv(di, DCOLS));
     JB = std::min<long>({JB, cdiv(dout, 64), JB_MAX});
     JB = std::max<long>(JB, cdiv(dout, NT <= 2 ? 512 : 256));   // LDS: rows x (Npad + 16) delta + merge buffer
     const int rpb = (int)(cdiv(cdiv(dout, JB), 8) * 8);
