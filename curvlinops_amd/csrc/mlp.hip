@@ -3983,7 +3983,10 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
   }
   // ---- data chain delta_{l-1} = delta_l W_l for l = L-1 .. 2, each step merged with the outer products that need delta_l
   // only (layer l; at the first step also the head's layer L); the last launch forms the remaining outer products
-  constexpr int OCW = NT <= 2 ? 256 : 128;
+#ifndef CLO_MID_OCW128
+#define CLO_MID_OCW128 0
+#endif
+  constexpr int OCW = (NT <= 2 && !CLO_MID_OCW128) ? 256 : 128;
   const size_t osmem = (size_t)NP * (MIDO_ROWS + 16 + OCW) * sizeof(float);
   // (MEASURED in round 6 and left OFF: the merged launch is 0.5 - 3 us SLOWER at every row count, profiles/
   // r06_c2_mid_merged_backward_ab.txt -- a read-only sweep and a write-only stream sharing the chip slow each other down by
@@ -4077,7 +4080,10 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
       hipLaunchKernelGGL((mid_dprev_kernel<NT, DCQ>), dim3((unsigned)gx, (unsigned)JBe), dim3(512), smem, st, dq);
       CLO_CHECK_LAUNCH("mid_dprev_kernel");
     }
-    if (!fin && NT > 2) {   // one pass over the slabs instead of one per consumer block
+#ifndef CLO_MID_NT2_STREAM
+#define CLO_MID_NT2_STREAM 0
+#endif
+    if (!fin && (NT > 2 || (NT == 2 && CLO_MID_NT2_STREAM))) {   // one pass over the slabs instead of one per consumer block
       const long total4 = (long)N * di / 4;
       hipLaunchKernelGGL(mid_delta_finish_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st, slab, JBe,
                          (long)NP * di, dphi[l - 1], dl[l - 1], total4);
@@ -4104,7 +4110,7 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
     for (int k = 0; k < count; ++k) aligned4 = aligned4 && dims[layers[k] - 1] % 4 == 0;
     // (measured: at <= 32 rows the tile-per-block kernel is 1.5 - 7 us faster -- its blocks are short there and delta_1 still
     // arrives as row-range slabs that every block would sum again; from 33 rows on the streaming form wins)
-    if (CLO_MLP_MID_OUTER2 && aligned4 && NT >= 3) return launch_mid_outer2<NT>(oa, count, beta, N, st);
+    if (CLO_MLP_MID_OUTER2 && aligned4 && (NT >= 3 || (NT == 2 && CLO_MID_NT2_STREAM))) return launch_mid_outer2<NT>(oa, count, beta, N, st);
     rc = beta != 0.f ? set_smem(mid_outer_kernel<NT, true, OCW>, osmem)
                      : set_smem(mid_outer_kernel<NT, false, OCW>, osmem);
     if (rc != CLO_OK) return rc;
