@@ -2025,6 +2025,7 @@ static int launch_mid_outer2(const MidOuterArgs &oa, int count, float beta, int 
   long strip_cols = 0;
   for (int k = 0; k < count; ++k) strip_cols += cdiv(oa.d_out[k], MO2_ROWS) * (long)oa.d_in[k];
   // about CLO_MO2_PER_CU resident blocks per CU (2, 3, 4 and 6 measured alike; 1 is 7 % slower), ranges of whole 64-column chunks
+  // (ranges of a multiple of 16 columns that fill the two-per-CU grid more evenly were measured: no difference, 65 ... 128 rows)
   const int cr = (int)std::max<long>(MO2_CW, cdiv(cdiv(strip_cols, (long)CLO_MO2_PER_CU * kNumCU), MO2_CW) * MO2_CW);
   int nb2 = 0;
   for (int k = 0; k < count; ++k) {

@@ -1,6 +1,6 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for n in 16 32; do
+for n in 128 512; do
 rm -rf /tmp/pr$n
 rocprofv3 --kernel-trace --stats -d /tmp/pr$n -o k -- python $R/tools/probe_c2.py $n > /tmp/probe_$n.log 2>&1
 grep "N=" /tmp/probe_$n.log
@@ -12,7 +12,7 @@ seen={}
 for row in con.execute("select * from kernels"):
     r=dict(zip(cols,row)); name=r['name']
     k=name.split('(')[0][-44:]
-    if ('mid_' in name or 'head_' in name):
+    if ("clo::" in name):
         d=seen.setdefault(k,[0,0.0,r]); d[0]+=1; d[1]+=r['duration']
 for k,(c,t,r) in seen.items():
     wg=r['workgroup_x']; blocks=r['grid_x']//wg*max(1,r['grid_y']//max(1,r['workgroup_y']))
