@@ -1885,7 +1885,10 @@ __global__ __launch_bounds__(512) void mid_outer_kernel(const MidOuterArgs p) {
 // through a double-buffered LDS tile 64 columns at a time (global loads of chunk c + 1 in flight behind the MFMAs and stores of chunk c,
 // one barrier per chunk), and the result leaves as 4 rows x 256 bytes per store instruction.  Ranges are sized so that the whole grid
 // is resident at once (about two blocks per CU).
-constexpr int MO2_ROWS = 128, MO2_CW = 64;
+#ifndef CLO_MO2_STAGE_DELTA
+#define CLO_MO2_STAGE_DELTA 1
+#endif
+constexpr int MO2_ROWS = 128, MO2_CW = 64, MO2_DPITCH = 144;
 struct MidOuter2Args {
   int nlayers;
   int first_block[OUTER_MAXL + 1];
@@ -1948,8 +1951,34 @@ __global__ __launch_bounds__(512) void mid_outer2_kernel(const MidOuter2Args p) 
   // the wave's 16 rows of delta^T: lane (l16, kg) holds delta[4 s + kg][j] for s = 0 .. KS - 1
   const int j = strip * MO2_ROWS + wave * 16 + l16;
   float af[KS];
+  const MidDelta &mdl = p.md[l];
+  const long ldd = mdl.ld_delta ? mdl.ld_delta : d_out;
+  if (CLO_MO2_STAGE_DELTA && !mdl.dslabs && ((ldd | (long)d_out) & 3) == 0 && (((unsigned long)mdl.delta) & 15ul) == 0) {
+    // a plain, aligned delta array: the block's strip [NP][128 rows j] goes through LDS -- coalesced 16-byte loads, 512 bytes per batch
+    // row -- instead of KS four-byte loads per lane that each touch four rows x 64 bytes (the buffer of the a_{l-1} chunks is free until
+    // the first chunk is stored; pitch 144: the four k groups of a fragment read hit disjoint banks)
+    float *S = s_o2;
+    float4 dv[NT];
 #pragma unroll
-  for (int s4 = 0; s4 < KS; ++s4) af[s4] = mid_delta_at<NT>(p.md[l], 4 * s4 + kg, j, N, d_out);
+    for (int u = 0; u < NT; ++u) {
+      const int e = u * 512 + tid, n = e >> 5, j4 = (e & 31) * 4, jg = strip * MO2_ROWS + j4;
+      const bool ok = n < N && jg < d_out;
+      dv[u] = ld4(mdl.delta + (ok ? (long)n * ldd + jg : 0L));
+      if (!ok) dv[u] = zero4();
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int e = u * 512 + tid, n = e >> 5, j4 = (e & 31) * 4;
+      *reinterpret_cast<float4 *>(S + n * MO2_DPITCH + j4) = dv[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < KS; ++s4) af[s4] = S[(4 * s4 + kg) * MO2_DPITCH + wave * 16 + l16];
+    __syncthreads();   // (every fragment is in registers before the first chunk overwrites the buffer)
+  } else {
+#pragma unroll
+    for (int s4 = 0; s4 < KS; ++s4) af[s4] = mid_delta_at<NT>(mdl, 4 * s4 + kg, j, N, d_out);
+  }
   if (p.out_b[l] && rg == 0) {   // bias gradient: column sums of delta
     float sb = 0.f;
 #pragma unroll
@@ -2010,6 +2039,8 @@ __global__ __launch_bounds__(512) void mid_outer2_kernel(const MidOuter2Args p) 
   MIDO_STAMP(3);
 }
 
+template <typename K>
+static int set_smem(K kernel, size_t bytes);
 // the outer products of `count` layers (fields of a MidOuterArgs filled as for mid_outer_kernel) in one mid_outer2_kernel launch
 #ifndef CLO_MO2_PER_CU
 #define CLO_MO2_PER_CU 2
@@ -2036,8 +2067,11 @@ static int launch_mid_outer2(const MidOuterArgs &oa, int count, float beta, int 
     nb2 += (int)cdiv(oa.d_out[k], MO2_ROWS) * o2.nranges[k];
   }
   o2.first_block[count] = nb2;
-  const size_t smem2 = (size_t)2 * NP * MO2_CW * sizeof(float);
-  static_assert(2 * NP * MO2_CW * sizeof(float) <= 64 * 1024, "within the default dynamic LDS limit");
+  const size_t smem2 = (size_t)std::max(2 * NP * MO2_CW, NP * MO2_DPITCH) * sizeof(float);   // chunk double buffer | staged delta strip
+  {
+    const int rc = beta != 0.f ? set_smem(mid_outer2_kernel<NT, true>, smem2) : set_smem(mid_outer2_kernel<NT, false>, smem2);
+    if (rc != CLO_OK) return rc;
+  }
   if (beta != 0.f) hipLaunchKernelGGL((mid_outer2_kernel<NT, true>), dim3(nb2), dim3(512), smem2, st, o2);
   else hipLaunchKernelGGL((mid_outer2_kernel<NT, false>), dim3(nb2), dim3(512), smem2, st, o2);
   CLO_CHECK_LAUNCH("mid_outer2_kernel");
