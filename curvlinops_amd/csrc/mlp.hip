@@ -2057,7 +2057,9 @@ static int launch_mid_outer2(const MidOuterArgs &oa, int count, float beta, int 
   for (int k = 0; k < count; ++k) strip_cols += cdiv(oa.d_out[k], MO2_ROWS) * (long)oa.d_in[k];
   // about CLO_MO2_PER_CU resident blocks per CU (2, 3, 4 and 6 measured alike; 1 is 7 % slower), ranges of whole 64-column chunks
   // (ranges of a multiple of 16 columns that fill the two-per-CU grid more evenly were measured: no difference, 65 ... 128 rows)
-  const int cr = (int)std::max<long>(MO2_CW, cdiv(cdiv(strip_cols, (long)CLO_MO2_PER_CU * kNumCU), MO2_CW) * MO2_CW);
+  const size_t smem_blk = (size_t)std::max(2 * NP * MO2_CW, NP * MO2_DPITCH) * sizeof(float);
+  const long per_cu = std::max<long>(1, std::min<long>(CLO_MO2_PER_CU, (160 * 1024) / (long)smem_blk));   // (beyond 128 rows: one block per CU)
+  const int cr = (int)std::max<long>(MO2_CW, cdiv(cdiv(strip_cols, per_cu * kNumCU), MO2_CW) * MO2_CW);
   int nb2 = 0;
   for (int k = 0; k < count; ++k) {
     o2.first_block[k] = nb2;
@@ -4490,6 +4492,7 @@ extern "C" int clo_mlp_ggn_matvec(int L, const int *dims, const int *acts, const
 #ifndef CLO_MLP_ROWS_OUTER2
 #define CLO_MLP_ROWS_OUTER2 1
 #endif
+  // (measured up to 192 rows, nine to twelve row tiles, one block per CU: 3 ... 15 us SLOWER than the GEMM engine there)
   const bool rows_outer2 = CLO_MLP_ROWS_OUTER2 && !skinny && N <= 128;
   MidOuterArgs pend{};
   pend.alpha = 1.f; pend.beta = beta; pend.N = N;
