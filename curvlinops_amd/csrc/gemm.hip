@@ -1428,7 +1428,11 @@ int launch_mlp_fwd3(const float *A, const float *dA, const float *W, const float
 #endif
   // (measured: 129 / 160 / 192 rows 267 -> 245 / 261 -> 243 / 276 -> 258 us; 257 ... 320 rows LOSE 23 us with five 64-row tiles)
   const bool pad64 = CLO_FWD3_PAD64 && N > 128 && N <= 192;
-  const int bm = tiny ? 32 : (N <= 32 ? 32 : (N <= 64 || pad64 ? 64 : 128));
+#ifndef CLO_FWD3_PAD32
+#define CLO_FWD3_PAD32 1
+#endif
+  const bool pad32 = CLO_FWD3_PAD32 && N > 64 && N <= 96;   // (three 32-row tiles instead of one 128-row tile that is a third padding)
+  const int bm = tiny ? 32 : (N <= 32 || pad32 ? 32 : (N <= 64 || pad64 ? 64 : 128));
   const int bn = tiny ? 64 : (bm == 128 ? 64 : 128);
   const int bk = tiny ? 64 : 16;
   p.tiles_m = (int)cdiv(N, bm);

@@ -1,6 +1,6 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for n in 128 512; do
+for n in 65 160 256; do
 rm -rf /tmp/pr$n
 rocprofv3 --kernel-trace --stats -d /tmp/pr$n -o k -- python $R/tools/probe_c2.py $n > /tmp/probe_$n.log 2>&1
 grep "N=" /tmp/probe_$n.log
