@@ -280,8 +280,8 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
     def _native_cost(n: int) -> float:
         """Relative time of one native product over ``n`` rows, re-fitted at the end of round 6 on C2
         (profiles/r06_c2_batch_sweep.txt: 8 rows 41 us on the persistent kernel; 9-16 rows 55-56 us, 17-32 rows 68-74 us,
-        33-48 rows 88-94 us and 49-64 rows 105-107 us on the MFMA chain; beyond that the GEMM path, 160 us at 65 rows,
-        177 at 128, 300 at 256, 500 at 512, 940 at 1024), in units of the 8-row product."""
+        33-48 rows 88-94 us and 49-64 rows 105-107 us on the MFMA chain; beyond that the GEMM path, 151 us at 65 rows,
+        172 at 128, 300 at 256, 500 at 512, 940 at 1024), in units of the 8-row product."""
         if n <= 8:
             return 1.0
         if n <= 16:
@@ -293,7 +293,7 @@ class CurvatureLinearOperator(EmpiricalRiskMixin, PyTorchLinearOperator):
         if n <= 64:
             return 2.60
         if n <= 128:
-            return 3.4 + n / 140.0
+            return 3.1 + n / 120.0
         return 2.1 + n / 49.5
 
     def _merge_native_batches(self, entries: list[tuple]) -> list[tuple]:
