@@ -4120,7 +4120,10 @@ static int mid_chain(int L, const int *dims, const int *acts, const float *const
 #ifndef CLO_MID_NT2_STREAM
 #define CLO_MID_NT2_STREAM 0
 #endif
-    if (!fin && (NT > 2 || (NT == 2 && CLO_MID_NT2_STREAM))) {   // one pass over the slabs instead of one per consumer block
+#ifndef CLO_MID_FINISH_MIN_NT
+#define CLO_MID_FINISH_MIN_NT 3
+#endif
+    if (!fin && (NT >= CLO_MID_FINISH_MIN_NT || (NT == 2 && CLO_MID_NT2_STREAM))) {   // one pass over the slabs instead of one per consumer block
       const long total4 = (long)N * di / 4;
       hipLaunchKernelGGL(mid_delta_finish_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st, slab, JBe,
                          (long)NP * di, dphi[l - 1], dl[l - 1], total4);
